@@ -1,0 +1,57 @@
+"""The numpy oracle against the golden outputs of the reference Denoiser (CPU, no GPU)."""
+import numpy as np
+import pytest
+
+from oracle import denoiser_ref, weights
+from tests.helpers import forward_case, max_abs, rel_l2, state_dict
+
+
+def test_state_dict_layout():
+    ks = weights.key_shapes()
+    assert len(ks) == 537
+    sd = state_dict()
+    assert sum(v.size for k, v in sd.items() if not k.endswith(".pe")) == 92923013  # parameter count
+    # the 9 layers must differ (reference clones one layer at init)
+    assert not np.array_equal(sd["decoder.layers.0.linear1.weight"], sd["decoder.layers.1.linear1.weight"])
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_sharp", "real", "oddlen"])
+def test_forward_matches_reference(name):
+    sd, inp, t, g = forward_case(name)
+    out, att = denoiser_ref.denoiser_forward(sd, inp["sample"], t, inp["memories"], inp["masks"])
+    assert out.shape == g["out"].shape
+    assert rel_l2(out, g["out"]) < 2e-5          # thread-count sensitive at ~1e-6
+    for j in range(5):
+        ref = g[f"att{j}"]
+        assert max_abs(att[j][: ref.shape[0]], ref) < 2e-4
+    # masked key columns are exactly zero, rows sum to one
+    for j, nm in enumerate(denoiser_ref.MEM_NAMES):
+        m = inp["masks"][nm]
+        if m is not None:
+            assert np.all(att[j][np.broadcast_to(m[:, None, None, :], att[j].shape)] == 0)
+        np.testing.assert_allclose(att[j].sum(-1), 1.0, atol=1e-5)
+
+
+def test_forward_long_memory():
+    sd, inp, t, g = forward_case("synth")
+    out, att = denoiser_ref.denoiser_forward(sd, inp["sample"], t, inp["memories"], inp["masks"])
+    assert rel_l2(out, g["out"]) < 2e-5
+    assert max_abs(att[1][..., :64], g["att1_head"]) < 2e-5
+    assert max_abs(att[0], g["att0"]) < 2e-5
+
+
+def test_rejects_what_the_reference_rejects():
+    sd, inp, t, _ = forward_case("tiny")
+    with pytest.raises(ValueError):  # odd L: broadcasting error at position_encoding.py:160-161
+        denoiser_ref.denoiser_forward(sd, inp["sample"][:, :15], t, inp["memories"], inp["masks"])
+    mems = list(inp["memories"])
+    mems[1] = np.zeros((mems[1].shape[0], 1025, 512), dtype=np.float32)
+    with pytest.raises(ValueError):  # S > 1024: position_encoding.py:135
+        denoiser_ref.denoiser_forward(sd, inp["sample"], t, mems, {})
+
+
+def test_per_row_timesteps_equal_scalar():
+    sd, inp, t, _ = forward_case("tiny")
+    a, _ = denoiser_ref.denoiser_forward(sd, inp["sample"], t, inp["memories"], inp["masks"], num_layers=2)
+    b, _ = denoiser_ref.denoiser_forward(sd, inp["sample"], np.full((7,), t), inp["memories"], inp["masks"], num_layers=2)
+    np.testing.assert_array_equal(a, b)
