@@ -1,0 +1,105 @@
+"""ctypes binding of libcfdenoise.so (the C ABI in include/cfdenoise.h).
+
+There is no CPU fallback: importing this module without the built library, or creating a handle
+without an MI355X, raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcfdenoise.so")
+
+NUM_MEM = 5
+MEM_NAMES = ("spkemb", "alsn", "tlsn", "apb", "lsnemb")
+PROF_CLASSES = ("gemm_token", "gemm_mem", "gemm_attn", "rows", "other")
+
+SYMBOLS = [
+    "cfd_create", "cfd_destroy", "cfd_last_error", "cfd_load_tensor", "cfd_finalize_weights",
+    "cfd_set_timestep_table", "cfd_forward", "cfd_sample_begin", "cfd_sample_steps", "cfd_sample_position",
+    "cfd_sample_read", "cfd_scheduler_step", "cfd_add_noise", "cfd_philox_normal", "cfd_profile_forward",
+    "cfd_test_gemm", "cfd_debug_stop_stage", "cfd_debug_read",
+]
+
+
+class CfdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libcfdenoise error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("latent_dim", C.c_int), ("text_encoded_dim", C.c_int), ("ff_size", C.c_int),
+                ("num_layers", C.c_int), ("num_heads", C.c_int), ("device", C.c_int)]
+
+
+class Memory(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("row_map", C.c_void_p), ("key_padding_mask", C.c_void_p),
+                ("U", C.c_int), ("S", C.c_int)]
+
+
+class SampleArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("L", C.c_int), ("G", C.c_int), ("guidance_weight", C.c_float * 8),
+                ("scheduler", C.c_int), ("num_train_timesteps", C.c_int), ("num_inference_steps", C.c_int),
+                ("clip_sample", C.c_int), ("eta", C.c_float), ("set_alpha_to_one", C.c_int),
+                ("steps_offset", C.c_int), ("alphas_cumprod", C.c_void_p), ("init_latents", C.c_void_p),
+                ("step_noise", C.c_void_p), ("seed", C.c_uint64), ("first_utterance", C.c_uint32),
+                ("preseq", C.c_void_p), ("preseq_len", C.c_int), ("mem", Memory * NUM_MEM)]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m convofusion_amd.build` "
+            "(hipcc --offload-arch=gfx950).  convofusion_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.cfd_last_error.restype = C.c_char_p
+    lib.cfd_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    lib.cfd_destroy.argtypes = [C.c_void_p]
+    lib.cfd_destroy.restype = None
+    lib.cfd_load_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int]
+    lib.cfd_finalize_weights.argtypes = [C.c_void_p]
+    lib.cfd_set_timestep_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.cfd_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                C.POINTER(Memory), C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]
+    lib.cfd_sample_begin.argtypes = [C.c_void_p, C.POINTER(SampleArgs), C.c_void_p]
+    lib.cfd_sample_steps.argtypes = [C.c_void_p, C.c_int]
+    lib.cfd_sample_position.argtypes = [C.c_void_p]
+    lib.cfd_sample_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.cfd_scheduler_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.cfd_add_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_size_t, C.c_void_p]
+    lib.cfd_philox_normal.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint32,
+                                      C.c_uint32, C.c_uint32, C.c_void_p]
+    lib.cfd_profile_forward.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    lib.cfd_test_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_void_p]
+    lib.cfd_debug_stop_stage.argtypes = [C.c_void_p, C.c_int]
+    lib.cfd_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("cfd_last_error", "cfd_destroy"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise CfdError(code, load().cfd_last_error().decode())
+    return code
+
+
+def create_handle(device_index=0, num_layers=9, latent_dim=128, d_model=512, ff_size=1024, num_heads=4):
+    lib = load()
+    cfg = Config(latent_dim, d_model, ff_size, num_layers, num_heads, device_index)
+    h = C.c_void_p()
+    check(lib.cfd_create(C.byref(cfg), C.byref(h)))
+    return h

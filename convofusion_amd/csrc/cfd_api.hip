@@ -1,0 +1,981 @@
+// libcfdenoise: handle, weight folding, the denoiser forward pipeline, the hipGraph-captured sampler
+// and the C ABI declared in include/cfdenoise.h.  gfx950 only; no CPU fallback anywhere.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cfdenoise.h"
+#include "gemm_sp.hpp"
+#include "rows.hpp"
+
+int g_cfd_naive_gemm = 0;
+
+static thread_local char g_err[1024] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIPCHK(expr)                                                                               \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) return fail(CFD_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+#define CHK(expr)            \
+  do {                       \
+    int _r = (expr);         \
+    if (_r != CFD_OK) return _r; \
+  } while (0)
+
+static const char* MEM_NAMES[CFD_NMEM] = {"spkemb", "alsn", "tlsn", "apb", "lsnemb"};
+
+struct DBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t n) {
+    if (n <= bytes) return CFD_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    HIPCHK(hipMalloc(&p, n));
+    bytes = n;
+    return CFD_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct LayerW {
+  DBuf wqk_sp, bqk, wv_sp, wo_sp, bo2, wtb1_sp, wtb2_sp, w1_sp, w2_sp, cross_bias;
+  const float *ln1g, *ln1b, *tb1g, *tb1b, *btb1, *ln2g, *ln2b, *tb2g, *tb2b, *btb2, *ln3g, *ln3b, *b1, *b2;
+};
+
+struct Problem {
+  int Be = 0, L = 0, Lp = 0;
+  long long M = 0;
+  int U[CFD_NMEM], S[CFD_NMEM], Sp[CFD_NMEM], off[CFD_NMEM], Sp_tot = 0;
+  const float* mem[CFD_NMEM];
+  const int* map[CFD_NMEM];
+  const uint8_t* mask[CFD_NMEM];
+  float* att[CFD_NMEM];
+  int tmode = 0;  // 0: all rows share the timestep of table row *d_step ; 1: row b uses table row b
+  int T = 1;      // rows in the temb tables
+};
+
+struct cfd_handle_s {
+  cfd_config cfg;
+  int nl = 0;
+  bool finalized = false;
+  std::map<std::string, DBuf> raw;
+  std::map<std::string, size_t> raw_numel;
+  // prepared weights
+  DBuf we_sp, wp_sp, we_all, be_all;
+  DBuf wk_all_sp[CFD_NMEM], wv_all_sp[CFD_NMEM];
+  std::vector<LayerW> lw;
+  int qpe_rows = 0, mpe_rows = 0;
+  // timestep sinusoid table
+  DBuf tsin;
+  int tsin_rows = 0;
+  // workspace
+  DBuf x, h_sp, qk_sp, vts_sp, ssc, sp_sp, o_sp, u_sp, sc, p_sp, eps, sample_sp;
+  DBuf n_sp[CFD_NMEM], kall_sp[CFD_NMEM], cb[CFD_NMEM], vt_all[CFD_NMEM];
+  DBuf temb_tab, h1_tab, ss_tab, trows;
+  DBuf d_step;  // [0] = loop index, [1] = constant 0
+  Problem pb;
+  // profiling
+  bool prof = false;
+  hipEvent_t pev[2] = {nullptr, nullptr};
+  float prof_ms[CFD_PROF_NCLASS];
+  int prof_n[CFD_PROF_NCLASS];
+  int stop_stage = 0;  // test hook: leave enqueue_denoise after this tap point (0 = run everything)
+  hipStream_t own_stream = nullptr;  // non-blocking stream the captured loop iteration replays on
+  // sampling run
+  bool run_open = false;
+  cfd_sample_args sargs;
+  hipStream_t run_stream = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  DBuf latents, coef, inoise, mem_own[CFD_NMEM];
+  int run_pos = 0;
+};
+typedef cfd_handle_s Ctx;
+
+static const float* rawp(Ctx* c, const std::string& name) {
+  auto it = c->raw.find(name);
+  return it == c->raw.end() ? nullptr : it->second.as<float>();
+}
+
+// ---- profiling brackets ---------------------------------------------------------------------------
+struct Bracket {
+  Ctx* c;
+  int cls;
+  hipStream_t st;
+  Bracket(Ctx* c_, int cls_, hipStream_t st_) : c(c_), cls(cls_), st(st_) {
+    if (c->prof) (void)hipEventRecord(c->pev[0], st);
+  }
+  ~Bracket() {
+    if (c->prof) {
+      (void)hipEventRecord(c->pev[1], st);
+      (void)hipEventSynchronize(c->pev[1]);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, c->pev[0], c->pev[1]);
+      c->prof_ms[cls] += ms;
+      c->prof_n[cls] += 1;
+    }
+  }
+};
+
+template <int MODE, class Epi>
+static int run_gemm(Ctx* c, int cls, const GemmArgs& a, const Epi& e, int nb, int nz, hipStream_t st, int cfg = 0) {
+  Bracket br(c, cls, st);
+  hipError_t err = launch_gemm<MODE, Epi>(a, e, nb, nz, st, cfg);
+  if (err != hipSuccess) return fail(CFD_E_HIP, "gemm launch failed: %s", hipGetErrorString(err));
+  return CFD_OK;
+}
+
+static GemmArgs gemm_args() {
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nslot = 1;
+  return a;
+}
+
+#define LAUNCH(cls, kernel, grid, block, st, ...)                                              \
+  do {                                                                                         \
+    Bracket _br(c, cls, st);                                                                   \
+    hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                               \
+    hipError_t _e = hipGetLastError();                                                         \
+    if (_e != hipSuccess) return fail(CFD_E_HIP, "%s launch failed: %s", #kernel, hipGetErrorString(_e)); \
+  } while (0)
+
+// ---- create / destroy -----------------------------------------------------------------------------
+extern "C" const char* cfd_last_error(void) { return g_err; }
+
+extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
+  if (!cfg || !out) return fail(CFD_E_ARG, "null argument");
+  if (cfg->latent_dim != CFD_LAT || cfg->text_encoded_dim != CFD_D || cfg->ff_size != CFD_FF ||
+      cfg->num_heads != CFD_NHEAD)
+    return fail(CFD_E_ARG, "unsupported dimensions: this build is specialised to latent 128, d_model 512, ff 1024, 4 heads "
+                           "(configs/modules/denoiser.yaml)");
+  if (cfg->num_layers < 1 || cfg->num_layers > CFD_MAX_LAYERS) return fail(CFD_E_ARG, "num_layers out of range");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(CFD_E_ARG, "device %d not present (%d devices)", cfg->device, ndev);
+  HIPCHK(hipSetDevice(cfg->device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(CFD_E_ARG, "libcfdenoise is built for gfx950 (MI355X) only; device reports %s", prop.gcnArchName);
+  Ctx* c = new Ctx();
+  c->cfg = *cfg;
+  c->nl = cfg->num_layers;
+  c->lw.resize(c->nl);
+  const char* env = getenv("CFD_NAIVE_GEMM");
+  g_cfd_naive_gemm = (env && atoi(env) != 0) ? 1 : 0;
+  if (c->d_step.ensure(16) != CFD_OK) { delete c; return CFD_E_HIP; }
+  if (hipMemset(c->d_step.p, 0, 16) != hipSuccess) { delete c; return fail(CFD_E_HIP, "memset"); }
+  (void)hipEventCreate(&c->pev[0]);
+  (void)hipEventCreate(&c->pev[1]);
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(CFD_E_HIP, "stream create"); }
+  *out = c;
+  return CFD_OK;
+}
+
+extern "C" void cfd_destroy(cfd_handle c) {
+  if (!c) return;
+  (void)hipSetDevice(c->cfg.device);
+  (void)hipDeviceSynchronize();
+  if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
+  if (c->graph) (void)hipGraphDestroy(c->graph);
+  for (auto& kv : c->raw) kv.second.release();
+  DBuf* all[] = {&c->we_sp, &c->wp_sp, &c->we_all, &c->be_all, &c->tsin, &c->x, &c->h_sp, &c->qk_sp, &c->vts_sp,
+                 &c->ssc, &c->sp_sp, &c->o_sp, &c->u_sp, &c->sc, &c->p_sp, &c->eps, &c->sample_sp, &c->temb_tab,
+                 &c->h1_tab, &c->ss_tab, &c->trows, &c->d_step, &c->latents, &c->coef, &c->inoise};
+  for (DBuf* b : all) b->release();
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    c->wk_all_sp[j].release(); c->wv_all_sp[j].release(); c->n_sp[j].release(); c->kall_sp[j].release();
+    c->cb[j].release(); c->vt_all[j].release(); c->mem_own[j].release();
+  }
+  for (auto& l : c->lw) {
+    DBuf* lb[] = {&l.wqk_sp, &l.bqk, &l.wv_sp, &l.wo_sp, &l.bo2, &l.wtb1_sp, &l.wtb2_sp, &l.w1_sp, &l.w2_sp, &l.cross_bias};
+    for (DBuf* b : lb) b->release();
+  }
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  if (c->pev[0]) (void)hipEventDestroy(c->pev[0]);
+  if (c->pev[1]) (void)hipEventDestroy(c->pev[1]);
+  delete c;
+}
+
+// ---- weights ----------------------------------------------------------------------------------------
+extern "C" int cfd_load_tensor(cfd_handle c, const char* name, const float* data, size_t numel, int is_device) {
+  if (!c || !name || !data || numel == 0) return fail(CFD_E_ARG, "null/empty argument");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  DBuf& b = c->raw[name];
+  CHK(b.ensure(numel * sizeof(float)));
+  HIPCHK(hipMemcpy(b.p, data, numel * sizeof(float), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  c->raw_numel[name] = numel;
+  c->finalized = false;
+  return CFD_OK;
+}
+
+static int need(Ctx* c, const std::string& name, size_t numel, const float** out, bool at_least = false) {
+  auto it = c->raw_numel.find(name);
+  if (it == c->raw_numel.end()) return fail(CFD_E_STATE, "missing tensor '%s' (state-dict key denoiser.%s)", name.c_str(), name.c_str());
+  if (at_least ? (it->second < numel || it->second % CFD_D) : (it->second != numel))
+    return fail(CFD_E_SHAPE, "tensor '%s' has %zu elements, expected %s%zu", name.c_str(), it->second, at_least ? ">= " : "", numel);
+  *out = c->raw[name].as<float>();
+  return CFD_OK;
+}
+
+static int to_sp(Ctx* c, const float* src, long long R, int K, DBuf& dst, long long dst_rows = -1) {
+  if (dst_rows < 0) dst_rows = R;
+  CHK(dst.ensure((size_t)dst_rows * K * 4));
+  if (dst_rows > R) HIPCHK(hipMemset(dst.p, 0, (size_t)dst_rows * K * 4));
+  const long long n = R * (K / 8);
+  hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, src, dst.as<char>(), R, K,
+                     (long long)K, (long long)K * 4);
+  HIPCHK(hipGetLastError());
+  return CFD_OK;
+}
+
+__global__ void scale_copy_kernel(const float* in, float* out, long long n, float s) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] * s;
+}
+__global__ void d2f_kernel(const double* in, float* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+__global__ void f2d_kernel(const float* in, double* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (double)in[i];
+}
+
+extern "C" int cfd_finalize_weights(cfd_handle c) {
+  if (!c) return fail(CFD_E_ARG, "null handle");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  const int D = CFD_D, nl = c->nl;
+  const float *t0, *t1;
+  // embed / projection / tables
+  CHK(need(c, "latent_embd.weight", (size_t)D * CFD_LAT, &t0));
+  CHK(to_sp(c, t0, D, CFD_LAT, c->we_sp));
+  CHK(need(c, "latent_embd.bias", D, &t0));
+  CHK(need(c, "latent_proj.weight", (size_t)CFD_LAT * D, &t0));
+  CHK(to_sp(c, t0, CFD_LAT, D, c->wp_sp));
+  CHK(need(c, "latent_proj.bias", CFD_LAT, &t0));
+  CHK(need(c, "time_embedding.linear_1.weight", (size_t)D * D, &t0));
+  CHK(need(c, "time_embedding.linear_1.bias", D, &t0));
+  CHK(need(c, "time_embedding.linear_2.weight", (size_t)D * D, &t0));
+  CHK(need(c, "time_embedding.linear_2.bias", D, &t0));
+  CHK(need(c, "bh_embedding.weight", 2 * D, &t0));
+  CHK(need(c, "condition_embedding.weight", 5 * D, &t0));
+  CHK(need(c, "decoder.norm.weight", D, &t0));
+  CHK(need(c, "decoder.norm.bias", D, &t0));
+  CHK(need(c, "query_pos.pe", D, &t0, true));
+  c->qpe_rows = (int)(c->raw_numel["query_pos.pe"] / D);
+  CHK(need(c, "mem_pos.pe", D, &t0, true));
+  c->mpe_rows = (int)(c->raw_numel["mem_pos.pe"] / D);
+
+  CHK(c->we_all.ensure((size_t)nl * 2 * 2 * D * D * 4));
+  CHK(c->be_all.ensure((size_t)nl * 2 * 2 * D * 4));
+  DBuf tmpf, tmpd1, tmpd2, vd1, vd2, accd;
+  CHK(tmpf.ensure((size_t)3 * D * D * 4));
+  CHK(tmpd1.ensure((size_t)D * D * 8));
+  CHK(tmpd2.ensure((size_t)D * D * 8));
+  CHK(vd1.ensure(D * 8));
+  CHK(vd2.ensure(D * 8));
+  CHK(accd.ensure(D * 8));
+  const long long kfeat = (long long)nl * D;
+  DBuf wk_f[CFD_NMEM], wv_f[CFD_NMEM];
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    CHK(wk_f[j].ensure((size_t)(kfeat + 32) * D * 4));
+    HIPCHK(hipMemset(wk_f[j].p, 0, (size_t)(kfeat + 32) * D * 4));
+    CHK(wv_f[j].ensure((size_t)kfeat * D * 4));
+  }
+  const dim3 blk(256);
+  auto grid1 = [](long long n) { return dim3((unsigned)((n + 255) / 256)); };
+
+  for (int l = 0; l < nl; ++l) {
+    LayerW& w = c->lw[l];
+    const std::string p = "decoder.layers." + std::to_string(l) + ".";
+    const float *ipw, *ipb, *ow, *ob;
+    // -- self attention: q rows scaled by sqrt(1/head_dim) (F.multi_head_attention_forward "q_scaled")
+    CHK(need(c, p + "self_attn.in_proj_weight", (size_t)3 * D * D, &ipw));
+    CHK(need(c, p + "self_attn.in_proj_bias", 3 * D, &ipb));
+    CHK(need(c, p + "self_attn.out_proj.weight", (size_t)D * D, &ow));
+    CHK(need(c, p + "self_attn.out_proj.bias", D, &ob));
+    const float qs = (float)std::sqrt(1.0 / (double)CFD_HD);
+    float* tf = tmpf.as<float>();
+    hipLaunchKernelGGL(scale_copy_kernel, grid1((long long)D * D), blk, 0, 0, ipw, tf, (long long)D * D, qs);
+    hipLaunchKernelGGL(scale_copy_kernel, grid1((long long)D * D), blk, 0, 0, ipw + (size_t)D * D, tf + (size_t)D * D,
+                       (long long)D * D, 1.0f);
+    CHK(to_sp(c, tf, 2 * D, D, w.wqk_sp));
+    CHK(w.bqk.ensure(2 * D * 4));
+    hipLaunchKernelGGL(scale_copy_kernel, grid1(D), blk, 0, 0, ipb, w.bqk.as<float>(), (long long)D, qs);
+    hipLaunchKernelGGL(scale_copy_kernel, grid1(D), blk, 0, 0, ipb + D, w.bqk.as<float>() + D, (long long)D, 1.0f);
+    CHK(to_sp(c, ipw + (size_t)2 * D * D, D, D, w.wv_sp));
+    CHK(to_sp(c, ow, D, D, w.wo_sp));
+    // softmax rows sum to one, so the value bias passes straight through: bo' = bo + Wo bv
+    CHK(w.bo2.ensure(D * 4));
+    hipLaunchKernelGGL((fold_mv_kernel<float, float, float>), grid1(D), blk, 0, 0, ow, (long long)D, 1LL, ipb + 2 * D,
+                       (const double*)nullptr, ob, w.bo2.as<float>(), D, D, 1.0, (const float*)nullptr);
+    // -- time blocks
+    for (int tb = 0; tb < 2; ++tb) {
+      const std::string q = p + (tb == 0 ? "time_block1." : "time_block2.");
+      CHK(need(c, q + "emb_layers.1.weight", (size_t)2 * D * D, &t0));
+      HIPCHK(hipMemcpy(c->we_all.as<float>() + ((size_t)(2 * l + tb) * 2 * D) * D, t0, (size_t)2 * D * D * 4, hipMemcpyDeviceToDevice));
+      CHK(need(c, q + "emb_layers.1.bias", 2 * D, &t0));
+      HIPCHK(hipMemcpy(c->be_all.as<float>() + (size_t)(2 * l + tb) * 2 * D, t0, (size_t)2 * D * 4, hipMemcpyDeviceToDevice));
+      CHK(need(c, q + "out_layers.2.weight", (size_t)D * D, &t0));
+      CHK(to_sp(c, t0, D, D, tb == 0 ? w.wtb1_sp : w.wtb2_sp));
+      CHK(need(c, q + "norm.weight", D, tb == 0 ? &w.tb1g : &w.tb2g));
+      CHK(need(c, q + "norm.bias", D, tb == 0 ? &w.tb1b : &w.tb2b));
+      CHK(need(c, q + "out_layers.2.bias", D, tb == 0 ? &w.btb1 : &w.btb2));
+    }
+    CHK(need(c, p + "norm1.weight", D, &w.ln1g)); CHK(need(c, p + "norm1.bias", D, &w.ln1b));
+    CHK(need(c, p + "norm2.weight", D, &w.ln2g)); CHK(need(c, p + "norm2.bias", D, &w.ln2b));
+    CHK(need(c, p + "norm3.weight", D, &w.ln3g)); CHK(need(c, p + "norm3.bias", D, &w.ln3b));
+    CHK(need(c, p + "linear1.weight", (size_t)CFD_FF * D, &t0)); CHK(to_sp(c, t0, CFD_FF, D, w.w1_sp));
+    CHK(need(c, p + "linear1.bias", CFD_FF, &w.b1));
+    CHK(need(c, p + "linear2.weight", (size_t)D * CFD_FF, &t0)); CHK(to_sp(c, t0, D, CFD_FF, w.w2_sp));
+    CHK(need(c, p + "linear2.bias", D, &w.b2));
+    // -- five single-head cross attentions + att_fuser, folded onto the memory side (DESIGN.md "Folding")
+    const float *fw, *fb;
+    CHK(need(c, p + "att_fuser.weight", (size_t)D * 5 * D, &fw));
+    CHK(need(c, p + "att_fuser.bias", D, &fb));
+    hipLaunchKernelGGL(f2d_kernel, grid1(D), blk, 0, 0, fb, accd.as<double>(), D);
+    const double cs = std::sqrt(1.0 / (double)D);  // one head of width 512
+    for (int j = 0; j < CFD_NMEM; ++j) {
+      const std::string a = p + "multihead_attn_" + MEM_NAMES[j];
+      const float *gam, *bet;
+      CHK(need(c, a + ".in_proj_weight", (size_t)3 * D * D, &ipw));
+      CHK(need(c, a + ".in_proj_bias", 3 * D, &ipb));
+      CHK(need(c, a + ".out_proj.weight", (size_t)D * D, &ow));
+      CHK(need(c, a + ".out_proj.bias", D, &ob));
+      CHK(need(c, p + MEM_NAMES[j] + "_norm.weight", D, &gam));
+      CHK(need(c, p + MEM_NAMES[j] + "_norm.bias", D, &bet));
+      const float *Wq = ipw, *Wk = ipw + (size_t)D * D, *Wv = ipw + (size_t)2 * D * D;
+      const float *bq = ipb, *bv = ipb + 2 * D;
+      // key side:  A[o][i] = cs * gamma[i] * sum_r Wq[r][o] Wk[r][i]      (scores = y . (A n))
+      hipLaunchKernelGGL((fold_mm_kernel<float, float, float>), grid1((long long)D * D), blk, 0, 0, Wq, 1LL, (long long)D, Wk,
+                         (long long)D, 1LL, wk_f[j].as<float>() + (size_t)l * D * D, (long long)D, D, D, D, cs, gam);
+      //            c[i]  = cs * gamma[i] * sum_r Wk[r][i] bq[r]          (key-dependent part of the q-bias term)
+      hipLaunchKernelGGL((fold_mv_kernel<float, float, float>), grid1(D), blk, 0, 0, Wk, 1LL, (long long)D, bq,
+                         (const double*)nullptr, (const float*)nullptr, wk_f[j].as<float>() + (size_t)(kfeat + l) * D, D, D, cs, gam);
+      // value side: VV = Wf_j Wo Wv diag(gamma)
+      hipLaunchKernelGGL((fold_mm_kernel<float, float, double>), grid1((long long)D * D), blk, 0, 0, ow, (long long)D, 1LL, Wv,
+                         (long long)D, 1LL, tmpd1.as<double>(), (long long)D, D, D, D, 1.0, (const float*)nullptr);
+      hipLaunchKernelGGL((fold_mm_kernel<float, double, float>), grid1((long long)D * D), blk, 0, 0, fw + (size_t)j * D,
+                         (long long)5 * D, 1LL, tmpd1.as<double>(), (long long)D, 1LL, wv_f[j].as<float>() + (size_t)l * D * D,
+                         (long long)D, D, D, D, 1.0, gam);
+      // constant: acc += Wf_j ( Wo (Wv beta + bv) + bo )
+      hipLaunchKernelGGL((fold_mv_kernel<float, float, double>), grid1(D), blk, 0, 0, Wv, (long long)D, 1LL, bet,
+                         (const double*)nullptr, bv, vd1.as<double>(), D, D, 1.0, (const float*)nullptr);
+      hipLaunchKernelGGL((fold_mv_kernel<float, double, double>), grid1(D), blk, 0, 0, ow, (long long)D, 1LL, vd1.as<double>(),
+                         (const double*)nullptr, ob, vd2.as<double>(), D, D, 1.0, (const float*)nullptr);
+      hipLaunchKernelGGL((fold_mv_kernel<float, double, double>), grid1(D), blk, 0, 0, fw + (size_t)j * D, (long long)5 * D, 1LL,
+                         vd2.as<double>(), (const double*)accd.as<double>(), (const float*)nullptr, vd1.as<double>(), D, D, 1.0,
+                         (const float*)nullptr);
+      HIPCHK(hipMemcpy(accd.p, vd1.p, D * 8, hipMemcpyDeviceToDevice));
+    }
+    CHK(w.cross_bias.ensure(D * 4));
+    hipLaunchKernelGGL(d2f_kernel, grid1(D), blk, 0, 0, accd.as<double>(), w.cross_bias.as<float>(), D);
+    HIPCHK(hipGetLastError());
+  }
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    CHK(to_sp(c, wk_f[j].as<float>(), kfeat + 32, D, c->wk_all_sp[j]));
+    CHK(to_sp(c, wv_f[j].as<float>(), kfeat, D, c->wv_all_sp[j]));
+  }
+  HIPCHK(hipDeviceSynchronize());
+  for (int j = 0; j < CFD_NMEM; ++j) { wk_f[j].release(); wv_f[j].release(); }
+  tmpf.release(); tmpd1.release(); tmpd2.release(); vd1.release(); vd2.release(); accd.release();
+  c->finalized = true;
+  return CFD_OK;
+}
+
+extern "C" int cfd_set_timestep_table(cfd_handle c, const float* rows, int n_rows) {
+  if (!c || !rows || n_rows < 1) return fail(CFD_E_ARG, "bad timestep table");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  CHK(c->tsin.ensure((size_t)n_rows * CFD_D * 4));
+  HIPCHK(hipMemcpy(c->tsin.p, rows, (size_t)n_rows * CFD_D * 4, hipMemcpyHostToDevice));
+  c->tsin_rows = n_rows;
+  return CFD_OK;
+}
+
+// ---- problem setup ----------------------------------------------------------------------------------
+static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], float* const att[CFD_NMEM], int tmode, int T) {
+  if (!c->finalized) return fail(CFD_E_STATE, "weights not finalized");
+  if (c->tsin_rows < 1) return fail(CFD_E_STATE, "timestep table not set");
+  if (Be < 1 || L < 2) return fail(CFD_E_ARG, "bad batch / length");
+  if (L % 2) return fail(CFD_E_SHAPE, "latent length %d is odd (reference: broadcasting error at position_encoding.py:160-161)", L);
+  if (L / 2 > c->qpe_rows) return fail(CFD_E_SHAPE, "L/2 = %d exceeds the query PE buffer (%d rows)", L / 2, c->qpe_rows);
+  Problem& p = c->pb;
+  p.Be = Be; p.L = L; p.Lp = (L + 31) / 32 * 32; p.M = (long long)Be * L; p.tmode = tmode; p.T = T;
+  if (p.Lp > SM_MAX_CHUNKS * 512) return fail(CFD_E_SHAPE, "L = %d exceeds the in-register softmax limit (%d)", L, SM_MAX_CHUNKS * 512);
+  int off = 0;
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    const cfd_memory& m = mem[j];
+    if (!m.data || m.U < 1 || m.S < 1) return fail(CFD_E_ARG, "memory %s: null/empty", MEM_NAMES[j]);
+    if (!m.row_map && m.U != Be) return fail(CFD_E_ARG, "memory %s: U = %d != Be = %d without a row_map", MEM_NAMES[j], m.U, Be);
+    if (tmode == 1 && m.row_map) return fail(CFD_E_ARG, "per-row timesteps need identity memory maps");
+    if (m.S > c->mpe_rows)
+      return fail(CFD_E_SHAPE, "memory %s has %d tokens, memory PE buffer has %d rows (reference: size mismatch at position_encoding.py:135)",
+                  MEM_NAMES[j], m.S, c->mpe_rows);
+    p.U[j] = m.U; p.S[j] = m.S; p.Sp[j] = (m.S + 31) / 32 * 32; p.off[j] = off; off += p.Sp[j];
+    if (p.Sp[j] > SM_MAX_CHUNKS * 512) return fail(CFD_E_SHAPE, "memory %s: %d keys exceed the in-register softmax limit", MEM_NAMES[j], m.S);
+    p.mem[j] = m.data; p.map[j] = m.row_map; p.mask[j] = m.key_padding_mask;
+    p.att[j] = att ? att[j] : nullptr;
+  }
+  p.Sp_tot = off;
+  const long long M = p.M;
+  const int nl = c->nl;
+  CHK(c->x.ensure((size_t)M * CFD_D * 4));
+  CHK(c->h_sp.ensure((size_t)M * CFD_D * 4));
+  CHK(c->qk_sp.ensure((size_t)M * 2 * CFD_D * 4));
+  CHK(c->vts_sp.ensure((size_t)Be * CFD_D * p.Lp * 4));
+  CHK(c->ssc.ensure((size_t)Be * CFD_NHEAD * L * p.Lp * 4));
+  CHK(c->sp_sp.ensure((size_t)Be * CFD_NHEAD * L * p.Lp * 4));
+  CHK(c->o_sp.ensure((size_t)M * CFD_D * 4));
+  CHK(c->u_sp.ensure((size_t)M * CFD_FF * 4));
+  CHK(c->sc.ensure((size_t)M * p.Sp_tot * 4));
+  CHK(c->p_sp.ensure((size_t)M * p.Sp_tot * 4));
+  CHK(c->eps.ensure((size_t)M * CFD_LAT * 4));
+  CHK(c->sample_sp.ensure((size_t)M * CFD_LAT * 4));
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    const size_t rows = (size_t)p.U[j] * p.Sp[j];
+    CHK(c->n_sp[j].ensure(rows * CFD_D * 4));
+    CHK(c->kall_sp[j].ensure(rows * nl * CFD_D * 4));
+    CHK(c->cb[j].ensure(rows * nl * 4));
+    CHK(c->vt_all[j].ensure(rows * nl * CFD_D * 4));
+  }
+  CHK(c->temb_tab.ensure((size_t)T * CFD_D * 4));
+  CHK(c->h1_tab.ensure((size_t)T * CFD_D * 4));
+  CHK(c->ss_tab.ensure((size_t)T * nl * 2 * 2 * CFD_D * 4));
+  CHK(c->trows.ensure((size_t)T * 4));
+  return CFD_OK;
+}
+
+// temb / TimeBlock modulation tables for the T timesteps in `trows_host` (embeddings.py:298-305,
+// cross_attention.py:432-434).  temb depends only on t, so a sampling run computes all of its steps once.
+static int build_time_tables(Ctx* c, const int32_t* trows_host, int T, hipStream_t st) {
+  for (int i = 0; i < T; ++i)
+    if (trows_host[i] < 0 || trows_host[i] >= c->tsin_rows)
+      return fail(CFD_E_ARG, "timestep %d outside the sinusoid table (0..%d)", trows_host[i], c->tsin_rows - 1);
+  HIPCHK(hipMemcpyAsync(c->trows.p, trows_host, (size_t)T * 4, hipMemcpyHostToDevice, st));
+  const int ry = T < 64 ? T : 64;
+  const float* W1 = rawp(c, "time_embedding.linear_1.weight");
+  const float* b1 = rawp(c, "time_embedding.linear_1.bias");
+  const float* W2 = rawp(c, "time_embedding.linear_2.weight");
+  const float* b2 = rawp(c, "time_embedding.linear_2.bias");
+  const int NE = c->nl * 2 * 2 * CFD_D;
+  LAUNCH(CFD_PROF_OTHER, small_linear_kernel, dim3(CFD_D / 4, ry), dim3(256), st, c->tsin.as<float>(), c->trows.as<int>(),
+         (long long)CFD_D, W1, b1, c->h1_tab.as<float>(), (long long)CFD_D, T, CFD_D, 0, 1);
+  LAUNCH(CFD_PROF_OTHER, small_linear_kernel, dim3(CFD_D / 4, ry), dim3(256), st, c->h1_tab.as<float>(), (const int*)nullptr,
+         (long long)CFD_D, W2, b2, c->temb_tab.as<float>(), (long long)CFD_D, T, CFD_D, 0, 0);
+  // 18 emb_layers at once: rows (2l+tb)*1024 + n ; "post 2" adds 1 to the scale half
+  // (post=2 tests n < 512 within each 1024 block -> handled by launching per time block)
+  for (int tb = 0; tb < c->nl * 2; ++tb) {
+    LAUNCH(CFD_PROF_OTHER, small_linear_kernel, dim3(2 * CFD_D / 4, ry), dim3(256), st, c->temb_tab.as<float>(), (const int*)nullptr,
+           (long long)CFD_D, c->we_all.as<float>() + (size_t)tb * 2 * CFD_D * CFD_D, c->be_all.as<float>() + (size_t)tb * 2 * CFD_D,
+           c->ss_tab.as<float>() + (size_t)tb * 2 * CFD_D, (long long)NE, T, 2 * CFD_D, 1, 2);
+  }
+  return CFD_OK;
+}
+
+// ---- the denoiser forward: Denoiser.forward (denoiser.py:173-386) --------------------------------------
+// Input: c->sample_sp (SP [M][128]); time tables built; output: c->eps (fp32 [M][128]).
+static int enqueue_denoise(Ctx* c, hipStream_t st) {
+  const Problem& p = c->pb;
+  const int nl = c->nl, L = p.L, Lp = p.Lp, Be = p.Be;
+  const long long M = p.M;
+  const int* dstep = p.tmode ? c->d_step.as<int>() + 1 : c->d_step.as<int>();
+  const long long ROWB = CFD_D * 4;  // bytes per SP row of 512
+  const dim3 blk(256);
+
+  // 1. latent embedding + body/hand embedding + query PE          (denoiser.py:187,316-326)
+  {
+    GemmArgs a = gemm_args();
+    a.X[0] = c->we_sp.as<char>(); a.ldx[0] = CFD_LAT * 4; a.I[0] = CFD_D; a.Iclamp[0] = CFD_D; a.kt[0] = CFD_LAT / 32;
+    a.Y = c->sample_sp.as<char>(); a.ldy = CFD_LAT * 4; a.J = (int)M; a.Jclamp = (int)M;
+    EpiEmbed e{c->x.as<float>(), rawp(c, "latent_embd.bias"), rawp(c, "bh_embedding.weight"), rawp(c, "query_pos.pe"), L};
+    CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
+  }
+  if (c->stop_stage == 1) return CFD_OK;
+  // 2. memories: + temb + condition id + PE, normalise           (denoiser.py:223-261,332-353)
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    MemPrepArgs a{p.mem[j], p.U[j], p.S[j], p.Sp[j], c->temb_tab.as<float>(), dstep, p.tmode,
+                  rawp(c, "condition_embedding.weight") + (size_t)j * CFD_D, rawp(c, "mem_pos.pe"), c->n_sp[j].as<char>()};
+    const long long rows = (long long)p.U[j] * p.Sp[j];
+    LAUNCH(CFD_PROF_ROWS, mem_prep_kernel, dim3((unsigned)((rows + 3) / 4)), blk, st, a);
+  }
+  // 3. memory-side projections for ALL layers at once: folded keys (+ key bias) and folded values^T
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    const int rows = p.U[j] * p.Sp[j];
+    {
+      GemmArgs a = gemm_args();
+      a.X[0] = c->wk_all_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = nl * CFD_D + 32; a.Iclamp[0] = nl * CFD_D + 32; a.kt[0] = CFD_D / 32;
+      a.Y = c->n_sp[j].as<char>(); a.ldy = ROWB; a.J = rows; a.Jclamp = rows;
+      EpiMemK e{c->kall_sp[j].as<char>(), (long long)nl * CFD_D * 4, c->cb[j].as<float>(), (long long)rows, nl * CFD_D, nl};
+      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
+    }
+    {
+      GemmArgs a = gemm_args();
+      a.X[0] = c->n_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = rows; a.Iclamp[0] = rows; a.kt[0] = CFD_D / 32;
+      a.Y = c->wv_all_sp[j].as<char>(); a.ldy = ROWB; a.J = nl * CFD_D; a.Jclamp = nl * CFD_D;
+      EpiSplit e{c->vt_all[j].as<char>(), (long long)rows * 4, 0, 0, nullptr, 0};
+      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
+    }
+  }
+
+  auto ln = [&](const float* g, const float* b, int adaln, int tbidx, char* out) -> int {
+    LnArgs a{c->x.as<float>(), out, M, g, b, adaln, c->ss_tab.as<float>() + (size_t)tbidx * 2 * CFD_D,
+             (long long)nl * 2 * 2 * CFD_D, dstep, p.tmode, L};
+    LAUNCH(CFD_PROF_ROWS, ln_rows_kernel, dim3((unsigned)((M + 3) / 4)), blk, st, a);
+    return CFD_OK;
+  };
+  auto token_gemm_resid = [&](const DBuf& w, int K, const char* y, const float* bias) -> int {
+    GemmArgs a = gemm_args();
+    a.X[0] = w.as<char>(); a.ldx[0] = (long long)K * 4; a.I[0] = CFD_D; a.Iclamp[0] = CFD_D; a.kt[0] = K / 32;
+    a.Y = y; a.ldy = (long long)K * 4; a.J = (int)M; a.Jclamp = (int)M;
+    EpiResid e{c->x.as<float>(), 0, bias};
+    return run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st);
+  };
+
+  for (int l = 0; l < nl; ++l) {
+    const LayerW& w = c->lw[l];
+    // ---- a. self attention: x += Wo softmax(q k^T) v                         (cross_attention.py:568-572)
+    CHK(ln(w.ln1g, w.ln1b, 0, 0, c->h_sp.as<char>()));
+    {  // q (pre-scaled) and k, token-major
+      GemmArgs a = gemm_args();
+      a.X[0] = w.wqk_sp.as<char>(); a.ldx[0] = ROWB; a.I[0] = 2 * CFD_D; a.Iclamp[0] = 2 * CFD_D; a.kt[0] = CFD_D / 32;
+      a.Y = c->h_sp.as<char>(); a.ldy = ROWB; a.J = (int)M; a.Jclamp = (int)M;
+      EpiSplit e{c->qk_sp.as<char>(), 2 * ROWB, 0, 0, w.bqk.as<float>(), 0};
+      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
+    }
+    {  // v^T per batch row: vts[b][f][l]
+      GemmArgs a = gemm_args();
+      a.X[0] = c->h_sp.as<char>(); a.ldx[0] = ROWB; a.xbs[0] = (long long)L * ROWB; a.I[0] = Lp; a.Iclamp[0] = L; a.kt[0] = CFD_D / 32;
+      a.Y = w.wv_sp.as<char>(); a.ldy = ROWB; a.J = CFD_D; a.Jclamp = CFD_D;
+      EpiSplit e{c->vts_sp.as<char>(), (long long)Lp * 4, (long long)CFD_D * Lp * 4, 0, nullptr, 0};
+      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, Be, 1, st)));
+    }
+    {  // scores[b][h][lq][lk]
+      GemmArgs a = gemm_args();
+      a.X[0] = c->qk_sp.as<char>() + (CFD_D / 32) * 128; a.ldx[0] = 2 * ROWB; a.xbs[0] = (long long)L * 2 * ROWB; a.xzs = (CFD_HD / 32) * 128;
+      a.I[0] = Lp; a.Iclamp[0] = L; a.kt[0] = CFD_HD / 32;
+      a.Y = c->qk_sp.as<char>(); a.ldy = 2 * ROWB; a.ybs = (long long)L * 2 * ROWB; a.yzs = (CFD_HD / 32) * 128; a.J = L; a.Jclamp = L;
+      EpiF32 e;
+      memset(&e, 0, sizeof(e));
+      e.out = c->ssc.as<float>(); e.ldo = Lp; e.obs = (long long)CFD_NHEAD * L * Lp; e.ozs = (long long)L * Lp;
+      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_ATTN, a, e, Be, CFD_NHEAD, st)));
+    }
+    {
+      SoftmaxArgs a;
+      memset(&a, 0, sizeof(a));
+      a.sc = c->ssc.as<float>(); a.P = c->sp_sp.as<char>(); a.ld = Lp; a.rows = (long long)Be * CFD_NHEAD * L; a.rows_per_b = CFD_NHEAD * L;
+      a.nseg = 1; a.S[0] = L; a.Sp[0] = Lp; a.nl = nl;
+      LAUNCH(CFD_PROF_ROWS, softmax_rows_kernel, dim3((unsigned)((a.rows + 3) / 4)), blk, st, a);
+    }
+    {  // o[b*L+l][h*128+d] = sum_lk P[lq][lk] v[lk][d]
+      GemmArgs a = gemm_args();
+      a.X[0] = c->vts_sp.as<char>(); a.ldx[0] = (long long)Lp * 4; a.xbs[0] = (long long)CFD_D * Lp * 4; a.xzs = (long long)CFD_HD * Lp * 4;
+      a.I[0] = CFD_HD; a.Iclamp[0] = CFD_HD; a.kt[0] = Lp / 32;
+      a.Y = c->sp_sp.as<char>(); a.ldy = (long long)Lp * 4; a.ybs = (long long)CFD_NHEAD * L * Lp * 4; a.yzs = (long long)L * Lp * 4;
+      a.J = L; a.Jclamp = L;
+      EpiSplit e{c->o_sp.as<char>(), ROWB, (long long)L * ROWB, (CFD_HD / 32) * 128, nullptr, 0};
+      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_ATTN, a, e, Be, CFD_NHEAD, st)));
+    }
+    CHK(token_gemm_resid(w.wo_sp, CFD_D, c->o_sp.as<char>(), w.bo2.as<float>()));
+    if (c->stop_stage == 2 + 4 * l) return CFD_OK;
+    // ---- b. time block 1                                                        (:575, :426-439)
+    CHK(ln(w.tb1g, w.tb1b, 1, 2 * l, c->h_sp.as<char>()));
+    CHK(token_gemm_resid(w.wtb1_sp, CFD_D, c->h_sp.as<char>(), w.btb1));
+    if (c->stop_stage == 3 + 4 * l) return CFD_OK;
+    // ---- c-e. five cross attentions + fuser, folded                             (:578-652)
+    CHK(ln(w.ln2g, w.ln2b, 0, 0, c->h_sp.as<char>()));
+    {  // scores against the folded keys of every memory
+      GemmArgs a = gemm_args();
+      a.nslot = CFD_NMEM;
+      EpiF32 e;
+      memset(&e, 0, sizeof(e));
+      for (int j = 0; j < CFD_NMEM; ++j) {
+        a.X[j] = c->kall_sp[j].as<char>() + (size_t)l * (CFD_D / 32) * 128; a.ldx[j] = (long long)nl * ROWB;
+        a.xbs[j] = (long long)p.Sp[j] * nl * ROWB; a.xmap[j] = p.map[j];
+        a.I[j] = p.Sp[j]; a.Iclamp[j] = p.Sp[j]; a.kt[j] = CFD_D / 32;
+        e.goff[j] = p.off[j]; e.gbias[j] = c->cb[j].as<float>() + (size_t)l * p.U[j] * p.Sp[j]; e.gmap[j] = p.map[j]; e.gstride[j] = p.Sp[j];
+      }
+      a.Y = c->h_sp.as<char>(); a.ldy = ROWB; a.ybs = (long long)L * ROWB; a.J = L; a.Jclamp = L;
+      e.out = c->sc.as<float>(); e.ldo = p.Sp_tot; e.obs = (long long)L * p.Sp_tot;
+      CHK((run_gemm<MODE_GROUPED>(c, CFD_PROF_GEMM_ATTN, a, e, Be, 1, st)));
+    }
+    {
+      SoftmaxArgs a;
+      memset(&a, 0, sizeof(a));
+      a.sc = c->sc.as<float>(); a.P = c->p_sp.as<char>(); a.ld = p.Sp_tot; a.rows = M; a.rows_per_b = L; a.nseg = CFD_NMEM;
+      for (int j = 0; j < CFD_NMEM; ++j) {
+        a.off[j] = p.off[j]; a.S[j] = p.S[j]; a.Sp[j] = p.Sp[j]; a.mask[j] = p.mask[j]; a.map[j] = p.map[j]; a.att[j] = p.att[j];
+      }
+      a.layer = l; a.nl = nl;
+      LAUNCH(CFD_PROF_ROWS, softmax_rows_kernel, dim3((unsigned)((M + 3) / 4)), blk, st, a);
+    }
+    {  // x += sum_j P_j . VV_j(n_j) + folded bias
+      GemmArgs a = gemm_args();
+      a.nslot = CFD_NMEM;
+      for (int j = 0; j < CFD_NMEM; ++j) {
+        const long long rows = (long long)p.U[j] * p.Sp[j];
+        a.X[j] = c->vt_all[j].as<char>() + (size_t)l * CFD_D * rows * 4; a.ldx[j] = rows * 4;
+        a.xbs[j] = (long long)(p.Sp[j] / 32) * 128; a.xmap[j] = p.map[j];
+        a.kt[j] = p.Sp[j] / 32;
+        a.I[j] = CFD_D; a.Iclamp[j] = CFD_D;
+      }
+      a.Y = c->p_sp.as<char>(); a.ldy = (long long)p.Sp_tot * 4; a.ybs = (long long)L * p.Sp_tot * 4; a.J = L; a.Jclamp = L;
+      EpiResid e{c->x.as<float>(), (long long)L * CFD_D, w.cross_bias.as<float>()};
+      CHK((run_gemm<MODE_SEGK>(c, CFD_PROF_GEMM_ATTN, a, e, Be, 1, st)));
+    }
+    if (c->stop_stage == 4 + 4 * l) return CFD_OK;
+    // ---- f. time block 2                                                        (:655)
+    CHK(ln(w.tb2g, w.tb2b, 1, 2 * l + 1, c->h_sp.as<char>()));
+    CHK(token_gemm_resid(w.wtb2_sp, CFD_D, c->h_sp.as<char>(), w.btb2));
+    // ---- g. FFN                                                                 (:659-661)
+    CHK(ln(w.ln3g, w.ln3b, 0, 0, c->h_sp.as<char>()));
+    {
+      GemmArgs a = gemm_args();
+      a.X[0] = w.w1_sp.as<char>(); a.ldx[0] = ROWB; a.I[0] = CFD_FF; a.Iclamp[0] = CFD_FF; a.kt[0] = CFD_D / 32;
+      a.Y = c->h_sp.as<char>(); a.ldy = ROWB; a.J = (int)M; a.Jclamp = (int)M;
+      EpiSplit e{c->u_sp.as<char>(), (long long)CFD_FF * 4, 0, 0, w.b1, 1};
+      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
+    }
+    CHK(token_gemm_resid(w.w2_sp, CFD_FF, c->u_sp.as<char>(), w.b2));
+    if (c->stop_stage == 5 + 4 * l) return CFD_OK;
+  }
+  // 7. final norm + latent projection                                             (cross_attention.py:238-239, denoiser.py:382)
+  CHK(ln(rawp(c, "decoder.norm.weight"), rawp(c, "decoder.norm.bias"), 0, 0, c->h_sp.as<char>()));
+  {
+    GemmArgs a = gemm_args();
+    a.X[0] = c->wp_sp.as<char>(); a.ldx[0] = ROWB; a.I[0] = CFD_LAT; a.Iclamp[0] = CFD_LAT; a.kt[0] = CFD_D / 32;
+    a.Y = c->h_sp.as<char>(); a.ldy = ROWB; a.J = (int)M; a.Jclamp = (int)M;
+    EpiF32 e;
+    memset(&e, 0, sizeof(e));
+    e.out = c->eps.as<float>(); e.ldo = CFD_LAT; e.bias = rawp(c, "latent_proj.bias");
+    CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
+  }
+  return CFD_OK;
+}
+
+// ---- cfd_forward ---------------------------------------------------------------------------------------
+extern "C" int cfd_forward(cfd_handle c, const float* sample, int Be, int L, const int32_t* timesteps, int n_t,
+                           const cfd_memory mem[CFD_NUM_MEM], float* out, float* const att[CFD_NUM_MEM], void* stream) {
+  if (!c || !sample || !timesteps || !mem || !out) return fail(CFD_E_ARG, "null argument");
+  if (c->run_open) return fail(CFD_E_STATE, "a sampling run is open on this handle");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  if (n_t != 1 && n_t != Be) return fail(CFD_E_ARG, "n_t must be 1 or Be");
+  hipStream_t st = (hipStream_t)stream;
+  const int tmode = (n_t == 1) ? 0 : 1;
+  CHK(setup_problem(c, Be, L, mem, att, tmode, n_t));
+  // tmode 0 reads table row d_step[0] which must be 0 outside a sampling run
+  HIPCHK(hipMemsetAsync(c->d_step.p, 0, 16, st));
+  CHK(build_time_tables(c, timesteps, n_t, st));
+  const long long n = c->pb.M * (CFD_LAT / 8);
+  LAUNCH(CFD_PROF_OTHER, to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), st, sample, c->sample_sp.as<char>(), c->pb.M,
+         CFD_LAT, (long long)CFD_LAT, (long long)CFD_LAT * 4);
+  CHK(enqueue_denoise(c, st));
+  HIPCHK(hipMemcpyAsync(out, c->eps.p, (size_t)c->pb.M * CFD_LAT * 4, hipMemcpyDeviceToDevice, st));
+  return CFD_OK;
+}
+
+extern "C" int cfd_profile_forward(cfd_handle c, float ms[CFD_PROF_NCLASS], int launches[CFD_PROF_NCLASS]) {
+  if (!c || !ms || !launches) return fail(CFD_E_ARG, "null argument");
+  if (c->pb.Be == 0) return fail(CFD_E_STATE, "no problem configured (call cfd_forward or cfd_sample_begin first)");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  if (c->run_open && c->run_pos >= c->sargs.num_inference_steps)
+    return fail(CFD_E_STATE, "sampling run is complete; profile before the last iteration");
+  hipStream_t st = c->run_open ? c->run_stream : nullptr;
+  HIPCHK(hipStreamSynchronize(st));
+  for (int k = 0; k < CFD_PROF_NCLASS; ++k) { c->prof_ms[k] = 0.f; c->prof_n[k] = 0; }
+  c->prof = true;
+  int r = enqueue_denoise(c, st);
+  c->prof = false;
+  HIPCHK(hipStreamSynchronize(st));
+  for (int k = 0; k < CFD_PROF_NCLASS; ++k) { ms[k] = c->prof_ms[k]; launches[k] = c->prof_n[k]; }
+  return r;
+}
+
+// ---- scheduler coefficients: diffusers 0.14.0 DDPMScheduler.step / DDIMScheduler.step, float32 ----------
+static void ddpm_coef(const float* ac, int T, int n_inf, int t, StepCoef* o) {
+  const int prev_t = t - T / n_inf;
+  const float ap_t = ac[t];
+  const float ap_prev = prev_t >= 0 ? ac[prev_t] : 1.0f;
+  const float bp_t = 1.0f - ap_t, bp_prev = 1.0f - ap_prev;
+  const float cur_alpha = ap_t / ap_prev;
+  const float cur_beta = 1.0f - cur_alpha;
+  o->sb = sqrtf(bp_t);
+  o->sa = sqrtf(ap_t);
+  o->c0 = (sqrtf(ap_prev) * cur_beta) / bp_t;
+  o->cx = sqrtf(cur_alpha) * bp_prev / bp_t;
+  float var = bp_prev / bp_t * cur_beta;
+  if (var < 1e-20f) var = 1e-20f;
+  o->sigma = t > 0 ? sqrtf(var) : 0.0f;
+  o->use_noise = t > 0 ? 1.0f : 0.0f;
+  o->pad0 = o->pad1 = 0.f;
+}
+static void ddim_coef(const float* ac, int T, int n_inf, int t, float eta, int set_alpha_to_one, StepCoef* o) {
+  const int prev_t = t - T / n_inf;
+  const float ap_t = ac[t];
+  const float ap_prev = prev_t >= 0 ? ac[prev_t] : (set_alpha_to_one ? 1.0f : ac[0]);
+  const float bp_t = 1.0f - ap_t, bp_prev = 1.0f - ap_prev;
+  const float var = (bp_prev / bp_t) * (1.0f - ap_t / ap_prev);
+  const float std = eta * sqrtf(var);
+  o->sb = sqrtf(bp_t);
+  o->sa = sqrtf(ap_t);
+  o->c0 = sqrtf(ap_prev);
+  o->cx = sqrtf(1.0f - ap_prev - std * std);
+  o->sigma = std;
+  o->use_noise = eta > 0.f ? 1.0f : 0.0f;
+  o->pad0 = o->pad1 = 0.f;
+}
+
+static int enqueue_loop_iteration(Ctx* c, hipStream_t st) {
+  const cfd_sample_args& s = c->sargs;
+  const long long n8 = (long long)s.B * s.L * (CFD_LAT / 8);
+  BeginArgs ba{c->latents.as<float>(), c->sample_sp.as<char>(), s.B, s.L, s.G, s.preseq, c->inoise.as<float>(), s.preseq_len,
+               c->coef.as<StepCoef>(), c->d_step.as<int>()};
+  LAUNCH(CFD_PROF_OTHER, begin_step_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), st, ba);
+  CHK(enqueue_denoise(c, st));
+  CfgStepArgs ca;
+  memset(&ca, 0, sizeof(ca));
+  ca.eps = c->eps.as<float>(); ca.latents = c->latents.as<float>(); ca.B = s.B; ca.L = s.L; ca.G = s.G;
+  for (int k = 0; k < 8; ++k) ca.w[k] = s.guidance_weight[k];
+  ca.kind = s.scheduler; ca.clip = s.clip_sample; ca.coef = c->coef.as<StepCoef>(); ca.d_step = c->d_step.as<int>();
+  ca.noise = s.step_noise; ca.seed = s.seed; ca.utt0 = s.first_utterance;
+  const long long n4 = (long long)s.B * s.L * CFD_LAT / 4;
+  LAUNCH(CFD_PROF_OTHER, cfg_step_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), st, ca);
+  LAUNCH(CFD_PROF_OTHER, advance_step_kernel, dim3(1), dim3(1), st, c->d_step.as<int>());
+  return CFD_OK;
+}
+
+extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void* stream) {
+  if (!c || !args) return fail(CFD_E_ARG, "null argument");
+  if (c->run_open) return fail(CFD_E_STATE, "a sampling run is already open");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  const cfd_sample_args& s = *args;
+  if (s.B < 1 || (s.G != 1 && s.G != 7 && (s.G < 1 || s.G > 8))) return fail(CFD_E_ARG, "bad B / G");
+  if (s.scheduler != 0 && s.scheduler != 1) return fail(CFD_E_ARG, "scheduler must be 0 (DDPM) or 1 (DDIM)");
+  if (!s.alphas_cumprod || s.num_train_timesteps < 1 || s.num_inference_steps < 1 || s.num_inference_steps > s.num_train_timesteps)
+    return fail(CFD_E_ARG, "bad scheduler tables");
+  if (s.preseq && (s.preseq_len < 1 || s.preseq_len > s.L)) return fail(CFD_E_ARG, "bad preseq_len");
+  hipStream_t st = (hipStream_t)stream;
+  c->sargs = s;
+  c->run_stream = st;
+  const int Be = s.G * s.B, N = s.num_inference_steps, T = s.num_train_timesteps;
+  CHK(setup_problem(c, Be, s.L, s.mem, nullptr, 0, N));
+  // timesteps: (arange(N) * (T // N)).round()[::-1] (+ steps_offset for DDIM)
+  std::vector<int32_t> ts(N);
+  std::vector<StepCoef> coef(N);
+  const int ratio = T / N;
+  for (int i = 0; i < N; ++i) {
+    int t = (N - 1 - i) * ratio;
+    if (s.scheduler == 1) t += s.steps_offset;
+    if (t < 0 || t >= T) return fail(CFD_E_ARG, "timestep %d out of range", t);
+    ts[i] = t;
+    if (s.scheduler == 0) ddpm_coef(s.alphas_cumprod, T, N, t, &coef[i]);
+    else ddim_coef(s.alphas_cumprod, T, N, t, s.eta, s.set_alpha_to_one, &coef[i]);
+  }
+  CHK(c->coef.ensure((size_t)N * sizeof(StepCoef)));
+  HIPCHK(hipMemcpyAsync(c->coef.p, coef.data(), (size_t)N * sizeof(StepCoef), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(c->d_step.p, 0, 16, st));
+  CHK(build_time_tables(c, ts.data(), N, st));
+  HIPCHK(hipStreamSynchronize(st));  // ts / coef host vectors go out of scope
+  const size_t lat_bytes = (size_t)s.B * s.L * CFD_LAT * 4;
+  CHK(c->latents.ensure(lat_bytes));
+  if (s.init_latents) {
+    HIPCHK(hipMemcpyAsync(c->latents.p, s.init_latents, lat_bytes, hipMemcpyDeviceToDevice, st));
+  } else {
+    const long long n = (long long)s.B * s.L * CFD_LAT / 4;
+    LAUNCH(CFD_PROF_OTHER, philox_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), st, c->latents.as<float>(), s.B,
+           s.L * CFD_LAT, (uint64_t)s.seed, 0u, s.first_utterance, 1u, 1.0f);
+  }
+  CHK(c->inoise.ensure(s.preseq ? (size_t)s.B * s.preseq_len * CFD_LAT * 4 : 16));
+  if (s.preseq) {
+    HIPCHK(hipMemcpy2DAsync(c->inoise.p, (size_t)s.preseq_len * CFD_LAT * 4, c->latents.p, (size_t)s.L * CFD_LAT * 4,
+                            (size_t)s.preseq_len * CFD_LAT * 4, s.B, hipMemcpyDeviceToDevice, st));
+  }
+  // capture one loop iteration
+  if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+  if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+  // eager warm-up of every kernel variant (sets function attributes outside capture); the iteration is
+  // idempotent on the workspace and we restore the state it mutates (latents, in-paint noise, step index).
+  {
+    DBuf save_lat, save_in;
+    CHK(save_lat.ensure(lat_bytes));
+    HIPCHK(hipMemcpyAsync(save_lat.p, c->latents.p, lat_bytes, hipMemcpyDeviceToDevice, st));
+    if (s.preseq) {
+      CHK(save_in.ensure(c->inoise.bytes));
+      HIPCHK(hipMemcpyAsync(save_in.p, c->inoise.p, c->inoise.bytes, hipMemcpyDeviceToDevice, st));
+    }
+    int r = enqueue_loop_iteration(c, st);
+    if (r != CFD_OK) return r;
+    HIPCHK(hipMemcpyAsync(c->latents.p, save_lat.p, lat_bytes, hipMemcpyDeviceToDevice, st));
+    if (s.preseq) HIPCHK(hipMemcpyAsync(c->inoise.p, save_in.p, c->inoise.bytes, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemsetAsync(c->d_step.p, 0, 16, st));
+    HIPCHK(hipStreamSynchronize(st));
+    save_lat.release();
+    save_in.release();
+  }
+  // capture and replay on the handle's own stream (the legacy default stream cannot be captured); all
+  // set-up work above was enqueued on the caller's stream and has been waited for.
+  hipStream_t cap = c->own_stream;
+  c->run_stream = cap;
+  HIPCHK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+  int r = enqueue_loop_iteration(c, cap);
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(cap, &g);
+  if (r != CFD_OK) { if (g) (void)hipGraphDestroy(g); return r; }
+  if (e != hipSuccess) return fail(CFD_E_HIP, "stream capture failed: %s", hipGetErrorString(e));
+  c->graph = g;
+  HIPCHK(hipGraphInstantiate(&c->gexec, c->graph, nullptr, nullptr, 0));
+  c->run_open = true;
+  c->run_pos = 0;
+  return CFD_OK;
+}
+
+extern "C" int cfd_sample_steps(cfd_handle c, int n) {
+  if (!c) return fail(CFD_E_ARG, "null handle");
+  if (!c->run_open) return fail(CFD_E_STATE, "no sampling run open");
+  if (n < 0 || c->run_pos + n > c->sargs.num_inference_steps)
+    return fail(CFD_E_ARG, "run has %d of %d iterations done; cannot run %d more", c->run_pos, c->sargs.num_inference_steps, n);
+  HIPCHK(hipSetDevice(c->cfg.device));
+  for (int i = 0; i < n; ++i) HIPCHK(hipGraphLaunch(c->gexec, c->run_stream));
+  c->run_pos += n;
+  return CFD_OK;
+}
+
+extern "C" int cfd_sample_position(cfd_handle c) { return (c && c->run_open) ? c->run_pos : -1; }
+
+extern "C" int cfd_sample_read(cfd_handle c, float* out, int close) {
+  if (!c || !out) return fail(CFD_E_ARG, "null argument");
+  if (!c->run_open) return fail(CFD_E_STATE, "no sampling run open");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  const size_t lat_bytes = (size_t)c->sargs.B * c->sargs.L * CFD_LAT * 4;
+  HIPCHK(hipMemcpyAsync(out, c->latents.p, lat_bytes, hipMemcpyDeviceToDevice, c->run_stream));
+  HIPCHK(hipStreamSynchronize(c->run_stream));
+  if (close) c->run_open = false;
+  return CFD_OK;
+}
+
+// ---- stand-alone scheduler ops ----------------------------------------------------------------------------
+__global__ void sched_step_kernel(const float* eps, const float* noise, float* x, size_t n, StepCoef c, int kind, int clip) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float e = eps[i], xv = x[i];
+  float x0 = (xv - c.sb * e) / c.sa;
+  if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+  float prev = (kind == 0) ? c.c0 * x0 + c.cx * xv : c.c0 * x0 + c.cx * e;
+  if (c.use_noise != 0.f) prev = prev + c.sigma * noise[i];
+  x[i] = prev;
+}
+__global__ void add_noise_kernel(const float* x0, const float* noise, float* out, size_t n, float sa, float sb) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = sa * x0[i] + sb * noise[i];
+}
+
+extern "C" int cfd_scheduler_step(cfd_handle c, int scheduler, const float* ac, int T, int n_inf, int t, int clip, float eta,
+                                  int set_alpha_to_one, const float* model_output, const float* noise, float* sample_inout,
+                                  size_t numel, void* stream) {
+  if (!c || !ac || !model_output || !sample_inout || t < 0 || t >= T || n_inf < 1) return fail(CFD_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  StepCoef k;
+  if (scheduler == 0) ddpm_coef(ac, T, n_inf, t, &k);
+  else ddim_coef(ac, T, n_inf, t, eta, set_alpha_to_one, &k);
+  if (k.use_noise != 0.f && !noise) return fail(CFD_E_ARG, "this step adds noise: pass the N(0,1) draw");
+  hipLaunchKernelGGL(sched_step_kernel, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, (hipStream_t)stream, model_output, noise,
+                     sample_inout, numel, k, scheduler, clip);
+  HIPCHK(hipGetLastError());
+  return CFD_OK;
+}
+
+extern "C" int cfd_add_noise(cfd_handle c, const float* ac, int t, const float* original, const float* noise, float* out,
+                             size_t numel, void* stream) {
+  if (!c || !ac || !original || !noise || !out || t < 0) return fail(CFD_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  const float sa = sqrtf(ac[t]), sb = sqrtf(1.0f - ac[t]);
+  hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, (hipStream_t)stream, original, noise, out,
+                     numel, sa, sb);
+  HIPCHK(hipGetLastError());
+  return CFD_OK;
+}
+
+extern "C" int cfd_philox_normal(cfd_handle c, float* out, int B, int per_utt, uint64_t seed, uint32_t step, uint32_t first_utt,
+                                 uint32_t stream_id, void* stream) {
+  if (!c || !out || B < 1 || per_utt < 4 || per_utt % 4) return fail(CFD_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  const long long n = (long long)B * per_utt / 4;
+  hipLaunchKernelGGL(philox_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, B, per_utt, seed,
+                     step, first_utt, stream_id, 1.0f);
+  HIPCHK(hipGetLastError());
+  return CFD_OK;
+}
+
+// ---- test hooks -----------------------------------------------------------------------------------------
+extern "C" int cfd_debug_stop_stage(cfd_handle c, int stage) {
+  if (!c) return fail(CFD_E_ARG, "null handle");
+  c->stop_stage = stage;
+  return CFD_OK;
+}
+
+extern "C" int cfd_debug_read(cfd_handle c, const char* what, float* dst_dev, size_t numel) {
+  if (!c || !what || !dst_dev) return fail(CFD_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  const DBuf* b = nullptr;
+  if (!strcmp(what, "x")) b = &c->x;
+  else if (!strcmp(what, "temb")) b = &c->temb_tab;
+  else if (!strcmp(what, "ss")) b = &c->ss_tab;
+  else if (!strcmp(what, "eps")) b = &c->eps;
+  else if (!strcmp(what, "sc")) b = &c->sc;
+  else if (!strcmp(what, "ssc")) b = &c->ssc;
+  else return fail(CFD_E_ARG, "unknown buffer '%s'", what);
+  if (numel * 4 > b->bytes) return fail(CFD_E_ARG, "buffer '%s' holds %zu bytes, asked for %zu", what, b->bytes, numel * 4);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(dst_dev, b->p, numel * 4, hipMemcpyDeviceToDevice));
+  return CFD_OK;
+}
+
+extern "C" int cfd_test_gemm(cfd_handle c, const float* X, const float* Y, float* out, int I, int J, int K, int tile_cfg,
+                             void* stream) {
+  if (!c || !X || !Y || !out || K % 32 || I % 4 || I < 4 || J < 1) return fail(CFD_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  hipStream_t st = (hipStream_t)stream;
+  DBuf xs, ys;
+  CHK(xs.ensure((size_t)I * K * 4));
+  CHK(ys.ensure((size_t)J * K * 4));
+  long long n = (long long)I * (K / 8);
+  hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, xs.as<char>(), (long long)I, K, (long long)K,
+                     (long long)K * 4);
+  n = (long long)J * (K / 8);
+  hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Y, ys.as<char>(), (long long)J, K, (long long)K,
+                     (long long)K * 4);
+  GemmArgs a = gemm_args();
+  a.X[0] = xs.as<char>(); a.ldx[0] = (long long)K * 4; a.I[0] = I; a.Iclamp[0] = I; a.kt[0] = K / 32;
+  a.Y = ys.as<char>(); a.ldy = (long long)K * 4; a.J = J; a.Jclamp = J;
+  EpiF32 e;
+  memset(&e, 0, sizeof(e));
+  e.out = out; e.ldo = I;
+  hipError_t err = launch_gemm<MODE_PLAIN, EpiF32>(a, e, 1, 1, st, tile_cfg);
+  if (err != hipSuccess) return fail(CFD_E_HIP, "gemm launch failed: %s", hipGetErrorString(err));
+  HIPCHK(hipStreamSynchronize(st));
+  xs.release();
+  ys.release();
+  return CFD_OK;
+}

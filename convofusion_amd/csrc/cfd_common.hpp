@@ -1,0 +1,76 @@
+// Common types and helpers for the ConvoFusion denoising-loop kernels (gfx950 / CDNA4 only).
+//
+// Numeric format used by every GEMM operand ("split-pair", SP): a float32 value v is carried as two
+// bfloat16 numbers hi = bf16(v), lo = bf16(v - hi); a product a*b is issued as THREE MFMAs
+// (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi) with fp32 accumulation -- ~2^-16 relative operand error,
+// i.e. fp32-class results from the bf16 matrix cores (the reference's 1e-3 budget on the final
+// latents cannot be met with plain bf16 operands: SURVEY.md fact 8).
+//
+// Memory layout of an SP matrix [R rows][K cols], K % 32 == 0: per row, K/32 groups of 128 bytes,
+// each group = 32 hi values (64 B) followed by the 32 lo values (64 B).  One 128-byte line thus
+// carries both halves of a 32-deep K-step for one row, which is what one LDS tile row holds.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CFD_D 512        // text_encoded_dim (configs/modules/denoiser.yaml:4)
+#define CFD_FF 1024      // ff_size (:6)
+#define CFD_LAT 128      // latent_dim[-1] (configs/config_cf_beatdnd.yaml latent_dim [1,128])
+#define CFD_NHEAD 4      // num_heads (:8)
+#define CFD_HD 128       // CFD_D / CFD_NHEAD
+#define CFD_NMEM 5       // spkemb, alsn, tlsn, apb, lsnemb (denoiser.py:220)
+#define CFD_MAX_LAYERS 16
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void split_f32(float v, __bf16& hi, __bf16& lo) {
+  hi = (__bf16)v;
+  lo = (__bf16)(v - (float)hi);
+}
+
+// store 4 consecutive-column values (col % 4 == 0) of one row into an SP matrix
+__device__ __forceinline__ void sp_store4(char* row_base, int col, float a, float b, float c, float d) {
+  bf16x4 h, l;
+  __bf16 t0, t1;
+  split_f32(a, t0, t1); h[0] = t0; l[0] = t1;
+  split_f32(b, t0, t1); h[1] = t0; l[1] = t1;
+  split_f32(c, t0, t1); h[2] = t0; l[2] = t1;
+  split_f32(d, t0, t1); h[3] = t0; l[3] = t1;
+  char* p = row_base + (size_t)(col >> 5) * 128 + (col & 31) * 2;
+  *reinterpret_cast<bf16x4*>(p) = h;
+  *reinterpret_cast<bf16x4*>(p + 64) = l;
+}
+
+// store 8 consecutive-column values (col % 8 == 0)
+__device__ __forceinline__ void sp_store8(char* row_base, int col, const float* v) {
+  bf16x8 h, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    __bf16 a, b;
+    split_f32(v[e], a, b);
+    h[e] = a;
+    l[e] = b;
+  }
+  char* p = row_base + (size_t)(col >> 5) * 128 + (col & 31) * 2;
+  *reinterpret_cast<bf16x8*>(p) = h;
+  *reinterpret_cast<bf16x8*>(p + 64) = l;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -1,0 +1,420 @@
+// Split-pair bf16x3 "NT" GEMM for gfx950:  D[i][j] = sum_k X[i][k] * Y[j][k]
+//
+//   X ("row operand", MFMA A) and Y ("column operand", MFMA B) are SP matrices (cfd_common.hpp) with
+//   K contiguous, so both fragments are 16-byte LDS reads.  The result tile is handed to an epilogue
+//   functor as 4 consecutive i for one j (the v_mfma_f32_16x16x32_bf16 C/D layout: row = 4*(lane>>4)+r,
+//   col = lane&15), i.e. outputs are written "out[j][i]" with i contiguous.  Calling it with
+//   X = weight[N][K], Y = activation[M][K] gives out[token][feature]; swapping the roles gives the
+//   transposed product (used to emit V^T for the P.V products without a transpose pass).
+//
+//   Block = 256 threads = WI x WJ waves, each wave owns TI x TJ MFMA tiles of 16x16.
+//   K-step = 32 (one 128-byte SP line per row: 4 hi chunks + 4 lo chunks of 16 B).
+//   Staging: global_load_lds_dwordx4 (16 B/lane, 8 rows x 128 B per wave-instruction) into a
+//   2-stage LDS ring; the LDS image is lane-linear, the bank swizzle chunk' = chunk ^ ((row>>1)&7)
+//   is applied on the per-lane SOURCE address and again on the fragment read (guide rule 21).
+//   Per K-step a wave issues TI*TJ*3 MFMAs (lo*hi, hi*lo, hi*hi) for 2*(TI+TJ) ds_read_b128.
+//
+//   MODE_PLAIN   one problem (optionally batched over blockIdx.y / .z with strides or an index map)
+//   MODE_GROUPED up to 5 problems sharing Y (cross-attention scores against the 5 memories)
+//   MODE_SEGK    one problem whose K range is the concatenation of up to 5 X segments (cross-attention
+//                P.V over the 5 memories, accumulated in registers)
+#pragma once
+#include "cfd_common.hpp"
+
+#define GEMM_SLOTS 5
+enum { MODE_PLAIN = 0, MODE_GROUPED = 1, MODE_SEGK = 2 };
+
+struct GemmArgs {
+  const char* X[GEMM_SLOTS];
+  long long ldx[GEMM_SLOTS];   // bytes
+  long long xbs[GEMM_SLOTS];   // bytes, multiplied by (xmap ? xmap[b] : b)
+  const int* xmap[GEMM_SLOTS];
+  long long xzs;               // bytes per blockIdx.z
+  int I[GEMM_SLOTS];           // D rows (store bound)
+  int Iclamp[GEMM_SLOTS];      // valid X rows (loads clamp to Iclamp-1)
+  int kt[GEMM_SLOTS];          // k-tiles of 32
+  int tiles_i[GEMM_SLOTS];
+  int tile_start[GEMM_SLOTS + 1];
+  int nslot;
+  const char* Y;
+  long long ldy, ybs, yzs;     // bytes
+  int J, Jclamp, tiles_j;
+};
+
+// compile-time-indexed select from a kernel-argument array (a runtime index would force the
+// by-value argument struct into scratch memory)
+template <class T>
+__device__ __forceinline__ T sel5(const T (&arr)[GEMM_SLOTS], int g) {
+  T v = arr[0];
+#pragma unroll
+  for (int q = 1; q < GEMM_SLOTS; ++q)
+    if (g == q) v = arr[q];
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Epilogues.  operator()(g, b, z, i, j, v): v = D[i..i+3][j] for group g, batch b, z.
+// ------------------------------------------------------------------------------------------------
+struct EpiF32 {  // out_f32[j][goff+i] = v (+ bias[i] | + key-bias of group g)
+  float* out;
+  long long ldo, obs, ozs;  // floats
+  const float* bias;
+  int goff[GEMM_SLOTS];
+  const float* gbias[GEMM_SLOTS];
+  const int* gmap[GEMM_SLOTS];
+  long long gstride[GEMM_SLOTS];
+  __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
+    float* p = out + (long long)b * obs + (long long)z * ozs + (long long)j * ldo + sel5(goff, g) + i;
+    const float* bb = nullptr;
+    const float* gb = sel5(gbias, g);
+    if (gb) {
+      const int* gm = sel5(gmap, g);
+      bb = gb + (long long)(gm ? gm[b] : b) * sel5(gstride, g) + i;
+    } else if (bias) bb = bias + i;
+    if (bb) {
+      const float4 t = *reinterpret_cast<const float4*>(bb);
+      v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    }
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+
+struct EpiSplit {  // out_sp[j][coloff + i] = split(act(v + bias[i]))
+  char* out;
+  long long ldo, obs, ozs;  // bytes
+  const float* bias;
+  int gelu;
+  __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
+    if (bias) {
+      const float4 t = *reinterpret_cast<const float4*>(bias + i);
+      v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    }
+    if (gelu) { v[0] = gelu_f(v[0]); v[1] = gelu_f(v[1]); v[2] = gelu_f(v[2]); v[3] = gelu_f(v[3]); }
+    sp_store4(out + (long long)b * obs + (long long)z * ozs + (long long)j * ldo, i, v[0], v[1], v[2], v[3]);
+  }
+};
+
+struct EpiResid {  // x[(b*rows_per_b + j)][i] += v + bias[i]   (row length CFD_D floats)
+  float* x;
+  long long obs;  // floats per batch
+  const float* bias;
+  __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
+    float* p = x + (long long)b * obs + (long long)j * CFD_D + i;
+    float4 r = *reinterpret_cast<const float4*>(p);
+    if (bias) {
+      const float4 t = *reinterpret_cast<const float4*>(bias + i);
+      r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+    }
+    r.x += v[0]; r.y += v[1]; r.z += v[2]; r.w += v[3];
+    *reinterpret_cast<float4*>(p) = r;
+  }
+};
+
+struct EpiEmbed {  // x0[j][i] = v + bias[i] + bh[(l&1)][i] + qpe[(l>>1)][i],  l = j % L   (denoiser.py:187,316-326)
+  float* x;
+  const float* bias;
+  const float* bh;   // [2][512]
+  const float* qpe;  // [>=L/2][512]
+  int L;
+  __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
+    const int l = j % L;
+    const float4 t0 = *reinterpret_cast<const float4*>(bias + i);
+    const float4 t1 = *reinterpret_cast<const float4*>(bh + (l & 1) * CFD_D + i);
+    const float4 t2 = *reinterpret_cast<const float4*>(qpe + (long long)(l >> 1) * CFD_D + i);
+    // same association as the reference: ((linear + bh) + pe)
+    float4 r;
+    r.x = ((v[0] + t0.x) + t1.x) + t2.x;
+    r.y = ((v[1] + t0.y) + t1.y) + t2.y;
+    r.z = ((v[2] + t0.z) + t1.z) + t2.z;
+    r.w = ((v[3] + t0.w) + t1.w) + t2.w;
+    *reinterpret_cast<float4*>(x + (long long)j * CFD_D + i) = r;
+  }
+};
+
+struct EpiMemK {  // i < nfeat: k_all_sp[j][i] = split(v);  nfeat <= i < nfeat+nl: cbias[i-nfeat][j] = v
+  char* kall;
+  long long ldk;  // bytes
+  float* cbias;
+  long long rows;  // cbias row length (= number of memory rows J)
+  int nfeat, nl;
+  __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
+    if (i < nfeat) {
+      sp_store4(kall + (long long)j * ldk, i, v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (i - nfeat + e < nl) cbias[(long long)(i - nfeat + e) * rows + j] = v[e];
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+template <int WI, int WJ, int TI, int TJ, int MODE, class Epi>
+__global__ void __launch_bounds__(256, 2) gemm_sp_kernel(const GemmArgs a, const Epi epi) {
+  static_assert(WI * WJ == 4, "4 waves per block");
+  constexpr int BI = WI * TI * 16, BJ = WJ * TJ * 16;
+  constexpr int STAGE = (BI + BJ) * 128;
+  constexpr int NGRP = (BI + BJ) / 8;
+  constexpr int GPW = (NGRP + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wi = wid / WJ, wj = wid % WJ;
+  const int b = blockIdx.y, z = blockIdx.z;
+
+  // XCD-aware tile order: blocks that land on one XCD (bid % 8 equal) walk a contiguous tile range,
+  // so the tiles_i blocks that re-read one Y (activation) tile hit the same L2.
+  int t;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  int g = 0;
+  if (MODE == MODE_GROUPED) {
+#pragma unroll
+    for (int s = 1; s < GEMM_SLOTS; ++s)
+      if (s < a.nslot && t >= a.tile_start[s]) g = s;
+    int ts = 0;
+#pragma unroll
+    for (int s = 1; s < GEMM_SLOTS; ++s)
+      if (g == s) ts = a.tile_start[s];
+    t -= ts;
+  }
+  const int tiles_i = sel5(a.tiles_i, g);
+  const int i0 = (t % tiles_i) * BI, j0 = (t / tiles_i) * BJ;
+  const int Ig = sel5(a.I, g);
+  const int Iclamp_g = sel5(a.Iclamp, g);
+
+  // X base for this (b, z): one slot in PLAIN / GROUPED mode, one per K segment in SEGK mode
+  const char* xb[GEMM_SLOTS];
+  const char* xbase_g = nullptr;
+  long long ldx_g = 0;
+  if (MODE == MODE_SEGK) {
+#pragma unroll
+    for (int s = 0; s < GEMM_SLOTS; ++s) {
+      xb[s] = nullptr;
+      if (s < a.nslot) {
+        const long long bi = a.xmap[s] ? a.xmap[s][b] : b;
+        xb[s] = a.X[s] + bi * a.xbs[s] + (long long)z * a.xzs;
+      }
+    }
+  } else {
+    const int* xm = sel5(a.xmap, g);
+    const long long bi = xm ? xm[b] : b;
+    xbase_g = sel5(a.X, g) + bi * sel5(a.xbs, g) + (long long)z * a.xzs;
+    ldx_g = sel5(a.ldx, g);
+  }
+  const char* yb = a.Y + (long long)b * a.ybs + (long long)z * a.yzs;
+
+  // staging bookkeeping: load-group gi covers tile rows gi*8 .. gi*8+7 (X rows first, then Y rows)
+  int srow[GPW];         // clamped global row
+  int schunk[GPW];       // swizzled source chunk byte offset
+  bool sisx[GPW];
+#pragma unroll
+  for (int n = 0; n < GPW; ++n) {
+    const int gi = wid + 4 * n;
+    const int r = gi * 8 + (lane >> 3);
+    const int cpos = lane & 7;
+    if (r < BI) {
+      sisx[n] = true;
+      srow[n] = min(i0 + r, Iclamp_g - 1);
+      schunk[n] = (cpos ^ ((r >> 1) & 7)) << 4;
+    } else {
+      const int rj = r - BI;
+      sisx[n] = false;
+      srow[n] = min(j0 + rj, a.Jclamp - 1);
+      schunk[n] = (cpos ^ ((rj >> 1) & 7)) << 4;
+    }
+  }
+
+  int nkt = 0;
+  if (MODE == MODE_SEGK) {
+#pragma unroll
+    for (int s = 0; s < GEMM_SLOTS; ++s)
+      if (s < a.nslot) nkt += a.kt[s];
+  } else {
+    nkt = sel5(a.kt, g);
+  }
+
+  auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
+    // X source for this k-tile
+    const char* xs;
+    long long ldx;
+    int ktl = kt;
+    if (MODE == MODE_SEGK) {
+      int s = 0;
+#pragma unroll
+      for (int q = 0; q < GEMM_SLOTS - 1; ++q)
+        if (s == q && q < a.nslot - 1 && ktl >= a.kt[q]) { ktl -= a.kt[q]; s = q + 1; }
+      xs = xb[0];
+      ldx = a.ldx[0];
+#pragma unroll
+      for (int q = 1; q < GEMM_SLOTS; ++q)
+        if (q == s) { xs = xb[q]; ldx = a.ldx[q]; }
+    } else {
+      xs = xbase_g;
+      ldx = ldx_g;
+    }
+#pragma unroll
+    for (int n = 0; n < GPW; ++n) {
+      const int gi = wid + 4 * n;
+      if (gi < NGRP) {
+        const char* src = sisx[n] ? xs + (long long)srow[n] * ldx + (long long)ktl * 128 + schunk[n]
+                                  : yb + (long long)srow[n] * a.ldy + (long long)kt * 128 + schunk[n];
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + buf * STAGE + gi * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  // fragment read offsets
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int sw = l15 >> 1;
+  const int xoff_h = (wi * TI * 16 + l15) * 128 + ((q4 ^ sw) << 4);
+  const int xoff_l = (wi * TI * 16 + l15) * 128 + (((4 + q4) ^ sw) << 4);
+  const int yoff_h = BI * 128 + (wj * TJ * 16 + l15) * 128 + ((q4 ^ sw) << 4);
+  const int yoff_l = BI * 128 + (wj * TJ * 16 + l15) * 128 + (((4 + q4) ^ sw) << 4);
+
+  f32x4 acc[TI][TJ];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);
+    const char* sb = smem + buf * STAGE;
+    bf16x8 xh[TI], xl[TI], yh[TJ], yl[TJ];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+      xh[ti] = *reinterpret_cast<const bf16x8*>(sb + xoff_h + ti * 2048);
+      xl[ti] = *reinterpret_cast<const bf16x8*>(sb + xoff_l + ti * 2048);
+    }
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      yh[tj] = *reinterpret_cast<const bf16x8*>(sb + yoff_h + tj * 2048);
+      yl[tj] = *reinterpret_cast<const bf16x8*>(sb + yoff_l + tj * 2048);
+    }
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl[ti], yh[tj], acc[ti][tj], 0, 0, 0);
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[ti], yl[tj], acc[ti][tj], 0, 0, 0);
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[ti], yh[tj], acc[ti][tj], 0, 0, 0);
+      }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      const int i = i0 + (wi * TI + ti) * 16 + q4 * 4;
+      const int j = j0 + (wj * TJ + tj) * 16 + l15;
+      if (i < Ig && j < a.J) epi(g, b, z, i, j, acc[ti][tj]);
+    }
+}
+
+// Reference kernel with the same operands / epilogues, one thread per (4 i, 1 j): used by the
+// CFD_NAIVE_GEMM=1 debug switch to separate MFMA-path bugs from host-side plumbing bugs.
+__device__ __forceinline__ float sp_load(const char* row, int col) {
+  const char* p = row + (size_t)(col >> 5) * 128 + (col & 31) * 2;
+  return (float)*reinterpret_cast<const __bf16*>(p) + (float)*reinterpret_cast<const __bf16*>(p + 64);
+}
+
+template <int MODE, class Epi>
+__global__ void gemm_sp_naive_kernel(const GemmArgs a, const Epi epi, int g_fixed) {
+  const int b = blockIdx.y, z = blockIdx.z;
+  const int g = g_fixed;
+  const int Ig = a.I[g];
+  const int nq = Ig / 4;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)nq * a.J) return;
+  const int i = (int)(idx % nq) * 4, j = (int)(idx / nq);
+  const char* yrow = a.Y + (long long)b * a.ybs + (long long)z * a.yzs + (long long)min(j, a.Jclamp - 1) * a.ldy;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int kbase = 0;
+  const int s0 = (MODE == MODE_SEGK) ? 0 : g, s1 = (MODE == MODE_SEGK) ? a.nslot : g + 1;
+  for (int s = s0; s < s1; ++s) {
+    const long long bi = a.xmap[s] ? a.xmap[s][b] : b;
+    const char* xs = a.X[s] + bi * a.xbs[s] + (long long)z * a.xzs;
+    for (int k = 0; k < a.kt[s] * 32; ++k) {
+      const float yv = sp_load(yrow, kbase + k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        acc[e] += sp_load(xs + (long long)min(i + e, a.Iclamp[s] - 1) * a.ldx[s], k) * yv;
+    }
+    kbase += a.kt[s] * 32;
+  }
+  epi(g, b, z, i, j, f32x4{acc[0], acc[1], acc[2], acc[3]});
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host-side launcher
+// ------------------------------------------------------------------------------------------------
+struct GemmCfgSel { int wi, wj, ti, tj; };
+
+extern int g_cfd_naive_gemm;  // set from CFD_NAIVE_GEMM env at cfd_create
+
+template <int WI, int WJ, int TI, int TJ, int MODE, class Epi>
+static hipError_t launch_cfg(GemmArgs a, const Epi& epi, int nb, int nz, hipStream_t st) {
+  constexpr int BI = WI * TI * 16, BJ = WJ * TJ * 16;
+  a.tiles_j = (a.J + BJ - 1) / BJ;
+  int total = 0;
+  const int ng = (MODE == MODE_GROUPED) ? a.nslot : 1;
+  for (int g = 0; g < ng; ++g) {
+    a.tiles_i[g] = (a.I[g] + BI - 1) / BI;
+    a.tile_start[g] = total;
+    total += a.tiles_i[g] * a.tiles_j;
+  }
+  a.tile_start[ng] = total;
+  constexpr int lds = 2 * (BI + BJ) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sp_kernel<WI, WJ, TI, TJ, MODE, Epi>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_sp_kernel<WI, WJ, TI, TJ, MODE, Epi>), dim3(total, nb, nz), dim3(256), lds, st, a, epi);
+  return hipGetLastError();
+}
+
+// cfg: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 128x16
+template <int MODE, class Epi>
+static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStream_t st, int cfg = 0) {
+  if (a.nslot < 1) a.nslot = 1;
+  if (g_cfd_naive_gemm) {
+    const int ng = (MODE == MODE_GROUPED) ? a.nslot : 1;
+    for (int g = 0; g < ng; ++g) {
+      const long long n = (long long)(a.I[g] / 4) * a.J;
+      if (n == 0) continue;
+      hipLaunchKernelGGL((gemm_sp_naive_kernel<MODE, Epi>), dim3((unsigned)((n + 255) / 256), nb, nz), dim3(256), 0, st,
+                         a, epi, g);
+    }
+    return hipGetLastError();
+  }
+  if (cfg == 0) {
+    int imax = 0;
+    const int ng = (MODE == MODE_GROUPED) ? a.nslot : 1;
+    long long big_tiles = 0;
+    for (int g = 0; g < ng; ++g) {
+      imax = a.I[g] > imax ? a.I[g] : imax;
+      big_tiles += (long long)((a.I[g] + 127) / 128) * ((a.J + 127) / 128);
+    }
+    big_tiles *= (long long)nb * nz;
+    if (a.J <= 16) cfg = 3;
+    else if (big_tiles >= 384 && a.J >= 96) cfg = 1;
+    else cfg = 2;
+  }
+  switch (cfg) {
+    case 1: return launch_cfg<2, 2, 4, 4, MODE, Epi>(a, epi, nb, nz, st);
+    case 2: return launch_cfg<2, 2, 2, 2, MODE, Epi>(a, epi, nb, nz, st);
+    default: return launch_cfg<4, 1, 2, 1, MODE, Epi>(a, epi, nb, nz, st);
+  }
+}

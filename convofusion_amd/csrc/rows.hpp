@@ -1,0 +1,433 @@
+// Row-wise / element-wise kernels of the denoising step (HBM-bound; one 64-lane wave per 512-wide row,
+// 8 contiguous floats per lane = two 16-byte loads, SP outputs written as 16-byte hi / lo chunks).
+#pragma once
+#include "cfd_common.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (+ optional AdaLN modulate + SiLU) : x fp32 [M][512] -> SP [M][512]
+//   plain : y = (x-mean)*rstd*g + b                                  cross_attention.py:568,578,659
+//   adaln : y = silu( LN(x)*(1+scale) + shift )                      TimeBlock.forward :426-439
+// ------------------------------------------------------------------------------------------------
+struct LnArgs {
+  const float* x;
+  char* out;
+  long long M;
+  const float* g;
+  const float* b;
+  int adaln;
+  const float* ss;        // (1+scale | shift) rows of 1024 floats for THIS time block, t-row stride ss_tstride
+  long long ss_tstride;
+  const int* d_step;
+  int tmode;              // 0: t-row = *d_step ; 1: t-row = row / L
+  int L;
+};
+
+__global__ void __launch_bounds__(256) ln_rows_kernel(const LnArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.M) return;
+  const float* xr = a.x + row * CFD_D + lane * 8;
+  float v[8];
+  {
+    const float4 p = *reinterpret_cast<const float4*>(xr);
+    const float4 q = *reinterpret_cast<const float4*>(xr + 4);
+    v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += v[e];
+  const float mean = wave_sum(s) * (1.0f / CFD_D);
+  float ss = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { v[e] -= mean; ss += v[e] * v[e]; }
+  const float var = wave_sum(ss) * (1.0f / CFD_D);
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  const float* gp = a.g + lane * 8;
+  const float* bp = a.b + lane * 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = v[e] * rstd * gp[e] + bp[e];
+  if (a.adaln) {
+    const long long trow = a.tmode ? (row / a.L) : (long long)(*a.d_step);
+    const float* sc = a.ss + trow * a.ss_tstride + lane * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e] * sc[e] + sc[CFD_D + e]);
+  }
+  sp_store8(a.out + row * (CFD_D * 4), lane * 8, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Memory preparation (denoiser.py:223-261 time add, :332-353 condition-id + sine PE) followed by the
+// per-layer memory LayerNorm's normalisation (cross_attention.py:581-585; its affine is folded into
+// the memory-side projection weights at load time):
+//   n[u][s][:] = normalise( raw[u][s] + temb[t] + E_cond[j] + pe[s] ),   rows s >= S are zero.
+// ------------------------------------------------------------------------------------------------
+struct MemPrepArgs {
+  const float* raw;   // [U][S][512]
+  int U, S, Sp;
+  const float* temb;  // [T][512]
+  const int* d_step;
+  int tmode;          // 0: t-row = *d_step ; 1: t-row = u
+  const float* cond;  // [512]
+  const float* pe;    // [>=S][512]
+  char* n_sp;         // SP [U*Sp][512]
+};
+
+__global__ void __launch_bounds__(256) mem_prep_kernel(const MemPrepArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)a.U * a.Sp) return;
+  const int u = (int)(row / a.Sp), s = (int)(row % a.Sp);
+  float v[8];
+  if (s >= a.S) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  } else {
+    const float* r = a.raw + ((long long)u * a.S + s) * CFD_D + lane * 8;
+    const float* te = a.temb + (long long)(a.tmode ? u : *a.d_step) * CFD_D + lane * 8;
+    const float* ce = a.cond + lane * 8;
+    const float* pe = a.pe + (long long)s * CFD_D + lane * 8;
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] = ((te[e] + r[e]) + ce[e]) + pe[e];
+      sum += v[e];
+    }
+    const float mean = wave_sum(sum) * (1.0f / CFD_D);
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[e] -= mean; ss += v[e] * v[e]; }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) * (1.0f / CFD_D) + 1e-5f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= rstd;
+  }
+  sp_store8(a.n_sp + row * (CFD_D * 4), lane * 8, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Masked softmax over up to 5 key segments of one score row; writes P (SP, zero in the padding) and
+// optionally the probabilities the reference returns as att_mats (cross_attention.py:227-234).
+// One wave per (b, l) row; a segment of Sp <= 2048 keys lives in registers (<= 4 chunks of 8 / lane).
+// ------------------------------------------------------------------------------------------------
+#define SM_MAX_CHUNKS 4
+struct SoftmaxArgs {
+  const float* sc;
+  char* P;
+  long long ld;        // floats per row (= total padded keys)
+  long long rows;
+  int rows_per_b;
+  int nseg;
+  int off[CFD_NMEM], S[CFD_NMEM], Sp[CFD_NMEM];
+  const uint8_t* mask[CFD_NMEM];  // [U][S] (1 = padded key), or null
+  const int* map[CFD_NMEM];       // b -> u, or null (u = b)
+  float* att[CFD_NMEM];           // [Be][nl][L][S] or null
+  int layer, nl;
+};
+
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const SoftmaxArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const int b = (int)(row / a.rows_per_b), l = (int)(row % a.rows_per_b);
+  const float* srow = a.sc + row * a.ld;
+  char* prow = a.P + row * a.ld * 4;
+#pragma unroll
+  for (int g = 0; g < CFD_NMEM; ++g) {
+    if (g >= a.nseg) break;
+    const int S = a.S[g], Sp = a.Sp[g], off = a.off[g];
+    const uint8_t* mk = nullptr;
+    if (a.mask[g]) mk = a.mask[g] + (long long)(a.map[g] ? a.map[g][b] : b) * S;
+    float v[SM_MAX_CHUNKS][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int n = 0; n < SM_MAX_CHUNKS; ++n) {
+      const int c0 = (lane + 64 * n) * 8;
+      if (c0 < Sp) {
+        const float4 p = *reinterpret_cast<const float4*>(srow + off + c0);
+        const float4 q = *reinterpret_cast<const float4*>(srow + off + c0 + 4);
+        v[n][0] = p.x; v[n][1] = p.y; v[n][2] = p.z; v[n][3] = p.w;
+        v[n][4] = q.x; v[n][5] = q.y; v[n][6] = q.z; v[n][7] = q.w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int s = c0 + e;
+          if (s >= S || (mk && mk[s])) v[n][e] = -INFINITY;
+          mx = fmaxf(mx, v[n][e]);
+        }
+      }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int n = 0; n < SM_MAX_CHUNKS; ++n) {
+      const int c0 = (lane + 64 * n) * 8;
+      if (c0 < Sp) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[n][e] = expf(v[n][e] - mx);  // all-masked row: (-inf)-(-inf) = NaN, as in the reference
+          sum += v[n][e];
+        }
+      }
+    }
+    sum = wave_sum(sum);
+    float* att = nullptr;
+    if (a.att[g]) att = a.att[g] + (((long long)b * a.nl + a.layer) * a.rows_per_b + l) * S;
+#pragma unroll
+    for (int n = 0; n < SM_MAX_CHUNKS; ++n) {
+      const int c0 = (lane + 64 * n) * 8;
+      if (c0 < Sp) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[n][e] = v[n][e] / sum;
+        sp_store8(prow, off + c0, v[n]);
+        if (att) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (c0 + e < S) att[c0 + e] = v[n][e];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 [R][K] -> SP [R][K]   (K % 8 == 0); used for weights at load time
+// ------------------------------------------------------------------------------------------------
+__global__ void to_split_kernel(const float* in, char* out, long long R, int K, long long ld_in, long long ld_out_bytes) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int kc = K / 8;
+  if (idx >= R * kc) return;
+  const long long r = idx / kc;
+  const int c = (int)(idx % kc) * 8;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = in[r * ld_in + c + e];
+  sp_store8(out + r * ld_out_bytes, c, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[r][n] = post( b[n] + sum_k in[r][k] * W[n][k] ),  K = 512.  One wave per output column n keeps its
+// weight row in registers and sweeps the R input rows.  (timestep MLP + the 18 TimeBlock emb_layers:
+// embeddings.py:298-305, cross_attention.py:432-434)
+//   in_act: 0 none, 1 silu on the input;  post: 0 none, 1 silu, 2 "first 512 columns get +1" (1+scale)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) small_linear_kernel(const float* in, const int* in_rows, long long ld_in,
+                                                           const float* W, const float* bias, float* out,
+                                                           long long ld_out, int R, int N, int in_act, int post) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float w[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) w[e] = W[(long long)n * CFD_D + lane * 8 + e];
+  const float bn = bias[n];
+  for (int r = blockIdx.y; r < R; r += gridDim.y) {
+    const float* ir = in + (long long)(in_rows ? in_rows[r] : r) * ld_in + lane * 8;
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = ir[e];
+      if (in_act == 1) x = silu_f(x);
+      s += x * w[e];
+    }
+    s = wave_sum(s) + bn;
+    if (post == 1) s = silu_f(s);
+    if (post == 2 && n < CFD_D) s = 1.0f + s;
+    if (lane == 0) out[(long long)r * ld_out + n] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Load-time weight folding in float64:  C[m][n] = alpha * rowscale? ... generic strided product
+//   C(m,n) = alpha * sum_k A(m,k) * B(k,n) * (colscale ? colscale[n] : 1) (+ addC ? addC(m,n) : 0)
+// A, B float or double with element strides; C float or double, row-major.
+// ------------------------------------------------------------------------------------------------
+template <class TA, class TB, class TC>
+__global__ void fold_mm_kernel(const TA* A, long long sam, long long sak, const TB* B, long long sbk, long long sbn,
+                               TC* C, long long ldc, int M, int N, int K, double alpha, const float* colscale) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)M * N) return;
+  const int m = (int)(idx / N), n = (int)(idx % N);
+  double acc = 0.0;
+  for (int k = 0; k < K; ++k) acc += (double)A[m * sam + k * sak] * (double)B[k * sbk + n * sbn];
+  acc *= alpha;
+  if (colscale) acc *= (double)colscale[n];
+  C[(long long)m * ldc + n] = (TC)acc;
+}
+
+// y[m] = alpha * sum_k A(m,k) x[k] (+ add[m])   in float64, output float or double
+template <class TA, class TX, class TY>
+__global__ void fold_mv_kernel(const TA* A, long long sam, long long sak, const TX* x, const double* add_d,
+                               const float* add_f, TY* y, int M, int K, double alpha, const float* rowscale) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  double acc = 0.0;
+  for (int k = 0; k < K; ++k) acc += (double)A[m * sam + k * sak] * (double)x[k];
+  acc *= alpha;
+  if (rowscale) acc *= (double)rowscale[m];
+  if (add_d) acc += add_d[m];
+  if (add_f) acc += (double)add_f[m];
+  y[m] = (TY)acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sampler element-wise kernels
+// ------------------------------------------------------------------------------------------------
+struct StepCoef {   // one row per loop iteration i (timestep t_i), float32 as diffusers computes them
+  float sb;         // sqrt(1 - abar_t)
+  float sa;         // sqrt(abar_t)
+  float c0;         // DDPM: x0 coefficient            | DDIM: sqrt(abar_prev)
+  float cx;         // DDPM: current-sample coefficient | DDIM: direction coefficient sqrt(1-abar_prev-std^2)
+  float sigma;      // noise std (0 when no noise is added)
+  float use_noise;  // 1.0 if a N(0,1) draw is added at this step
+  float pad0, pad1;
+};
+
+// Philox4x32-10 (restated in oracle/philox_ref.py, checked there against the Random123 known answers)
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float4 philox_normal4(uint64_t seed, uint32_t group, uint32_t step, uint32_t utt,
+                                                 uint32_t stream) {
+  uint32_t w[4];
+  philox4x32_10(group, step, utt, stream, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+  float u[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) u[e] = ((float)(w[e] >> 8) + 0.5f) * 5.9604644775390625e-08f;  // 2^-24
+  const float r0 = sqrtf(-2.0f * logf(u[0])), r1 = sqrtf(-2.0f * logf(u[2]));
+  const float t0 = 6.283185307179586f * u[1], t1 = 6.283185307179586f * u[3];
+  return make_float4(r0 * cosf(t0), r0 * sinf(t0), r1 * cosf(t1), r1 * sinf(t1));
+}
+
+// fill [B][L*128] with N(0,1): stream 1 = initial latents (convofusion.py:412-419)
+__global__ void philox_fill_kernel(float* out, int B, int per_utt, uint64_t seed, uint32_t step, uint32_t utt0,
+                                   uint32_t stream, float scale) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int gpu = per_utt / 4;
+  if (idx >= (long long)B * gpu) return;
+  const int b = (int)(idx / gpu), g = (int)(idx % gpu);
+  float4 z = philox_normal4(seed, (uint32_t)g, step, utt0 + b, stream);
+  z.x *= scale; z.y *= scale; z.z *= scale; z.w *= scale;
+  *reinterpret_cast<float4*>(out + (long long)b * per_utt + g * 4) = z;
+}
+
+// Start of loop iteration i: optional in-painting overwrite of the first `pl` tokens
+// (unbounded_synthesis.py:70-76, including its aliasing quirk at i == 0), then replicate the latents
+// G times into the SP denoiser input (convofusion.py:499-501).
+struct BeginArgs {
+  float* latents;        // [B][L][128]
+  char* sample_sp;       // SP [G*B*L][128]
+  int B, L, G;
+  const float* preseq;   // [B][pl][128] or null
+  float* inoise;         // [B][pl][128] noise used for the overwrite (rewritten at i == 0)
+  int pl;
+  const StepCoef* coef;
+  const int* d_step;
+};
+
+__global__ void begin_step_kernel(const BeginArgs a) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one thread = 8 elements
+  const long long n8 = (long long)a.B * a.L * (CFD_LAT / 8);
+  if (idx >= n8) return;
+  const int c = (int)(idx % (CFD_LAT / 8)) * 8;
+  const long long bl = idx / (CFD_LAT / 8);
+  const int l = (int)(bl % a.L), b = (int)(bl / a.L);
+  float* lp = a.latents + bl * CFD_LAT + c;
+  float v[8];
+  if (a.preseq && l < a.pl) {
+    const int i = *a.d_step;
+    const float sa = a.coef[i].sa, sb = a.coef[i].sb;
+    const long long po = ((long long)b * a.pl + l) * CFD_LAT + c;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] = sa * a.preseq[po + e] + sb * a.inoise[po + e];
+      lp[e] = v[e];
+      if (i == 0) a.inoise[po + e] = v[e];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = lp[e];
+  }
+  for (int g = 0; g < a.G; ++g)
+    sp_store8(a.sample_sp + (((long long)g * a.B + b) * a.L + l) * (CFD_LAT * 4), c, v);
+}
+
+// Modality-guidance combine (convofusion.py:527-541) + scheduler step (diffusers 0.14.0 DDPM / DDIM).
+struct CfgStepArgs {
+  const float* eps;      // [G*B][L][128]
+  float* latents;        // [B][L][128] in/out
+  int B, L, G;
+  float w[8];            // guidance weight of chunk k (k >= 1); chunk 0 is the unconditional one
+  int kind;              // 0 DDPM, 1 DDIM
+  int clip;
+  const StepCoef* coef;
+  const int* d_step;
+  const float* noise;    // injected [n_steps][B][L][128] or null -> Philox
+  unsigned long long seed;
+  unsigned int utt0;
+};
+
+__global__ void cfg_step_kernel(const CfgStepArgs a) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one thread = 4 elements
+  const int per_utt = a.L * CFD_LAT;
+  const long long n4 = (long long)a.B * per_utt / 4;
+  if (idx >= n4) return;
+  const int i = *a.d_step;
+  const StepCoef c = a.coef[i];
+  const long long e0 = idx * 4;
+  const long long chunk = (long long)a.B * per_utt;
+  const float4 u4 = *reinterpret_cast<const float4*>(a.eps + e0);
+  const float u[4] = {u4.x, u4.y, u4.z, u4.w};
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.G > 1) {
+    // reference association: ((((text + audio) + spk) + apb) + lsnid) + all, each = (g*w)*(e_k - e_0)
+    for (int k = 1; k < a.G; ++k) {
+      const float4 e4 = *reinterpret_cast<const float4*>(a.eps + k * chunk + e0);
+      const float e[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float term = a.w[k] * (e[q] - u[q]);
+        acc[q] = (k == 1) ? term : acc[q] + term;
+      }
+    }
+  }
+  float4 x4 = *reinterpret_cast<const float4*>(a.latents + e0);
+  float x[4] = {x4.x, x4.y, x4.z, x4.w};
+  float z[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c.use_noise != 0.f) {
+    if (a.noise) {
+      const float4 n4v = *reinterpret_cast<const float4*>(a.noise + (long long)i * chunk + e0);
+      z[0] = n4v.x; z[1] = n4v.y; z[2] = n4v.z; z[3] = n4v.w;
+    } else {
+      const int b = (int)(e0 / per_utt), g = (int)((e0 % per_utt) / 4);
+      const float4 n4v = philox_normal4(a.seed, (uint32_t)g, (uint32_t)i, a.utt0 + b, 0u);
+      z[0] = n4v.x; z[1] = n4v.y; z[2] = n4v.z; z[3] = n4v.w;
+    }
+  }
+  float o[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float eps = (a.G > 1) ? u[q] + acc[q] : u[q];
+    float x0 = (x[q] - c.sb * eps) / c.sa;
+    if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+    float prev;
+    if (a.kind == 0) prev = c.c0 * x0 + c.cx * x[q];
+    else prev = c.c0 * x0 + c.cx * eps;
+    if (c.use_noise != 0.f) prev = prev + c.sigma * z[q];
+    o[q] = prev;
+  }
+  *reinterpret_cast<float4*>(a.latents + e0) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+__global__ void advance_step_kernel(int* d_step) { *d_step += 1; }

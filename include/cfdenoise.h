@@ -1,0 +1,166 @@
+/* libcfdenoise -- C ABI of the MI355X-native ConvoFusion denoising loop.
+ *
+ * The reference (m-hamza-mughal/convofusion) is pure Python/PyTorch and has no FFI; its plug point
+ * for this path is `instantiate_from_config` on a dotted class path (convofusion/config.py:16-31,
+ * configs/modules/denoiser.yaml:2, configs/modules/scheduler.yaml:2).  This header is the boundary a
+ * replacement binds underneath that plug point: plain pointers and sizes, no torch types.  Each
+ * entry point names the reference interface it replaces.  All `dev` pointers are device (HBM)
+ * pointers, e.g. `tensor.data_ptr()`; the caller owns every buffer it passes.  A handle may be used
+ * from one host thread at a time.  Every function returns 0 on success or a negative CFD_E_* code;
+ * cfd_last_error() then describes the failure (the reference raises Python exceptions instead:
+ * TypeError / ValueError / torch shape errors, denoiser.py:113,123,171,280).
+ */
+#ifndef CFDENOISE_H
+#define CFDENOISE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFD_OK 0
+#define CFD_E_ARG (-1)      /* bad argument / unsupported configuration (reference: TypeError/ValueError) */
+#define CFD_E_SHAPE (-2)    /* shape the reference also rejects: odd L, L/2 or S beyond the PE buffers */
+#define CFD_E_STATE (-3)    /* call order (weights not finalized, no sampling run open, ...) */
+#define CFD_E_HIP (-4)      /* HIP runtime error */
+
+#define CFD_NUM_MEM 5       /* memory tuple order: spkemb, alsn, tlsn, apb, lsnemb (denoiser.py:220) */
+
+typedef struct cfd_handle_s* cfd_handle;
+
+/* Replaces Denoiser.__init__ (convofusion/models/architectures/denoiser.py:18-171) for the shipped
+ * configuration (configs/modules/denoiser.yaml): condition text+audio, arch trans_dec, pre-norm, gelu,
+ * sine PEs.  Dimensions other than the ones below are rejected with CFD_E_ARG. */
+typedef struct {
+  int latent_dim;        /* 128  (latent_dim[-1]) */
+  int text_encoded_dim;  /* 512 */
+  int ff_size;           /* 1024 */
+  int num_layers;        /* 9 (1..16 accepted) */
+  int num_heads;         /* 4 */
+  int device;            /* HIP device ordinal */
+} cfd_config;
+
+int cfd_create(const cfd_config* cfg, cfd_handle* out);
+void cfd_destroy(cfd_handle h);
+const char* cfd_last_error(void);
+
+/* Replaces nn.Module.load_state_dict for the `denoiser.*` entries of the checkpoint
+ * (layout: SURVEY.md section 8b; test.py:109-111 -> base.py:106-123).  `name` is the key without the
+ * `denoiser.` prefix, e.g. "decoder.layers.0.self_attn.in_proj_weight"; `data` is float32, `numel`
+ * elements, on the host (is_device = 0) or the device (1).  Buffers `query_pos.pe` / `mem_pos.pe`
+ * may be longer than the checkpoint's 1024 rows (closed-form sine table extended by the caller). */
+int cfd_load_tensor(cfd_handle h, const char* name, const float* data, size_t numel, int is_device);
+
+/* After the last cfd_load_tensor: checks that every tensor is present, folds and re-lays-out the
+ * weights on the device (float64 folding, then split-bf16 GEMM operands). */
+int cfd_finalize_weights(cfd_handle h);
+
+/* Sinusoid rows of the timestep embedding for integer timesteps 0..n_rows-1
+ * (get_timestep_embedding, convofusion/models/architectures/tools/embeddings.py:245-285, computed by
+ * the caller exactly as the reference does: [cos | sin] halves, 512 floats per row), host float32. */
+int cfd_set_timestep_table(cfd_handle h, const float* rows, int n_rows);
+
+/* One memory of the conditioning tuple.  `data` [U][S][512] float32 (dev) holds the U DISTINCT
+ * memories; `row_map` (dev int32 [Be], or NULL meaning U == Be, identity) says which one each
+ * effective-batch row uses -- the 7-way guidance batch repeats each utterance's memory and one shared
+ * unconditional memory (convofusion.py:909-929), which the memory-side projections exploit.
+ * `key_padding_mask` [U][S] uint8 (dev, 1 = ignore key; nn.MultiheadAttention key_padding_mask,
+ * cross_attention.py:587-626) or NULL. */
+typedef struct {
+  const float* data;
+  const int32_t* row_map;
+  const uint8_t* key_padding_mask;
+  int U;
+  int S;
+} cfd_memory;
+
+/* Replaces Denoiser.forward (denoiser.py:173-386).
+ *   sample      dev [Be][L][128]
+ *   timesteps   HOST int32, n_t == 1 (one timestep for every row, the sampler's case) or n_t == Be
+ *   mem[5]      conditioning tuple
+ *   out         dev [Be][L][128]   predicted noise
+ *   att[5]      dev [Be][num_layers][L][S_j] attention probabilities (cross_attention.py:227-234), or
+ *               NULL pointers to skip materialising them
+ * Enqueued on `stream` (a hipStream_t, may be NULL = default stream); no host sync inside. */
+int cfd_forward(cfd_handle h, const float* sample, int Be, int L, const int32_t* timesteps, int n_t,
+                const cfd_memory mem[CFD_NUM_MEM], float* out, float* const att[CFD_NUM_MEM], void* stream);
+
+/* Replaces Convofusion._diffusion_reverse (convofusion/models/modeltype/convofusion.py:391-549) and
+ * its in-painting copy diffusion_reverse_forecast (unbounded_synthesis.py:28-187), together with the
+ * diffusers-0.14.0 scheduler calls inside them (set_timesteps / step / add_noise). */
+typedef struct {
+  int B;                      /* utterances */
+  int L;                      /* latent tokens (16 in the product; must be even) */
+  int G;                      /* guidance chunks: 7 (clf_guidance_drops + 1, convofusion.py:60) or 1 */
+  float guidance_weight[8];   /* weight of chunk k >= 1 in  e_0 + sum_k w_k (e_k - e_0)
+                                 reference: {-, 7.5, 7.5, 7.5, 7.5, 7.5, 0}  (convofusion.py:529-541) */
+  int scheduler;              /* 0 = DDPMScheduler (fixed_small), 1 = DDIMScheduler */
+  int num_train_timesteps;    /* 1000 */
+  int num_inference_steps;    /* scheduler.set_timesteps(N) */
+  int clip_sample;            /* configs/modules/scheduler.yaml:11 */
+  float eta;                  /* DDIM only */
+  int set_alpha_to_one;       /* DDIM only */
+  int steps_offset;           /* DDIM only */
+  const float* alphas_cumprod;/* HOST float32 [num_train_timesteps] (the scheduler's table) */
+  const float* init_latents;  /* dev [B][L][128] N(0,1) draws (scaled by init_noise_sigma = 1), or NULL:
+                                 drawn on the device, Philox stream 1 */
+  const float* step_noise;    /* dev [num_inference_steps][B][L][128] or NULL: Philox stream 0 */
+  uint64_t seed;              /* Philox key */
+  uint32_t first_utterance;   /* global id of utterance 0 (shards draw independent sub-streams) */
+  const float* preseq;        /* dev [B][preseq_len][128] previous-window latents to in-paint, or NULL */
+  int preseq_len;
+  cfd_memory mem[CFD_NUM_MEM];/* Be = G*B rows */
+} cfd_sample_args;
+
+/* Opens a sampling run: builds the per-step coefficient and timestep-embedding tables, draws / copies
+ * the initial latents and captures ONE loop iteration (replicate -> denoiser -> guidance -> scheduler
+ * step) as a hipGraph on `stream`. */
+int cfd_sample_begin(cfd_handle h, const cfd_sample_args* args, void* stream);
+/* Replays the captured iteration `n` more times (asynchronously on the run's stream). */
+int cfd_sample_steps(cfd_handle h, int n);
+/* Number of iterations executed so far in the open run. */
+int cfd_sample_position(cfd_handle h);
+/* Copies the current latents to `out` (dev [B][L][128]); with close != 0 also ends the run. */
+int cfd_sample_read(cfd_handle h, float* out, int close);
+
+/* Stand-alone scheduler ops on device tensors (diffusers 0.14.0 `scheduler.step(...).prev_sample` and
+ * `add_noise`), for callers that drive their own loop (unbounded_synthesis.py:75,181). */
+int cfd_scheduler_step(cfd_handle h, int scheduler, const float* alphas_cumprod, int num_train_timesteps,
+                       int num_inference_steps, int t, int clip_sample, float eta, int set_alpha_to_one,
+                       const float* model_output, const float* noise, float* sample_inout, size_t numel,
+                       void* stream);
+int cfd_add_noise(cfd_handle h, const float* alphas_cumprod_host, int t, const float* original,
+                  const float* noise, float* out, size_t numel, void* stream);
+
+/* Device N(0,1) draws of the product's counter-based stream (DESIGN.md "RNG"): out dev [B][per_utt]. */
+int cfd_philox_normal(cfd_handle h, float* out, int B, int per_utt, uint64_t seed, uint32_t step,
+                      uint32_t first_utterance, uint32_t stream_id, void* stream);
+
+/* Measurement hook for bench.py: runs ONE denoiser forward of the currently configured problem eagerly
+ * with every kernel class bracketed by HIP events on the launch stream; returns milliseconds per class
+ * and the number of launches per class.  Classes: see CFD_PROF_* below. */
+#define CFD_PROF_GEMM_TOKEN 0    /* token-side projections (QK, V^T, Wo, TimeBlocks, FFN, embed, proj) */
+#define CFD_PROF_GEMM_MEM 1      /* memory-side K / V^T projections */
+#define CFD_PROF_GEMM_ATTN 2     /* attention score and P.V products */
+#define CFD_PROF_ROWS 3          /* LayerNorm / AdaLN / softmax / memory prep */
+#define CFD_PROF_OTHER 4
+#define CFD_PROF_NCLASS 5
+int cfd_profile_forward(cfd_handle h, float ms[CFD_PROF_NCLASS], int launches[CFD_PROF_NCLASS]);
+
+/* Test hook: D[j][i] = sum_k X[i][k] Y[j][k] through the split-bf16 MFMA kernel.
+ * X dev float32 [I][K], Y dev float32 [J][K], out dev float32 [J][I]; K % 32 == 0, I % 4 == 0.
+ * tile_cfg: 0 auto, 1 = 128x128, 2 = 64x64, 3 = 128x16. */
+int cfd_test_gemm(cfd_handle h, const float* X, const float* Y, float* out, int I, int J, int K, int tile_cfg,
+                  void* stream);
+
+/* Test hooks: stop the forward pipeline after tap point `stage` (0 = off; 1 = after the latent embedding;
+ * 2+4l / 3+4l / 4+4l / 5+4l = layer l after self-attention / time block 1 / cross-attention / the layer),
+ * and read an internal float32 buffer ("x" residual stream [M][512], "temb", "ss", "eps", "sc", "ssc"). */
+int cfd_debug_stop_stage(cfd_handle h, int stage);
+int cfd_debug_read(cfd_handle h, const char* what, float* dst_dev, size_t numel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

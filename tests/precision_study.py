@@ -28,6 +28,9 @@ def to_fp16(x):
     return np.asarray(x, dtype=F32).astype(np.float16).astype(F32)
 
 
+WEIGHT_IDS = set()
+
+
 def make_mm(scheme):
     rnd = to_bf16 if scheme.startswith("bf16") else to_fp16
     terms = int(scheme[-1])
@@ -36,7 +39,10 @@ def make_mm(scheme):
 
     def split(x):
         key = (x.__array_interface__["data"][0], x.shape, x.strides)
-        big = x.size >= 65536 and x.base is not None  # views of the (persistent) weight arrays
+        r = x
+        while r.base is not None:
+            r = r.base
+        big = id(r) in WEIGHT_IDS  # only views of the persistent weight arrays are cached
         if big and key in cache:
             return cache[key]
         h = rnd(x)
@@ -82,6 +88,7 @@ def patched(scheme):
 def main():
     schemes = sys.argv[1:] or ["bf16x3", "fp16x3"]
     sd = state_dict()
+    WEIGHT_IDS.update(id(v) for v in sd.values())
     seed = 2024
     B, L, S, pad = 1, 16, (6, 20, 6, 8, 1), (2, 0, 1, 0, 0)
     cb = inputs.make_cfg_batch(seed=seed, B=B, L=L, S=S, pad_tail=pad)

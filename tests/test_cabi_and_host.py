@@ -1,0 +1,118 @@
+"""CPU (-m "not gpu"): the C-ABI library builds, loads and exports every symbol include/cfdenoise.h
+declares; host-side mirrors (state-dict layout, scheduler tables, config validation, sharding over gloo)."""
+import os
+import re
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load_golden, state_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from convofusion_amd import _lib, build
+    build.build()
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "cfdenoise.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(cfd_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    from convofusion_amd import _lib
+    # natural C layout of the header's structs on x86-64
+    assert C.sizeof(_lib.Config) == 24
+    assert C.sizeof(_lib.Memory) == 32
+    assert _lib.SampleArgs.mem.offset % 8 == 0 and C.sizeof(_lib.SampleArgs) == _lib.SampleArgs.mem.offset + 5 * 32
+
+
+def test_denoiser_mirror_state_dict_and_validation():
+    from convofusion_amd.denoiser import Denoiser, sine_pe, sinusoid_table
+    from oracle import denoiser_ref, weights
+    from tests.gpu_helpers import ABL, DENOISER_KW
+    m = Denoiser(ablation=ABL, **DENOISER_KW)
+    ks = weights.key_shapes()
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == ks          # reference layout, 537 entries
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state_dict().items()}, strict=True)
+    assert sum(p.numel() for p in m.parameters()) == 92923013
+    np.testing.assert_allclose(sine_pe(1024).numpy(), weights.sine_pe(1024), atol=2e-4)  # torch vs numpy sin/cos/exp ulps
+    np.testing.assert_allclose(sinusoid_table(1000).numpy(), denoiser_ref.timestep_embedding(np.arange(1000)), atol=2e-4)
+    np.testing.assert_array_equal(sinusoid_table(1000)[0].numpy(), denoiser_ref.timestep_embedding(np.arange(1))[0])
+    with pytest.raises(TypeError):
+        Denoiser(ablation=ABL, **{**DENOISER_KW, "condition": "action"})
+    with pytest.raises(ValueError):
+        Denoiser(ablation=ABL, **{**DENOISER_KW, "arch": "trans_enc"})
+    with pytest.raises(ValueError):
+        Denoiser(ablation=SimpleNamespace(SKIP_CONNECT=True, VAE_TYPE="convofusion", DIFF_PE_TYPE="mld", CAUSAL_ATTN=False), **DENOISER_KW)
+    with pytest.raises(RuntimeError):   # the product never computes on the CPU
+        m.engine(torch.device("cpu"))
+
+
+def test_scheduler_mirror_tables_and_timesteps():
+    from convofusion_amd import scheduler
+    from tests.gpu_helpers import SCHED_KW
+    g = load_golden("scheduler_tables")
+    s = scheduler.DDPMScheduler(variance_type="fixed_small", **SCHED_KW)
+    np.testing.assert_array_equal(s.betas.numpy(), g["betas"])
+    np.testing.assert_array_equal(s.alphas_cumprod.numpy(), g["alphas_cumprod"])
+    assert s.init_noise_sigma == 1.0 and len(s) == 1000
+    s.set_timesteps(1000)
+    assert int(s.timesteps[0]) == 999 and int(s.timesteps[-1]) == 0
+    d = scheduler.DDIMScheduler(steps_offset=1, **SCHED_KW)
+    d.set_timesteps(50)
+    assert int(d.timesteps[0]) == 981
+    with pytest.raises(NotImplementedError):
+        scheduler.DDPMScheduler(variance_type="learned", **SCHED_KW)
+    with pytest.raises(RuntimeError):
+        s.step(torch.zeros(1, 2, 128), 5, torch.zeros(1, 2, 128))  # CPU tensors: no fallback
+
+
+def test_shard_helpers():
+    from convofusion_amd.distributed import shard_cfg_batch, shard_range
+    assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    t = torch.arange(7 * 5).reshape(7 * 5, 1)
+    s = shard_cfg_batch(t, 1, 3, 5)
+    assert s.reshape(7, 2).tolist() == [[5 * c + 1, 5 * c + 2] for c in range(7)]
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from convofusion_amd.distributed import sample_sharded
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    total, L = 5, 4
+    enc = [torch.arange(7 * total, dtype=torch.float32).reshape(7 * total, 1, 1).expand(7 * total, 2, 512).contiguous() for _ in range(5)]
+
+    def fake_sample(e, masks, B, first_utterance):
+        # latents are a function of the global utterance id and of the full-conditioning chunk's memory
+        assert e[0].shape[0] == 7 * B
+        ids = torch.arange(first_utterance, first_utterance + B, dtype=torch.float32)
+        return (ids[:, None, None] + e[0].reshape(7, B, 2, 512)[6, :, 0, 0][:, None, None] * 100).expand(B, L, 128).contiguous()
+
+    out = sample_sharded(fake_sample, enc, {"tlsn": None}, total)
+    q.put((rank, out[:, 0, 0].tolist()))
+    dist.destroy_process_group()
+
+
+def test_sharded_sampling_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = [float(u + (6 * 5 + u) * 100) for u in range(5)]
+    assert res[0] == want and res[1] == want
