@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""Benchmark of the denoising loop (BASELINE.json metric: denoise-steps/sec, B=32 utterances per GPU,
+196-token latents, 1500 audio tokens, 1000-step DDPM schedule, 7-way guidance => denoiser batch 224).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one iteration of the captured loop for the rank's 32 utterances: replicate latents x7,
+denoiser forward, guidance combine, scheduler step.  Inputs are resident in HBM before the timed region.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+B_PER_GPU = 32
+L = 196
+S = (32, 1500, 32, 8, 1)
+G = 7
+NL = 9
+
+
+def canonical_flops_per_step(Be, Lq, Ss, nl=NL):
+    """reference formulation, GEMM + attention only, 2 FLOP/MAC, no de-duplication."""
+    sS = sum(Ss)
+    macs_row = 65536 * Lq * 2 + 524288 + nl * (6553600 * Lq + 1024 * Lq * Lq + 524288 * sS + 1024 * Lq * sS + 1048576)
+    return 2.0 * macs_row * Be
+
+
+def executed_gemm_flops(Be, Lq, Ss, U, nl=NL):
+    """Algorithmic (single-product) FLOPs of the GEMMs the HIP pipeline actually launches, per class.
+    Every product is issued as 3 bf16 MFMAs, so MFMA-issued FLOPs are 3x these."""
+    M = Be * Lq
+    Lp = (Lq + 31) // 32 * 32
+    Sp = [(s + 31) // 32 * 32 for s in Ss]
+    tok = 2.0 * M * 512 * 128 + 2.0 * M * 128 * 512                       # embed + latent proj
+    tok += nl * 2.0 * M * 512 * (1024 + 512 + 512 + 512 + 512 + 1024 + 1024)  # qk, v^T, Wo, TB1, TB2, FFN1, FFN2
+    mem = sum(2.0 * u * sp * 512 * (2 * nl * 512) for u, sp in zip(U, Sp))
+    att = nl * (2.0 * Be * 4 * Lq * Lp * 128 * 2 + sum(2.0 * Be * Lq * sp * 512 * 2 for sp in Sp))
+    return {"gemm_token": tok, "gemm_mem": mem, "gemm_attn": att}
+
+
+def make_model(device, seed=1234):
+    from convofusion_amd.denoiser import Denoiser
+    abl = SimpleNamespace(SKIP_CONNECT=True, VAE_TYPE="convofusion", DIFF_PE_TYPE="convofusion", CAUSAL_ATTN=False)
+    torch.manual_seed(seed)
+    m = Denoiser(ablation=abl, nfeats=189, condition="text+audio", latent_dim=[1, 128], ff_size=1024, num_layers=NL,
+                 num_heads=4, dropout=0.1, normalize_before=True, activation="gelu", flip_sin_to_cos=True,
+                 position_embedding="sine", arch="trans_dec", freq_shift=0, text_encoded_dim=512, audio_encoded_dim=512)
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():   # random-init weights of the reference architecture; layers perturbed independently
+        for name, p in m.named_parameters():
+            if p.dim() >= 2:
+                p.add_(0.02 * torch.randn(p.shape, generator=g))
+    return m.to(device).eval()
+
+
+def make_inputs(B, device, seed):
+    """Synthetic conditioning in the 7-chunk guidance pattern:
+    per memory B conditional tensors + one shared unconditional tensor; text memories mask their last 8 keys."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    cond_chunks = {0: (3, 6), 1: (2, 6), 2: (1, 6), 3: (4, 6), 4: (5, 6)}
+    mems, masks = [], {}
+    names = ("spkemb", "alsn", "tlsn", "apb", "lsnemb")
+    for j, s in enumerate(S):
+        cond = torch.randn(B, s, 512, generator=g)
+        unc = torch.randn(1, s, 512, generator=g)
+        uq = torch.cat([unc, cond], 0)
+        rm = torch.zeros(G, B, dtype=torch.long)
+        for c in cond_chunks[j]:
+            rm[c] = 1 + torch.arange(B)
+        mems.append(uq[rm.reshape(-1)].to(device))
+        if names[j] in ("spkemb", "tlsn"):
+            mk = torch.zeros(G * B, s, dtype=torch.bool)
+            mk[:, s - 8:] = True
+            masks[names[j]] = mk.to(device)
+        else:
+            masks[names[j]] = None
+    return mems, masks
+
+
+def cpu_baseline(model, n_fwd=2):
+    """The CPU oracle (numpy restatement of the reference op sequence; kind = "port") timed on this box's
+    host cores on a bounded sample: single-utterance steps (Be=7) of the same workload; a B=32 step is 32 of them."""
+    from oracle import denoiser_ref, sampler_ref, weights
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    sd = weights.extend_pe(sd, 1536)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((7, L, 128)).astype(np.float32)
+    mems = [rng.standard_normal((7, s, 512)).astype(np.float32) for s in S]
+    denoiser_ref.denoiser_forward(sd, x[:, :16], 10, [m[:, : min(s, 32)] for m, s in zip(mems, S)], {}, num_layers=1)  # warm BLAS
+    t0 = time.time()
+    for i in range(n_fwd):
+        eps, _ = denoiser_ref.denoiser_forward(sd, x, 999 - i, mems, {})
+        sampler_ref.cfg_combine(eps, 7.5)
+    dt = (time.time() - t0) / n_fwd
+    return {"value": 1.0 / (dt * B_PER_GPU), "unit": "denoise-steps/s (B=32)", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n_fwd} single-utterance steps (Be=7, L={L}, S={S}) of the numpy oracle at {dt:.2f} s each; "
+                      f"a B=32 step counted as 32 of them"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shape", default="C2", choices=["C2", "R"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py measures the HIP path on an MI355X; there is no CPU fallback"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    global L, S
+    if args.shape == "R":
+        L, S = 16, (24, 161, 24, 8, 1)
+
+    from convofusion_amd import scheduler
+    from convofusion_amd.distributed import gather_latents
+    from convofusion_amd.sampler import SamplingRun
+
+    model = make_model(device)
+    mems, masks = make_inputs(B_PER_GPU, device, seed=1234 + rank)
+    sch = scheduler.DDPMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012,
+                                  beta_schedule="scaled_linear", variance_type="fixed_small", clip_sample=True)
+    n_sched = 1000
+    assert args.steps + args.warmup <= n_sched
+    run = SamplingRun(model, sch, mems, masks, B_PER_GPU, L, n_sched, guidance_scale=7.5, seed=0,
+                      first_utterance=rank * B_PER_GPU)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    run.steps(args.warmup)
+    run.read()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    run.steps(args.steps)
+    local = run.read()                         # syncs the run's stream
+    total = gather_latents(local, world * B_PER_GPU) if world > 1 else local
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert torch.isfinite(total).all()
+
+    # per-kernel-class timing with HIP events on the launch stream (one eager forward of the same problem)
+    prof = run.profile()
+    run.close()
+
+    if rank == 0:
+        Be = G * B_PER_GPU
+        U = [B_PER_GPU + 1] * 5
+        canon = canonical_flops_per_step(Be, L, S)
+        ex = executed_gemm_flops(Be, L, S, U)
+        classes = {k: {"ms": round(v[0], 4), "launches": v[1]} for k, v in prof.items()}
+        dom = max(("gemm_token", "gemm_mem", "gemm_attn"), key=lambda k: prof[k][0])
+        dom_ms = prof[dom][0]
+        achieved = ex[dom] / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        for k in ex:
+            classes[k]["algorithmic_tflop"] = round(ex[k] / 1e12, 4)
+            classes[k]["tflops"] = round(ex[k] / (prof[k][0] * 1e-3) / 1e12, 1) if prof[k][0] > 0 else None
+        out = {
+            "metric": "denoise-steps/sec (B=32 per GPU, 196-token latent, 1500 audio tokens, 1000-step DDPM schedule)",
+            "value": world * args.steps / dt,
+            "unit": "denoise-steps/s (32-utterance batches, summed over GPUs)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16x3 split operands, f32 accumulate (f32-equivalent)",
+            "data": "synthetic",
+            "config": {"workload": f"configs[1]: B={B_PER_GPU}/GPU synthetic, L={L}, S={S}, 7-way guidance (denoiser batch {Be}), "
+                                   f"DDPM 1000-step schedule, {args.steps} timed iterations of the hipGraph-captured loop",
+                       "shape": args.shape, "parallelism": f"batch-shard x{world}, one all_gather of latents"},
+            "utterance_steps_per_s": world * B_PER_GPU * args.steps / dt,
+            "canonical_tflop_per_step": canon / 1e12,
+            "canonical_tflops": world * canon * args.steps / dt / 1e12,
+            "roofline": {"bound": "mfma", "kernel": f"gemm_sp_kernel ({dom})", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "note": "algorithmic FLOPs; each product is 3 bf16 MFMAs, so the MFMA pipe sees 3x this"},
+            "kernel_classes": classes,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,22 +21,38 @@
 #define CFD_NMEM 5       // spkemb, alsn, tlsn, apb, lsnemb (denoiser.py:220)
 #define CFD_MAX_LAYERS 16
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+// Element type of the split pair.  CFD_SPLIT_F16=1 (default): two IEEE half floats (11+11 significant
+// bits, ~2^-22 operand error; inputs are saturated to +-65504); CFD_SPLIT_F16=0: two bfloat16 (8+8 bits,
+// ~2^-16, full float32 range).  Both run on the same-rate v_mfma_f32_16x16x32_{f16,bf16}.
+#ifndef CFD_SPLIT_F16
+#define CFD_SPLIT_F16 1
+#endif
+#if CFD_SPLIT_F16
+typedef _Float16 sp_t;
+#define SP_MFMA __builtin_amdgcn_mfma_f32_16x16x32_f16
+#else
+typedef __bf16 sp_t;
+#define SP_MFMA __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#endif
+typedef __attribute__((ext_vector_type(8))) sp_t bf16x8;   // 8 split-pair elements (one MFMA operand fragment)
+typedef __attribute__((ext_vector_type(4))) sp_t bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __forceinline__ void split_f32(float v, __bf16& hi, __bf16& lo) {
-  hi = (__bf16)v;
-  lo = (__bf16)(v - (float)hi);
+__device__ __forceinline__ void split_f32(float v, sp_t& hi, sp_t& lo) {
+#if CFD_SPLIT_F16
+  v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+#endif
+  hi = (sp_t)v;
+  lo = (sp_t)(v - (float)hi);
 }
 
 // store 4 consecutive-column values (col % 4 == 0) of one row into an SP matrix
 __device__ __forceinline__ void sp_store4(char* row_base, int col, float a, float b, float c, float d) {
   bf16x4 h, l;
-  __bf16 t0, t1;
+  sp_t t0, t1;
   split_f32(a, t0, t1); h[0] = t0; l[0] = t1;
   split_f32(b, t0, t1); h[1] = t0; l[1] = t1;
   split_f32(c, t0, t1); h[2] = t0; l[2] = t1;
@@ -51,7 +67,7 @@ __device__ __forceinline__ void sp_store8(char* row_base, int col, const float* 
   bf16x8 h, l;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    __bf16 a, b;
+    sp_t a, b;
     split_f32(v[e], a, b);
     h[e] = a;
     l[e] = b;

@@ -303,9 +303,9 @@ __global__ void __launch_bounds__(256, 2) gemm_sp_kernel(const GemmArgs a, const
     for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
       for (int tj = 0; tj < TJ; ++tj) {
-        acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl[ti], yh[tj], acc[ti][tj], 0, 0, 0);
-        acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[ti], yl[tj], acc[ti][tj], 0, 0, 0);
-        acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[ti], yh[tj], acc[ti][tj], 0, 0, 0);
+        acc[ti][tj] = SP_MFMA(xl[ti], yh[tj], acc[ti][tj], 0, 0, 0);
+        acc[ti][tj] = SP_MFMA(xh[ti], yl[tj], acc[ti][tj], 0, 0, 0);
+        acc[ti][tj] = SP_MFMA(xh[ti], yh[tj], acc[ti][tj], 0, 0, 0);
       }
     __syncthreads();
   }
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(256, 2) gemm_sp_kernel(const GemmArgs a, const
 // CFD_NAIVE_GEMM=1 debug switch to separate MFMA-path bugs from host-side plumbing bugs.
 __device__ __forceinline__ float sp_load(const char* row, int col) {
   const char* p = row + (size_t)(col >> 5) * 128 + (col & 31) * 2;
-  return (float)*reinterpret_cast<const __bf16*>(p) + (float)*reinterpret_cast<const __bf16*>(p + 64);
+  return (float)*reinterpret_cast<const sp_t*>(p) + (float)*reinterpret_cast<const sp_t*>(p + 64);
 }
 
 template <int MODE, class Epi>

@@ -53,7 +53,7 @@ def test_gemm_split_bf16_accuracy(ops, cfg, shape):
     assert np.isfinite(got).all()
     scale = np.sqrt((Y.astype(np.float64) ** 2).sum(1))[:, None] * np.sqrt((X.astype(np.float64) ** 2).sum(1))[None, :]
     err = np.abs(got - want) / scale
-    assert err.max() < 3e-6, (err.max(), np.unravel_index(err.argmax(), err.shape))
+    assert err.max() < 1e-5, (err.max(), np.unravel_index(err.argmax(), err.shape))
     rel = np.linalg.norm(got - want) / np.linalg.norm(want)
     assert rel < 1e-5, rel
 
@@ -100,3 +100,15 @@ def test_scheduler_step_and_add_noise(kind):
             np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
     got = s.add_noise(torch.from_numpy(x).cuda(), torch.from_numpy(z).cuda(), torch.tensor([321]))
     np.testing.assert_allclose(got.cpu().numpy(), r.add_noise(x, z, np.array([321])), rtol=1e-6, atol=1e-6)
+
+
+def test_mfma_subnormal_operands(ops):
+    """Do the MFMA inputs keep fp16 subnormals?  (Decides whether small split-pair 'lo' halves survive.)"""
+    I = J = 16
+    K = 32
+    X = np.zeros((I, K), np.float32)
+    X[np.arange(I), np.arange(I)] = 1.0
+    Y = np.full((J, K), 3e-6, np.float32)
+    got = _gemm(ops, X, Y, 2)
+    print("subnormal probe: D =", got[0, 0], "(input 3e-6; fp16 subnormal spacing 5.96e-8)")
+    assert abs(got[0, 0] - 3e-6) < 1e-7
