@@ -6,8 +6,11 @@ without an MI355X, raises.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- must be imported BEFORE the library: torch bundles its own libamdhip64 and the two
+#                               HIP runtimes must not both be loaded (loading ours first breaks device discovery)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcfdenoise.so")
+LIB_PATH = os.environ.get("CFD_LIB", os.path.join(HERE, "libcfdenoise.so"))  # CFD_LIB: developer override
 
 NUM_MEM = 5
 MEM_NAMES = ("spkemb", "alsn", "tlsn", "apb", "lsnemb")
@@ -17,7 +20,7 @@ SYMBOLS = [
     "cfd_create", "cfd_destroy", "cfd_last_error", "cfd_load_tensor", "cfd_finalize_weights",
     "cfd_set_timestep_table", "cfd_forward", "cfd_sample_begin", "cfd_sample_steps", "cfd_sample_position",
     "cfd_sample_read", "cfd_scheduler_step", "cfd_add_noise", "cfd_philox_normal", "cfd_profile_forward",
-    "cfd_test_gemm", "cfd_debug_stop_stage", "cfd_debug_read",
+    "cfd_test_gemm", "cfd_debug_stop_stage", "cfd_debug_read", "cfd_bench_gemm",
 ]
 
 
@@ -81,6 +84,7 @@ def load():
     lib.cfd_profile_forward.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.cfd_test_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_void_p]
+    lib.cfd_bench_gemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.cfd_debug_stop_stage.argtypes = [C.c_void_p, C.c_int]
     lib.cfd_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
     for name in SYMBOLS:

@@ -16,6 +16,7 @@
 #include "rows.hpp"
 
 int g_cfd_naive_gemm = 0;
+int g_cfd_gemm_cfg = 0;
 
 static thread_local char g_err[1024] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -92,7 +93,8 @@ struct cfd_handle_s {
   // workspace
   DBuf x, h_sp, qk_sp, vts_sp, ssc, sp_sp, o_sp, u_sp, sc, p_sp, eps, sample_sp;
   DBuf n_sp[CFD_NMEM], kall_sp[CFD_NMEM], cb[CFD_NMEM], vt_all[CFD_NMEM];
-  DBuf temb_tab, h1_tab, ss_tab, trows;
+  DBuf temb_tab, h1_tab, ss_tab, trows, iota;
+  int nchunks_env = 0;
   DBuf d_step;  // [0] = loop index, [1] = constant 0
   Problem pb;
   // profiling
@@ -185,6 +187,10 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   c->lw.resize(c->nl);
   const char* env = getenv("CFD_NAIVE_GEMM");
   g_cfd_naive_gemm = (env && atoi(env) != 0) ? 1 : 0;
+  env = getenv("CFD_CHUNKS");
+  c->nchunks_env = env ? atoi(env) : 0;
+  env = getenv("CFD_GEMM_CFG");
+  g_cfd_gemm_cfg = env ? atoi(env) : 0;
   if (c->d_step.ensure(16) != CFD_OK) { delete c; return CFD_E_HIP; }
   if (hipMemset(c->d_step.p, 0, 16) != hipSuccess) { delete c; return fail(CFD_E_HIP, "memset"); }
   (void)hipEventCreate(&c->pev[0]);
@@ -422,6 +428,12 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
   if (Be < 1 || L < 2) return fail(CFD_E_ARG, "bad batch / length");
   if (L % 2) return fail(CFD_E_SHAPE, "latent length %d is odd (reference: broadcasting error at position_encoding.py:160-161)", L);
   if (L / 2 > c->qpe_rows) return fail(CFD_E_SHAPE, "L/2 = %d exceeds the query PE buffer (%d rows)", L / 2, c->qpe_rows);
+  if ((size_t)Be * 4 > c->iota.bytes) {   // identity row map (memories passed without de-duplication)
+    CHK(c->iota.ensure((size_t)Be * 4));
+    std::vector<int> id(Be);
+    for (int i = 0; i < Be; ++i) id[i] = i;
+    HIPCHK(hipMemcpy(c->iota.p, id.data(), (size_t)Be * 4, hipMemcpyHostToDevice));
+  }
   Problem& p = c->pb;
   p.Be = Be; p.L = L; p.Lp = (L + 31) / 32 * 32; p.M = (long long)Be * L; p.tmode = tmode; p.T = T;
   if (p.Lp > SM_MAX_CHUNKS * 512) return fail(CFD_E_SHAPE, "L = %d exceeds the in-register softmax limit (%d)", L, SM_MAX_CHUNKS * 512);
@@ -436,7 +448,7 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
                   MEM_NAMES[j], m.S, c->mpe_rows);
     p.U[j] = m.U; p.S[j] = m.S; p.Sp[j] = (m.S + 31) / 32 * 32; p.off[j] = off; off += p.Sp[j];
     if (p.Sp[j] > SM_MAX_CHUNKS * 512) return fail(CFD_E_SHAPE, "memory %s: %d keys exceed the in-register softmax limit", MEM_NAMES[j], m.S);
-    p.mem[j] = m.data; p.map[j] = m.row_map; p.mask[j] = m.key_padding_mask;
+    p.mem[j] = m.data; p.map[j] = m.row_map ? m.row_map : c->iota.as<int>(); p.mask[j] = m.key_padding_mask;
     p.att[j] = att ? att[j] : nullptr;
   }
   p.Sp_tot = off;
@@ -497,23 +509,15 @@ static int build_time_tables(Ctx* c, const int32_t* trows_host, int T, hipStream
 
 // ---- the denoiser forward: Denoiser.forward (denoiser.py:173-386) --------------------------------------
 // Input: c->sample_sp (SP [M][128]); time tables built; output: c->eps (fp32 [M][128]).
-static int enqueue_denoise(Ctx* c, hipStream_t st) {
-  const Problem& p = c->pb;
-  const int nl = c->nl, L = p.L, Lp = p.Lp, Be = p.Be;
-  const long long M = p.M;
-  const int* dstep = p.tmode ? c->d_step.as<int>() + 1 : c->d_step.as<int>();
-  const long long ROWB = CFD_D * 4;  // bytes per SP row of 512
-  const dim3 blk(256);
+static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int nrows);
 
-  // 1. latent embedding + body/hand embedding + query PE          (denoiser.py:187,316-326)
-  {
-    GemmArgs a = gemm_args();
-    a.X[0] = c->we_sp.as<char>(); a.ldx[0] = CFD_LAT * 4; a.I[0] = CFD_D; a.Iclamp[0] = CFD_D; a.kt[0] = CFD_LAT / 32;
-    a.Y = c->sample_sp.as<char>(); a.ldy = CFD_LAT * 4; a.J = (int)M; a.Jclamp = (int)M;
-    EpiEmbed e{c->x.as<float>(), rawp(c, "latent_embd.bias"), rawp(c, "bh_embedding.weight"), rawp(c, "query_pos.pe"), L};
-    CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
-  }
-  if (c->stop_stage == 1) return CFD_OK;
+// memory-side work of one forward: shared by every row chunk
+static int enqueue_memside(Ctx* c, hipStream_t st) {
+  const Problem& p = c->pb;
+  const int nl = c->nl;
+  const int* dstep = p.tmode ? c->d_step.as<int>() + 1 : c->d_step.as<int>();
+  const long long ROWB = CFD_D * 4;
+  const dim3 blk(256);
   // 2. memories: + temb + condition id + PE, normalise           (denoiser.py:223-261,332-353)
   for (int j = 0; j < CFD_NMEM; ++j) {
     MemPrepArgs a{p.mem[j], p.U[j], p.S[j], p.Sp[j], c->temb_tab.as<float>(), dstep, p.tmode,
@@ -540,9 +544,58 @@ static int enqueue_denoise(Ctx* c, hipStream_t st) {
     }
   }
 
+  return CFD_OK;
+}
+
+// Optional row chunking (CFD_CHUNKS=n): effective-batch rows are independent, so the token-side pipeline can
+// run chunk by chunk.  Measured on MI355X at the benchmark shape this is SLOWER (23.1 / 25.0 / 28.1 / 33.5 ms
+// per step for 1 / 2 / 4 / 8 chunks): the kernels are not HBM-bound enough for Infinity-Cache residency of
+// the intermediates to pay for the smaller grids.  Kept as a developer knob; default is one chunk.
+static int pick_chunks(Ctx* c) {
+  const Problem& p = c->pb;
+  if (c->stop_stage || c->nchunks_env <= 1) return 1;
+  return c->nchunks_env < p.Be ? c->nchunks_env : p.Be;
+}
+
+static int enqueue_denoise(Ctx* c, hipStream_t st) {
+  CHK(enqueue_memside(c, st));
+  const int Be = c->pb.Be;
+  const int n = pick_chunks(c);
+  for (int k = 0; k < n; ++k) {
+    const int r0 = (int)((long long)Be * k / n), r1 = (int)((long long)Be * (k + 1) / n);
+    if (r1 > r0) CHK(enqueue_rows(c, st, r0, r1 - r0));
+  }
+  return CFD_OK;
+}
+
+static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
+  const Problem& p = c->pb;
+  const int nl = c->nl, L = p.L, Lp = p.Lp;
+  const long long M = (long long)Be * L;
+  const int* dstep = p.tmode ? c->d_step.as<int>() + 1 : c->d_step.as<int>();
+  const long long ROWB = CFD_D * 4;  // bytes per SP row of 512
+  const dim3 blk(256);
+  const char* sample_sp = c->sample_sp.as<char>() + (size_t)row0 * L * CFD_LAT * 4;
+  float* eps_out = c->eps.as<float>() + (size_t)row0 * L * CFD_LAT;
+  const int* mapj[CFD_NMEM];
+  float* attj[CFD_NMEM];
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    mapj[j] = p.map[j] + row0;
+    attj[j] = p.att[j] ? p.att[j] + (size_t)row0 * nl * L * p.S[j] : nullptr;
+  }
+
+  // 1. latent embedding + body/hand embedding + query PE          (denoiser.py:187,316-326)
+  {
+    GemmArgs a = gemm_args();
+    a.X[0] = c->we_sp.as<char>(); a.ldx[0] = CFD_LAT * 4; a.I[0] = CFD_D; a.Iclamp[0] = CFD_D; a.kt[0] = CFD_LAT / 32;
+    a.Y = sample_sp; a.ldy = CFD_LAT * 4; a.J = (int)M; a.Jclamp = (int)M;
+    EpiEmbed e{c->x.as<float>(), rawp(c, "latent_embd.bias"), rawp(c, "bh_embedding.weight"), rawp(c, "query_pos.pe"), L};
+    CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
+  }
+  if (c->stop_stage == 1) return CFD_OK;
   auto ln = [&](const float* g, const float* b, int adaln, int tbidx, char* out) -> int {
     LnArgs a{c->x.as<float>(), out, M, g, b, adaln, c->ss_tab.as<float>() + (size_t)tbidx * 2 * CFD_D,
-             (long long)nl * 2 * 2 * CFD_D, dstep, p.tmode, L};
+             (long long)nl * 2 * 2 * CFD_D, dstep, p.tmode, L, row0};
     LAUNCH(CFD_PROF_ROWS, ln_rows_kernel, dim3((unsigned)((M + 3) / 4)), blk, st, a);
     return CFD_OK;
   };
@@ -606,17 +659,23 @@ static int enqueue_denoise(Ctx* c, hipStream_t st) {
     if (c->stop_stage == 3 + 4 * l) return CFD_OK;
     // ---- c-e. five cross attentions + fuser, folded                             (:578-652)
     CHK(ln(w.ln2g, w.ln2b, 0, 0, c->h_sp.as<char>()));
-    {  // scores against the folded keys of every memory
+    // scores against the folded keys of every memory; long memories and short (<= 64 keys) memories go to
+    // different tile shapes so that an 8-key memory does not cost a 128-key tile
+    for (int pass = 0; pass < 2; ++pass) {
       GemmArgs a = gemm_args();
-      a.nslot = CFD_NMEM;
       EpiF32 e;
       memset(&e, 0, sizeof(e));
+      int n = 0;
       for (int j = 0; j < CFD_NMEM; ++j) {
-        a.X[j] = c->kall_sp[j].as<char>() + (size_t)l * (CFD_D / 32) * 128; a.ldx[j] = (long long)nl * ROWB;
-        a.xbs[j] = (long long)p.Sp[j] * nl * ROWB; a.xmap[j] = p.map[j];
-        a.I[j] = p.Sp[j]; a.Iclamp[j] = p.Sp[j]; a.kt[j] = CFD_D / 32;
-        e.goff[j] = p.off[j]; e.gbias[j] = c->cb[j].as<float>() + (size_t)l * p.U[j] * p.Sp[j]; e.gmap[j] = p.map[j]; e.gstride[j] = p.Sp[j];
+        if ((p.Sp[j] <= 64) != (pass == 1)) continue;
+        a.X[n] = c->kall_sp[j].as<char>() + (size_t)l * (CFD_D / 32) * 128; a.ldx[n] = (long long)nl * ROWB;
+        a.xbs[n] = (long long)p.Sp[j] * nl * ROWB; a.xmap[n] = mapj[j];
+        a.I[n] = p.Sp[j]; a.Iclamp[n] = p.Sp[j]; a.kt[n] = CFD_D / 32;
+        e.goff[n] = p.off[j]; e.gbias[n] = c->cb[j].as<float>() + (size_t)l * p.U[j] * p.Sp[j]; e.gmap[n] = mapj[j]; e.gstride[n] = p.Sp[j];
+        ++n;
       }
+      if (!n) continue;
+      a.nslot = n;
       a.Y = c->h_sp.as<char>(); a.ldy = ROWB; a.ybs = (long long)L * ROWB; a.J = L; a.Jclamp = L;
       e.out = c->sc.as<float>(); e.ldo = p.Sp_tot; e.obs = (long long)L * p.Sp_tot;
       CHK((run_gemm<MODE_GROUPED>(c, CFD_PROF_GEMM_ATTN, a, e, Be, 1, st)));
@@ -626,7 +685,7 @@ static int enqueue_denoise(Ctx* c, hipStream_t st) {
       memset(&a, 0, sizeof(a));
       a.sc = c->sc.as<float>(); a.P = c->p_sp.as<char>(); a.ld = p.Sp_tot; a.rows = M; a.rows_per_b = L; a.nseg = CFD_NMEM;
       for (int j = 0; j < CFD_NMEM; ++j) {
-        a.off[j] = p.off[j]; a.S[j] = p.S[j]; a.Sp[j] = p.Sp[j]; a.mask[j] = p.mask[j]; a.map[j] = p.map[j]; a.att[j] = p.att[j];
+        a.off[j] = p.off[j]; a.S[j] = p.S[j]; a.Sp[j] = p.Sp[j]; a.mask[j] = p.mask[j]; a.map[j] = mapj[j]; a.att[j] = attj[j];
       }
       a.layer = l; a.nl = nl;
       LAUNCH(CFD_PROF_ROWS, softmax_rows_kernel, dim3((unsigned)((M + 3) / 4)), blk, st, a);
@@ -637,7 +696,7 @@ static int enqueue_denoise(Ctx* c, hipStream_t st) {
       for (int j = 0; j < CFD_NMEM; ++j) {
         const long long rows = (long long)p.U[j] * p.Sp[j];
         a.X[j] = c->vt_all[j].as<char>() + (size_t)l * CFD_D * rows * 4; a.ldx[j] = rows * 4;
-        a.xbs[j] = (long long)(p.Sp[j] / 32) * 128; a.xmap[j] = p.map[j];
+        a.xbs[j] = (long long)(p.Sp[j] / 32) * 128; a.xmap[j] = mapj[j];
         a.kt[j] = p.Sp[j] / 32;
         a.I[j] = CFD_D; a.Iclamp[j] = CFD_D;
       }
@@ -669,7 +728,7 @@ static int enqueue_denoise(Ctx* c, hipStream_t st) {
     a.Y = c->h_sp.as<char>(); a.ldy = ROWB; a.J = (int)M; a.Jclamp = (int)M;
     EpiF32 e;
     memset(&e, 0, sizeof(e));
-    e.out = c->eps.as<float>(); e.ldo = CFD_LAT; e.bias = rawp(c, "latent_proj.bias");
+    e.out = eps_out; e.ldo = CFD_LAT; e.bias = rawp(c, "latent_proj.bias");
     CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
   }
   return CFD_OK;
@@ -977,5 +1036,54 @@ extern "C" int cfd_test_gemm(cfd_handle c, const float* X, const float* Y, float
   HIPCHK(hipStreamSynchronize(st));
   xs.release();
   ys.release();
+  return CFD_OK;
+}
+
+// Micro-benchmark hook: `iters` launches of the MFMA GEMM (EpiResid epilogue: x[j][i] += D + bias) on device-resident
+// SP operands filled from a float32 pattern; returns the average milliseconds per launch (HIP events).
+extern "C" int cfd_bench_gemm(cfd_handle c, int I, int J, int K, int tile_cfg, int iters, float* ms_out) {
+  if (!c || !ms_out || K % 32 || I != CFD_D || J < 1 || iters < 1) return fail(CFD_E_ARG, "bad argument (I must be 512)");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  DBuf xf, yf, xs, ys, out;
+  CHK(xf.ensure((size_t)I * K * 4));
+  CHK(yf.ensure((size_t)J * K * 4));
+  CHK(xs.ensure((size_t)I * K * 4));
+  CHK(ys.ensure((size_t)J * K * 4));
+  CHK(out.ensure((size_t)J * I * 4));
+  HIPCHK(hipMemset(out.p, 0, (size_t)J * I * 4));
+  long long n = (long long)I * K / 4;
+  hipLaunchKernelGGL(philox_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, xf.as<float>(), 1, I * K, 1ull, 0u, 0u, 3u, 0.05f);
+  n = (long long)J * K / 4;
+  hipLaunchKernelGGL(philox_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, yf.as<float>(), 1, (int)((long long)J * K), 2ull, 0u, 0u, 3u, 1.0f);
+  n = (long long)I * (K / 8);
+  hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, xf.as<float>(), xs.as<char>(), (long long)I, K, (long long)K, (long long)K * 4);
+  n = (long long)J * (K / 8);
+  hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, yf.as<float>(), ys.as<char>(), (long long)J, K, (long long)K, (long long)K * 4);
+  GemmArgs a = gemm_args();
+  a.X[0] = xs.as<char>(); a.ldx[0] = (long long)K * 4; a.I[0] = I; a.Iclamp[0] = I; a.kt[0] = K / 32;
+  a.Y = ys.as<char>(); a.ldy = (long long)K * 4; a.J = J; a.Jclamp = J;
+  EpiResid e{out.as<float>(), 0, nullptr};
+  EpiNull en{out.as<float>()};
+  EpiF32 ef;
+  memset(&ef, 0, sizeof(ef));
+  ef.out = out.as<float>(); ef.ldo = I;
+  const char* ev = getenv("CFD_BENCH_EPI");
+  const int epi_kind = ev ? atoi(ev) : 0;   // 0 residual RMW, 1 no stores, 2 plain fp32 store
+  auto go = [&]() -> hipError_t {
+    if (epi_kind == 1) return launch_gemm<MODE_PLAIN, EpiNull>(a, en, 1, 1, nullptr, tile_cfg);
+    if (epi_kind == 2) return launch_gemm<MODE_PLAIN, EpiF32>(a, ef, 1, 1, nullptr, tile_cfg);
+    return launch_gemm<MODE_PLAIN, EpiResid>(a, e, 1, 1, nullptr, tile_cfg);
+  };
+  hipError_t err = go();   // warm-up
+  if (err != hipSuccess) return fail(CFD_E_HIP, "gemm launch failed: %s", hipGetErrorString(err));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipEventRecord(c->pev[0], nullptr));
+  for (int i = 0; i < iters; ++i) (void)go();
+  HIPCHK(hipEventRecord(c->pev[1], nullptr));
+  HIPCHK(hipEventSynchronize(c->pev[1]));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, c->pev[0], c->pev[1]));
+  *ms_out = ms / iters;
+  xf.release(); yf.release(); xs.release(); ys.release(); out.release();
   return CFD_OK;
 }

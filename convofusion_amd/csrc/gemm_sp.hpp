@@ -21,6 +21,9 @@
 #pragma once
 #include "cfd_common.hpp"
 
+#ifndef CFD_EXP
+#define CFD_EXP 0
+#endif
 #define GEMM_SLOTS 5
 enum { MODE_PLAIN = 0, MODE_GROUPED = 1, MODE_SEGK = 2 };
 
@@ -110,6 +113,14 @@ struct EpiResid {  // x[(b*rows_per_b + j)][i] += v + bias[i]   (row length CFD_
   }
 };
 
+struct EpiNull {  // timing experiments only: keeps the accumulators live, stores nothing
+  float* sink;
+  __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
+    asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+    if (i < -1) sink[0] = v[0];
+  }
+};
+
 struct EpiEmbed {  // x0[j][i] = v + bias[i] + bh[(l&1)][i] + qpe[(l>>1)][i],  l = j % L   (denoiser.py:187,316-326)
   float* x;
   const float* bias;
@@ -149,13 +160,20 @@ struct EpiMemK {  // i < nfeat: k_all_sp[j][i] = split(v);  nfeat <= i < nfeat+n
 };
 
 // ------------------------------------------------------------------------------------------------
-template <int WI, int WJ, int TI, int TJ, int MODE, class Epi>
-__global__ void __launch_bounds__(256, 2) gemm_sp_kernel(const GemmArgs a, const Epi epi) {
-  static_assert(WI * WJ == 4, "4 waves per block");
+// NSTAGE == 2: one k-tile of prefetch, __syncthreads() per k-step (small / ragged tile configs).
+// NSTAGE == 3: two k-tiles of prefetch kept in flight ACROSS the per-k-step barrier: counted
+//              s_waitcnt vmcnt(GPW) + raw s_barrier (a __syncthreads() would drain the LDS-DMA queue).
+//              Requires every wave to issue exactly GPW loads per stage.
+template <int WI, int WJ, int TI, int TJ, int NSTAGE, int MODE, class Epi>
+__global__ void __launch_bounds__(WI * WJ * 64, (WI * WJ * 64) / 256 * ((WI * TI + WJ * TJ) * 16 * 128 * NSTAGE > 80 * 1024 ? 1 : 2))
+gemm_sp_kernel(const GemmArgs a, const Epi epi) {
+  constexpr int NW = WI * WJ;
   constexpr int BI = WI * TI * 16, BJ = WJ * TJ * 16;
   constexpr int STAGE = (BI + BJ) * 128;
-  constexpr int NGRP = (BI + BJ) / 8;
-  constexpr int GPW = (NGRP + 3) / 4;
+  constexpr int XG = BI / 8, YG = BJ / 8;                // 8-row load groups per operand tile
+  constexpr int XPW = (XG + NW - 1) / NW, YPW = (YG + NW - 1) / NW;
+  constexpr int GPW = XPW + YPW;
+  static_assert(NSTAGE == 2 || (XG % NW == 0 && YG % NW == 0), "3-stage pipeline needs uniform load counts per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
@@ -208,25 +226,26 @@ __global__ void __launch_bounds__(256, 2) gemm_sp_kernel(const GemmArgs a, const
   }
   const char* yb = a.Y + (long long)b * a.ybs + (long long)z * a.yzs;
 
-  // staging bookkeeping: load-group gi covers tile rows gi*8 .. gi*8+7 (X rows first, then Y rows)
-  int srow[GPW];         // clamped global row
-  int schunk[GPW];       // swizzled source chunk byte offset
-  bool sisx[GPW];
+  // staging bookkeeping: wave `wid` loads X groups wid, wid+NW, ... and Y groups wid, wid+NW, ...
+  // (a group = 8 tile rows x 128 B = one global_load_lds_dwordx4 wave-instruction)
+  const int cpos = lane & 7, rsub = lane >> 3;
+  int xrow[XPW], xchunk[XPW];
+  long long yoff[YPW];
 #pragma unroll
-  for (int n = 0; n < GPW; ++n) {
-    const int gi = wid + 4 * n;
-    const int r = gi * 8 + (lane >> 3);
-    const int cpos = lane & 7;
-    if (r < BI) {
-      sisx[n] = true;
-      srow[n] = min(i0 + r, Iclamp_g - 1);
-      schunk[n] = (cpos ^ ((r >> 1) & 7)) << 4;
-    } else {
-      const int rj = r - BI;
-      sisx[n] = false;
-      srow[n] = min(j0 + rj, a.Jclamp - 1);
-      schunk[n] = (cpos ^ ((rj >> 1) & 7)) << 4;
-    }
+  for (int n = 0; n < XPW; ++n) {
+    const int r = (wid + NW * n) * 8 + rsub;
+    xrow[n] = min(i0 + r, Iclamp_g - 1);
+    xchunk[n] = (cpos ^ ((r >> 1) & 7)) << 4;
+  }
+#pragma unroll
+  for (int n = 0; n < YPW; ++n) {
+    const int r = (wid + NW * n) * 8 + rsub;
+    yoff[n] = (long long)min(j0 + r, a.Jclamp - 1) * a.ldy + ((cpos ^ ((r >> 1) & 7)) << 4);
+  }
+  long long xoff[XPW];
+  if (MODE != MODE_SEGK) {
+#pragma unroll
+    for (int n = 0; n < XPW; ++n) xoff[n] = (long long)xrow[n] * ldx_g + xchunk[n];
   }
 
   int nkt = 0;
@@ -239,32 +258,40 @@ __global__ void __launch_bounds__(256, 2) gemm_sp_kernel(const GemmArgs a, const
   }
 
   auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
-    // X source for this k-tile
-    const char* xs;
-    long long ldx;
-    int ktl = kt;
+#if CFD_EXP == 2   // timing experiment: only the first two k-tiles are ever loaded
+    if (kt > 1) return;
+#endif
+    char* sbuf = smem + buf * STAGE;
     if (MODE == MODE_SEGK) {
-      int s = 0;
+      int s = 0, ktl = kt;
 #pragma unroll
       for (int q = 0; q < GEMM_SLOTS - 1; ++q)
         if (s == q && q < a.nslot - 1 && ktl >= a.kt[q]) { ktl -= a.kt[q]; s = q + 1; }
-      xs = xb[0];
-      ldx = a.ldx[0];
+      const char* xs = xb[0];
+      long long ldx = a.ldx[0];
 #pragma unroll
       for (int q = 1; q < GEMM_SLOTS; ++q)
         if (q == s) { xs = xb[q]; ldx = a.ldx[q]; }
+#pragma unroll
+      for (int n = 0; n < XPW; ++n) {
+        const int gi = wid + NW * n;
+        if (XG % NW == 0 || gi < XG)
+          __builtin_amdgcn_global_load_lds((gptr_t)(xs + (long long)xrow[n] * ldx + (long long)ktl * 128 + xchunk[n]),
+                                           (lptr_t)(sbuf + gi * 1024), 16, 0, 0);
+      }
     } else {
-      xs = xbase_g;
-      ldx = ldx_g;
+#pragma unroll
+      for (int n = 0; n < XPW; ++n) {
+        const int gi = wid + NW * n;
+        if (XG % NW == 0 || gi < XG)
+          __builtin_amdgcn_global_load_lds((gptr_t)(xbase_g + xoff[n] + (long long)kt * 128), (lptr_t)(sbuf + gi * 1024), 16, 0, 0);
+      }
     }
 #pragma unroll
-    for (int n = 0; n < GPW; ++n) {
-      const int gi = wid + 4 * n;
-      if (gi < NGRP) {
-        const char* src = sisx[n] ? xs + (long long)srow[n] * ldx + (long long)ktl * 128 + schunk[n]
-                                  : yb + (long long)srow[n] * a.ldy + (long long)kt * 128 + schunk[n];
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + buf * STAGE + gi * 1024), 16, 0, 0);
-      }
+    for (int n = 0; n < YPW; ++n) {
+      const int gi = wid + NW * n;
+      if (YG % NW == 0 || gi < YG)
+        __builtin_amdgcn_global_load_lds((gptr_t)(yb + yoff[n] + (long long)kt * 128), (lptr_t)(sbuf + BI * 128 + gi * 1024), 16, 0, 0);
     }
   };
 
@@ -282,11 +309,7 @@ __global__ void __launch_bounds__(256, 2) gemm_sp_kernel(const GemmArgs a, const
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  stage(0, 0);
-  __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);
+  auto compute = [&](int buf) __attribute__((always_inline)) {
     const char* sb = smem + buf * STAGE;
     bf16x8 xh[TI], xl[TI], yh[TJ], yl[TJ];
 #pragma unroll
@@ -299,6 +322,15 @@ __global__ void __launch_bounds__(256, 2) gemm_sp_kernel(const GemmArgs a, const
       yh[tj] = *reinterpret_cast<const bf16x8*>(sb + yoff_h + tj * 2048);
       yl[tj] = *reinterpret_cast<const bf16x8*>(sb + yoff_l + tj * 2048);
     }
+#if CFD_EXP == 3 || CFD_EXP == 4
+    __builtin_amdgcn_sched_barrier(0);   // V1 experiment: every fragment read is issued before the first MFMA
+#endif
+#if CFD_EXP == 1   // timing experiment: LDS reads kept live, no MFMA
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) asm volatile("" ::"v"(xh[ti]), "v"(xl[ti]));
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) asm volatile("" ::"v"(yh[tj]), "v"(yl[tj]));
+#else
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
@@ -307,7 +339,40 @@ __global__ void __launch_bounds__(256, 2) gemm_sp_kernel(const GemmArgs a, const
         acc[ti][tj] = SP_MFMA(xh[ti], yl[tj], acc[ti][tj], 0, 0, 0);
         acc[ti][tj] = SP_MFMA(xh[ti], yh[tj], acc[ti][tj], 0, 0, 0);
       }
+#endif
+  };
+
+  if (NSTAGE == 2) {
+    stage(0, 0);
     __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);
+      compute(buf);
+      __syncthreads();
+    }
+  } else {
+    // tiles kt+1 and kt+2 are in flight while tile kt is consumed
+    stage(0, 0);
+    if (nkt > 1) {
+      stage(1, 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPW) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    int buf = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+      int nb2 = buf + 2;
+      if (nb2 >= 3) nb2 -= 3;
+      if (kt + 2 < nkt) stage(kt + 2, nb2);   // buffer (kt+2)%3 was last read in iteration kt-1
+      compute(buf);
+      if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPW) : "memory");   // tile kt+1 has landed
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of `buf` are done before others overwrite it
+      __builtin_amdgcn_s_barrier();
+      buf = (buf == 2) ? 0 : buf + 1;
+    }
   }
 
 #pragma unroll
@@ -360,8 +425,9 @@ __global__ void gemm_sp_naive_kernel(const GemmArgs a, const Epi epi, int g_fixe
 struct GemmCfgSel { int wi, wj, ti, tj; };
 
 extern int g_cfd_naive_gemm;  // set from CFD_NAIVE_GEMM env at cfd_create
+extern int g_cfd_gemm_cfg;    // CFD_GEMM_CFG env: force one tile configuration (tuning / A-B runs)
 
-template <int WI, int WJ, int TI, int TJ, int MODE, class Epi>
+template <int WI, int WJ, int TI, int TJ, int NSTAGE, int MODE, class Epi>
 static hipError_t launch_cfg(GemmArgs a, const Epi& epi, int nb, int nz, hipStream_t st) {
   constexpr int BI = WI * TI * 16, BJ = WJ * TJ * 16;
   a.tiles_j = (a.J + BJ - 1) / BJ;
@@ -373,19 +439,20 @@ static hipError_t launch_cfg(GemmArgs a, const Epi& epi, int nb, int nz, hipStre
     total += a.tiles_i[g] * a.tiles_j;
   }
   a.tile_start[ng] = total;
-  constexpr int lds = 2 * (BI + BJ) * 128;
+  constexpr int lds = NSTAGE * (BI + BJ) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sp_kernel<WI, WJ, TI, TJ, MODE, Epi>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sp_kernel<WI, WJ, TI, TJ, NSTAGE, MODE, Epi>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_sp_kernel<WI, WJ, TI, TJ, MODE, Epi>), dim3(total, nb, nz), dim3(256), lds, st, a, epi);
+  hipLaunchKernelGGL((gemm_sp_kernel<WI, WJ, TI, TJ, NSTAGE, MODE, Epi>), dim3(total, nb, nz), dim3(WI * WJ * 64), lds, st, a, epi);
   return hipGetLastError();
 }
 
-// cfg: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 128x16
+// cfg: 0 = auto, 1 = 128x128 (4 waves, 2-stage), 2 = 64x64, 3 = 128x16, 4 = 128x256 (8 waves, 3-stage), 5 = 128x128 3-stage,
+//      6 = 128x112 (J in (128, 224]: the 196-token attention products), 7 = 32x128 (memories of <= 64 keys)
 template <int MODE, class Epi>
 static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStream_t st, int cfg = 0) {
   if (a.nslot < 1) a.nslot = 1;
@@ -399,22 +466,27 @@ static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStr
     }
     return hipGetLastError();
   }
+  if (cfg == 0) cfg = g_cfd_gemm_cfg;
   if (cfg == 0) {
-    int imax = 0;
     const int ng = (MODE == MODE_GROUPED) ? a.nslot : 1;
     long long big_tiles = 0;
-    for (int g = 0; g < ng; ++g) {
-      imax = a.I[g] > imax ? a.I[g] : imax;
-      big_tiles += (long long)((a.I[g] + 127) / 128) * ((a.J + 127) / 128);
-    }
+    for (int g = 0; g < ng; ++g) big_tiles += (long long)((a.I[g] + 127) / 128) * ((a.J + 255) / 256);
     big_tiles *= (long long)nb * nz;
+    int imax = 0;
+    for (int g = 0; g < ng; ++g) imax = a.I[g] > imax ? a.I[g] : imax;
     if (a.J <= 16) cfg = 3;
-    else if (big_tiles >= 384 && a.J >= 96) cfg = 1;
+    else if (imax <= 64 && a.J >= 96) cfg = 7;
+    else if (a.J > 128 && a.J <= 224 && big_tiles * 2 >= 256) cfg = 6;
+    else if (big_tiles * 2 >= 384 && a.J >= 96) cfg = 1;
     else cfg = 2;
   }
   switch (cfg) {
-    case 1: return launch_cfg<2, 2, 4, 4, MODE, Epi>(a, epi, nb, nz, st);
-    case 2: return launch_cfg<2, 2, 2, 2, MODE, Epi>(a, epi, nb, nz, st);
-    default: return launch_cfg<4, 1, 2, 1, MODE, Epi>(a, epi, nb, nz, st);
+    case 1: return launch_cfg<2, 2, 4, 4, 2, MODE, Epi>(a, epi, nb, nz, st);
+    case 2: return launch_cfg<2, 2, 2, 2, 2, MODE, Epi>(a, epi, nb, nz, st);
+    case 4: return launch_cfg<2, 4, 4, 4, 3, MODE, Epi>(a, epi, nb, nz, st);
+    case 5: return launch_cfg<2, 2, 4, 4, 3, MODE, Epi>(a, epi, nb, nz, st);
+    case 6: return launch_cfg<4, 1, 2, 7, 2, MODE, Epi>(a, epi, nb, nz, st);
+    case 7: return launch_cfg<1, 4, 2, 2, 2, MODE, Epi>(a, epi, nb, nz, st);
+    default: return launch_cfg<4, 1, 2, 1, 2, MODE, Epi>(a, epi, nb, nz, st);
   }
 }

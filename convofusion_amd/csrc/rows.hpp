@@ -18,8 +18,9 @@ struct LnArgs {
   const float* ss;        // (1+scale | shift) rows of 1024 floats for THIS time block, t-row stride ss_tstride
   long long ss_tstride;
   const int* d_step;
-  int tmode;              // 0: t-row = *d_step ; 1: t-row = row / L
+  int tmode;              // 0: t-row = *d_step ; 1: t-row = trow0 + row / L
   int L;
+  int trow0;
 };
 
 __global__ void __launch_bounds__(256) ln_rows_kernel(const LnArgs a) {
@@ -47,7 +48,7 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const LnArgs a) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = v[e] * rstd * gp[e] + bp[e];
   if (a.adaln) {
-    const long long trow = a.tmode ? (row / a.L) : (long long)(*a.d_step);
+    const long long trow = a.tmode ? (a.trow0 + row / a.L) : (long long)(*a.d_step);
     const float* sc = a.ss + trow * a.ss_tstride + lane * 8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e] * sc[e] + sc[CFD_D + e]);

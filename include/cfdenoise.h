@@ -158,6 +158,8 @@ int cfd_test_gemm(cfd_handle h, const float* X, const float* Y, float* out, int 
  * 2+4l / 3+4l / 4+4l / 5+4l = layer l after self-attention / time block 1 / cross-attention / the layer),
  * and read an internal float32 buffer ("x" residual stream [M][512], "temb", "ss", "eps", "sc", "ssc"). */
 int cfd_debug_stop_stage(cfd_handle h, int stage);
+/* Micro-benchmark: average ms of `iters` launches of the [J x K] x [512 x K]^T residual GEMM (I must be 512). */
+int cfd_bench_gemm(cfd_handle h, int I, int J, int K, int tile_cfg, int iters, float* ms_out);
 int cfd_debug_read(cfd_handle h, const char* what, float* dst_dev, size_t numel);
 
 #ifdef __cplusplus

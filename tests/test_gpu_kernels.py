@@ -27,20 +27,20 @@ def _gemm(ops, X, Y, cfg):
     return out.cpu().numpy()
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7])
 def test_mfma_layout_identity(ops, cfg):
     """A = I against an ASYMMETRIC B: catches swapped row/col maps, k-permutations and swizzle bugs."""
-    I = J = 128
+    I, J = 128, 256
     K = 128
     X = np.zeros((I, K), np.float32)
     X[np.arange(I), np.arange(I) % K] = 1.0
-    Y = (np.arange(J)[:, None] * 100 + np.arange(K)[None, :] + 1).astype(np.float32)  # <= 14 bits: exact in hi+lo
+    Y = (np.arange(J)[:, None] * 50 + np.arange(K)[None, :] + 1).astype(np.float32)  # <= 14 bits: exact in hi+lo
     want = Y.astype(np.float64) @ X.astype(np.float64).T
     got = _gemm(ops, X, Y, cfg)
     np.testing.assert_array_equal(got, want.astype(np.float32))
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("shape", [(512, 300, 512), (1536, 77, 128), (36, 16, 1504), (128, 1000, 32), (4640, 130, 512)])
 def test_gemm_split_bf16_accuracy(ops, cfg, shape):
     """D = Y X^T through the 3-MFMA split path; ragged I/J edges; fp32-class accuracy."""
