@@ -179,15 +179,22 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wi = wid / WJ, wj = wid % WJ;
-  const int b = blockIdx.y, z = blockIdx.z;
-
-  // XCD-aware tile order: blocks that land on one XCD (bid % 8 equal) walk a contiguous tile range,
-  // so the tiles_i blocks that re-read one Y (activation) tile hit the same L2.
-  int t;
+  // XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs in LINEAR dispatch order
+  // (x fastest, then y, z), and each XCD has a private L2.  Blocks that land on one XCD (linear id % 8 equal)
+  // are given a contiguous range of the (batch, tile) space, so the tiles that re-read one activation tile --
+  // and, for batched launches, all tiles of one batch row -- share an L2 instead of each fetching from HBM.
+  int t, b, z;
   {
-    const int nblk = gridDim.x, bid = blockIdx.x;
-    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    const int nx = gridDim.x, ny = gridDim.y;
+    const long long total = (long long)nx * ny * gridDim.z;
+    const long long lin = blockIdx.x + (long long)nx * (blockIdx.y + (long long)ny * blockIdx.z);
+    const long long q = total >> 3, k = lin >> 3;
+    const int r = (int)(total & 7), xcd = (int)(lin & 7);
+    const long long v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    t = (int)(v % nx);
+    const long long bz = v / nx;
+    b = (int)(bz % ny);
+    z = (int)(bz / ny);
   }
   int g = 0;
   if (MODE == MODE_GROUPED) {
