@@ -1,0 +1,149 @@
+// Fused (flash-style) self-attention for the 4-head, head-dim-128 block (cross_attention.py:568-572):
+//   o[b, q, h*128:(h+1)*128] = softmax_k( q_h . k_h ) v_h          (q pre-scaled by 1/sqrt(128) in the weights)
+// One workgroup = 8 waves = 128 queries of one (batch row, head); keys are consumed in tiles of 64 with an
+// online softmax, so neither the score matrix nor the probabilities ever leave the chip.
+//
+// MFMA orientation (v_mfma_f32_16x16x32, split-pair operands, 3 MFMAs per product):
+//   S^T[key][q] = sum_d K[key][d] Q[q][d]      K tile from LDS (A operand), Q fragments in registers (B operand)
+//   O^T[f][q]  += sum_key V^T[f][key] P[q][key] V^T tile from LDS (A operand), P straight from the S accumulators
+// A lane (q = lane&15, g = lane>>4) ends the first product holding S[q][16t + 4g + r] (t, r = 0..3).  Feeding those
+// registers as the B operand of the second product means k-slot (8g + e) of 32-key step s is key
+// 32s + 16(e>>2) + 4g + (e&3): the V^T tile must list its keys in that order, which the V^T GEMM's epilogue
+// produces for free (EpiSplit::perm32) -- no transpose, no LDS round trip for P.
+#pragma once
+#include "cfd_common.hpp"
+
+struct SelfAttnArgs {
+  const char* qk;   // SP [M][1024]: q at columns h*128.., k at columns 512 + h*128..
+  const char* vts;  // SP [Be][512][Lv]: V^T per batch row, keys permuted inside every 32-block, Lv = roundup(L, 64)
+  char* o;          // SP [M][512]
+  int L, Lv;
+};
+
+#define SELF_ATTN_WAVES 8
+__global__ void __launch_bounds__(SELF_ATTN_WAVES * 64, 4) self_attn_fused_kernel(const SelfAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // K tile 32 KB | V^T tile 32 KB
+  constexpr int KOFF = 0, VOFF = 32768;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, q4 = lane >> 4, sw = l15 >> 1;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q = blockIdx.x * (SELF_ATTN_WAVES * 16) + wid * 16 + l15;
+  const bool qvalid = q < a.L;
+  const int qc = qvalid ? q : a.L - 1;
+  const long long ROW = 4096;  // bytes per qk row (1024 columns)
+
+  // Q fragments (B operand): lane holds d = 32*ks + 8*q4 .. +7 of its query
+  bf16x8 qh[4], ql[4];
+  {
+    const char* qp = a.qk + ((long long)b * a.L + qc) * ROW + (long long)(h * 4) * 128 + q4 * 16;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qh[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 128);
+      ql[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 128 + 64);
+    }
+  }
+  f32x4 o[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) o[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, lsum = 0.f;
+
+  const int cpos = lane & 7, rsub = lane >> 3;
+  const int nkv = (a.L + 63) / 64;
+  for (int kt = 0; kt < nkv; ++kt) {
+    __syncthreads();   // previous tile fully consumed
+    // K tile: 4 k-steps x 64 keys x 128 B ; group g = ks*8 + rg covers rows rg*8..rg*8+7 of k-step ks
+#pragma unroll
+    for (int n = 0; n < 32 / SELF_ATTN_WAVES; ++n) {
+      const int g = wid + SELF_ATTN_WAVES * n, ks = g >> 3, rg = g & 7;
+      const int r = rg * 8 + rsub;
+      const int key = min(kt * 64 + r, a.L - 1);
+      const char* src = a.qk + ((long long)b * a.L + key) * ROW + (long long)(16 + h * 4 + ks) * 128 + ((cpos ^ ((r >> 1) & 7)) << 4);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + KOFF + ks * 8192 + rg * 1024), 16, 0, 0);
+    }
+    // V^T tile: 2 k-steps x 128 features x 128 B
+#pragma unroll
+    for (int n = 0; n < 32 / SELF_ATTN_WAVES; ++n) {
+      const int g = wid + SELF_ATTN_WAVES * n, ks = g >> 4, rg = g & 15;
+      const int r = rg * 8 + rsub;
+      const char* src = a.vts + ((long long)b * CFD_D + h * 128 + r) * ((long long)a.Lv * 4) + (long long)(kt * 2 + ks) * 128 +
+                        ((cpos ^ ((r >> 1) & 7)) << 4);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + VOFF + ks * 16384 + rg * 1024), 16, 0, 0);
+    }
+    __syncthreads();
+
+    // S^T tile: 64 keys x 16 queries per wave
+    f32x4 s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const char* kp = smem + KOFF + ks * 8192 + (t * 16 + l15) * 128;
+        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(kp + ((q4 ^ sw) << 4));
+        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(kp + (((4 + q4) ^ sw) << 4));
+        s[t] = SP_MFMA(xl, qh[ks], s[t], 0, 0, 0);
+        s[t] = SP_MFMA(xh, ql[ks], s[t], 0, 0, 0);
+        s[t] = SP_MFMA(xh, qh[ks], s[t], 0, 0, 0);
+      }
+    }
+    // mask the padding keys, online softmax over this tile (a query's 64 scores live in 4 lanes x 16 registers)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 64 + 16 * t + 4 * q4 + r;
+        if (key >= a.L) s[t][r] = -INFINITY;
+        mx = fmaxf(mx, s[t][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx);
+    const float scale = __expf(m - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[t][r] = __expf(s[t][r] - m_new);
+        ps += s[t][r];
+      }
+    ps += __shfl_xor(ps, 16, 64);
+    ps += __shfl_xor(ps, 32, 64);
+    lsum = lsum * scale + ps;
+    m = m_new;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) { o[f][0] *= scale; o[f][1] *= scale; o[f][2] *= scale; o[f][3] *= scale; }
+
+    // O^T += V^T P^T : P fragments come straight out of the S registers (k-slot order matches perm32)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 ph, pl;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sp_t hi, lo;
+        split_f32(s[2 * s2 + (e >> 2)][e & 3], hi, lo);
+        ph[e] = hi;
+        pl[e] = lo;
+      }
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const char* vp = smem + VOFF + s2 * 16384 + (f * 16 + l15) * 128;
+        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(vp + ((q4 ^ sw) << 4));
+        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(vp + (((4 + q4) ^ sw) << 4));
+        o[f] = SP_MFMA(xl, ph, o[f], 0, 0, 0);
+        o[f] = SP_MFMA(xh, pl, o[f], 0, 0, 0);
+        o[f] = SP_MFMA(xh, ph, o[f], 0, 0, 0);
+      }
+    }
+  }
+  if (qvalid) {
+    const float inv = 1.0f / lsum;
+    char* orow = a.o + ((long long)b * a.L + q) * (CFD_D * 4);
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+      sp_store4(orow, h * 128 + f * 16 + q4 * 4, o[f][0] * inv, o[f][1] * inv, o[f][2] * inv, o[f][3] * inv);
+  }
+}

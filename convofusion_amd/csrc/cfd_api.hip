@@ -14,6 +14,7 @@
 #include "../../include/cfdenoise.h"
 #include "gemm_sp.hpp"
 #include "rows.hpp"
+#include "attn_fused.hpp"
 
 int g_cfd_naive_gemm = 0;
 int g_cfd_gemm_cfg = 0;
@@ -95,6 +96,7 @@ struct cfd_handle_s {
   DBuf n_sp[CFD_NMEM], kall_sp[CFD_NMEM], cb[CFD_NMEM], vt_all[CFD_NMEM];
   DBuf temb_tab, h1_tab, ss_tab, trows, iota;
   int nchunks_env = 0;
+  bool fused_self = true;   // CFD_FUSED_SELF=0 selects the GEMM -> softmax -> GEMM self-attention
   DBuf d_step;  // [0] = loop index, [1] = constant 0
   Problem pb;
   // profiling
@@ -187,6 +189,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   c->lw.resize(c->nl);
   const char* env = getenv("CFD_NAIVE_GEMM");
   g_cfd_naive_gemm = (env && atoi(env) != 0) ? 1 : 0;
+  env = getenv("CFD_FUSED_SELF");
+  c->fused_self = !(env && atoi(env) == 0);
   env = getenv("CFD_CHUNKS");
   c->nchunks_env = env ? atoi(env) : 0;
   env = getenv("CFD_GEMM_CFG");
@@ -457,7 +461,7 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
   CHK(c->x.ensure((size_t)M * CFD_D * 4));
   CHK(c->h_sp.ensure((size_t)M * CFD_D * 4));
   CHK(c->qk_sp.ensure((size_t)M * 2 * CFD_D * 4));
-  CHK(c->vts_sp.ensure((size_t)Be * CFD_D * p.Lp * 4));
+  CHK(c->vts_sp.ensure((size_t)Be * CFD_D * ((L + 63) / 64 * 64) * 4));
   CHK(c->ssc.ensure((size_t)Be * CFD_NHEAD * L * p.Lp * 4));
   CHK(c->sp_sp.ensure((size_t)Be * CFD_NHEAD * L * p.Lp * 4));
   CHK(c->o_sp.ensure((size_t)M * CFD_D * 4));
@@ -539,7 +543,7 @@ static int enqueue_memside(Ctx* c, hipStream_t st) {
       GemmArgs a = gemm_args();
       a.X[0] = c->n_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = rows; a.Iclamp[0] = rows; a.kt[0] = CFD_D / 32;
       a.Y = c->wv_all_sp[j].as<char>(); a.ldy = ROWB; a.J = nl * CFD_D; a.Jclamp = nl * CFD_D;
-      EpiSplit e{c->vt_all[j].as<char>(), (long long)rows * 4, 0, 0, nullptr, 0};
+      EpiSplit e{c->vt_all[j].as<char>(), (long long)rows * 4, 0, 0, nullptr, 0, 0};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }
   }
@@ -615,16 +619,29 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       GemmArgs a = gemm_args();
       a.X[0] = w.wqk_sp.as<char>(); a.ldx[0] = ROWB; a.I[0] = 2 * CFD_D; a.Iclamp[0] = 2 * CFD_D; a.kt[0] = CFD_D / 32;
       a.Y = c->h_sp.as<char>(); a.ldy = ROWB; a.J = (int)M; a.Jclamp = (int)M;
-      EpiSplit e{c->qk_sp.as<char>(), 2 * ROWB, 0, 0, w.bqk.as<float>(), 0};
+      EpiSplit e{c->qk_sp.as<char>(), 2 * ROWB, 0, 0, w.bqk.as<float>(), 0, 0};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
     }
-    {  // v^T per batch row: vts[b][f][l]
+    const bool fused_self = c->fused_self;
+    const int Lv = fused_self ? (L + 63) / 64 * 64 : Lp;
+    {  // v^T per batch row: vts[b][f][l] (keys in P-fragment order for the fused kernel)
       GemmArgs a = gemm_args();
-      a.X[0] = c->h_sp.as<char>(); a.ldx[0] = ROWB; a.xbs[0] = (long long)L * ROWB; a.I[0] = Lp; a.Iclamp[0] = L; a.kt[0] = CFD_D / 32;
+      a.X[0] = c->h_sp.as<char>(); a.ldx[0] = ROWB; a.xbs[0] = (long long)L * ROWB; a.I[0] = Lv; a.Iclamp[0] = L; a.kt[0] = CFD_D / 32;
       a.Y = w.wv_sp.as<char>(); a.ldy = ROWB; a.J = CFD_D; a.Jclamp = CFD_D;
-      EpiSplit e{c->vts_sp.as<char>(), (long long)Lp * 4, (long long)CFD_D * Lp * 4, 0, nullptr, 0};
+      EpiSplit e{c->vts_sp.as<char>(), (long long)Lv * 4, (long long)CFD_D * Lv * 4, 0, nullptr, 0, fused_self ? 1 : 0};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, Be, 1, st)));
     }
+    if (fused_self) {
+      SelfAttnArgs a{c->qk_sp.as<char>(), c->vts_sp.as<char>(), c->o_sp.as<char>(), L, Lv};
+      static bool attr = false;
+      if (!attr) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        attr = true;
+      }
+      Bracket br(c, CFD_PROF_GEMM_ATTN, st);
+      hipLaunchKernelGGL(self_attn_fused_kernel, dim3((L + SELF_ATTN_WAVES * 16 - 1) / (SELF_ATTN_WAVES * 16), CFD_NHEAD, Be), dim3(SELF_ATTN_WAVES * 64), 65536, st, a);
+      HIPCHK(hipGetLastError());
+    } else {
     {  // scores[b][h][lq][lk]
       GemmArgs a = gemm_args();
       a.X[0] = c->qk_sp.as<char>() + (CFD_D / 32) * 128; a.ldx[0] = 2 * ROWB; a.xbs[0] = (long long)L * 2 * ROWB; a.xzs = (CFD_HD / 32) * 128;
@@ -648,8 +665,9 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       a.I[0] = CFD_HD; a.Iclamp[0] = CFD_HD; a.kt[0] = Lp / 32;
       a.Y = c->sp_sp.as<char>(); a.ldy = (long long)Lp * 4; a.ybs = (long long)CFD_NHEAD * L * Lp * 4; a.yzs = (long long)L * Lp * 4;
       a.J = L; a.Jclamp = L;
-      EpiSplit e{c->o_sp.as<char>(), ROWB, (long long)L * ROWB, (CFD_HD / 32) * 128, nullptr, 0};
+      EpiSplit e{c->o_sp.as<char>(), ROWB, (long long)L * ROWB, (CFD_HD / 32) * 128, nullptr, 0, 0};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_ATTN, a, e, Be, CFD_NHEAD, st)));
+    }
     }
     CHK(token_gemm_resid(w.wo_sp, CFD_D, c->o_sp.as<char>(), w.bo2.as<float>()));
     if (c->stop_stage == 2 + 4 * l) return CFD_OK;
@@ -714,7 +732,7 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       GemmArgs a = gemm_args();
       a.X[0] = w.w1_sp.as<char>(); a.ldx[0] = ROWB; a.I[0] = CFD_FF; a.Iclamp[0] = CFD_FF; a.kt[0] = CFD_D / 32;
       a.Y = c->h_sp.as<char>(); a.ldy = ROWB; a.J = (int)M; a.Jclamp = (int)M;
-      EpiSplit e{c->u_sp.as<char>(), (long long)CFD_FF * 4, 0, 0, w.b1, 1};
+      EpiSplit e{c->u_sp.as<char>(), (long long)CFD_FF * 4, 0, 0, w.b1, 1, 0};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
     }
     CHK(token_gemm_resid(w.w2_sp, CFD_FF, c->u_sp.as<char>(), w.b2));

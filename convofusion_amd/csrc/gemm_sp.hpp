@@ -19,6 +19,8 @@
 //   MODE_SEGK    one problem whose K range is the concatenation of up to 5 X segments (cross-attention
 //                P.V over the 5 memories, accumulated in registers)
 #pragma once
+#include <type_traits>
+
 #include "cfd_common.hpp"
 
 #ifndef CFD_EXP
@@ -66,19 +68,20 @@ struct EpiF32 {  // out_f32[j][goff+i] = v (+ bias[i] | + key-bias of group g)
   const float* gbias[GEMM_SLOTS];
   const int* gmap[GEMM_SLOTS];
   long long gstride[GEMM_SLOTS];
-  __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
-    float* p = out + (long long)b * obs + (long long)z * ozs + (long long)j * ldo + sel5(goff, g) + i;
+  static constexpr bool kPrefetch = true;   // operands of the epilogue are loaded before the K loop (see kernel)
+  typedef float4 Pre;
+  __device__ __forceinline__ Pre prefetch(int g, int b, int z, int i, int j) const {
     const float* bb = nullptr;
     const float* gb = sel5(gbias, g);
     if (gb) {
       const int* gm = sel5(gmap, g);
       bb = gb + (long long)(gm ? gm[b] : b) * sel5(gstride, g) + i;
     } else if (bias) bb = bias + i;
-    if (bb) {
-      const float4 t = *reinterpret_cast<const float4*>(bb);
-      v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-    }
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    return bb ? *reinterpret_cast<const float4*>(bb) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v, const Pre& t) const {
+    float* p = out + (long long)b * obs + (long long)z * ozs + (long long)j * ldo + sel5(goff, g) + i;
+    *reinterpret_cast<float4*>(p) = make_float4(v[0] + t.x, v[1] + t.y, v[2] + t.z, v[3] + t.w);
   }
 };
 
@@ -87,13 +90,16 @@ struct EpiSplit {  // out_sp[j][coloff + i] = split(act(v + bias[i]))
   long long ldo, obs, ozs;  // bytes
   const float* bias;
   int gelu;
+  int perm32;  // store column 32S+16h+4q+r at position 32S+8q+4h+r (k-slot order of attn_fused.hpp's P fragments)
+  static constexpr bool kPrefetch = false;
   __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
     if (bias) {
       const float4 t = *reinterpret_cast<const float4*>(bias + i);
       v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
     }
     if (gelu) { v[0] = gelu_f(v[0]); v[1] = gelu_f(v[1]); v[2] = gelu_f(v[2]); v[3] = gelu_f(v[3]); }
-    sp_store4(out + (long long)b * obs + (long long)z * ozs + (long long)j * ldo, i, v[0], v[1], v[2], v[3]);
+    const int col = perm32 ? ((i & ~31) | (((i >> 2) & 3) << 3) | (((i >> 4) & 1) << 2)) : i;
+    sp_store4(out + (long long)b * obs + (long long)z * ozs + (long long)j * ldo, col, v[0], v[1], v[2], v[3]);
   }
 };
 
@@ -101,6 +107,9 @@ struct EpiResid {  // x[(b*rows_per_b + j)][i] += v + bias[i]   (row length CFD_
   float* x;
   long long obs;  // floats per batch
   const float* bias;
+  // (Reading the residual rows before the K loop was tried: +46 VGPRs and no gain -- 92 vs 86 us on the
+  //  43904x512x512 product; the epilogue is bandwidth-, not latency-limited.)
+  static constexpr bool kPrefetch = false;
   __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
     float* p = x + (long long)b * obs + (long long)j * CFD_D + i;
     float4 r = *reinterpret_cast<const float4*>(p);
@@ -114,6 +123,7 @@ struct EpiResid {  // x[(b*rows_per_b + j)][i] += v + bias[i]   (row length CFD_
 };
 
 struct EpiNull {  // timing experiments only: keeps the accumulators live, stores nothing
+  static constexpr bool kPrefetch = false;
   float* sink;
   __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
     asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
@@ -127,6 +137,7 @@ struct EpiEmbed {  // x0[j][i] = v + bias[i] + bh[(l&1)][i] + qpe[(l>>1)][i],  l
   const float* bh;   // [2][512]
   const float* qpe;  // [>=L/2][512]
   int L;
+  static constexpr bool kPrefetch = false;
   __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
     const int l = j % L;
     const float4 t0 = *reinterpret_cast<const float4*>(bias + i);
@@ -148,6 +159,7 @@ struct EpiMemK {  // i < nfeat: k_all_sp[j][i] = split(v);  nfeat <= i < nfeat+n
   float* cbias;
   long long rows;  // cbias row length (= number of memory rows J)
   int nfeat, nl;
+  static constexpr bool kPrefetch = false;
   __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
     if (i < nfeat) {
       sp_store4(kall + (long long)j * ldk, i, v[0], v[1], v[2], v[3]);
@@ -158,6 +170,9 @@ struct EpiMemK {  // i < nfeat: k_all_sp[j][i] = split(v);  nfeat <= i < nfeat+n
     }
   }
 };
+
+template <class E, bool P = E::kPrefetch> struct EpiPre { struct type {}; };
+template <class E> struct EpiPre<E, true> { typedef typename E::Pre type; };
 
 // ------------------------------------------------------------------------------------------------
 // NSTAGE == 2: one k-tile of prefetch, __syncthreads() per k-step (small / ragged tile configs).
@@ -316,6 +331,20 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // epilogue operands (residual rows / bias vectors) are requested now and consumed after the K loop
+  struct NoPre {};
+  typename std::conditional<Epi::kPrefetch, typename EpiPre<Epi>::type, NoPre>::type pre[TI][TJ];
+  if constexpr (Epi::kPrefetch) {
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        const int i = min(i0 + (wi * TI + ti) * 16 + q4 * 4, Ig - 4);
+        const int j = min(j0 + (wj * TJ + tj) * 16 + l15, a.J - 1);
+        pre[ti][tj] = epi.prefetch(g, b, z, i, j);
+      }
+  }
+
   auto compute = [&](int buf) __attribute__((always_inline)) {
     const char* sb = smem + buf * STAGE;
     bf16x8 xh[TI], xl[TI], yh[TJ], yl[TJ];
@@ -388,7 +417,10 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
     for (int tj = 0; tj < TJ; ++tj) {
       const int i = i0 + (wi * TI + ti) * 16 + q4 * 4;
       const int j = j0 + (wj * TJ + tj) * 16 + l15;
-      if (i < Ig && j < a.J) epi(g, b, z, i, j, acc[ti][tj]);
+      if (i < Ig && j < a.J) {
+        if constexpr (Epi::kPrefetch) epi(g, b, z, i, j, acc[ti][tj], pre[ti][tj]);
+        else epi(g, b, z, i, j, acc[ti][tj]);
+      }
     }
 }
 
@@ -423,7 +455,8 @@ __global__ void gemm_sp_naive_kernel(const GemmArgs a, const Epi epi, int g_fixe
     }
     kbase += a.kt[s] * 32;
   }
-  epi(g, b, z, i, j, f32x4{acc[0], acc[1], acc[2], acc[3]});
+  if constexpr (Epi::kPrefetch) epi(g, b, z, i, j, f32x4{acc[0], acc[1], acc[2], acc[3]}, epi.prefetch(g, b, z, i, j));
+  else epi(g, b, z, i, j, f32x4{acc[0], acc[1], acc[2], acc[3]});
 }
 
 // ------------------------------------------------------------------------------------------------
