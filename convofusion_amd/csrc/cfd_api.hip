@@ -856,7 +856,9 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
   hipStream_t st = (hipStream_t)stream;
   c->sargs = s;
   c->run_stream = st;
-  const int Be = s.G * s.B, N = s.num_inference_steps, T = s.num_train_timesteps;
+  if (s.skip_zero_weight_chunks)   // chunk-major batch: dropping trailing chunks = using the first G' * B rows
+    while (c->sargs.G > 1 && s.guidance_weight[c->sargs.G - 1] == 0.0f) c->sargs.G -= 1;
+  const int Be = c->sargs.G * s.B, N = s.num_inference_steps, T = s.num_train_timesteps;
   CHK(setup_problem(c, Be, s.L, s.mem, nullptr, 0, N));
   // timesteps: (arange(N) * (T // N)).round()[::-1] (+ steps_offset for DDIM)
   std::vector<int32_t> ts(N);

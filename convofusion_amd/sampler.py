@@ -62,7 +62,7 @@ class SamplingRun:
 
     def __init__(self, denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
                  guidance_scale=7.5, guidance_chunks=CFG_CHUNKS, eta=0.0, init_latents=None, step_noise=None,
-                 seed=0, first_utterance=0, preseq=None, dedup=True):
+                 seed=0, first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False):
         if not isinstance(denoiser, Denoiser):
             raise TypeError("denoiser must be a convofusion_amd.denoiser.Denoiser")
         dev = encoder_hidden_states[0].device
@@ -119,6 +119,10 @@ class SamplingRun:
         a.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         a.first_utterance = int(first_utterance)
         a.mem = marr
+        # the full-conditioning chunk enters the combine with weight guidance_scale * 0 (convofusion.py:538):
+        # optionally do not evaluate it (identical latents, 1/7 less work; the reference needs it only for
+        # the per-step attention maps it logs)
+        a.skip_zero_weight_chunks = 1 if skip_zero_weight_chunks else 0
         self._args = a
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
@@ -162,10 +166,11 @@ class SamplingRun:
 
 def sample(denoiser, scheduler, encoder_hidden_states, cond_masks=None, *, B, L=16, num_inference_steps=1000,
            guidance_scale=7.5, guidance_chunks=CFG_CHUNKS, eta=0.0, init_latents=None, step_noise=None, seed=0,
-           first_utterance=0, preseq=None, dedup=True):
+           first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False):
     """Run the whole loop; returns latents [B, L, 128] (batch-first)."""
     run = SamplingRun(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
-                      guidance_scale, guidance_chunks, eta, init_latents, step_noise, seed, first_utterance, preseq, dedup)
+                      guidance_scale, guidance_chunks, eta, init_latents, step_noise, seed, first_utterance, preseq, dedup,
+                      skip_zero_weight_chunks)
     run.steps(num_inference_steps)
     return run.read(close=True)
 

@@ -111,6 +111,10 @@ typedef struct {
   const float* preseq;        /* dev [B][preseq_len][128] previous-window latents to in-paint, or NULL */
   int preseq_len;
   cfd_memory mem[CFD_NUM_MEM];/* Be = G*B rows */
+  int skip_zero_weight_chunks;/* != 0: trailing guidance chunks whose weight is exactly 0 are not evaluated.  The
+                                 reference computes the full-conditioning chunk and multiplies it by
+                                 guidance_scale * 0 (convofusion.py:538); its forward only feeds the per-step
+                                 attention maps, which the fused loop does not keep.  Results are identical. */
 } cfd_sample_args;
 
 /* Opens a sampling run: builds the per-step coefficient and timestep-embedding tables, draws / copies

@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     # natural C layout of the header's structs on x86-64
     assert C.sizeof(_lib.Config) == 24
     assert C.sizeof(_lib.Memory) == 32
-    assert _lib.SampleArgs.mem.offset % 8 == 0 and C.sizeof(_lib.SampleArgs) == _lib.SampleArgs.mem.offset + 5 * 32
+    assert _lib.SampleArgs.mem.offset % 8 == 0 and C.sizeof(_lib.SampleArgs) == _lib.SampleArgs.mem.offset + 5 * 32 + 8
 
 
 def test_denoiser_mirror_state_dict_and_validation():

@@ -65,6 +65,21 @@ def test_dedup_is_exact():
     assert torch.equal(a, b)
 
 
+def test_skipping_the_zero_weight_chunk_is_exact():
+    """The full-conditioning chunk has guidance weight 7.5 * 0: not evaluating it must not change a bit."""
+    import torch
+    from convofusion_amd.sampler import sample
+    from tests.gpu_helpers import hip_denoiser, to_dev
+    B, L, S = 3, 16, (24, 161, 24, 8, 1)
+    cb = inputs.make_cfg_batch(seed=6, B=B, L=L, S=S, pad_tail=(4, 0, 6, 0, 0))
+    m = hip_denoiser(1234, 1.0)
+    mems = [to_dev(x) for x in cb["memories"]]
+    masks = {k: to_dev(v) for k, v in cb["masks"].items()}
+    a = sample(m, _sched("ddpm"), mems, masks, B=B, L=L, num_inference_steps=4, seed=11)
+    b = sample(m, _sched("ddpm"), mems, masks, B=B, L=L, num_inference_steps=4, seed=11, skip_zero_weight_chunks=True)
+    assert torch.equal(a, b)
+
+
 def test_device_rng_stream_matches_oracle():
     """No injected noise: the on-device Philox stream (init latents + per-step noise) is reproduced by the
     oracle's restatement, so the whole loop can be checked end-to-end against the oracle."""
