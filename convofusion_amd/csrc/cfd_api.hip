@@ -536,14 +536,14 @@ static int enqueue_memside(Ctx* c, hipStream_t st) {
       GemmArgs a = gemm_args();
       a.X[0] = c->wk_all_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = nl * CFD_D + 32; a.Iclamp[0] = nl * CFD_D + 32; a.kt[0] = CFD_D / 32;
       a.Y = c->n_sp[j].as<char>(); a.ldy = ROWB; a.J = rows; a.Jclamp = rows;
-      EpiMemK e{c->kall_sp[j].as<char>(), (long long)nl * CFD_D * 4, c->cb[j].as<float>(), (long long)rows, nl * CFD_D, nl};
+      EpiMemK e{c->kall_sp[j].as<char>(), (long long)rows, c->cb[j].as<float>(), nl * CFD_D, nl};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }
     {
       GemmArgs a = gemm_args();
       a.X[0] = c->n_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = rows; a.Iclamp[0] = rows; a.kt[0] = CFD_D / 32;
       a.Y = c->wv_all_sp[j].as<char>(); a.ldy = ROWB; a.J = nl * CFD_D; a.Jclamp = nl * CFD_D;
-      EpiSplit e{c->vt_all[j].as<char>(), (long long)rows * 4, 0, 0, nullptr, 0, 0};
+      EpiMemV e{c->vt_all[j].as<char>(), p.Sp[j], p.U[j]};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }
   }
@@ -686,8 +686,8 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       int n = 0;
       for (int j = 0; j < CFD_NMEM; ++j) {
         if ((p.Sp[j] <= 64) != (pass == 1)) continue;
-        a.X[n] = c->kall_sp[j].as<char>() + (size_t)l * (CFD_D / 32) * 128; a.ldx[n] = (long long)nl * ROWB;
-        a.xbs[n] = (long long)p.Sp[j] * nl * ROWB; a.xmap[n] = mapj[j];
+        a.X[n] = c->kall_sp[j].as<char>() + (size_t)l * p.U[j] * p.Sp[j] * ROWB; a.ldx[n] = ROWB;
+        a.xbs[n] = (long long)p.Sp[j] * ROWB; a.xmap[n] = mapj[j];
         a.I[n] = p.Sp[j]; a.Iclamp[n] = p.Sp[j]; a.kt[n] = CFD_D / 32;
         e.goff[n] = p.off[j]; e.gbias[n] = c->cb[j].as<float>() + (size_t)l * p.U[j] * p.Sp[j]; e.gmap[n] = mapj[j]; e.gstride[n] = p.Sp[j];
         ++n;
@@ -713,8 +713,8 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       a.nslot = CFD_NMEM;
       for (int j = 0; j < CFD_NMEM; ++j) {
         const long long rows = (long long)p.U[j] * p.Sp[j];
-        a.X[j] = c->vt_all[j].as<char>() + (size_t)l * CFD_D * rows * 4; a.ldx[j] = rows * 4;
-        a.xbs[j] = (long long)(p.Sp[j] / 32) * 128; a.xmap[j] = mapj[j];
+        a.X[j] = c->vt_all[j].as<char>() + (size_t)l * p.U[j] * CFD_D * p.Sp[j] * 4; a.ldx[j] = (long long)p.Sp[j] * 4;
+        a.xbs[j] = (long long)CFD_D * p.Sp[j] * 4; a.xmap[j] = mapj[j];
         a.kt[j] = p.Sp[j] / 32;
         a.I[j] = CFD_D; a.Iclamp[j] = CFD_D;
       }
@@ -1075,6 +1075,10 @@ extern "C" int cfd_bench_gemm(cfd_handle c, int I, int J, int K, int tile_cfg, i
   hipLaunchKernelGGL(philox_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, xf.as<float>(), 1, I * K, 1ull, 0u, 0u, 3u, 0.05f);
   n = (long long)J * K / 4;
   hipLaunchKernelGGL(philox_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, yf.as<float>(), 1, (int)((long long)J * K), 2ull, 0u, 0u, 3u, 1.0f);
+  if (getenv("CFD_BENCH_ZERO")) {   // power/clock probe: all-zero operands
+    HIPCHK(hipMemset(xf.p, 0, (size_t)I * K * 4));
+    HIPCHK(hipMemset(yf.p, 0, (size_t)J * K * 4));
+  }
   n = (long long)I * (K / 8);
   hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, xf.as<float>(), xs.as<char>(), (long long)I, K, (long long)K, (long long)K * 4);
   n = (long long)J * (K / 8);

@@ -26,6 +26,8 @@
 #ifndef CFD_EXP
 #define CFD_EXP 0
 #endif
+// s_waitcnt immediate (gfx9 encoding): vmcnt = N (bits 3:0 and 15:14), expcnt = 7 (no wait), lgkmcnt = 0
+#define WAIT_VM_LGKM0(N) ((((N) & 15) | 0x70 | ((((N) >> 4) & 3) << 14)))
 #define GEMM_SLOTS 5
 enum { MODE_PLAIN = 0, MODE_GROUPED = 1, MODE_SEGK = 2 };
 
@@ -153,21 +155,33 @@ struct EpiEmbed {  // x0[j][i] = v + bias[i] + bh[(l&1)][i] + qpe[(l>>1)][i],  l
   }
 };
 
-struct EpiMemK {  // i < nfeat: k_all_sp[j][i] = split(v);  nfeat <= i < nfeat+nl: cbias[i-nfeat][j] = v
+struct EpiMemK {  // i < nfeat: K_layer[i/512][j][i%512] = split(v)  (one contiguous [rows][512] SP matrix per layer);
+                  // nfeat <= i < nfeat+nl: cbias[i-nfeat][j] = v
   char* kall;
-  long long ldk;  // bytes
+  long long rows;  // memory rows J (= cbias row length)
   float* cbias;
-  long long rows;  // cbias row length (= number of memory rows J)
   int nfeat, nl;
   static constexpr bool kPrefetch = false;
   __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
     if (i < nfeat) {
-      sp_store4(kall + (long long)j * ldk, i, v[0], v[1], v[2], v[3]);
+      const int layer = i >> 9, o = i & (CFD_D - 1);
+      sp_store4(kall + ((long long)layer * rows + j) * (CFD_D * 4), o, v[0], v[1], v[2], v[3]);
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (i - nfeat + e < nl) cbias[(long long)(i - nfeat + e) * rows + j] = v[e];
     }
+  }
+};
+
+struct EpiMemV {  // V^T_layer_u[j/512][i/Sp][j%512][i%Sp] = split(v): one contiguous [512][Sp] SP block per (layer, memory)
+  char* vt;
+  int Sp, U;
+  static constexpr bool kPrefetch = false;
+  __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
+    const int layer = j >> 9, f = j & (CFD_D - 1);
+    const int u = i / Sp, s = i - u * Sp;
+    sp_store4(vt + (((long long)layer * U + u) * CFD_D + f) * ((long long)Sp * 4), s, v[0], v[1], v[2], v[3]);
   }
 };
 
@@ -180,7 +194,7 @@ template <class E> struct EpiPre<E, true> { typedef typename E::Pre type; };
 //              s_waitcnt vmcnt(GPW) + raw s_barrier (a __syncthreads() would drain the LDS-DMA queue).
 //              Requires every wave to issue exactly GPW loads per stage.
 template <int WI, int WJ, int TI, int TJ, int NSTAGE, int MODE, class Epi>
-__global__ void __launch_bounds__(WI * WJ * 64, (WI * WJ * 64) / 256 * ((WI * TI + WJ * TJ) * 16 * 128 * NSTAGE > 80 * 1024 ? 1 : 2))
+__global__ void __launch_bounds__(WI * WJ * 64, (WI * WJ * 64) / 256 * ((WI * TI + WJ * TJ) * 16 * 128 * (NSTAGE == 4 ? 3 : NSTAGE) > 80 * 1024 ? 1 : (NSTAGE == 1 ? 3 : 2)))
 gemm_sp_kernel(const GemmArgs a, const Epi epi) {
   constexpr int NW = WI * WJ;
   constexpr int BI = WI * TI * 16, BJ = WJ * TJ * 16;
@@ -194,6 +208,18 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wi = wid / WJ, wj = wid % WJ;
+#if CFD_EXP == 5 || CFD_EXP == 6
+  {  // experiment: de-phase the co-resident workgroups of a CU (odd wave slots start ~3 us late)
+    const unsigned hwid = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
+    if (hwid & 1) {
+#if CFD_EXP == 5
+      __builtin_amdgcn_s_sleep(100);
+#else
+      __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
+#endif
+    }
+  }
+#endif
   // XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs in LINEAR dispatch order
   // (x fastest, then y, z), and each XCD has a private L2.  Blocks that land on one XCD (linear id % 8 equal)
   // are given a contiguous range of the (batch, tile) space, so the tiles that re-read one activation tile --
@@ -378,7 +404,16 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
 #endif
   };
 
-  if (NSTAGE == 2) {
+  if constexpr (NSTAGE == 1) {
+    // single LDS buffer: no intra-block overlap at all, but only 32 KB per 128x128 block, so 3-4 blocks share a
+    // CU and cover each other's load / epilogue phases
+    for (int kt = 0; kt < nkt; ++kt) {
+      stage(kt, 0);
+      __syncthreads();
+      compute(0);
+      __syncthreads();
+    }
+  } else if constexpr (NSTAGE == 2) {
     stage(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
@@ -387,7 +422,7 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
       compute(buf);
       __syncthreads();
     }
-  } else {
+  } else if constexpr (NSTAGE == 3) {
     // tiles kt+1 and kt+2 are in flight while tile kt is consumed
     stage(0, 0);
     if (nkt > 1) {
@@ -408,6 +443,79 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of `buf` are done before others overwrite it
       __builtin_amdgcn_s_barrier();
       buf = (buf == 2) ? 0 : buf + 1;
+    }
+  } else {
+    // NSTAGE == 4 ("software-pipelined"): 3 LDS buffers + register double-buffered fragments.
+    // While the MFMAs of tile kt run on one register set, the LDS reads of tile kt+1 fill the other set and the
+    // LDS-DMA of tiles kt+2 / kt+3 is in flight; one barrier per k-step.  Two waves that share a SIMD run in
+    // lock-step (they alternate on the matrix pipe), so without this their LDS-read phases coincide and the
+    // pipe idles ~40 % (measured: MFMA + LDS reads alone reach only 54 % of the 16-cycle issue rate).
+    struct Frags { bf16x8 xh[TI], xl[TI], yh[TJ], yl[TJ]; };
+    auto load_frags = [&](Frags& f, int buf) __attribute__((always_inline)) {
+      const char* sb = smem + buf * STAGE;
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) {
+        f.xh[ti] = *reinterpret_cast<const bf16x8*>(sb + xoff_h + ti * 2048);
+        f.xl[ti] = *reinterpret_cast<const bf16x8*>(sb + xoff_l + ti * 2048);
+      }
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        f.yh[tj] = *reinterpret_cast<const bf16x8*>(sb + yoff_h + tj * 2048);
+        f.yl[tj] = *reinterpret_cast<const bf16x8*>(sb + yoff_l + tj * 2048);
+      }
+    };
+    auto mfma_all = [&](const Frags& f) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) {
+          acc[ti][tj] = SP_MFMA(f.xl[ti], f.yh[tj], acc[ti][tj], 0, 0, 0);
+          acc[ti][tj] = SP_MFMA(f.xh[ti], f.yl[tj], acc[ti][tj], 0, 0, 0);
+          acc[ti][tj] = SP_MFMA(f.xh[ti], f.yh[tj], acc[ti][tj], 0, 0, 0);
+        }
+    };
+    // one k-step: `cur` holds tile kt (reads issued one step ago), `nxt` receives tile kt+1 (LAST = no next tile)
+    auto kstep = [&](Frags& cur, Frags& nxt, int kt, auto last_tag) __attribute__((always_inline)) {
+      constexpr bool LAST = decltype(last_tag)::value;
+      // my DMA share of tile kt+1 has landed (only tile kt+2's loads may still be in flight) and my reads of
+      // tile kt's buffer are complete; after the barrier both hold for every wave.  The waits are BUILTINS so
+      // that hipcc's own wait-count bookkeeping knows the fragments are ready and inserts no lgkmcnt(0) between
+      // the next tile's ds_reads and this tile's MFMAs (the reads must also be unconditional for that).
+      if (!LAST && kt + 2 < nkt) __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(GPW));
+      else __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(0));
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      int bk = kt % 3;
+      if (!LAST && kt + 3 < nkt) stage(kt + 3, bk);   // tile kt's buffer is free now
+      int bn = bk + 1;
+      if (bn == 3) bn = 0;
+      if (!LAST) load_frags(nxt, bn);                  // async LDS reads, consumed in the next k-step
+      __builtin_amdgcn_sched_barrier(0);               // reads are issued BEFORE the MFMAs they overlap with
+      mfma_all(cur);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    stage(0, 0);
+    if (nkt > 1) stage(1, 1);
+    if (nkt > 2) stage(2, 2);
+    if (nkt > 2) __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(2 * GPW));
+    else if (nkt > 1) __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(GPW));
+    else __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(0));
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    Frags fa, fb;
+    load_frags(fa, 0);
+    int kt = 0;
+    for (; kt + 2 < nkt; kt += 2) {
+      kstep(fa, fb, kt, std::false_type{});
+      kstep(fb, fa, kt + 1, std::false_type{});
+    }
+    if (nkt - kt == 2) {
+      kstep(fa, fb, kt, std::false_type{});
+      kstep(fb, fa, kt + 1, std::true_type{});
+    } else {
+      kstep(fa, fb, kt, std::true_type{});
     }
   }
 
@@ -479,7 +587,7 @@ static hipError_t launch_cfg(GemmArgs a, const Epi& epi, int nb, int nz, hipStre
     total += a.tiles_i[g] * a.tiles_j;
   }
   a.tile_start[ng] = total;
-  constexpr int lds = NSTAGE * (BI + BJ) * 128;
+  constexpr int lds = (NSTAGE == 4 ? 3 : NSTAGE) * (BI + BJ) * 128;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sp_kernel<WI, WJ, TI, TJ, NSTAGE, MODE, Epi>),
@@ -527,6 +635,9 @@ static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStr
     case 5: return launch_cfg<2, 2, 4, 4, 3, MODE, Epi>(a, epi, nb, nz, st);
     case 6: return launch_cfg<4, 1, 2, 7, 2, MODE, Epi>(a, epi, nb, nz, st);
     case 7: return launch_cfg<1, 4, 2, 2, 2, MODE, Epi>(a, epi, nb, nz, st);
+    case 12: return launch_cfg<2, 2, 4, 4, 1, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 128, single LDS buffer, 3+ blocks / CU
+    case 10: return launch_cfg<2, 4, 4, 4, 4, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 256, 8 waves, software-pipelined
+    case 11: return launch_cfg<2, 2, 4, 4, 4, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 128, 4 waves, software-pipelined
     default: return launch_cfg<4, 1, 2, 1, 2, MODE, Epi>(a, epi, nb, nz, st);
   }
 }
