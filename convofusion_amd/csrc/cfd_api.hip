@@ -75,6 +75,11 @@ struct Problem {
   float* att[CFD_NMEM];
   int tmode = 0;  // 0: all rows share the timestep of table row *d_step ; 1: row b uses table row b
   int T = 1;      // rows in the temb tables
+  // Rows that share one memory of the LARGEST memory type in long consecutive runs (the guidance batch repeats
+  // the unconditional audio memory for 5 of its 7 chunks): their attention against that memory is one big
+  // un-batched product per run instead of a 196-row product per batch row.
+  int jbig = -1, nruns = 0, nlong = 0, nshort = 0;
+  int run_row0[8], run_len[8], run_u[8];
 };
 
 struct cfd_handle_s {
@@ -94,7 +99,8 @@ struct cfd_handle_s {
   // workspace
   DBuf x, h_sp, qk_sp, vts_sp, ssc, sp_sp, o_sp, u_sp, sc, p_sp, eps, sample_sp;
   DBuf n_sp[CFD_NMEM], kall_sp[CFD_NMEM], cb[CFD_NMEM], vt_all[CFD_NMEM];
-  DBuf temb_tab, h1_tab, ss_tab, trows, iota;
+  DBuf temb_tab, h1_tab, ss_tab, trows, iota, long_rows, short_rows;
+  bool use_runs = true;   // CFD_RUNS=0 disables the shared-memory run optimisation
   int nchunks_env = 0;
   bool fused_self = true;   // CFD_FUSED_SELF=0 selects the GEMM -> softmax -> GEMM self-attention
   DBuf d_step;  // [0] = loop index, [1] = constant 0
@@ -189,6 +195,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   c->lw.resize(c->nl);
   const char* env = getenv("CFD_NAIVE_GEMM");
   g_cfd_naive_gemm = (env && atoi(env) != 0) ? 1 : 0;
+  env = getenv("CFD_RUNS");
+  c->use_runs = !(env && atoi(env) == 0);
   env = getenv("CFD_FUSED_SELF");
   c->fused_self = !(env && atoi(env) == 0);
   env = getenv("CFD_CHUNKS");
@@ -456,6 +464,34 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
     p.att[j] = att ? att[j] : nullptr;
   }
   p.Sp_tot = off;
+  p.jbig = -1; p.nruns = 0; p.nlong = 0; p.nshort = Be;
+  if (c->use_runs && tmode == 0) {
+    int jb = 0;
+    for (int j = 1; j < CFD_NMEM; ++j)
+      if (p.Sp[j] > p.Sp[jb]) jb = j;
+    if (p.Sp[jb] > 64 && mem[jb].row_map) {
+      std::vector<int> hmap(Be), lrows, srows;
+      HIPCHK(hipMemcpy(hmap.data(), mem[jb].row_map, (size_t)Be * 4, hipMemcpyDeviceToHost));
+      for (int b0 = 0; b0 < Be;) {
+        int b1 = b0 + 1;
+        while (b1 < Be && hmap[b1] == hmap[b0]) ++b1;
+        if (b1 - b0 >= 4 && p.nruns < 8) {
+          p.run_row0[p.nruns] = b0; p.run_len[p.nruns] = b1 - b0; p.run_u[p.nruns] = hmap[b0]; ++p.nruns;
+          for (int b = b0; b < b1; ++b) lrows.push_back(b);
+        } else {
+          for (int b = b0; b < b1; ++b) srows.push_back(b);
+        }
+        b0 = b1;
+      }
+      if (p.nruns > 0) {
+        p.jbig = jb; p.nlong = (int)lrows.size(); p.nshort = (int)srows.size();
+        CHK(c->long_rows.ensure(lrows.size() * 4 + 16));
+        CHK(c->short_rows.ensure(srows.size() * 4 + 16));
+        HIPCHK(hipMemcpy(c->long_rows.p, lrows.data(), lrows.size() * 4, hipMemcpyHostToDevice));
+        if (!srows.empty()) HIPCHK(hipMemcpy(c->short_rows.p, srows.data(), srows.size() * 4, hipMemcpyHostToDevice));
+      }
+    }
+  }
   const long long M = p.M;
   const int nl = c->nl;
   CHK(c->x.ensure((size_t)M * CFD_D * 4));
@@ -677,27 +713,47 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     if (c->stop_stage == 3 + 4 * l) return CFD_OK;
     // ---- c-e. five cross attentions + fuser, folded                             (:578-652)
     CHK(ln(w.ln2g, w.ln2b, 0, 0, c->h_sp.as<char>()));
-    // scores against the folded keys of every memory; long memories and short (<= 64 keys) memories go to
-    // different tile shapes so that an 8-key memory does not cost a 128-key tile
-    for (int pass = 0; pass < 2; ++pass) {
+    // scores against the folded keys of every memory.  Long memories and short (<= 64 keys) memories go to
+    // different tile shapes; rows in a shared-memory run of the largest memory use one un-batched product per run.
+    const bool runs = p.nruns > 0 && row0 == 0 && Be == p.Be;
+    auto scores_grouped = [&](bool small, int skip_j, const int* brow, int nb) -> int {
       GemmArgs a = gemm_args();
       EpiF32 e;
       memset(&e, 0, sizeof(e));
       int n = 0;
       for (int j = 0; j < CFD_NMEM; ++j) {
-        if ((p.Sp[j] <= 64) != (pass == 1)) continue;
+        if ((p.Sp[j] <= 64) != small || j == skip_j) continue;
         a.X[n] = c->kall_sp[j].as<char>() + (size_t)l * p.U[j] * p.Sp[j] * ROWB; a.ldx[n] = ROWB;
         a.xbs[n] = (long long)p.Sp[j] * ROWB; a.xmap[n] = mapj[j];
         a.I[n] = p.Sp[j]; a.Iclamp[n] = p.Sp[j]; a.kt[n] = CFD_D / 32;
         e.goff[n] = p.off[j]; e.gbias[n] = c->cb[j].as<float>() + (size_t)l * p.U[j] * p.Sp[j]; e.gmap[n] = mapj[j]; e.gstride[n] = p.Sp[j];
         ++n;
       }
-      if (!n) continue;
-      a.nslot = n;
+      if (!n || nb <= 0) return CFD_OK;
+      a.nslot = n; a.brow = brow;
       a.Y = c->h_sp.as<char>(); a.ldy = ROWB; a.ybs = (long long)L * ROWB; a.J = L; a.Jclamp = L;
       e.out = c->sc.as<float>(); e.ldo = p.Sp_tot; e.obs = (long long)L * p.Sp_tot;
-      CHK((run_gemm<MODE_GROUPED>(c, CFD_PROF_GEMM_ATTN, a, e, Be, 1, st)));
+      return run_gemm<MODE_GROUPED>(c, CFD_PROF_GEMM_ATTN, a, e, nb, 1, st);
+    };
+    if (!runs) {
+      CHK(scores_grouped(false, -1, nullptr, Be));
+    } else {
+      CHK(scores_grouped(false, -1, c->short_rows.as<int>(), p.nshort));
+      CHK(scores_grouped(false, p.jbig, c->long_rows.as<int>(), p.nlong));
+      const int j = p.jbig;
+      for (int r = 0; r < p.nruns; ++r) {
+        GemmArgs a = gemm_args();
+        a.X[0] = c->kall_sp[j].as<char>() + ((size_t)l * p.U[j] + p.run_u[r]) * p.Sp[j] * ROWB; a.ldx[0] = ROWB;
+        a.I[0] = p.Sp[j]; a.Iclamp[0] = p.Sp[j]; a.kt[0] = CFD_D / 32;
+        a.Y = c->h_sp.as<char>() + (size_t)p.run_row0[r] * L * ROWB; a.ldy = ROWB; a.J = p.run_len[r] * L; a.Jclamp = a.J;
+        EpiF32 e;
+        memset(&e, 0, sizeof(e));
+        e.out = c->sc.as<float>() + (size_t)p.run_row0[r] * L * p.Sp_tot; e.ldo = p.Sp_tot; e.goff[0] = p.off[j];
+        e.gbias[0] = c->cb[j].as<float>() + ((size_t)l * p.U[j] + p.run_u[r]) * p.Sp[j]; e.gstride[0] = 0;
+        CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_ATTN, a, e, 1, 1, st)));
+      }
     }
+    CHK(scores_grouped(true, -1, nullptr, Be));
     {
       SoftmaxArgs a;
       memset(&a, 0, sizeof(a));
@@ -708,19 +764,39 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       a.layer = l; a.nl = nl;
       LAUNCH(CFD_PROF_ROWS, softmax_rows_kernel, dim3((unsigned)((M + 3) / 4)), blk, st, a);
     }
-    {  // x += sum_j P_j . VV_j(n_j) + folded bias
+    // x += sum_j P_j . VV_j(n_j) + folded bias
+    auto pv_segk = [&](int skip_j, const int* brow, int nb) -> int {
+      if (nb <= 0) return CFD_OK;
       GemmArgs a = gemm_args();
-      a.nslot = CFD_NMEM;
+      int n = 0;
       for (int j = 0; j < CFD_NMEM; ++j) {
-        const long long rows = (long long)p.U[j] * p.Sp[j];
-        a.X[j] = c->vt_all[j].as<char>() + (size_t)l * p.U[j] * CFD_D * p.Sp[j] * 4; a.ldx[j] = (long long)p.Sp[j] * 4;
-        a.xbs[j] = (long long)CFD_D * p.Sp[j] * 4; a.xmap[j] = mapj[j];
-        a.kt[j] = p.Sp[j] / 32;
-        a.I[j] = CFD_D; a.Iclamp[j] = CFD_D;
+        if (j == skip_j) continue;
+        a.X[n] = c->vt_all[j].as<char>() + (size_t)l * p.U[j] * CFD_D * p.Sp[j] * 4; a.ldx[n] = (long long)p.Sp[j] * 4;
+        a.xbs[n] = (long long)CFD_D * p.Sp[j] * 4; a.xmap[n] = mapj[j];
+        a.kt[n] = p.Sp[j] / 32; a.yk0[n] = p.off[j] / 32;
+        a.I[n] = CFD_D; a.Iclamp[n] = CFD_D;
+        ++n;
       }
+      a.nslot = n; a.brow = brow;
       a.Y = c->p_sp.as<char>(); a.ldy = (long long)p.Sp_tot * 4; a.ybs = (long long)L * p.Sp_tot * 4; a.J = L; a.Jclamp = L;
       EpiResid e{c->x.as<float>(), (long long)L * CFD_D, w.cross_bias.as<float>()};
-      CHK((run_gemm<MODE_SEGK>(c, CFD_PROF_GEMM_ATTN, a, e, Be, 1, st)));
+      return run_gemm<MODE_SEGK>(c, CFD_PROF_GEMM_ATTN, a, e, nb, 1, st);
+    };
+    if (!runs) {
+      CHK(pv_segk(-1, nullptr, Be));
+    } else {
+      CHK(pv_segk(-1, c->short_rows.as<int>(), p.nshort));
+      CHK(pv_segk(p.jbig, c->long_rows.as<int>(), p.nlong));
+      const int j = p.jbig;
+      for (int r = 0; r < p.nruns; ++r) {
+        GemmArgs a = gemm_args();
+        a.X[0] = c->vt_all[j].as<char>() + ((size_t)l * p.U[j] + p.run_u[r]) * CFD_D * p.Sp[j] * 4; a.ldx[0] = (long long)p.Sp[j] * 4;
+        a.I[0] = CFD_D; a.Iclamp[0] = CFD_D; a.kt[0] = p.Sp[j] / 32;
+        a.Y = c->p_sp.as<char>() + (size_t)p.run_row0[r] * L * p.Sp_tot * 4 + (size_t)(p.off[j] / 32) * 128;
+        a.ldy = (long long)p.Sp_tot * 4; a.J = p.run_len[r] * L; a.Jclamp = a.J;
+        EpiResid e{c->x.as<float>() + (size_t)p.run_row0[r] * L * CFD_D, 0, nullptr};
+        CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_ATTN, a, e, 1, 1, st)));
+      }
     }
     if (c->stop_stage == 4 + 4 * l) return CFD_OK;
     // ---- f. time block 2                                                        (:655)

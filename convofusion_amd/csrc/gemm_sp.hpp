@@ -46,6 +46,8 @@ struct GemmArgs {
   const char* Y;
   long long ldy, ybs, yzs;     // bytes
   int J, Jclamp, tiles_j;
+  const int* brow;             // optional: batch index -> effective batch row (launches over a subset of rows)
+  int yk0[GEMM_SLOTS];         // MODE_SEGK: first k-tile of segment s inside Y (segments need not be adjacent)
 };
 
 // compile-time-indexed select from a kernel-argument array (a runtime index would force the
@@ -236,6 +238,7 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
     const long long bz = v / nx;
     b = (int)(bz % ny);
     z = (int)(bz / ny);
+    if (a.brow) b = a.brow[b];
   }
   int g = 0;
   if (MODE == MODE_GROUPED) {
@@ -310,6 +313,7 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
     if (kt > 1) return;
 #endif
     char* sbuf = smem + buf * STAGE;
+    int ykt = kt;
     if (MODE == MODE_SEGK) {
       int s = 0, ktl = kt;
 #pragma unroll
@@ -317,9 +321,11 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
         if (s == q && q < a.nslot - 1 && ktl >= a.kt[q]) { ktl -= a.kt[q]; s = q + 1; }
       const char* xs = xb[0];
       long long ldx = a.ldx[0];
+      int yk = a.yk0[0];
 #pragma unroll
       for (int q = 1; q < GEMM_SLOTS; ++q)
-        if (q == s) { xs = xb[q]; ldx = a.ldx[q]; }
+        if (q == s) { xs = xb[q]; ldx = a.ldx[q]; yk = a.yk0[q]; }
+      ykt = yk + ktl;
 #pragma unroll
       for (int n = 0; n < XPW; ++n) {
         const int gi = wid + NW * n;
@@ -339,7 +345,7 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
     for (int n = 0; n < YPW; ++n) {
       const int gi = wid + NW * n;
       if (YG % NW == 0 || gi < YG)
-        __builtin_amdgcn_global_load_lds((gptr_t)(yb + yoff[n] + (long long)kt * 128), (lptr_t)(sbuf + BI * 128 + gi * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(yb + yoff[n] + (long long)ykt * 128), (lptr_t)(sbuf + BI * 128 + gi * 1024), 16, 0, 0);
     }
   };
 
@@ -541,7 +547,7 @@ __device__ __forceinline__ float sp_load(const char* row, int col) {
 
 template <int MODE, class Epi>
 __global__ void gemm_sp_naive_kernel(const GemmArgs a, const Epi epi, int g_fixed) {
-  const int b = blockIdx.y, z = blockIdx.z;
+  const int b = a.brow ? a.brow[blockIdx.y] : blockIdx.y, z = blockIdx.z;
   const int g = g_fixed;
   const int Ig = a.I[g];
   const int nq = Ig / 4;
@@ -555,6 +561,7 @@ __global__ void gemm_sp_naive_kernel(const GemmArgs a, const Epi epi, int g_fixe
   for (int s = s0; s < s1; ++s) {
     const long long bi = a.xmap[s] ? a.xmap[s][b] : b;
     const char* xs = a.X[s] + bi * a.xbs[s] + (long long)z * a.xzs;
+    if (MODE == MODE_SEGK) kbase = a.yk0[s] * 32;
     for (int k = 0; k < a.kt[s] * 32; ++k) {
       const float yv = sp_load(yrow, kbase + k);
 #pragma unroll
