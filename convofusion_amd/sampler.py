@@ -57,12 +57,42 @@ def dedup_memories(encoder_hidden_states, cond_masks=None):
     return uniq, maps, umasks
 
 
+def build_guidance_batch(cond, uncond, cond_masks=None, uncond_masks=None):
+    """Structured alternative to materialising the 7x replicated conditioning batch and de-duplicating it again.
+
+    ``cond``   : 5 tensors [B, S_j, 512]  -- each utterance's own (spk_emb, alsn, tlsn, apb, lsnemb)
+    ``uncond`` : 5 tensors [1, S_j, 512]  -- the shared unconditional memories (dummy text, -90 dB Mel,
+                 activity bit 2, listener id 0; reference convofusion.py:909-929)
+    Returns (unique memories 5x[(B+1), S_j, 512], row_maps 5x int32[7B], unique masks dict) in the
+    reference's chunk order [all_drop, text_only, audio_only, spk_only, apb_only, lsnid_only, full]
+    (convofusion.py:527-541); pass them to ``SamplingRun(..., dedup=False, row_maps=...)``."""
+    cond_chunks = {0: (3, 6), 1: (2, 6), 2: (1, 6), 3: (4, 6), 4: (5, 6)}   # memory j is conditional in these chunks
+    B = cond[0].shape[0]
+    uniq, maps, masks = [], [], {}
+    for j, name in enumerate(_lib.MEM_NAMES):
+        uniq.append(torch.cat([uncond[j].to(cond[j].dtype), cond[j]], dim=0).contiguous())
+        rm = torch.zeros((CFG_CHUNKS, B), dtype=torch.int32)
+        for c in cond_chunks[j]:
+            rm[c] = 1 + torch.arange(B, dtype=torch.int32)
+        maps.append(rm.reshape(-1).to(cond[j].device))
+        cm = (cond_masks or {}).get(name)
+        um = (uncond_masks or {}).get(name)
+        if cm is None and um is None:
+            masks[name] = None
+        else:
+            S = cond[j].shape[1]
+            cm = cm if cm is not None else torch.zeros((B, S), dtype=torch.bool, device=cond[j].device)
+            um = um if um is not None else torch.zeros((1, S), dtype=torch.bool, device=cond[j].device)
+            masks[name] = torch.cat([um.to(torch.bool), cm.to(torch.bool)], dim=0).contiguous()
+    return uniq, maps, masks
+
+
 class SamplingRun:
     """An open sampling run on the device (thin wrapper over cfd_sample_begin/steps/read)."""
 
     def __init__(self, denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
                  guidance_scale=7.5, guidance_chunks=CFG_CHUNKS, eta=0.0, init_latents=None, step_noise=None,
-                 seed=0, first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False):
+                 seed=0, first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False, row_maps=None):
         if not isinstance(denoiser, Denoiser):
             raise TypeError("denoiser must be a convofusion_amd.denoiser.Denoiser")
         dev = encoder_hidden_states[0].device
@@ -72,9 +102,13 @@ class SamplingRun:
         self.device = dev
         self.B, self.L, self.N = B, L, num_inference_steps
         G = guidance_chunks
-        if encoder_hidden_states[0].shape[0] != G * B:
+        if row_maps is not None:       # already-distinct memories + maps (build_guidance_batch)
+            if any(int(m.numel()) != G * B for m in row_maps):
+                raise ValueError(f"row_maps must have G*B = {G * B} entries")
+            mems, maps, masks = list(encoder_hidden_states), list(row_maps), dict(cond_masks or {})
+        elif encoder_hidden_states[0].shape[0] != G * B:
             raise ValueError(f"conditioning batch is {encoder_hidden_states[0].shape[0]} rows, expected G*B = {G * B}")
-        if dedup:
+        elif dedup:
             mems, maps, masks = dedup_memories(encoder_hidden_states, cond_masks)
         else:
             mems, maps, masks = list(encoder_hidden_states), None, dict(cond_masks or {})
@@ -166,11 +200,11 @@ class SamplingRun:
 
 def sample(denoiser, scheduler, encoder_hidden_states, cond_masks=None, *, B, L=16, num_inference_steps=1000,
            guidance_scale=7.5, guidance_chunks=CFG_CHUNKS, eta=0.0, init_latents=None, step_noise=None, seed=0,
-           first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False):
+           first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False, row_maps=None):
     """Run the whole loop; returns latents [B, L, 128] (batch-first)."""
     run = SamplingRun(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
                       guidance_scale, guidance_chunks, eta, init_latents, step_noise, seed, first_utterance, preseq, dedup,
-                      skip_zero_weight_chunks)
+                      skip_zero_weight_chunks, row_maps)
     run.steps(num_inference_steps)
     return run.read(close=True)
 
@@ -198,7 +232,10 @@ def _loop_from_model(model, encoder_hidden_states, cond_masks, preseq, focus_ind
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())   # per-step noise stream keyed off torch's global generator
     return sample(model.denoiser, model.scheduler, encoder_hidden_states, cond_masks, B=bsz, L=L,
                   num_inference_steps=n_steps, guidance_scale=model.guidance_scale, guidance_chunks=G, eta=eta,
-                  init_latents=init_latents, seed=seed, preseq=preseq)
+                  init_latents=init_latents, seed=seed, preseq=preseq,
+                  # the full-conditioning chunk has guidance weight 0 (convofusion.py:538) and the fused loop keeps no
+                  # attention maps, so its forward is dead work: identical latents without it
+                  skip_zero_weight_chunks=True)
 
 
 def diffusion_reverse(model, encoder_hidden_states, lengths=None, cond_masks=dict(), focus_indices=[], *,

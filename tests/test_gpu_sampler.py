@@ -91,6 +91,27 @@ def test_skipping_the_zero_weight_chunk_is_exact():
     assert torch.equal(a, b)
 
 
+def test_structured_guidance_batch_equals_replicated_batch():
+    """build_guidance_batch (distinct memories + maps, no 7x materialisation) == the reference's replicated batch."""
+    import torch
+    from convofusion_amd.sampler import build_guidance_batch, sample
+    from tests.gpu_helpers import hip_denoiser, to_dev
+    B, L, S = 3, 16, (24, 161, 24, 8, 1)
+    cb = inputs.make_cfg_batch(seed=8, B=B, L=L, S=S, pad_tail=(4, 0, 6, 0, 0))
+    m = hip_denoiser(1234, 1.0)
+    rep = sample(m, _sched("ddpm"), [to_dev(x) for x in cb["memories"]], {k: to_dev(v) for k, v in cb["masks"].items()},
+                 B=B, L=L, num_inference_steps=3, seed=4)
+    uq = [to_dev(u) for u in cb["unique"]]
+    cond, unc = [u[1:] for u in uq], [u[:1] for u in uq]
+    cm = {k: (to_dev(v)[6 * B:] if v is not None else None) for k, v in cb["masks"].items()}    # chunk 6 = full conditioning
+    um = {k: (to_dev(v)[:1] if v is not None else None) for k, v in cb["masks"].items()}         # chunk 0 = all dropped
+    mems, maps, masks = build_guidance_batch(cond, unc, cm, um)
+    for j in range(5):
+        assert torch.equal(maps[j].cpu(), torch.from_numpy(cb["row_map"][j]))
+    st = sample(m, _sched("ddpm"), mems, masks, B=B, L=L, num_inference_steps=3, seed=4, row_maps=maps)
+    assert torch.equal(rep, st)
+
+
 def test_device_rng_stream_matches_oracle():
     """No injected noise: the on-device Philox stream (init latents + per-step noise) is reproduced by the
     oracle's restatement, so the whole loop can be checked end-to-end against the oracle."""
