@@ -469,7 +469,9 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
     int jb = 0;
     for (int j = 1; j < CFD_NMEM; ++j)
       if (p.Sp[j] > p.Sp[jb]) jb = j;
-    if (p.Sp[jb] > 64 && mem[jb].row_map) {
+    // worth it only for long latents and long memories (measured: 20.6 vs 21.2 ms at L=196 / 1500 keys, but
+    // 3.60 vs 3.15 ms at L=16 / 161 keys, where the extra launches dominate)
+    if (p.Sp[jb] >= 256 && L >= 64 && mem[jb].row_map) {
       std::vector<int> hmap(Be), lrows, srows;
       HIPCHK(hipMemcpy(hmap.data(), mem[jb].row_map, (size_t)Be * 4, hipMemcpyDeviceToHost));
       for (int b0 = 0; b0 < Be;) {

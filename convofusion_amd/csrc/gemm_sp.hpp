@@ -642,6 +642,8 @@ static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStr
     case 5: return launch_cfg<2, 2, 4, 4, 3, MODE, Epi>(a, epi, nb, nz, st);
     case 6: return launch_cfg<4, 1, 2, 7, 2, MODE, Epi>(a, epi, nb, nz, st);
     case 7: return launch_cfg<1, 4, 2, 2, 2, MODE, Epi>(a, epi, nb, nz, st);
+    case 13: return launch_cfg<2, 2, 8, 4, 4, MODE, Epi>(a, epi, nb, nz, st);  // 256 x 128, 4 waves x (128 x 64), software-pipelined
+    case 14: return launch_cfg<2, 2, 4, 8, 4, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 256, 4 waves x (64 x 128), software-pipelined
     case 12: return launch_cfg<2, 2, 4, 4, 1, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 128, single LDS buffer, 3+ blocks / CU
     case 10: return launch_cfg<2, 4, 4, 4, 4, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 256, 8 waves, software-pipelined
     case 11: return launch_cfg<2, 2, 4, 4, 4, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 128, 4 waves, software-pipelined
