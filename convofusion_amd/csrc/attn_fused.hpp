@@ -34,13 +34,13 @@ __global__ void __launch_bounds__(SELF_ATTN_WAVES * 64, 4) self_attn_fused_kerne
   const long long ROW = 4096;  // bytes per qk row (1024 columns)
 
   // Q fragments (B operand): lane holds d = 32*ks + 8*q4 .. +7 of its query
-  bf16x8 qh[4], ql[4];
+  spx8 qh[4], ql[4];
   {
     const char* qp = a.qk + ((long long)b * a.L + qc) * ROW + (long long)(h * 4) * 128 + q4 * 16;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      qh[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 128);
-      ql[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 128 + 64);
+      qh[ks] = *reinterpret_cast<const spx8*>(qp + ks * 128);
+      ql[ks] = *reinterpret_cast<const spx8*>(qp + ks * 128 + 64);
     }
   }
   f32x4 o[8];
@@ -81,8 +81,8 @@ __global__ void __launch_bounds__(SELF_ATTN_WAVES * 64, 4) self_attn_fused_kerne
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const char* kp = smem + KOFF + ks * 8192 + (t * 16 + l15) * 128;
-        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(kp + ((q4 ^ sw) << 4));
-        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(kp + (((4 + q4) ^ sw) << 4));
+        const spx8 xh = *reinterpret_cast<const spx8*>(kp + ((q4 ^ sw) << 4));
+        const spx8 xl = *reinterpret_cast<const spx8*>(kp + (((4 + q4) ^ sw) << 4));
         s[t] = SP_MFMA(xl, qh[ks], s[t], 0, 0, 0);
         s[t] = SP_MFMA(xh, ql[ks], s[t], 0, 0, 0);
         s[t] = SP_MFMA(xh, qh[ks], s[t], 0, 0, 0);
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(SELF_ATTN_WAVES * 64, 4) self_attn_fused_kerne
     // O^T += V^T P^T : P fragments come straight out of the S registers (k-slot order matches perm32)
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8 ph, pl;
+      spx8 ph, pl;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         sp_t hi, lo;
@@ -131,8 +131,8 @@ __global__ void __launch_bounds__(SELF_ATTN_WAVES * 64, 4) self_attn_fused_kerne
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
         const char* vp = smem + VOFF + s2 * 16384 + (f * 16 + l15) * 128;
-        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(vp + ((q4 ^ sw) << 4));
-        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(vp + (((4 + q4) ^ sw) << 4));
+        const spx8 xh = *reinterpret_cast<const spx8*>(vp + ((q4 ^ sw) << 4));
+        const spx8 xl = *reinterpret_cast<const spx8*>(vp + (((4 + q4) ^ sw) << 4));
         o[f] = SP_MFMA(xl, ph, o[f], 0, 0, 0);
         o[f] = SP_MFMA(xh, pl, o[f], 0, 0, 0);
         o[f] = SP_MFMA(xh, ph, o[f], 0, 0, 0);

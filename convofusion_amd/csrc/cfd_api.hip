@@ -574,6 +574,7 @@ static int enqueue_memside(Ctx* c, hipStream_t st) {
       GemmArgs a = gemm_args();
       a.X[0] = c->wk_all_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = nl * CFD_D + 32; a.Iclamp[0] = nl * CFD_D + 32; a.kt[0] = CFD_D / 32;
       a.Y = c->n_sp[j].as<char>(); a.ldy = ROWB; a.J = rows; a.Jclamp = rows;
+      a.super_i = 8; a.super_j = 8;
       EpiMemK e{c->kall_sp[j].as<char>(), (long long)rows, c->cb[j].as<float>(), nl * CFD_D, nl};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }
@@ -581,6 +582,7 @@ static int enqueue_memside(Ctx* c, hipStream_t st) {
       GemmArgs a = gemm_args();
       a.X[0] = c->n_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = rows; a.Iclamp[0] = rows; a.kt[0] = CFD_D / 32;
       a.Y = c->wv_all_sp[j].as<char>(); a.ldy = ROWB; a.J = nl * CFD_D; a.Jclamp = nl * CFD_D;
+      a.super_i = 8; a.super_j = 8;
       EpiMemV e{c->vt_all[j].as<char>(), p.Sp[j], p.U[j]};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }

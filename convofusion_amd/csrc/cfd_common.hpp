@@ -1,14 +1,14 @@
 // Common types and helpers for the ConvoFusion denoising-loop kernels (gfx950 / CDNA4 only).
 //
-// Numeric format used by every GEMM operand ("split-pair", SP): a float32 value v is carried as two
-// bfloat16 numbers hi = bf16(v), lo = bf16(v - hi); a product a*b is issued as THREE MFMAs
-// (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi) with fp32 accumulation -- ~2^-16 relative operand error,
-// i.e. fp32-class results from the bf16 matrix cores (the reference's 1e-3 budget on the final
-// latents cannot be met with plain bf16 operands: SURVEY.md fact 8).
+// Numeric format used by every GEMM operand ("split pair", SP): a float32 value v is carried as two 16-bit
+// floats hi = f16(v), lo = f16(v - hi) (fp16 by default, bf16 with -DCFD_SPLIT_F16=0); a product a*b is issued as
+// THREE MFMAs (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi) with fp32 accumulation: ~2^-22 (fp16) / 2^-16 (bf16) relative
+// operand error, i.e. fp32-class results from the 16-bit matrix cores.  (The reference's 1e-3 budget on the final
+// latents cannot be met with plain bf16 operands: SURVEY.md fact 8; measurements: DESIGN.md section 2.)
 //
-// Memory layout of an SP matrix [R rows][K cols], K % 32 == 0: per row, K/32 groups of 128 bytes,
-// each group = 32 hi values (64 B) followed by the 32 lo values (64 B).  One 128-byte line thus
-// carries both halves of a 32-deep K-step for one row, which is what one LDS tile row holds.
+// Memory layout of an SP matrix [R rows][K cols], K % 32 == 0: per row, K/32 groups of 128 bytes, each group =
+// 32 hi values (64 B) followed by the 32 lo values (64 B).  One 128-byte line thus carries both halves of a
+// 32-deep K-step for one row, which is what one LDS tile row holds.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,8 +34,8 @@ typedef _Float16 sp_t;
 typedef __bf16 sp_t;
 #define SP_MFMA __builtin_amdgcn_mfma_f32_16x16x32_bf16
 #endif
-typedef __attribute__((ext_vector_type(8))) sp_t bf16x8;   // 8 split-pair elements (one MFMA operand fragment)
-typedef __attribute__((ext_vector_type(4))) sp_t bf16x4;
+typedef __attribute__((ext_vector_type(8))) sp_t spx8;   // 8 halves = one MFMA operand fragment per lane
+typedef __attribute__((ext_vector_type(4))) sp_t spx4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -51,20 +51,20 @@ __device__ __forceinline__ void split_f32(float v, sp_t& hi, sp_t& lo) {
 
 // store 4 consecutive-column values (col % 4 == 0) of one row into an SP matrix
 __device__ __forceinline__ void sp_store4(char* row_base, int col, float a, float b, float c, float d) {
-  bf16x4 h, l;
+  spx4 h, l;
   sp_t t0, t1;
   split_f32(a, t0, t1); h[0] = t0; l[0] = t1;
   split_f32(b, t0, t1); h[1] = t0; l[1] = t1;
   split_f32(c, t0, t1); h[2] = t0; l[2] = t1;
   split_f32(d, t0, t1); h[3] = t0; l[3] = t1;
   char* p = row_base + (size_t)(col >> 5) * 128 + (col & 31) * 2;
-  *reinterpret_cast<bf16x4*>(p) = h;
-  *reinterpret_cast<bf16x4*>(p + 64) = l;
+  *reinterpret_cast<spx4*>(p) = h;
+  *reinterpret_cast<spx4*>(p + 64) = l;
 }
 
 // store 8 consecutive-column values (col % 8 == 0)
 __device__ __forceinline__ void sp_store8(char* row_base, int col, const float* v) {
-  bf16x8 h, l;
+  spx8 h, l;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     sp_t a, b;
@@ -73,8 +73,8 @@ __device__ __forceinline__ void sp_store8(char* row_base, int col, const float* 
     l[e] = b;
   }
   char* p = row_base + (size_t)(col >> 5) * 128 + (col & 31) * 2;
-  *reinterpret_cast<bf16x8*>(p) = h;
-  *reinterpret_cast<bf16x8*>(p + 64) = l;
+  *reinterpret_cast<spx8*>(p) = h;
+  *reinterpret_cast<spx8*>(p + 64) = l;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -1,31 +1,29 @@
-// Split-pair bf16x3 "NT" GEMM for gfx950:  D[i][j] = sum_k X[i][k] * Y[j][k]
+// Split-pair "NT" GEMM for gfx950:  D[i][j] = sum_k X[i][k] * Y[j][k], every product issued as 3 MFMAs
+// (lo*hi + hi*lo + hi*hi of the fp16 -- or bf16 -- halves, fp32 accumulate; see cfd_common.hpp).
 //
-//   X ("row operand", MFMA A) and Y ("column operand", MFMA B) are SP matrices (cfd_common.hpp) with
-//   K contiguous, so both fragments are 16-byte LDS reads.  The result tile is handed to an epilogue
-//   functor as 4 consecutive i for one j (the v_mfma_f32_16x16x32_bf16 C/D layout: row = 4*(lane>>4)+r,
-//   col = lane&15), i.e. outputs are written "out[j][i]" with i contiguous.  Calling it with
-//   X = weight[N][K], Y = activation[M][K] gives out[token][feature]; swapping the roles gives the
-//   transposed product (used to emit V^T for the P.V products without a transpose pass).
+//   X ("row operand", MFMA A) and Y ("column operand", MFMA B) are SP matrices with K contiguous, so both
+//   fragments are 16-byte LDS reads.  The result tile is handed to an epilogue functor as 4 consecutive i for
+//   one j (the v_mfma_f32_16x16x32 C/D layout: row = 4*(lane>>4)+r, col = lane&15), i.e. outputs are written
+//   "out[j][i]" with i contiguous.  X = weight[N][K], Y = activation[M][K] gives out[token][feature]; swapping
+//   the roles gives the transposed product (V^T for the P.V products, no transpose pass).
 //
-//   Block = 256 threads = WI x WJ waves, each wave owns TI x TJ MFMA tiles of 16x16.
-//   K-step = 32 (one 128-byte SP line per row: 4 hi chunks + 4 lo chunks of 16 B).
-//   Staging: global_load_lds_dwordx4 (16 B/lane, 8 rows x 128 B per wave-instruction) into a
-//   2-stage LDS ring; the LDS image is lane-linear, the bank swizzle chunk' = chunk ^ ((row>>1)&7)
-//   is applied on the per-lane SOURCE address and again on the fragment read (guide rule 21).
-//   Per K-step a wave issues TI*TJ*3 MFMAs (lo*hi, hi*lo, hi*hi) for 2*(TI+TJ) ds_read_b128.
+//   Block = WI x WJ waves, each wave owns TI x TJ MFMA tiles of 16x16; K-step = 32 (one 128-byte SP line per
+//   row: 4 hi chunks + 4 lo chunks of 16 B).  Staging: global_load_lds_dwordx4 (16 B/lane, 8 rows x 128 B per
+//   wave-instruction) into an LDS ring; the LDS image is lane-linear, the bank swizzle
+//   chunk' = chunk ^ ((row>>1)&7) is applied on the per-lane SOURCE address and again on the fragment read
+//   (SQ_LDS_BANK_CONFLICT = 0 measured).  Per K-step a wave issues TI*TJ*3 MFMAs for 2*(TI+TJ) ds_read_b128.
 //
-//   MODE_PLAIN   one problem (optionally batched over blockIdx.y / .z with strides or an index map)
+//   MODE_PLAIN   one problem (optionally batched over blockIdx.y / .z with strides, an index map or a row list)
 //   MODE_GROUPED up to 5 problems sharing Y (cross-attention scores against the 5 memories)
-//   MODE_SEGK    one problem whose K range is the concatenation of up to 5 X segments (cross-attention
-//                P.V over the 5 memories, accumulated in registers)
+//   MODE_SEGK    one problem whose K range is the concatenation of up to 5 X segments (cross-attention P.V over
+//                the 5 memories, accumulated in registers)
+//
+//   Tile configurations are listed at launch_gemm(); DESIGN.md section 7 has the measurements that chose them.
 #pragma once
 #include <type_traits>
 
 #include "cfd_common.hpp"
 
-#ifndef CFD_EXP
-#define CFD_EXP 0
-#endif
 // s_waitcnt immediate (gfx9 encoding): vmcnt = N (bits 3:0 and 15:14), expcnt = 7 (no wait), lgkmcnt = 0
 #define WAIT_VM_LGKM0(N) ((((N) & 15) | 0x70 | ((((N) >> 4) & 3) << 14)))
 #define GEMM_SLOTS 5
@@ -46,6 +44,7 @@ struct GemmArgs {
   const char* Y;
   long long ldy, ybs, yzs;     // bytes
   int J, Jclamp, tiles_j;
+  int super_i, super_j;        // MODE_PLAIN: > 0 selects the super-tiled block order (see kernel)
   const int* brow;             // optional: batch index -> effective batch row (launches over a subset of rows)
   int yk0[GEMM_SLOTS];         // MODE_SEGK: first k-tile of segment s inside Y (segments need not be adjacent)
 };
@@ -196,7 +195,7 @@ template <class E> struct EpiPre<E, true> { typedef typename E::Pre type; };
 //              s_waitcnt vmcnt(GPW) + raw s_barrier (a __syncthreads() would drain the LDS-DMA queue).
 //              Requires every wave to issue exactly GPW loads per stage.
 template <int WI, int WJ, int TI, int TJ, int NSTAGE, int MODE, class Epi>
-__global__ void __launch_bounds__(WI * WJ * 64, (WI * WJ * 64) / 256 * ((WI * TI + WJ * TJ) * 16 * 128 * (NSTAGE == 4 ? 3 : NSTAGE) > 80 * 1024 ? 1 : (NSTAGE == 1 ? 3 : 2)))
+__global__ void __launch_bounds__(WI * WJ * 64, (WI * WJ * 64) / 256 * ((WI * TI + WJ * TJ) * 16 * 128 * (NSTAGE == 4 ? 3 : NSTAGE) > 80 * 1024 ? 1 : ((NSTAGE == 1 || (WI * TI + WJ * TJ) * 16 * 128 * NSTAGE <= 52 * 1024) ? 3 : 2)))
 gemm_sp_kernel(const GemmArgs a, const Epi epi) {
   constexpr int NW = WI * WJ;
   constexpr int BI = WI * TI * 16, BJ = WJ * TJ * 16;
@@ -210,18 +209,6 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wi = wid / WJ, wj = wid % WJ;
-#if CFD_EXP == 5 || CFD_EXP == 6
-  {  // experiment: de-phase the co-resident workgroups of a CU (odd wave slots start ~3 us late)
-    const unsigned hwid = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
-    if (hwid & 1) {
-#if CFD_EXP == 5
-      __builtin_amdgcn_s_sleep(100);
-#else
-      __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
-#endif
-    }
-  }
-#endif
   // XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs in LINEAR dispatch order
   // (x fastest, then y, z), and each XCD has a private L2.  Blocks that land on one XCD (linear id % 8 equal)
   // are given a contiguous range of the (batch, tile) space, so the tiles that re-read one activation tile --
@@ -252,7 +239,26 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
     t -= ts;
   }
   const int tiles_i = sel5(a.tiles_i, g);
-  const int i0 = (t % tiles_i) * BI, j0 = (t / tiles_i) * BJ;
+  int ti_blk = t % tiles_i, tj_blk = t / tiles_i;
+  if (MODE == MODE_PLAIN && a.super_i > 0) {
+    // both operands exceed an XCD's 4 MiB L2 (memory-side projections: 9.5 MB of weights x 100 MB of rows):
+    // walk the tile grid in super_i x super_j super-tiles so each panel is fetched once per super-tile row/column
+    // instead of once per tile (measured 3.9 GB -> ~1 GB of fetch per launch)
+    const int SI = a.super_i, SJ = a.super_j;
+    const int nsi = (tiles_i + SI - 1) / SI;
+    const int per_band = tiles_i * SJ;                 // tiles in one band of SJ tile-columns
+    const int band = t / per_band, r = t - band * per_band;
+    const int wj = min(SJ, a.tiles_j - band * SJ);     // columns in this (possibly last, narrower) band
+    const int per_super = SI * wj;
+    int sidx = r / per_super, rr = r - sidx * per_super;
+    if (sidx >= nsi) { sidx = nsi - 1; rr = r - sidx * per_super; }
+    const int hi = min(SI, tiles_i - sidx * SI);       // rows in this (possibly last, shorter) super-tile
+    // tiles before this super-tile in the band: sidx * SI * wj (all full-height super-tiles)
+    rr = r - sidx * SI * wj;
+    ti_blk = sidx * SI + rr % hi;
+    tj_blk = band * SJ + rr / hi;
+  }
+  const int i0 = ti_blk * BI, j0 = tj_blk * BJ;
   const int Ig = sel5(a.I, g);
   const int Iclamp_g = sel5(a.Iclamp, g);
 
@@ -309,9 +315,6 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
   }
 
   auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
-#if CFD_EXP == 2   // timing experiment: only the first two k-tiles are ever loaded
-    if (kt > 1) return;
-#endif
     char* sbuf = smem + buf * STAGE;
     int ykt = kt;
     if (MODE == MODE_SEGK) {
@@ -379,26 +382,17 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
 
   auto compute = [&](int buf) __attribute__((always_inline)) {
     const char* sb = smem + buf * STAGE;
-    bf16x8 xh[TI], xl[TI], yh[TJ], yl[TJ];
+    spx8 xh[TI], xl[TI], yh[TJ], yl[TJ];
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti) {
-      xh[ti] = *reinterpret_cast<const bf16x8*>(sb + xoff_h + ti * 2048);
-      xl[ti] = *reinterpret_cast<const bf16x8*>(sb + xoff_l + ti * 2048);
+      xh[ti] = *reinterpret_cast<const spx8*>(sb + xoff_h + ti * 2048);
+      xl[ti] = *reinterpret_cast<const spx8*>(sb + xoff_l + ti * 2048);
     }
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
-      yh[tj] = *reinterpret_cast<const bf16x8*>(sb + yoff_h + tj * 2048);
-      yl[tj] = *reinterpret_cast<const bf16x8*>(sb + yoff_l + tj * 2048);
+      yh[tj] = *reinterpret_cast<const spx8*>(sb + yoff_h + tj * 2048);
+      yl[tj] = *reinterpret_cast<const spx8*>(sb + yoff_l + tj * 2048);
     }
-#if CFD_EXP == 3 || CFD_EXP == 4
-    __builtin_amdgcn_sched_barrier(0);   // V1 experiment: every fragment read is issued before the first MFMA
-#endif
-#if CFD_EXP == 1   // timing experiment: LDS reads kept live, no MFMA
-#pragma unroll
-    for (int ti = 0; ti < TI; ++ti) asm volatile("" ::"v"(xh[ti]), "v"(xl[ti]));
-#pragma unroll
-    for (int tj = 0; tj < TJ; ++tj) asm volatile("" ::"v"(yh[tj]), "v"(yl[tj]));
-#else
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
@@ -407,7 +401,6 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
         acc[ti][tj] = SP_MFMA(xh[ti], yl[tj], acc[ti][tj], 0, 0, 0);
         acc[ti][tj] = SP_MFMA(xh[ti], yh[tj], acc[ti][tj], 0, 0, 0);
       }
-#endif
   };
 
   if constexpr (NSTAGE == 1) {
@@ -456,18 +449,18 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
     // LDS-DMA of tiles kt+2 / kt+3 is in flight; one barrier per k-step.  Two waves that share a SIMD run in
     // lock-step (they alternate on the matrix pipe), so without this their LDS-read phases coincide and the
     // pipe idles ~40 % (measured: MFMA + LDS reads alone reach only 54 % of the 16-cycle issue rate).
-    struct Frags { bf16x8 xh[TI], xl[TI], yh[TJ], yl[TJ]; };
+    struct Frags { spx8 xh[TI], xl[TI], yh[TJ], yl[TJ]; };
     auto load_frags = [&](Frags& f, int buf) __attribute__((always_inline)) {
       const char* sb = smem + buf * STAGE;
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti) {
-        f.xh[ti] = *reinterpret_cast<const bf16x8*>(sb + xoff_h + ti * 2048);
-        f.xl[ti] = *reinterpret_cast<const bf16x8*>(sb + xoff_l + ti * 2048);
+        f.xh[ti] = *reinterpret_cast<const spx8*>(sb + xoff_h + ti * 2048);
+        f.xl[ti] = *reinterpret_cast<const spx8*>(sb + xoff_l + ti * 2048);
       }
 #pragma unroll
       for (int tj = 0; tj < TJ; ++tj) {
-        f.yh[tj] = *reinterpret_cast<const bf16x8*>(sb + yoff_h + tj * 2048);
-        f.yl[tj] = *reinterpret_cast<const bf16x8*>(sb + yoff_l + tj * 2048);
+        f.yh[tj] = *reinterpret_cast<const spx8*>(sb + yoff_h + tj * 2048);
+        f.yl[tj] = *reinterpret_cast<const spx8*>(sb + yoff_l + tj * 2048);
       }
     };
     auto mfma_all = [&](const Frags& f) __attribute__((always_inline)) {
@@ -644,6 +637,8 @@ static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStr
     case 7: return launch_cfg<1, 4, 2, 2, 2, MODE, Epi>(a, epi, nb, nz, st);
     case 13: return launch_cfg<2, 2, 8, 4, 4, MODE, Epi>(a, epi, nb, nz, st);  // 256 x 128, 4 waves x (128 x 64), software-pipelined
     case 14: return launch_cfg<2, 2, 4, 8, 4, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 256, 4 waves x (64 x 128), software-pipelined
+    case 15: return launch_cfg<2, 2, 4, 2, 2, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 64 (48 KB LDS: 3 blocks / CU)
+    case 16: return launch_cfg<2, 2, 2, 4, 2, MODE, Epi>(a, epi, nb, nz, st);  // 64 x 128
     case 12: return launch_cfg<2, 2, 4, 4, 1, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 128, single LDS buffer, 3+ blocks / CU
     case 10: return launch_cfg<2, 4, 4, 4, 4, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 256, 8 waves, software-pipelined
     case 11: return launch_cfg<2, 2, 4, 4, 4, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 128, 4 waves, software-pipelined

@@ -133,6 +133,27 @@ def test_device_rng_stream_matches_oracle():
     assert e < TRAJ_TOL
 
 
+def test_shared_memory_run_path_matches_oracle():
+    """Long latents + a long audio memory switch on the un-batched attention products for rows that share the
+    unconditional memory (cfd_api.hip 'runs'); check that path end-to-end against the oracle."""
+    from convofusion_amd.sampler import sample
+    from tests.gpu_helpers import hip_denoiser, to_dev
+    B, L, S, n = 2, 64, (8, 256, 8, 8, 1), 2
+    seed = 31
+    cb = inputs.make_cfg_batch(seed=12, B=B, L=L, S=S, pad_tail=(2, 0, 1, 0, 0))
+    sd = state_dict()
+    want, _, _ = sampler_ref.diffusion_reverse(
+        lambda x, t, e, mk: denoiser_ref.denoiser_forward(sd, x, t, e, mk), scheduler_ref.DDPMSchedulerRef(),
+        cb["memories"], cb["masks"], philox_ref.normal_tensor(seed, 0, range(B), 1, L),
+        lambda i, t: philox_ref.normal_tensor(seed, i, range(B), 0, L), num_inference_steps=n)
+    m = hip_denoiser(1234, 1.0)
+    got = sample(m, _sched("ddpm"), [to_dev(x) for x in cb["memories"]], {k: to_dev(v) for k, v in cb["masks"].items()},
+                 B=B, L=L, num_inference_steps=n, seed=seed)
+    e = rel_l2(got.permute(1, 0, 2).cpu().numpy(), want)
+    print("run path vs oracle", e)
+    assert e < TRAJ_TOL
+
+
 def test_model_level_drop_in():
     """diffusion_reverse(model, ...) reads the same attributes the reference method reads from ``self``."""
     from types import SimpleNamespace
