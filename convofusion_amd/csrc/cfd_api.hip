@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -72,6 +73,7 @@ struct Problem {
   const float* mem[CFD_NMEM];
   const int* map[CFD_NMEM];
   const uint8_t* mask[CFD_NMEM];
+  int has_mask[CFD_NMEM];
   float* att[CFD_NMEM];
   int tmode = 0;  // 0: all rows share the timestep of table row *d_step ; 1: row b uses table row b
   int T = 1;      // rows in the temb tables
@@ -99,7 +101,7 @@ struct cfd_handle_s {
   // workspace
   DBuf x, h_sp, qk_sp, vts_sp, ssc, sp_sp, o_sp, u_sp, sc, p_sp, eps, sample_sp;
   DBuf n_sp[CFD_NMEM], kall_sp[CFD_NMEM], cb[CFD_NMEM], vt_all[CFD_NMEM];
-  DBuf temb_tab, h1_tab, ss_tab, trows, iota, long_rows, short_rows;
+  DBuf temb_tab, h1_tab, ss_tab, trows, iota, long_rows, short_rows, zero_mask;
   bool use_runs = true;   // CFD_RUNS=0 disables the shared-memory run optimisation
   int nchunks_env = 0;
   bool fused_self = true;   // CFD_FUSED_SELF=0 selects the GEMM -> softmax -> GEMM self-attention
@@ -464,6 +466,18 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
     p.att[j] = att ? att[j] : nullptr;
   }
   p.Sp_tot = off;
+  {  // memories without a key-padding mask get an all-zero one, so the softmax kernel needs no null test
+    size_t need = (size_t)Be * L;   // (the un-fused self-attention softmax indexes it per batch row)
+    for (int j = 0; j < CFD_NMEM; ++j) need = std::max(need, (size_t)p.U[j] * p.S[j]);
+    if (need > c->zero_mask.bytes) {
+      CHK(c->zero_mask.ensure(need));
+      HIPCHK(hipMemset(c->zero_mask.p, 0, need));
+    }
+    for (int j = 0; j < CFD_NMEM; ++j) {
+      p.has_mask[j] = p.mask[j] != nullptr;
+      if (!p.mask[j]) p.mask[j] = c->zero_mask.as<uint8_t>();
+    }
+  }
   p.jbig = -1; p.nruns = 0; p.nlong = 0; p.nshort = Be;
   if (c->use_runs && tmode == 0) {
     int jb = 0;
@@ -697,6 +711,7 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       memset(&a, 0, sizeof(a));
       a.sc = c->ssc.as<float>(); a.P = c->sp_sp.as<char>(); a.ld = Lp; a.rows = (long long)Be * CFD_NHEAD * L; a.rows_per_b = CFD_NHEAD * L;
       a.nseg = 1; a.S[0] = L; a.Sp[0] = Lp; a.nl = nl;
+      for (int j = 0; j < CFD_NMEM; ++j) a.mask[j] = c->zero_mask.as<uint8_t>();
       LAUNCH(CFD_PROF_ROWS, softmax_rows_kernel, dim3((unsigned)((a.rows + 3) / 4)), blk, st, a);
     }
     {  // o[b*L+l][h*128+d] = sum_lk P[lq][lk] v[lk][d]
@@ -763,7 +778,7 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       memset(&a, 0, sizeof(a));
       a.sc = c->sc.as<float>(); a.P = c->p_sp.as<char>(); a.ld = p.Sp_tot; a.rows = M; a.rows_per_b = L; a.nseg = CFD_NMEM;
       for (int j = 0; j < CFD_NMEM; ++j) {
-        a.off[j] = p.off[j]; a.S[j] = p.S[j]; a.Sp[j] = p.Sp[j]; a.mask[j] = p.mask[j]; a.map[j] = mapj[j]; a.att[j] = attj[j];
+        a.off[j] = p.off[j]; a.S[j] = p.S[j]; a.Sp[j] = p.Sp[j]; a.mask[j] = p.mask[j]; a.has_mask[j] = p.has_mask[j]; a.map[j] = mapj[j]; a.att[j] = attj[j];
       }
       a.layer = l; a.nl = nl;
       LAUNCH(CFD_PROF_ROWS, softmax_rows_kernel, dim3((unsigned)((M + 3) / 4)), blk, st, a);

@@ -118,11 +118,25 @@ struct SoftmaxArgs {
   int rows_per_b;
   int nseg;
   int off[CFD_NMEM], S[CFD_NMEM], Sp[CFD_NMEM];
-  const uint8_t* mask[CFD_NMEM];  // [U][S] (1 = padded key), or null
+  const uint8_t* mask[CFD_NMEM];  // [U][S] (1 = padded key); NEVER null (the host passes an all-zero mask)
+  int has_mask[CFD_NMEM];         // 0: the mask is the all-zero stand-in (long segments skip the byte loads)
   const int* map[CFD_NMEM];       // b -> u, or null (u = b)
   float* att[CFD_NMEM];           // [Be][nl][L][S] or null
   int layer, nl;
 };
+
+// Segments of <= 64 keys (text / activity-bit / listener-id memories) are handled TOGETHER, one 8-lane group per
+// segment, so a row costs one load->reduce->store round for all of them instead of one serialised round each.
+__device__ __forceinline__ void softmax_store(const SoftmaxArgs& a, int g, int b, int l, char* prow, int c0, float* v) {
+  const int S = a.S[g];
+  sp_store8(prow, a.off[g] + c0, v);
+  if (a.att[g]) {
+    float* att = a.att[g] + (((long long)b * a.nl + a.layer) * a.rows_per_b + l) * S;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (c0 + e < S) att[c0 + e] = v[e];
+  }
+}
 
 __global__ void __launch_bounds__(256) softmax_rows_kernel(const SoftmaxArgs a) {
   const int lane = threadIdx.x & 63;
@@ -131,12 +145,67 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const SoftmaxArgs a) 
   const int b = (int)(row / a.rows_per_b), l = (int)(row % a.rows_per_b);
   const float* srow = a.sc + row * a.ld;
   char* prow = a.P + row * a.ld * 4;
+
+  // ---- short segments: lane group (lane >> 3) <-> the k-th short segment, lane & 7 <-> chunk of 8 keys ------
+  {
+    int myseg = -1, k = 0;
+#pragma unroll
+    for (int g = 0; g < CFD_NMEM; ++g)
+      if (g < a.nseg && a.Sp[g] <= 64) {
+        if (k == (lane >> 3)) myseg = g;
+        ++k;
+      }
+    if (k > 0) {   // wave-uniform
+      int S = 1, Sp = 0, off = 0;
+      const uint8_t* mk = a.mask[0];
+#pragma unroll
+      for (int g = 0; g < CFD_NMEM; ++g)
+        if (g == myseg) {
+          S = a.S[g]; Sp = a.Sp[g]; off = a.off[g];
+          mk = a.mask[g] + (long long)(a.map[g] ? a.map[g][b] : b) * S;
+        }
+      const int c0 = (lane & 7) * 8;
+      const bool act = myseg >= 0 && c0 < Sp;
+      float v[8];
+      float mx = -INFINITY;
+      if (act) {
+        const float4 p = *reinterpret_cast<const float4*>(srow + off + c0);
+        const float4 q = *reinterpret_cast<const float4*>(srow + off + c0 + 4);
+        v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int s = c0 + e;
+          const bool dead = (s >= S) | (mk[min(s, S - 1)] != 0);   // branch-free: the mask pointer is never null
+          v[e] = dead ? -INFINITY : v[e];
+          mx = fmaxf(mx, v[e]);
+        }
+      }
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      float sum = 0.f;
+      if (act) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] = expf(v[e] - mx); sum += v[e]; }
+      }
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      if (act) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] / sum;
+#pragma unroll
+        for (int g = 0; g < CFD_NMEM; ++g)
+          if (g == myseg) softmax_store(a, g, b, l, prow, c0, v);
+      }
+    }
+  }
+
+  // ---- long segments: the whole wave per segment, <= 4 chunks of 8 keys per lane in registers -----------------
 #pragma unroll
   for (int g = 0; g < CFD_NMEM; ++g) {
     if (g >= a.nseg) break;
     const int S = a.S[g], Sp = a.Sp[g], off = a.off[g];
-    const uint8_t* mk = nullptr;
-    if (a.mask[g]) mk = a.mask[g] + (long long)(a.map[g] ? a.map[g][b] : b) * S;
+    if (Sp <= 64) continue;
+    const uint8_t* mk = a.mask[g] + (long long)(a.map[g] ? a.map[g][b] : b) * S;
     float v[SM_MAX_CHUNKS][8];
     float mx = -INFINITY;
 #pragma unroll
@@ -150,7 +219,9 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const SoftmaxArgs a) 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int s = c0 + e;
-          if (s >= S || (mk && mk[s])) v[n][e] = -INFINITY;
+          bool dead = s >= S;
+          if (a.has_mask[g]) dead |= mk[min(s, S - 1)] != 0;   // wave-uniform condition
+          v[n][e] = dead ? -INFINITY : v[n][e];
           mx = fmaxf(mx, v[n][e]);
         }
       }
@@ -169,20 +240,13 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const SoftmaxArgs a) 
       }
     }
     sum = wave_sum(sum);
-    float* att = nullptr;
-    if (a.att[g]) att = a.att[g] + (((long long)b * a.nl + a.layer) * a.rows_per_b + l) * S;
 #pragma unroll
     for (int n = 0; n < SM_MAX_CHUNKS; ++n) {
       const int c0 = (lane + 64 * n) * 8;
       if (c0 < Sp) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[n][e] = v[n][e] / sum;
-        sp_store8(prow, off + c0, v[n]);
-        if (att) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (c0 + e < S) att[c0 + e] = v[n][e];
-        }
+        softmax_store(a, g, b, l, prow, c0, v[n]);
       }
     }
   }
