@@ -88,5 +88,6 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// v_exp_f32-based exponential (__expf): ~1e-7 relative near 0, grows with |x| only where the result is negligible
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }

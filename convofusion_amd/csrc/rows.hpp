@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const SoftmaxArgs a) 
       float sum = 0.f;
       if (act) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { v[e] = expf(v[e] - mx); sum += v[e]; }
+        for (int e = 0; e < 8; ++e) { v[e] = __expf(v[e] - mx); sum += v[e]; }
       }
 #pragma unroll
       for (int o = 4; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const SoftmaxArgs a) 
       if (c0 < Sp) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          v[n][e] = expf(v[n][e] - mx);  // all-masked row: (-inf)-(-inf) = NaN, as in the reference
+          v[n][e] = __expf(v[n][e] - mx);  // all-masked row: (-inf)-(-inf) = NaN, as in the reference
           sum += v[n][e];
         }
       }
