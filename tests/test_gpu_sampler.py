@@ -202,3 +202,39 @@ def test_full_size_properties(shape):
     g1 = sample(m, _sched("ddpm"), [x[:B] for x in mems], {k: (v[:B] if v is not None else None) for k, v in masks.items()},
                 B=B, L=L, num_inference_steps=2, seed=2, guidance_chunks=1)
     assert torch.allclose(g7, g1, rtol=0, atol=1e-6)
+
+
+def test_ddim_with_eta_matches_oracle():
+    """DDIM with eta > 0 draws per-step noise from the device Philox stream (diffusers 0.14.0 DDIMScheduler.step)."""
+    from convofusion_amd.sampler import sample
+    from tests.gpu_helpers import hip_denoiser, to_dev
+    B, L, S, n, eta, seed = 2, 16, (6, 20, 6, 8, 1), 5, 0.5, 123
+    cb = inputs.make_cfg_batch(seed=21, B=B, L=L, S=S, pad_tail=(2, 0, 1, 0, 0))
+    sd = state_dict()
+    want, _, _ = sampler_ref.diffusion_reverse(
+        lambda x, t, e, mk: denoiser_ref.denoiser_forward(sd, x, t, e, mk), scheduler_ref.DDIMSchedulerRef(),
+        cb["memories"], cb["masks"], philox_ref.normal_tensor(seed, 0, range(B), 1, L),
+        lambda i, t: philox_ref.normal_tensor(seed, i, range(B), 0, L), num_inference_steps=n, eta=eta)
+    got = sample(hip_denoiser(1234, 1.0), _sched("ddim"), [to_dev(x) for x in cb["memories"]],
+                 {k: to_dev(v) for k, v in cb["masks"].items()}, B=B, L=L, num_inference_steps=n, eta=eta, seed=seed)
+    e = rel_l2(got.permute(1, 0, 2).cpu().numpy(), want)
+    print("ddim eta=0.5 vs oracle", e)
+    assert e < TRAJ_TOL
+
+
+@pytest.mark.parametrize("env", [{"CFD_NAIVE_GEMM": "1"}, {"CFD_GEMM_CFG": "2"}, {"CFD_CHUNKS": "3"},
+                                 {"CFD_FUSED_SELF": "0"}, {"CFD_RUNS": "0"}])
+def test_developer_knobs_keep_parity(env):
+    """The debug / tuning switches (read once at cfd_create) must not change results: run the golden forward and
+    the 20-step trajectory test in a child process under each of them."""
+    import os
+    import subprocess
+    import sys
+    e = dict(os.environ, **env)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x",
+                        "tests/test_gpu_forward.py::test_forward_matches_reference_golden",
+                        "tests/test_gpu_sampler.py::test_sampler_matches_reference_trajectory[ddpm20_b2]",
+                        "tests/test_gpu_sampler.py::test_shared_memory_run_path_matches_oracle"],
+                       cwd=root, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
