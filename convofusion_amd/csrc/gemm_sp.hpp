@@ -26,6 +26,9 @@
 
 // s_waitcnt immediate (gfx9 encoding): vmcnt = N (bits 3:0 and 15:14), expcnt = 7 (no wait), lgkmcnt = 0
 #define WAIT_VM_LGKM0(N) ((((N) & 15) | 0x70 | ((((N) >> 4) & 3) << 14)))
+#ifndef CFD_WIDE_EPI
+#define CFD_WIDE_EPI 1
+#endif
 #define GEMM_SLOTS 5
 enum { MODE_PLAIN = 0, MODE_GROUPED = 1, MODE_SEGK = 2 };
 
@@ -369,14 +372,30 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
   // epilogue operands (residual rows / bias vectors) are requested now and consumed after the K loop
   struct NoPre {};
   typename std::conditional<Epi::kPrefetch, typename EpiPre<Epi>::type, NoPre>::type pre[TI][TJ];
+  // Epilogue lane mapping.  Native MFMA layout: a lane owns 4 consecutive i of ONE row j, so a wave store touches 16
+  // rows x 64 B (16 half cache lines).  With CFD_WIDE_EPI the accumulator tile goes through LDS once and is handed
+  // out again with LPR = 4*TI lanes per row: a wave store then covers 64/LPR rows x (TI*64) contiguous bytes.
+  constexpr bool WIDE = CFD_WIDE_EPI && (TI == 2 || TI == 4 || TI == 8);
+  constexpr int LPR = TI * 4;            // lanes per output row (wide mapping)
+  constexpr int RPI = 64 / LPR;          // rows per wave instruction
+  constexpr int NIT = 16 / RPI;          // instructions per 16-row tile band
+  auto epi_ij = [&](int tj, int k, int& i, int& j) __attribute__((always_inline)) {   // k: ti (native) or it (wide)
+    if (WIDE) {
+      i = i0 + wi * TI * 16 + (lane % LPR) * 4;
+      j = j0 + (wj * TJ + tj) * 16 + k * RPI + lane / LPR;
+    } else {
+      i = i0 + (wi * TI + k) * 16 + q4 * 4;
+      j = j0 + (wj * TJ + tj) * 16 + l15;
+    }
+  };
   if constexpr (Epi::kPrefetch) {
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
       for (int tj = 0; tj < TJ; ++tj) {
-        const int i = min(i0 + (wi * TI + ti) * 16 + q4 * 4, Ig - 4);
-        const int j = min(j0 + (wj * TJ + tj) * 16 + l15, a.J - 1);
-        pre[ti][tj] = epi.prefetch(g, b, z, i, j);
+        int i, j;
+        epi_ij(tj, ti, i, j);   // WIDE: NIT == TI, so the [TI][TJ] array has exactly one slot per instruction
+        pre[ti][tj] = epi.prefetch(g, b, z, min(i, Ig - 4), min(j, a.J - 1));
       }
   }
 
@@ -518,17 +537,43 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
     }
   }
 
-#pragma unroll
-  for (int ti = 0; ti < TI; ++ti)
+  if constexpr (WIDE) {
+    static_assert(NIT == TI, "one epilogue instruction per MFMA tile");
+    // every wave re-lays its tile band by band through a private LDS strip (the staging ring is free now)
+    constexpr int RS = TI * 64 + 16;                 // row stride in bytes (+16: conflict-free 16-byte writes)
+    char* strip = smem + wid * (16 * RS);
+    __syncthreads();                                  // all waves are done with the last k-tile
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
-      const int i = i0 + (wi * TI + ti) * 16 + q4 * 4;
-      const int j = j0 + (wj * TJ + tj) * 16 + l15;
-      if (i < Ig && j < a.J) {
-        if constexpr (Epi::kPrefetch) epi(g, b, z, i, j, acc[ti][tj], pre[ti][tj]);
-        else epi(g, b, z, i, j, acc[ti][tj]);
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+        *reinterpret_cast<f32x4*>(strip + l15 * RS + (ti * 16 + q4 * 4) * 4) = acc[ti][tj];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private strip: no barrier needed
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        int i, j;
+        epi_ij(tj, it, i, j);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(strip + (it * RPI + lane / LPR) * RS + (lane % LPR) * 16);
+        if (i < Ig && j < a.J) {
+          if constexpr (Epi::kPrefetch) epi(g, b, z, i, j, v, pre[it][tj]);
+          else epi(g, b, z, i, j, v);
+        }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next band overwrites the strip
     }
+  } else {
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        int i, j;
+        epi_ij(tj, ti, i, j);
+        if (i < Ig && j < a.J) {
+          if constexpr (Epi::kPrefetch) epi(g, b, z, i, j, acc[ti][tj], pre[ti][tj]);
+          else epi(g, b, z, i, j, acc[ti][tj]);
+        }
+      }
+  }
 }
 
 // Reference kernel with the same operands / epilogues, one thread per (4 i, 1 j): used by the
