@@ -29,6 +29,9 @@
 #ifndef CFD_WIDE_EPI
 #define CFD_WIDE_EPI 1
 #endif
+#ifndef CFD_LATE_RESID
+#define CFD_LATE_RESID 0
+#endif
 #define GEMM_SLOTS 5
 enum { MODE_PLAIN = 0, MODE_GROUPED = 1, MODE_SEGK = 2 };
 
@@ -116,6 +119,22 @@ struct EpiResid {  // x[(b*rows_per_b + j)][i] += v + bias[i]   (row length CFD_
   // (Reading the residual rows before the K loop was tried: +46 VGPRs and no gain -- 92 vs 86 us on the
   //  43904x512x512 product; the epilogue is bandwidth-, not latency-limited.)
   static constexpr bool kPrefetch = false;
+  // The residual rows of a tile are requested together, just before the last k-step's MFMAs (kLate): one exposed
+  // HBM round trip per tile instead of one per 16-row band of the epilogue.
+  static constexpr bool kLate = true;
+  typedef float4 Late;
+  __device__ __forceinline__ Late late_load(int g, int b, int z, int i, int j) const {
+    return *reinterpret_cast<const float4*>(x + (long long)b * obs + (long long)j * CFD_D + i);
+  }
+  __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v, Late r) const {
+    float* p = x + (long long)b * obs + (long long)j * CFD_D + i;
+    if (bias) {
+      const float4 t = *reinterpret_cast<const float4*>(bias + i);
+      r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+    }
+    r.x += v[0]; r.y += v[1]; r.z += v[2]; r.w += v[3];
+    *reinterpret_cast<float4*>(p) = r;
+  }
   __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
     float* p = x + (long long)b * obs + (long long)j * CFD_D + i;
     float4 r = *reinterpret_cast<const float4*>(p);
@@ -189,6 +208,10 @@ struct EpiMemV {  // V^T_layer_u[j/512][i/Sp][j%512][i%Sp] = split(v): one conti
   }
 };
 
+template <class E, class = void> struct EpiHasLate { static constexpr bool value = false; };
+template <class E> struct EpiHasLate<E, typename std::enable_if<E::kLate>::type> { static constexpr bool value = true; };
+template <class E, bool P = EpiHasLate<E>::value> struct EpiLateT { struct type {}; };
+template <class E> struct EpiLateT<E, true> { typedef typename E::Late type; };
 template <class E, bool P = E::kPrefetch> struct EpiPre { struct type {}; };
 template <class E> struct EpiPre<E, true> { typedef typename E::Pre type; };
 
@@ -399,6 +422,23 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
       }
   }
 
+  // residual rows requested before the last k-step (EpiResid::kLate)
+  constexpr bool LATE = CFD_LATE_RESID && WIDE && EpiHasLate<Epi>::value && NSTAGE == 2 && TI * TJ <= 16;
+  typename EpiLateT<Epi, LATE>::type late[LATE ? NIT : 1][LATE ? TJ : 1];
+  auto late_issue = [&]() __attribute__((always_inline)) {
+    if constexpr (LATE) {
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          int i, j;
+          epi_ij(tj, it, i, j);
+          late[it][tj] = epi.late_load(g, b, z, min(i, Ig - 4), min(j, a.J - 1));
+        }
+      asm volatile("" ::: "memory");   // keep the requests ahead of the last k-step's LDS reads / MFMAs
+    }
+  };
+
   auto compute = [&](int buf) __attribute__((always_inline)) {
     const char* sb = smem + buf * STAGE;
     spx8 xh[TI], xl[TI], yh[TJ], yl[TJ];
@@ -437,8 +477,9 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
     for (int kt = 0; kt < nkt; ++kt) {
       const int buf = kt & 1;
       if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);
+      else late_issue();
       compute(buf);
-      __syncthreads();
+      if (!LATE || kt + 1 < nkt) __syncthreads();   // (LATE: the epilogue's own barrier follows, without a vmcnt drain)
     }
   } else if constexpr (NSTAGE == 3) {
     // tiles kt+1 and kt+2 are in flight while tile kt is consumed
@@ -542,7 +583,12 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
     // every wave re-lays its tile band by band through a private LDS strip (the staging ring is free now)
     constexpr int RS = TI * 64 + 16;                 // row stride in bytes (+16: conflict-free 16-byte writes)
     char* strip = smem + wid * (16 * RS);
-    __syncthreads();                                  // all waves are done with the last k-tile
+    if constexpr (LATE) {                             // all waves are done with the last k-tile; the residual
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // requests stay in flight across the barrier
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __syncthreads();
+    }
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
 #pragma unroll
@@ -556,6 +602,7 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(strip + (it * RPI + lane / LPR) * RS + (lane % LPR) * 16);
         if (i < Ig && j < a.J) {
           if constexpr (Epi::kPrefetch) epi(g, b, z, i, j, v, pre[it][tj]);
+          else if constexpr (LATE) epi(g, b, z, i, j, v, late[it][tj]);
           else epi(g, b, z, i, j, v);
         }
       }
@@ -684,6 +731,8 @@ static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStr
     case 14: return launch_cfg<2, 2, 4, 8, 4, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 256, 4 waves x (64 x 128), software-pipelined
     case 15: return launch_cfg<2, 2, 4, 2, 2, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 64 (48 KB LDS: 3 blocks / CU)
     case 16: return launch_cfg<2, 2, 2, 4, 2, MODE, Epi>(a, epi, nb, nz, st);  // 64 x 128
+    case 17: return launch_cfg<4, 1, 2, 11, 2, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 176: 43904 rows = 250 x 176 - 96
+    case 18: return launch_cfg<8, 1, 2, 11, 2, MODE, Epi>(a, epi, nb, nz, st);  // 256 x 176, 8 waves
     case 12: return launch_cfg<2, 2, 4, 4, 1, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 128, single LDS buffer, 3+ blocks / CU
     case 10: return launch_cfg<2, 4, 4, 4, 4, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 256, 8 waves, software-pipelined
     case 11: return launch_cfg<2, 2, 4, 4, 4, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 128, 4 waves, software-pipelined
