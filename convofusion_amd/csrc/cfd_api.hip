@@ -76,6 +76,11 @@ struct Problem {
   int has_mask[CFD_NMEM];
   float* att[CFD_NMEM];
   int tmode = 0;  // 0: all rows share the timestep of table row *d_step ; 1: row b uses table row b
+  // Sampling loop only: the effective batch is G replicas (chunk-major) of the same B latent rows, so everything
+  // before the first cross-attention -- embedding, layer 0's self-attention and first time block -- is identical
+  // for the G replicas of an utterance (same input, same timestep; the memories enter only at the cross-attention).
+  // It is computed for the first B rows and copied to the other chunks.  0 = off (cfd_forward: arbitrary rows).
+  int share_B = 0;
   int T = 1;      // rows in the temb tables
   // Rows that share one memory of the LARGEST memory type in long consecutive runs (the guidance batch repeats
   // the unconditional audio memory for 5 of its 7 chunks): their attention against that memory is one big
@@ -105,6 +110,7 @@ struct cfd_handle_s {
   bool use_runs = true;   // CFD_RUNS=0 disables the shared-memory run optimisation
   int nchunks_env = 0;
   bool fused_self = true;   // CFD_FUSED_SELF=0 selects the GEMM -> softmax -> GEMM self-attention
+  bool share0 = true;       // CFD_SHARE0=0: evaluate the pre-cross-attention part of layer 0 for every guidance replica
   DBuf d_step;  // [0] = loop index, [1] = constant 0
   Problem pb;
   // profiling
@@ -204,6 +210,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   c->use_runs = !(env && atoi(env) == 0);
   env = getenv("CFD_FUSED_SELF");
   c->fused_self = !(env && atoi(env) == 0);
+  env = getenv("CFD_SHARE0");
+  c->share0 = !(env && atoi(env) == 0);
   env = getenv("CFD_CHUNKS");
   c->nchunks_env = env ? atoi(env) : 0;
   env = getenv("CFD_GEMM_CFG");
@@ -297,6 +305,15 @@ __global__ void d2f_kernel(const double* in, float* out, int n) {
 __global__ void f2d_kernel(const float* in, double* out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (double)in[i];
+}
+
+// x[g][:] = x[0][:] for g = 1 .. G-1 (n4 float4 per replica): hands the shared pre-cross-attention state of layer 0
+// to every guidance chunk
+__global__ void replicate_rows_kernel(float4* x, long long n4, int G) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = x[i];
+  for (int g = 1; g < G; ++g) x[(long long)g * n4 + i] = v;
 }
 
 extern "C" int cfd_finalize_weights(cfd_handle c) {
@@ -465,6 +482,7 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
   }
   Problem& p = c->pb;
   p.Be = Be; p.L = L; p.Lp = (L + 31) / 32 * 32; p.M = (long long)Be * L; p.tmode = tmode; p.T = T;
+  p.share_B = 0;
   if (p.Lp > SM_MAX_CHUNKS * 512) return fail(CFD_E_SHAPE, "L = %d exceeds the in-register softmax limit (%d)", L, SM_MAX_CHUNKS * 512);
   int off = 0;
   for (int j = 0; j < CFD_NMEM; ++j) {
@@ -671,37 +689,44 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     attj[j] = p.att[j] ? p.att[j] + (size_t)row0 * nl * L * p.S[j] : nullptr;
   }
 
+  // rows that run the replica-independent head of the network (see Problem::share_B)
+  const bool share = p.share_B > 0 && row0 == 0 && Be == p.Be && Be % p.share_B == 0 && Be > p.share_B && !c->stop_stage;
+  const int Bs = share ? p.share_B : Be;
+  const long long Ms = (long long)Bs * L;
   // 1. latent embedding + body/hand embedding + query PE          (denoiser.py:187,316-326)
   {
     GemmArgs a = gemm_args();
     a.X[0] = c->we_sp.as<char>(); a.ldx[0] = CFD_LAT * 4; a.I[0] = CFD_D; a.Iclamp[0] = CFD_D; a.kt[0] = CFD_LAT / 32;
-    a.Y = sample_sp; a.ldy = CFD_LAT * 4; a.J = (int)M; a.Jclamp = (int)M;
+    a.Y = sample_sp; a.ldy = CFD_LAT * 4; a.J = (int)Ms; a.Jclamp = (int)Ms;
     EpiEmbed e{c->x.as<float>(), rawp(c, "latent_embd.bias"), rawp(c, "bh_embedding.weight"), rawp(c, "query_pos.pe"), L};
     CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
   }
   if (c->stop_stage == 1) return CFD_OK;
-  auto ln = [&](const float* g, const float* b, int adaln, int tbidx, char* out) -> int {
-    LnArgs a{c->x.as<float>(), out, M, g, b, adaln, c->ss_tab.as<float>() + (size_t)tbidx * 2 * CFD_D,
+  auto ln = [&](const float* g, const float* b, int adaln, int tbidx, char* out, long long rows) -> int {
+    LnArgs a{c->x.as<float>(), out, rows, g, b, adaln, c->ss_tab.as<float>() + (size_t)tbidx * 2 * CFD_D,
              (long long)nl * 2 * 2 * CFD_D, dstep, p.tmode, L, row0};
-    LAUNCH(CFD_PROF_ROWS, ln_rows_kernel, dim3((unsigned)((M + 3) / 4)), blk, st, a);
+    LAUNCH(CFD_PROF_ROWS, ln_rows_kernel, dim3((unsigned)((rows + 3) / 4)), blk, st, a);
     return CFD_OK;
   };
-  auto token_gemm_resid = [&](const DBuf& w, int K, const char* y, const float* bias) -> int {
+  auto token_gemm_resid = [&](const DBuf& w, int K, const char* y, const float* bias, long long rows) -> int {
     GemmArgs a = gemm_args();
     a.X[0] = w.as<char>(); a.ldx[0] = (long long)K * 4; a.I[0] = CFD_D; a.Iclamp[0] = CFD_D; a.kt[0] = K / 32;
-    a.Y = y; a.ldy = (long long)K * 4; a.J = (int)M; a.Jclamp = (int)M;
+    a.Y = y; a.ldy = (long long)K * 4; a.J = (int)rows; a.Jclamp = (int)rows;
     EpiResid e{c->x.as<float>(), 0, bias};
     return run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st);
   };
 
   for (int l = 0; l < nl; ++l) {
     const LayerW& w = c->lw[l];
+    // rows of sub-layers a and b: layer 0 runs them once per utterance when the batch is G replicas of it
+    const int Ba = (l == 0) ? Bs : Be;
+    const long long Ma = (long long)Ba * L;
     // ---- a. self attention: x += Wo softmax(q k^T) v                         (cross_attention.py:568-572)
-    CHK(ln(w.ln1g, w.ln1b, 0, 0, c->h_sp.as<char>()));
+    CHK(ln(w.ln1g, w.ln1b, 0, 0, c->h_sp.as<char>(), Ma));
     {  // q (pre-scaled) and k, token-major
       GemmArgs a = gemm_args();
       a.X[0] = w.wqk_sp.as<char>(); a.ldx[0] = ROWB; a.I[0] = 2 * CFD_D; a.Iclamp[0] = 2 * CFD_D; a.kt[0] = CFD_D / 32;
-      a.Y = c->h_sp.as<char>(); a.ldy = ROWB; a.J = (int)M; a.Jclamp = (int)M;
+      a.Y = c->h_sp.as<char>(); a.ldy = ROWB; a.J = (int)Ma; a.Jclamp = (int)Ma;
       EpiSplit e{c->qk_sp.as<char>(), 2 * ROWB, 0, 0, w.bqk.as<float>(), 0, 0};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
     }
@@ -712,7 +737,7 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       a.X[0] = c->h_sp.as<char>(); a.ldx[0] = ROWB; a.xbs[0] = (long long)L * ROWB; a.I[0] = Lv; a.Iclamp[0] = L; a.kt[0] = CFD_D / 32;
       a.Y = w.wv_sp.as<char>(); a.ldy = ROWB; a.J = CFD_D; a.Jclamp = CFD_D;
       EpiSplit e{c->vts_sp.as<char>(), (long long)Lv * 4, (long long)CFD_D * Lv * 4, 0, nullptr, 0, fused_self ? 1 : 0};
-      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, Be, 1, st)));
+      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, Ba, 1, st)));
     }
     if (fused_self) {
       SelfAttnArgs a{c->qk_sp.as<char>(), c->vts_sp.as<char>(), c->o_sp.as<char>(), L, Lv};
@@ -722,7 +747,7 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
         attr = true;
       }
       Bracket br(c, CFD_PROF_GEMM_ATTN, st);
-      hipLaunchKernelGGL(self_attn_fused_kernel, dim3((L + SELF_ATTN_WAVES * 16 - 1) / (SELF_ATTN_WAVES * 16), CFD_NHEAD, Be), dim3(SELF_ATTN_WAVES * 64), 65536, st, a);
+      hipLaunchKernelGGL(self_attn_fused_kernel, dim3((L + SELF_ATTN_WAVES * 16 - 1) / (SELF_ATTN_WAVES * 16), CFD_NHEAD, Ba), dim3(SELF_ATTN_WAVES * 64), 65536, st, a);
       HIPCHK(hipGetLastError());
     } else {
     {  // scores[b][h][lq][lk]
@@ -733,12 +758,12 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       EpiF32 e;
       memset(&e, 0, sizeof(e));
       e.out = c->ssc.as<float>(); e.ldo = Lp; e.obs = (long long)CFD_NHEAD * L * Lp; e.ozs = (long long)L * Lp;
-      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_ATTN, a, e, Be, CFD_NHEAD, st)));
+      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_ATTN, a, e, Ba, CFD_NHEAD, st)));
     }
     {
       SoftmaxArgs a;
       memset(&a, 0, sizeof(a));
-      a.sc = c->ssc.as<float>(); a.P = c->sp_sp.as<char>(); a.ld = Lp; a.rows = (long long)Be * CFD_NHEAD * L; a.rows_per_b = CFD_NHEAD * L;
+      a.sc = c->ssc.as<float>(); a.P = c->sp_sp.as<char>(); a.ld = Lp; a.rows = (long long)Ba * CFD_NHEAD * L; a.rows_per_b = CFD_NHEAD * L;
       a.nseg = 1; a.S[0] = L; a.Sp[0] = Lp; a.nl = nl;
       for (int j = 0; j < CFD_NMEM; ++j) a.mask[j] = c->zero_mask.as<uint8_t>();
       LAUNCH(CFD_PROF_ROWS, softmax_rows_kernel, dim3((unsigned)((a.rows + 3) / 4)), blk, st, a);
@@ -750,17 +775,22 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       a.Y = c->sp_sp.as<char>(); a.ldy = (long long)Lp * 4; a.ybs = (long long)CFD_NHEAD * L * Lp * 4; a.yzs = (long long)L * Lp * 4;
       a.J = L; a.Jclamp = L;
       EpiSplit e{c->o_sp.as<char>(), ROWB, (long long)L * ROWB, (CFD_HD / 32) * 128, nullptr, 0, 0};
-      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_ATTN, a, e, Be, CFD_NHEAD, st)));
+      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_ATTN, a, e, Ba, CFD_NHEAD, st)));
     }
     }
-    CHK(token_gemm_resid(w.wo_sp, CFD_D, c->o_sp.as<char>(), w.bo2.as<float>()));
+    CHK(token_gemm_resid(w.wo_sp, CFD_D, c->o_sp.as<char>(), w.bo2.as<float>(), Ma));
     if (c->stop_stage == 2 + 4 * l) return CFD_OK;
     // ---- b. time block 1                                                        (:575, :426-439)
-    CHK(ln(w.tb1g, w.tb1b, 1, 2 * l, c->h_sp.as<char>()));
-    CHK(token_gemm_resid(w.wtb1_sp, CFD_D, c->h_sp.as<char>(), w.btb1));
+    CHK(ln(w.tb1g, w.tb1b, 1, 2 * l, c->h_sp.as<char>(), Ma));
+    CHK(token_gemm_resid(w.wtb1_sp, CFD_D, c->h_sp.as<char>(), w.btb1, Ma));
     if (c->stop_stage == 3 + 4 * l) return CFD_OK;
+    if (Ma != M) {   // every guidance chunk starts its first cross-attention from the same state
+      const long long n4 = Ma * (CFD_D / 4);
+      LAUNCH(CFD_PROF_ROWS, replicate_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), blk, st, reinterpret_cast<float4*>(c->x.as<float>()), n4,
+             (int)(M / Ma));
+    }
     // ---- c-e. five cross attentions + fuser, folded                             (:578-652)
-    CHK(ln(w.ln2g, w.ln2b, 0, 0, c->h_sp.as<char>()));
+    CHK(ln(w.ln2g, w.ln2b, 0, 0, c->h_sp.as<char>(), M));
     // scores against the folded keys of every memory.  Long memories and short (<= 64 keys) memories go to
     // different tile shapes; rows in a shared-memory run of the largest memory use one un-batched product per run.
     const bool runs = p.nruns > 0 && row0 == 0 && Be == p.Be;
@@ -861,10 +891,10 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     }
     if (c->stop_stage == 4 + 4 * l) return CFD_OK;
     // ---- f. time block 2                                                        (:655)
-    CHK(ln(w.tb2g, w.tb2b, 1, 2 * l + 1, c->h_sp.as<char>()));
-    CHK(token_gemm_resid(w.wtb2_sp, CFD_D, c->h_sp.as<char>(), w.btb2));
+    CHK(ln(w.tb2g, w.tb2b, 1, 2 * l + 1, c->h_sp.as<char>(), M));
+    CHK(token_gemm_resid(w.wtb2_sp, CFD_D, c->h_sp.as<char>(), w.btb2, M));
     // ---- g. FFN                                                                 (:659-661)
-    CHK(ln(w.ln3g, w.ln3b, 0, 0, c->h_sp.as<char>()));
+    CHK(ln(w.ln3g, w.ln3b, 0, 0, c->h_sp.as<char>(), M));
     {
       GemmArgs a = gemm_args();
       a.X[0] = w.w1_sp.as<char>(); a.ldx[0] = ROWB; a.I[0] = CFD_FF; a.Iclamp[0] = CFD_FF; a.kt[0] = CFD_D / 32;
@@ -872,11 +902,11 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       EpiSplit e{c->u_sp.as<char>(), (long long)CFD_FF * 4, 0, 0, w.b1, 1, 0};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
     }
-    CHK(token_gemm_resid(w.w2_sp, CFD_FF, c->u_sp.as<char>(), w.b2));
+    CHK(token_gemm_resid(w.w2_sp, CFD_FF, c->u_sp.as<char>(), w.b2, M));
     if (c->stop_stage == 5 + 4 * l) return CFD_OK;
   }
   // 7. final norm + latent projection                                             (cross_attention.py:238-239, denoiser.py:382)
-  CHK(ln(rawp(c, "decoder.norm.weight"), rawp(c, "decoder.norm.bias"), 0, 0, c->h_sp.as<char>()));
+  CHK(ln(rawp(c, "decoder.norm.weight"), rawp(c, "decoder.norm.bias"), 0, 0, c->h_sp.as<char>(), M));
   {
     GemmArgs a = gemm_args();
     a.X[0] = c->wp_sp.as<char>(); a.ldx[0] = ROWB; a.I[0] = CFD_LAT; a.Iclamp[0] = CFD_LAT; a.kt[0] = CFD_D / 32;
@@ -997,6 +1027,7 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
     while (c->sargs.G > 1 && s.guidance_weight[c->sargs.G - 1] == 0.0f) c->sargs.G -= 1;
   const int Be = c->sargs.G * s.B, N = s.num_inference_steps, T = s.num_train_timesteps;
   CHK(setup_problem(c, Be, s.L, s.mem, nullptr, 0, N));
+  if (c->share0 && c->sargs.G > 1) c->pb.share_B = s.B;   // begin_step_kernel writes G identical copies of the B rows
   // timesteps: (arange(N) * (T // N)).round()[::-1] (+ steps_offset for DDIM)
   std::vector<int32_t> ts(N);
   std::vector<StepCoef> coef(N);

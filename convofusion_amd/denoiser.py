@@ -195,7 +195,10 @@ class Denoiser(nn.Module):
             need = max(mem_len, sd["mem_pos.pe"].shape[0])
             for name, t in sd.items():
                 if name == "mem_pos.pe" and need > t.shape[0]:
-                    t = sine_pe(need, self.text_encoded_dim)
+                    # keep the checkpoint's rows bit for bit (they are what the reference adds; a re-computed
+                    # table can differ from a loaded buffer in the last bit) and append the closed form
+                    ext = sine_pe(need, self.text_encoded_dim).to(t.device, t.dtype)
+                    t = torch.cat([t, ext[t.shape[0]:]], dim=0)
                 t = t.detach().to(torch.float32).contiguous()
                 _lib.check(lib.cfd_load_tensor(self._handle, name.encode(), C.c_void_p(t.data_ptr()), t.numel(),
                                                1 if t.is_cuda else 0))

@@ -91,6 +91,32 @@ def test_skipping_the_zero_weight_chunk_is_exact():
     assert torch.equal(a, b)
 
 
+def test_sharing_the_head_of_layer_0_between_guidance_replicas_is_exact():
+    """The embedding, layer 0's self-attention and its first time block see the same latents and the same timestep
+    in all 7 guidance chunks: evaluating them once per utterance (default) must not change a bit against
+    evaluating them for every replica (CFD_SHARE0=0, read at cfd_create)."""
+    import os
+    import torch
+    from convofusion_amd.denoiser import Denoiser
+    from convofusion_amd.sampler import sample
+    from tests.gpu_helpers import ABL, DENOISER_KW, hip_denoiser, to_dev
+    B, L, S = 3, 16, (24, 161, 24, 8, 1)
+    cb = inputs.make_cfg_batch(seed=8, B=B, L=L, S=S, pad_tail=(4, 0, 6, 0, 0))
+    mems = [to_dev(x) for x in cb["memories"]]
+    masks = {k: to_dev(v) for k, v in cb["masks"].items()}
+    m = hip_denoiser(1234, 1.0)
+    a = sample(m, _sched("ddpm"), mems, masks, B=B, L=L, num_inference_steps=4, seed=11)
+    os.environ["CFD_SHARE0"] = "0"
+    try:
+        m2 = Denoiser(ablation=ABL, **DENOISER_KW)
+        m2.load_state_dict(m.state_dict(), strict=True)
+        m2 = m2.cuda().eval()
+        b = sample(m2, _sched("ddpm"), mems, masks, B=B, L=L, num_inference_steps=4, seed=11)
+    finally:
+        del os.environ["CFD_SHARE0"]
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_structured_guidance_batch_equals_replicated_batch():
     """build_guidance_batch (distinct memories + maps, no 7x materialisation) == the reference's replicated batch."""
     import torch
@@ -223,7 +249,7 @@ def test_ddim_with_eta_matches_oracle():
 
 
 @pytest.mark.parametrize("env", [{"CFD_NAIVE_GEMM": "1"}, {"CFD_GEMM_CFG": "2"}, {"CFD_CHUNKS": "3"},
-                                 {"CFD_FUSED_SELF": "0"}, {"CFD_RUNS": "0"}, {"CFD_BRANCHES": "1"}])
+                                 {"CFD_FUSED_SELF": "0"}, {"CFD_RUNS": "0"}, {"CFD_BRANCHES": "1"}, {"CFD_SHARE0": "0"}])
 def test_developer_knobs_keep_parity(env):
     """The debug / tuning switches (read once at cfd_create) must not change results: run the golden forward and
     the 20-step trajectory test in a child process under each of them."""
