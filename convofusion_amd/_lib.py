@@ -20,7 +20,7 @@ SYMBOLS = [
     "cfd_create", "cfd_destroy", "cfd_last_error", "cfd_load_tensor", "cfd_finalize_weights",
     "cfd_set_timestep_table", "cfd_forward", "cfd_sample_begin", "cfd_sample_steps", "cfd_sample_position",
     "cfd_sample_read", "cfd_scheduler_step", "cfd_add_noise", "cfd_philox_normal", "cfd_profile_forward",
-    "cfd_test_gemm", "cfd_debug_stop_stage", "cfd_debug_read", "cfd_bench_gemm",
+    "cfd_test_gemm", "cfd_debug_stop_stage", "cfd_debug_read", "cfd_bench_gemm", "cfd_linear_act",
 ]
 
 
@@ -86,6 +86,8 @@ def load():
     lib.cfd_test_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_void_p]
     lib.cfd_bench_gemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    lib.cfd_linear_act.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p]
     lib.cfd_debug_stop_stage.argtypes = [C.c_void_p, C.c_int]
     lib.cfd_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
     for name in SYMBOLS:

@@ -1175,6 +1175,19 @@ extern "C" int cfd_philox_normal(cfd_handle c, float* out, int B, int per_utt, u
   return CFD_OK;
 }
 
+// ---- conditioning producers ---------------------------------------------------------------------------------
+extern "C" int cfd_linear_act(cfd_handle c, const float* x, long long n_rows, int K, const float* W, const float* b, int N, int act,
+                              float* out, void* stream) {
+  if (!c || !x || !W || !out || n_rows < 1 || K < 1 || N < 1 || act < 0 || act > 2) return fail(CFD_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  const long long gy = (n_rows + 31) / 32;
+  if (gy > 65535) return fail(CFD_E_ARG, "too many rows for one launch (%lld)", n_rows);
+  hipLaunchKernelGGL(linear_act_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)gy), dim3(256), 0, (hipStream_t)stream, x, n_rows, K, W, b,
+                     N, act, out);
+  HIPCHK(hipGetLastError());
+  return CFD_OK;
+}
+
 // ---- test hooks -----------------------------------------------------------------------------------------
 extern "C" int cfd_debug_stop_stage(cfd_handle c, int stage) {
   if (!c) return fail(CFD_E_ARG, "null handle");

@@ -496,3 +496,60 @@ __global__ void cfg_step_kernel(const CfgStepArgs a) {
 }
 
 __global__ void advance_step_kernel(int* d_step) { *d_step += 1; }
+
+// ------------------------------------------------------------------------------------------------
+// out[r][n] = act( b[n] + sum_k x[r][k] W[n][k] ), float32 FMA chain in ascending k (nn.Linear + activation).
+// Conditioning producers that run once per batch or once per step on a few thousand rows -- the audio encoder
+// (audioenc.py:12-21,33-34), the partner-latent projection of the dyadic path (condfuser.py:22-27) -- so a plain
+// LDS-tiled fp32 kernel: 32 rows x 64 outputs per 256-thread block, k in chunks of 32.
+//   act: 0 none, 1 GELU (erf form, nn.GELU()), 2 LeakyReLU(0.1)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) linear_act_kernel(const float* __restrict__ x, long long n_rows, int K, const float* __restrict__ W,
+                                                         const float* __restrict__ b, int N, int act, float* __restrict__ out) {
+  __shared__ float xs[32][33];
+  __shared__ float ws[64][33];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;               // 4 output columns, 2 rows per thread
+  const long long r0 = (long long)blockIdx.y * 32;
+  const int n0 = blockIdx.x * 64;
+  float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  for (int k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q, rr = e >> 5, kk = e & 31;
+      const long long r = r0 + rr;
+      xs[rr][kk] = (r < n_rows && k0 + kk < K) ? x[r * K + k0 + kk] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = tid + 256 * q, nn = e >> 5, kk = e & 31;
+      ws[nn][kk] = (n0 + nn < N && k0 + kk < K) ? W[(long long)(n0 + nn) * K + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+      const float x0 = xs[ty * 2][kk], x1 = xs[ty * 2 + 1][kk];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float w = ws[tx * 4 + c][kk];
+        acc[0][c] = fmaf(x0, w, acc[0][c]);
+        acc[1][c] = fmaf(x1, w, acc[1][c]);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const long long r = r0 + ty * 2 + rr;
+    if (r >= n_rows) continue;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int n = n0 + tx * 4 + c;
+      if (n >= N) continue;
+      float v = acc[rr][c] + (b ? b[n] : 0.f);
+      if (act == 1) v = gelu_f(v);
+      else if (act == 2) v = v > 0.f ? v : 0.1f * v;
+      out[r * N + n] = v;
+    }
+  }
+}

@@ -137,6 +137,16 @@ int cfd_scheduler_step(cfd_handle h, int scheduler, const float* alphas_cumprod,
 int cfd_add_noise(cfd_handle h, const float* alphas_cumprod_host, int t, const float* original,
                   const float* noise, float* out, size_t numel, void* stream);
 
+/* Conditioning producers on device tensors: out[r][n] = act(b[n] + sum_k x[r][k] W[n][k]), float32 -- one
+ * nn.Linear (+ activation) of the small MLPs that make the memories: AudioConvEncoder.main / .out_net
+ * (convofusion/models/architectures/audioenc.py:12-21,33-34: Linear, LeakyReLU(0.1), Linear, LeakyReLU(0.1), Linear;
+ * dropout is the identity at inference) and TextAudioMotionFuser.latent_proj (condfuser.py:22-27: Linear, GELU,
+ * Linear, GELU), which the dyadic path applies to the partner's current latents every step (BASELINE config 5).
+ *   x dev [n_rows][K], W dev [N][K] (nn.Linear.weight), b dev [N] or NULL, out dev [n_rows][N]
+ *   act: 0 none, 1 nn.GELU() (erf form), 2 nn.LeakyReLU(0.1) */
+int cfd_linear_act(cfd_handle h, const float* x, long long n_rows, int K, const float* W, const float* b, int N, int act,
+                   float* out, void* stream);
+
 /* Device N(0,1) draws of the product's counter-based stream (DESIGN.md "RNG"): out dev [B][per_utt]. */
 int cfd_philox_normal(cfd_handle h, float* out, int B, int per_utt, uint64_t seed, uint32_t step,
                       uint32_t first_utterance, uint32_t stream_id, void* stream);

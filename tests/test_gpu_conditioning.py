@@ -1,0 +1,101 @@
+"""GPU tests (through the C ABI): conditioning producers and the dyadic reactive loop against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import conditioning_ref, denoiser_ref, dyadic_ref, inputs, philox_ref, scheduler_ref
+from tests.helpers import state_dict
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "conditioning.npz"))
+ENC = {k[4:]: G[k] for k in G.files if k.startswith("enc.")}
+FUS = {k[4:]: G[k] for k in G.files if k.startswith("fus.")}
+
+
+def rel(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b.astype(np.float64)))
+
+
+def _fuser():
+    import torch
+    from convofusion_amd.conditioning import default_fuser
+    f = default_fuser()
+    f.load_state_dict({k: torch.from_numpy(v) for k, v in FUS.items()}, strict=True)
+    return f.cuda().eval()
+
+
+def test_audio_conv_encoder_matches_reference_golden():
+    import torch
+    from convofusion_amd.conditioning import AudioConvEncoder
+    enc = AudioConvEncoder(input_size=80, hidden_size=256, latent_dim=512, max_seq_len=128, fps=25, sample_rate=16000, hop_length=160)
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in ENC.items()}, strict=True)
+    enc = enc.cuda().eval()
+    out = enc(torch.from_numpy(G["mel"]).cuda()).cpu().numpy()
+    assert out.shape == G["audio_out"].shape
+    assert rel(out, G["audio_out"]) < 1e-6 and float(np.abs(out - G["audio_out"]).max()) < 2e-4   # |values| ~ 50
+
+
+@pytest.mark.parametrize("rows,K,N,act", [(1, 80, 256, 2), (33, 128, 512, 1), (70, 96, 65, 0), (5, 31, 3, 1)])
+def test_linear_act_ragged_shapes(rows, K, N, act):
+    """Row, feature and k tails that are not multiples of the 32 x 64 x 32 tile."""
+    import torch
+    from convofusion_amd.conditioning import linear_act
+    rng = np.random.Generator(np.random.PCG64(rows * 1000 + K))
+    x = rng.standard_normal((rows, K), dtype=np.float32)
+    w = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal((N,), dtype=np.float32)
+    want = conditioning_ref.linear(x, w, b)
+    want = {0: lambda v: v, 1: conditioning_ref.gelu, 2: conditioning_ref.leaky_relu}[act](want)
+    got = linear_act(torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda(), torch.from_numpy(b).cuda(), act).cpu().numpy()
+    assert got.shape == want.shape and float(np.abs(got - want).max()) < 1e-5
+
+
+def test_fuser_matches_reference_golden():
+    import torch
+    f = _fuser()
+    got = f.project_latents(torch.from_numpy(G["lat"]).cuda()).cpu().numpy()
+    assert rel(got, G["proj_out"]) < 1e-6
+    spk = torch.zeros((4, 5, 512), device="cuda")
+    with torch.no_grad():
+        _, _, _, apb, lsn = f(spk, spk, spk, torch.from_numpy(G["bits"]).cuda(), [int(v) for v in G["lsn_id"]])
+    assert np.array_equal(apb.cpu().numpy(), G["apb"]) and np.array_equal(lsn.cpu().numpy(), G["lsnemb"])
+
+
+def test_dyadic_loop_matches_oracle():
+    """BASELINE config 5 at a size the oracle finishes in seconds: B=2 per side, L=16, 5 DDPM iterations,
+    identical init latents and per-step noise on both paths; tolerance = the trajectory budget (1e-3 relative)."""
+    import torch
+    from convofusion_amd import scheduler
+    from convofusion_amd.denoiser import Denoiser
+    from convofusion_amd.dyadic import sample_dyadic
+    from tests.gpu_helpers import ABL, DENOISER_KW, SCHED_KW, hip_denoiser, to_dev
+    B, L, n = 2, 16, 5
+    S = (L, 20, 6, 8, 1)
+    ca = inputs.make_cfg_batch(seed=31, B=B, L=L, S=S)
+    cb = inputs.make_cfg_batch(seed=32, B=B, L=L, S=S)
+    cond_a = [u[1:] for u in ca["unique"]]
+    cond_b = [u[1:] for u in cb["unique"]]
+    uncond = [u[:1] for u in ca["unique"]]
+    init_a, init_b = ca["init"], cb["init"]
+    noise = {s: np.stack([philox_ref.normal_tensor(77 + s, i, range(B), 0, L) for i in range(n)]) for s in (0, 1)}
+    sd = state_dict()
+    den = lambda x, t, e, mk: denoiser_ref.denoiser_forward(sd, x, t, e, mk)
+    want_a, want_b = dyadic_ref.dyadic_reverse(den, den, scheduler_ref.DDPMSchedulerRef(), scheduler_ref.DDPMSchedulerRef(), FUS,
+                                               cond_a, cond_b, uncond, init_a, init_b, lambda i, t: noise[0][i],
+                                               lambda i, t: noise[1][i], num_inference_steps=n)
+    ma = hip_denoiser(1234, 1.0)
+    mb = Denoiser(ablation=ABL, **DENOISER_KW)
+    mb.load_state_dict(ma.state_dict(), strict=True)
+    mb = mb.cuda().eval()
+    got_a, got_b = sample_dyadic(ma, mb, scheduler.DDPMScheduler(**SCHED_KW), _fuser(), [to_dev(x) for x in cond_a],
+                                 [to_dev(x) for x in cond_b], [to_dev(x) for x in uncond], B=B, L=L, num_inference_steps=n,
+                                 init_latents_a=to_dev(init_a), init_latents_b=to_dev(init_b), step_noise_a=to_dev(noise[0]),
+                                 step_noise_b=to_dev(noise[1]))
+    ea, eb = rel(got_a.cpu().numpy(), want_a), rel(got_b.cpu().numpy(), want_b)
+    print("dyadic vs oracle: rel L2", ea, eb)
+    assert ea < 1e-3 and eb < 1e-3
+    # one open sampling run per handle: the same module on both sides is refused
+    with pytest.raises(ValueError):
+        sample_dyadic(ma, ma, scheduler.DDPMScheduler(**SCHED_KW), _fuser(), [to_dev(x) for x in cond_a], [to_dev(x) for x in cond_b],
+                      [to_dev(x) for x in uncond], B=B, L=L, num_inference_steps=n)
