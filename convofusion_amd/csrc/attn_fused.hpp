@@ -30,6 +30,8 @@ __global__ void __launch_bounds__(SELF_ATTN_WAVES * 64, 4) self_attn_fused_kerne
   const int b = blockIdx.z, h = blockIdx.y;
   const int q = blockIdx.x * (SELF_ATTN_WAVES * 16) + wid * 16 + l15;
   const bool qvalid = q < a.L;
+  // A wave whose 16 queries all lie beyond L (the second workgroup of L = 196 has three) only helps with staging.
+  const bool wave_active = (int)(blockIdx.x * (SELF_ATTN_WAVES * 16)) + wid * 16 < a.L;   // wave-uniform
   const int qc = qvalid ? q : a.L - 1;
   const long long ROW = 4096;  // bytes per qk row (1024 columns)
 
@@ -71,6 +73,7 @@ __global__ void __launch_bounds__(SELF_ATTN_WAVES * 64, 4) self_attn_fused_kerne
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + VOFF + ks * 16384 + rg * 1024), 16, 0, 0);
     }
     __syncthreads();
+    if (!wave_active) continue;
 
     // S^T tile: 64 keys x 16 queries per wave
     f32x4 s[4];
