@@ -1,0 +1,72 @@
+"""Condense the raw outputs of tools/profile_round.sh into profiles/ (tracked).
+  --aggregate-only (on the GPU box): per-(kernel, grid) means of FETCH_SIZE / WRITE_SIZE -> gpurun_out/<tag>_hbm_traffic.csv
+  default (build container): copy the bench lines, the rocprofv3 kernel-stats summary and the traffic table into
+  profiles/<tag>_*, and write profiles/hbm_traffic_gemm.json (the figure bench.py reports as roofline.traffic).
+FETCH_SIZE is doubled: on gfx950 it counts 128-byte requests as 64 bytes (MI355X_MICROARCH.md, HBM)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+PROF = os.path.join(ROOT, "profiles")
+
+
+def aggregate():
+    acc = defaultdict(lambda: {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
+    for name in ("fetch", "write"):
+        for f in glob.glob(os.path.join(OUT, f"{tag}_pmc_{name}", "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                a = acc[(r["Kernel_Name"], int(r["Grid_Size"]))][r["Counter_Name"]]
+                a[0] += float(r["Counter_Value"])
+                a[1] += 1
+    rows = []
+    for (k, g), v in acc.items():
+        fs, fn = v["FETCH_SIZE"]
+        ws, wn = v["WRITE_SIZE"]
+        if fn == 0 and wn == 0:
+            continue
+        rows.append((k, g, max(fn, wn), fs / max(fn, 1), 2 * fs / max(fn, 1) / 1024, ws / max(wn, 1) / 1024))
+    rows.sort(key=lambda r: -(r[4] + r[5]) * r[2])
+    with open(os.path.join(OUT, f"{tag}_hbm_traffic.csv"), "w", newline="") as fo:
+        w = csv.writer(fo)
+        w.writerow(["kernel", "grid_threads", "launches_in_trace", "FETCH_SIZE_KB_raw_per_launch", "read_MB_per_launch_(2xFETCH)",
+                    "write_MB_per_launch_(WRITE_SIZE)"])
+        for r in rows:
+            w.writerow([r[0], r[1], r[2], round(r[3]), round(r[4], 1), round(r[5], 1)])
+
+
+def publish():
+    os.makedirs(PROF, exist_ok=True)
+    for src, dst in ((f"{tag}_bench_c2.json", f"{tag}_bench_c2.json"), (f"{tag}_bench_realshape.json", f"{tag}_bench_realshape.json"),
+                     (f"{tag}_rocprof_stdout.log", f"{tag}_bench_c2_rocprof_stdout.log"), (f"{tag}_hbm_traffic.csv", f"{tag}_bench_c2_hbm_traffic.csv")):
+        p = os.path.join(OUT, src)
+        if os.path.exists(p):
+            shutil.copy(p, os.path.join(PROF, dst))
+    stats = glob.glob(os.path.join(OUT, f"{tag}_stats", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(PROF, f"{tag}_bench_c2_kernel_stats.csv"))
+    t = os.path.join(PROF, f"{tag}_bench_c2_hbm_traffic.csv")
+    if os.path.exists(t):
+        tot, n = 0.0, 0
+        for r in csv.DictReader(open(t)):
+            if "gemm_sp_kernel" in r["kernel"]:
+                k = int(r["launches_in_trace"])
+                tot += (float(r["read_MB_per_launch_(2xFETCH)"]) + float(r["write_MB_per_launch_(WRITE_SIZE)"])) * 1e6 * k
+                n += k
+        json.dump({"bytes_per_launch_mean": tot / max(n, 1), "launches_in_trace": n,
+                   "source": f"profiles/{tag}_bench_c2_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
+                             "`bench.py --steps 3 --warmup 1`; FETCH doubled per MI355X_MICROARCH.md HBM note for gfx950)"},
+                  open(os.path.join(PROF, "hbm_traffic_gemm.json"), "w"), indent=1)
+    print("published:", sorted(os.listdir(PROF)))
+
+
+if "--aggregate-only" in sys.argv:
+    aggregate()
+else:
+    publish()
