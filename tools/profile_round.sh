@@ -12,9 +12,9 @@ export TMPDIR=/tmp
 python bench.py --steps 20 --warmup 3 > $out/${tag}_bench_c2.json 2> $out/${tag}_bench_c2.err
 python bench.py --steps 50 --warmup 5 --shape R --no-cpu-baseline > $out/${tag}_bench_realshape.json 2>> $out/${tag}_bench_c2.err
 rm -rf $out/${tag}_stats $out/${tag}_pmc_fetch $out/${tag}_pmc_write
-rocprofv3 --kernel-trace --stats -d $out/${tag}_stats -o run -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/${tag}_rocprof_stdout.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_pmc_fetch -o run -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_pmc_write -o run -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o run -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/${tag}_rocprof_stdout.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -o run -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmc_write -o run -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_write.log 2>&1
 # the raw per-dispatch counter files are large: keep only per-kernel aggregates
 python tools/profile_post.py $tag --aggregate-only
 rm -rf $out/${tag}_pmc_fetch $out/${tag}_pmc_write
