@@ -130,6 +130,14 @@ struct cfd_handle_s {
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
   DBuf latents, coef, inoise, mem_own[CFD_NMEM];
+  // Internal chunk order of a sampling run: chunk k of the caller's chunk-major batch lives at rows
+  // chunk_pos[k] * B.  Chunks whose rows all use ONE shared copy of the largest memory (the unconditional audio
+  // memory: 5 of the 7 guidance chunks, not adjacent in the reference's order) are moved next to each other, so
+  // their attention against it is one un-batched product instead of one per contiguous run.  Every per-row result
+  // is unchanged (rows are independent); the guidance combine reads chunk k at its position.  CFD_PERMUTE=0: off.
+  int chunk_pos[8];
+  DBuf perm_map[CFD_NMEM];
+  bool permute = true;
   int run_pos = 0;
 };
 typedef cfd_handle_s Ctx;
@@ -210,6 +218,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   c->use_runs = !(env && atoi(env) == 0);
   env = getenv("CFD_FUSED_SELF");
   c->fused_self = !(env && atoi(env) == 0);
+  env = getenv("CFD_PERMUTE");
+  c->permute = !(env && atoi(env) == 0);
   env = getenv("CFD_SHARE0");
   c->share0 = !(env && atoi(env) == 0);
   env = getenv("CFD_CHUNKS");
@@ -245,7 +255,7 @@ extern "C" void cfd_destroy(cfd_handle c) {
   for (DBuf* b : all) b->release();
   for (int j = 0; j < CFD_NMEM; ++j) {
     c->wk_all_sp[j].release(); c->wv_all_sp[j].release(); c->n_sp[j].release(); c->kall_sp[j].release();
-    c->cb[j].release(); c->vt_all[j].release(); c->mem_own[j].release();
+    c->cb[j].release(); c->vt_all[j].release(); c->mem_own[j].release(); c->perm_map[j].release();
   }
   for (auto& l : c->lw) {
     DBuf* lb[] = {&l.wqk_sp, &l.bqk, &l.wv_sp, &l.wo_sp, &l.bo2, &l.wtb1_sp, &l.wtb2_sp, &l.w1_sp, &l.w2_sp, &l.cross_bias};
@@ -1001,7 +1011,7 @@ static int enqueue_loop_iteration(Ctx* c, hipStream_t st) {
   CfgStepArgs ca;
   memset(&ca, 0, sizeof(ca));
   ca.eps = c->eps.as<float>(); ca.latents = c->latents.as<float>(); ca.B = s.B; ca.L = s.L; ca.G = s.G;
-  for (int k = 0; k < 8; ++k) ca.w[k] = s.guidance_weight[k];
+  for (int k = 0; k < 8; ++k) { ca.w[k] = s.guidance_weight[k]; ca.pos[k] = c->chunk_pos[k]; }
   ca.kind = s.scheduler; ca.clip = s.clip_sample; ca.coef = c->coef.as<StepCoef>(); ca.d_step = c->d_step.as<int>();
   ca.noise = s.step_noise; ca.seed = s.seed; ca.utt0 = s.first_utterance;
   const long long n4 = (long long)s.B * s.L * CFD_LAT / 4;
@@ -1026,7 +1036,53 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
   if (s.skip_zero_weight_chunks)   // chunk-major batch: dropping trailing chunks = using the first G' * B rows
     while (c->sargs.G > 1 && s.guidance_weight[c->sargs.G - 1] == 0.0f) c->sargs.G -= 1;
   const int Be = c->sargs.G * s.B, N = s.num_inference_steps, T = s.num_train_timesteps;
-  CHK(setup_problem(c, Be, s.L, s.mem, nullptr, 0, N));
+  for (int k = 0; k < 8; ++k) c->chunk_pos[k] = k;
+  cfd_memory mem_in[CFD_NMEM];
+  for (int j = 0; j < CFD_NMEM; ++j) mem_in[j] = s.mem[j];
+  {
+    // chunk permutation (see chunk_pos): group the chunks that use one shared copy of the largest memory
+    const int G = c->sargs.G, B = s.B;
+    bool all_maps = c->permute && G > 2;
+    int jb = 0;
+    for (int j = 0; j < CFD_NMEM; ++j) {
+      if (!s.mem[j].row_map) all_maps = false;
+      if (s.mem[j].S > s.mem[jb].S) jb = j;
+    }
+    if (all_maps) {
+      std::vector<int> hm(Be);
+      HIPCHK(hipMemcpy(hm.data(), s.mem[jb].row_map, (size_t)Be * 4, hipMemcpyDeviceToHost));
+      std::vector<int> key(G);   // the shared memory index of a uniform chunk, or -1
+      for (int g = 0; g < G; ++g) {
+        key[g] = hm[(size_t)g * B];
+        for (int u = 1; u < B; ++u)
+          if (hm[(size_t)g * B + u] != key[g]) { key[g] = -1; break; }
+      }
+      std::vector<int> order;   // order[position] = original chunk: uniform chunks grouped by key, first occurrence first
+      std::vector<char> used(G, 0);
+      for (int g = 0; g < G; ++g) {
+        if (used[g] || key[g] < 0) continue;
+        for (int h = g; h < G; ++h)
+          if (!used[h] && key[h] == key[g]) { order.push_back(h); used[h] = 1; }
+      }
+      for (int g = 0; g < G; ++g)
+        if (!used[g]) order.push_back(g);
+      bool ident = true;
+      for (int pnum = 0; pnum < G; ++pnum) ident = ident && order[pnum] == pnum;
+      if (!ident) {
+        for (int pnum = 0; pnum < G; ++pnum) c->chunk_pos[order[pnum]] = pnum;
+        std::vector<int> pm(Be);
+        for (int j = 0; j < CFD_NMEM; ++j) {
+          HIPCHK(hipMemcpy(hm.data(), s.mem[j].row_map, (size_t)Be * 4, hipMemcpyDeviceToHost));
+          for (int pnum = 0; pnum < G; ++pnum)
+            for (int u = 0; u < B; ++u) pm[(size_t)pnum * B + u] = hm[(size_t)order[pnum] * B + u];
+          CHK(c->perm_map[j].ensure((size_t)Be * 4));
+          HIPCHK(hipMemcpy(c->perm_map[j].p, pm.data(), (size_t)Be * 4, hipMemcpyHostToDevice));
+          mem_in[j].row_map = c->perm_map[j].as<int32_t>();
+        }
+      }
+    }
+  }
+  CHK(setup_problem(c, Be, s.L, mem_in, nullptr, 0, N));
   if (c->share0 && c->sargs.G > 1) c->pb.share_B = s.B;   // begin_step_kernel writes G identical copies of the B rows
   // timesteps: (arange(N) * (T // N)).round()[::-1] (+ steps_offset for DDIM)
   std::vector<int32_t> ts(N);

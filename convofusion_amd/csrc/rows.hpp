@@ -434,6 +434,7 @@ struct CfgStepArgs {
   float* latents;        // [B][L][128] in/out
   int B, L, G;
   float w[8];            // guidance weight of chunk k (k >= 1); chunk 0 is the unconditional one
+  int pos[8];            // chunk k's rows start at row pos[k] * B of eps (the engine may reorder chunks internally)
   int kind;              // 0 DDPM, 1 DDIM
   int clip;
   const StepCoef* coef;
@@ -452,13 +453,13 @@ __global__ void cfg_step_kernel(const CfgStepArgs a) {
   const StepCoef c = a.coef[i];
   const long long e0 = idx * 4;
   const long long chunk = (long long)a.B * per_utt;
-  const float4 u4 = *reinterpret_cast<const float4*>(a.eps + e0);
+  const float4 u4 = *reinterpret_cast<const float4*>(a.eps + a.pos[0] * chunk + e0);
   const float u[4] = {u4.x, u4.y, u4.z, u4.w};
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (a.G > 1) {
     // reference association: ((((text + audio) + spk) + apb) + lsnid) + all, each = (g*w)*(e_k - e_0)
     for (int k = 1; k < a.G; ++k) {
-      const float4 e4 = *reinterpret_cast<const float4*>(a.eps + k * chunk + e0);
+      const float4 e4 = *reinterpret_cast<const float4*>(a.eps + a.pos[k] * chunk + e0);
       const float e[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {

@@ -91,29 +91,32 @@ def test_skipping_the_zero_weight_chunk_is_exact():
     assert torch.equal(a, b)
 
 
-def test_sharing_the_head_of_layer_0_between_guidance_replicas_is_exact():
-    """The embedding, layer 0's self-attention and its first time block see the same latents and the same timestep
-    in all 7 guidance chunks: evaluating them once per utterance (default) must not change a bit against
-    evaluating them for every replica (CFD_SHARE0=0, read at cfd_create)."""
+@pytest.mark.parametrize("knob", ["CFD_SHARE0", "CFD_PERMUTE"])
+def test_structural_shortcuts_of_the_loop_are_exact(knob):
+    """CFD_SHARE0: the embedding, layer 0's self-attention and its first time block see the same latents and the
+    same timestep in all 7 guidance chunks; evaluating them once per utterance (default) must not change a bit
+    against evaluating them for every replica.  CFD_PERMUTE: the engine reorders the guidance chunks internally so
+    that the chunks sharing the unconditional audio memory are adjacent (one un-batched attention product instead
+    of one per run); rows are independent, so this must not change a bit either.  (Knobs are read at cfd_create.)"""
     import os
     import torch
     from convofusion_amd.denoiser import Denoiser
     from convofusion_amd.sampler import sample
     from tests.gpu_helpers import ABL, DENOISER_KW, hip_denoiser, to_dev
-    B, L, S = 3, 16, (24, 161, 24, 8, 1)
+    B, L, S = 3, 64, (24, 288, 24, 8, 1)   # long enough for the shared-memory run path (L >= 64, >= 256 keys)
     cb = inputs.make_cfg_batch(seed=8, B=B, L=L, S=S, pad_tail=(4, 0, 6, 0, 0))
     mems = [to_dev(x) for x in cb["memories"]]
     masks = {k: to_dev(v) for k, v in cb["masks"].items()}
     m = hip_denoiser(1234, 1.0)
     a = sample(m, _sched("ddpm"), mems, masks, B=B, L=L, num_inference_steps=4, seed=11)
-    os.environ["CFD_SHARE0"] = "0"
+    os.environ[knob] = "0"
     try:
         m2 = Denoiser(ablation=ABL, **DENOISER_KW)
         m2.load_state_dict(m.state_dict(), strict=True)
         m2 = m2.cuda().eval()
         b = sample(m2, _sched("ddpm"), mems, masks, B=B, L=L, num_inference_steps=4, seed=11)
     finally:
-        del os.environ["CFD_SHARE0"]
+        del os.environ[knob]
     assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
@@ -122,7 +125,7 @@ def test_structured_guidance_batch_equals_replicated_batch():
     import torch
     from convofusion_amd.sampler import build_guidance_batch, sample
     from tests.gpu_helpers import hip_denoiser, to_dev
-    B, L, S = 3, 16, (24, 161, 24, 8, 1)
+    B, L, S = 3, 64, (24, 288, 24, 8, 1)   # long enough for the shared-memory run path (L >= 64, >= 256 keys)
     cb = inputs.make_cfg_batch(seed=8, B=B, L=L, S=S, pad_tail=(4, 0, 6, 0, 0))
     m = hip_denoiser(1234, 1.0)
     rep = sample(m, _sched("ddpm"), [to_dev(x) for x in cb["memories"]], {k: to_dev(v) for k, v in cb["masks"].items()},
@@ -249,7 +252,7 @@ def test_ddim_with_eta_matches_oracle():
 
 
 @pytest.mark.parametrize("env", [{"CFD_NAIVE_GEMM": "1"}, {"CFD_GEMM_CFG": "2"}, {"CFD_CHUNKS": "3"},
-                                 {"CFD_FUSED_SELF": "0"}, {"CFD_RUNS": "0"}, {"CFD_BRANCHES": "1"}, {"CFD_SHARE0": "0"}])
+                                 {"CFD_FUSED_SELF": "0"}, {"CFD_RUNS": "0"}, {"CFD_BRANCHES": "1"}, {"CFD_SHARE0": "0"}, {"CFD_PERMUTE": "0"}])
 def test_developer_knobs_keep_parity(env):
     """The debug / tuning switches (read once at cfd_create) must not change results: run the golden forward and
     the 20-step trajectory test in a child process under each of them."""
