@@ -110,6 +110,12 @@ struct cfd_handle_s {
   bool use_runs = true;   // CFD_RUNS=0 disables the shared-memory run optimisation
   int nchunks_env = 0;
   bool fused_self = true;   // CFD_FUSED_SELF=0 selects the GEMM -> softmax -> GEMM self-attention
+  // CFD_TILE_SM=1: the shared-memory runs do their softmax per 128-key tile inside the two attention products
+  // (EpiTileSoftmax / EpiResidFold, gemm_sp.hpp): no fp32 score matrix, 378 MB less HBM traffic per layer.  Parity-
+  // tested, but measured neutral on MI355X (57.1 vs 57.0 steps/s: the exp / reduction work added to the score
+  // product's epilogue costs what the lighter softmax launch saves), so the simpler path stays the default.
+  bool tile_sm = false;
+  DBuf sm_stats, sm_alpha, run_flags;
   bool share0 = true;       // CFD_SHARE0=0: evaluate the pre-cross-attention part of layer 0 for every guidance replica
   DBuf d_step;  // [0] = loop index, [1] = constant 0
   Problem pb;
@@ -175,6 +181,14 @@ static int run_gemm(Ctx* c, int cls, const GemmArgs& a, const Epi& e, int nb, in
   return CFD_OK;
 }
 
+template <class Epi>
+static int run_gemm_128(Ctx* c, int cls, const GemmArgs& a, const Epi& e, hipStream_t st) {
+  Bracket br(c, cls, st);
+  hipError_t err = launch_gemm_128<Epi>(a, e, st);
+  if (err != hipSuccess) return fail(CFD_E_HIP, "gemm launch failed: %s", hipGetErrorString(err));
+  return CFD_OK;
+}
+
 static GemmArgs gemm_args() {
   GemmArgs a;
   memset(&a, 0, sizeof(a));
@@ -218,6 +232,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   c->use_runs = !(env && atoi(env) == 0);
   env = getenv("CFD_FUSED_SELF");
   c->fused_self = !(env && atoi(env) == 0);
+  env = getenv("CFD_TILE_SM");
+  c->tile_sm = env && atoi(env) != 0;
   env = getenv("CFD_PERMUTE");
   c->permute = !(env && atoi(env) == 0);
   env = getenv("CFD_SHARE0");
@@ -251,7 +267,8 @@ extern "C" void cfd_destroy(cfd_handle c) {
   for (auto& kv : c->raw) kv.second.release();
   DBuf* all[] = {&c->we_sp, &c->wp_sp, &c->we_all, &c->be_all, &c->tsin, &c->x, &c->h_sp, &c->qk_sp, &c->vts_sp,
                  &c->ssc, &c->sp_sp, &c->o_sp, &c->u_sp, &c->sc, &c->p_sp, &c->eps, &c->sample_sp, &c->temb_tab,
-                 &c->h1_tab, &c->ss_tab, &c->trows, &c->d_step, &c->latents, &c->coef, &c->inoise};
+                 &c->h1_tab, &c->ss_tab, &c->trows, &c->d_step, &c->latents, &c->coef, &c->inoise, &c->sm_stats, &c->sm_alpha,
+                 &c->run_flags};
   for (DBuf* b : all) b->release();
   for (int j = 0; j < CFD_NMEM; ++j) {
     c->wk_all_sp[j].release(); c->wv_all_sp[j].release(); c->n_sp[j].release(); c->kall_sp[j].release();
@@ -544,6 +561,15 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
       }
       if (p.nruns > 0) {
         p.jbig = jb; p.nlong = (int)lrows.size(); p.nshort = (int)srows.size();
+        {   // tile-softmax path of the runs: per-token, per-128-key-tile statistics and fold weights; run-row flags
+          const size_t nt = (size_t)(p.Sp[jb] + 127) / 128;
+          CHK(c->sm_stats.ensure((size_t)Be * L * nt * 8));
+          CHK(c->sm_alpha.ensure((size_t)Be * L * nt * 4));
+          std::vector<uint8_t> fl(Be, 0);
+          for (int b : lrows) fl[b] = 1;
+          CHK(c->run_flags.ensure((size_t)Be));
+          HIPCHK(hipMemcpy(c->run_flags.p, fl.data(), (size_t)Be, hipMemcpyHostToDevice));
+        }
         CHK(c->long_rows.ensure(lrows.size() * 4 + 16));
         CHK(c->short_rows.ensure(srows.size() * 4 + 16));
         HIPCHK(hipMemcpy(c->long_rows.p, lrows.data(), lrows.size() * 4, hipMemcpyHostToDevice));
@@ -804,6 +830,9 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     // scores against the folded keys of every memory.  Long memories and short (<= 64 keys) memories go to
     // different tile shapes; rows in a shared-memory run of the largest memory use one un-batched product per run.
     const bool runs = p.nruns > 0 && row0 == 0 && Be == p.Be;
+    // runs: softmax per score tile inside the products (no fp32 score matrix) unless the caller wants the
+    // normalised attention maps of that memory
+    const bool tile_sm = runs && c->tile_sm && !g_cfd_naive_gemm && !p.att[p.jbig];
     auto scores_grouped = [&](bool small, int skip_j, const int* brow, int nb, hipStream_t sst) -> int {
       GemmArgs a = gemm_args();
       EpiF32 e;
@@ -838,6 +867,20 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
         a.X[0] = c->kall_sp[j].as<char>() + ((size_t)l * p.U[j] + p.run_u[r]) * p.Sp[j] * ROWB; a.ldx[0] = ROWB;
         a.I[0] = p.Sp[j]; a.Iclamp[0] = p.Sp[j]; a.kt[0] = CFD_D / 32;
         a.Y = c->h_sp.as<char>() + (size_t)p.run_row0[r] * L * ROWB; a.ldy = ROWB; a.J = p.run_len[r] * L; a.Jclamp = a.J;
+        if (tile_sm) {
+          // softmax per 128-key tile inside the product: tile-relative probabilities go straight to P
+          const int nt = (p.Sp[j] + 127) / 128;
+          const size_t tok0 = (size_t)p.run_row0[r] * L;
+          EpiTileSoftmax e;
+          e.out = c->p_sp.as<char>() + tok0 * p.Sp_tot * 4 + (size_t)(p.off[j] / 32) * 128; e.ldo = (long long)p.Sp_tot * 4;
+          e.key_bias = c->cb[j].as<float>() + ((size_t)l * p.U[j] + p.run_u[r]) * p.Sp[j];
+          e.mask = p.mask[j] + (size_t)p.run_u[r] * p.S[j]; e.has_mask = p.has_mask[j]; e.S = p.S[j];
+          e.stats = c->sm_stats.as<float2>() + tok0 * nt; e.ntiles = nt;
+          CHK(run_gemm_128(c, CFD_PROF_GEMM_ATTN, a, e, rs));
+          LAUNCH(CFD_PROF_ROWS, attn_alpha_kernel, dim3((unsigned)((a.J + 255) / 256)), blk, rs, c->sm_stats.as<float2>() + tok0 * nt,
+                 c->sm_alpha.as<float>() + tok0 * nt, (long long)a.J, nt);
+          continue;
+        }
         EpiF32 e;
         memset(&e, 0, sizeof(e));
         e.out = c->sc.as<float>() + (size_t)p.run_row0[r] * L * p.Sp_tot; e.ldo = p.Sp_tot; e.goff[0] = p.off[j];
@@ -856,6 +899,7 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
         a.off[j] = p.off[j]; a.S[j] = p.S[j]; a.Sp[j] = p.Sp[j]; a.mask[j] = p.mask[j]; a.has_mask[j] = p.has_mask[j]; a.map[j] = mapj[j]; a.att[j] = attj[j];
       }
       a.layer = l; a.nl = nl;
+      if (tile_sm) { a.skip_seg = p.jbig; a.skip_rows = c->run_flags.as<uint8_t>(); }
       LAUNCH(CFD_PROF_ROWS, softmax_rows_kernel, dim3((unsigned)((M + 3) / 4)), blk, st, a);
     }
     // x += sum_j P_j . VV_j(n_j) + folded bias
@@ -892,6 +936,14 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
         a.I[0] = CFD_D; a.Iclamp[0] = CFD_D; a.kt[0] = p.Sp[j] / 32;
         a.Y = c->p_sp.as<char>() + (size_t)p.run_row0[r] * L * p.Sp_tot * 4 + (size_t)(p.off[j] / 32) * 128;
         a.ldy = (long long)p.Sp_tot * 4; a.J = p.run_len[r] * L; a.Jclamp = a.J;
+        if (tile_sm) {
+          const int nt = (p.Sp[j] + 127) / 128;
+          EpiResidFold e;
+          e.x = c->x.as<float>() + (size_t)p.run_row0[r] * L * CFD_D; e.obs = 0; e.bias = nullptr;
+          e.alpha = c->sm_alpha.as<float>() + (size_t)p.run_row0[r] * L * nt; e.ntiles = nt;
+          CHK(run_gemm_128(c, CFD_PROF_GEMM_ATTN, a, e, rs));
+          continue;
+        }
         EpiResid e{c->x.as<float>() + (size_t)p.run_row0[r] * L * CFD_D, 0, nullptr};
         CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_ATTN, a, e, 1, 1, rs)));
       }

@@ -101,6 +101,9 @@ struct EpiSplit {  // out_sp[j][coloff + i] = split(act(v + bias[i]))
   int gelu;
   int perm32;  // store column 32S+16h+4q+r at position 32S+8q+4h+r (k-slot order of attn_fused.hpp's P fragments)
   static constexpr bool kPrefetch = false;
+  // wide epilogue: a lane gets 8 consecutive i (i % 8 == 0) -> one 16-byte hi and one 16-byte lo store instead of
+  // two 8-byte pairs (half the store instructions for the same bytes)
+  static constexpr bool kStore8 = true;
   __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
     if (bias) {
       const float4 t = *reinterpret_cast<const float4*>(bias + i);
@@ -109,6 +112,24 @@ struct EpiSplit {  // out_sp[j][coloff + i] = split(act(v + bias[i]))
     if (gelu) { v[0] = gelu_f(v[0]); v[1] = gelu_f(v[1]); v[2] = gelu_f(v[2]); v[3] = gelu_f(v[3]); }
     const int col = perm32 ? ((i & ~31) | (((i >> 2) & 3) << 3) | (((i >> 4) & 1) << 2)) : i;
     sp_store4(out + (long long)b * obs + (long long)z * ozs + (long long)j * ldo, col, v[0], v[1], v[2], v[3]);
+  }
+  __device__ __forceinline__ void store8(int g, int b, int z, int i, int j, f32x4 v0, f32x4 v1) const {
+    if (perm32) {   // the k-slot permutation moves groups of 4: two 4-wide stores
+      (*this)(g, b, z, i, j, v0);
+      (*this)(g, b, z, i + 4, j, v1);
+      return;
+    }
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    if (bias) {
+      const float4 t0 = *reinterpret_cast<const float4*>(bias + i);
+      const float4 t1 = *reinterpret_cast<const float4*>(bias + i + 4);
+      v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+    }
+    if (gelu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+    }
+    sp_store8(out + (long long)b * obs + (long long)z * ozs + (long long)j * ldo, i, v);
   }
 };
 
@@ -145,6 +166,43 @@ struct EpiResid {  // x[(b*rows_per_b + j)][i] += v + bias[i]   (row length CFD_
     r.x += v[0]; r.y += v[1]; r.z += v[2]; r.w += v[3];
     *reinterpret_cast<float4*>(p) = r;
   }
+};
+
+// Attention scores against ONE shared memory, softmax-ed per 128-key tile inside the epilogue ("tile softmax"):
+//   P_rel[token][key] = exp(s - m_tile[token])  written as SP,   stats[token][tile] = (m_tile, sum_tile P_rel)
+// with s = D + key_bias[key], keys >= S or masked -> -inf.  attn_alpha_kernel turns the per-tile statistics into
+// alpha[token][tile] = exp(m_tile - m_row) / l_row, and the P.V product (EpiResidFold) accumulates
+// sum_tile alpha * (V^T P_rel) -- the softmax of the whole row without the fp32 score matrix ever reaching HBM.
+// Only for tile configuration 1 (128 keys x 128 tokens, 2 x 2 waves); the kernel body implements the reductions.
+struct EpiTileSoftmax {
+  static constexpr bool kPrefetch = false;
+  static constexpr bool kTileSoftmax = true;
+  char* out;                 // SP [tokens][ldo bytes]; column i = key
+  long long ldo;             // bytes
+  const float* key_bias;     // [>= I] (the folded q-bias term of this memory and layer)
+  const uint8_t* mask;       // [S] key-padding mask of the shared memory (never null)
+  int has_mask;              // 0: the mask is the all-zero stand-in (no byte loads)
+  int S;                     // valid keys
+  float2* stats;             // [tokens][ntiles]
+  int ntiles;
+  static constexpr bool kStore8 = true;
+  __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
+    sp_store4(out + (long long)j * ldo, i, v[0], v[1], v[2], v[3]);
+  }
+  __device__ __forceinline__ void store8(int g, int b, int z, int i, int j, f32x4 v0, f32x4 v1) const {
+    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    sp_store8(out + (long long)j * ldo, i, v);
+  }
+};
+
+// x[j][i] += sum_tile alpha[j][tile] * partial_tile[i][j]: EpiResid for a P.V product whose P is tile-relative
+// (EpiTileSoftmax); the kernel folds the running partial sum into the total every `kFoldSteps` k-steps.
+struct EpiResidFold : EpiResid {
+  static constexpr bool kLate = false;
+  static constexpr bool kFold = true;
+  static constexpr int kFoldSteps = 4;   // 128-key score tiles / 32-key k-steps
+  const float* alpha;        // [tokens][ntiles]
+  int ntiles;
 };
 
 struct EpiNull {  // timing experiments only: keeps the accumulators live, stores nothing
@@ -208,6 +266,12 @@ struct EpiMemV {  // V^T_layer_u[j/512][i/Sp][j%512][i%Sp] = split(v): one conti
   }
 };
 
+template <class E, class = void> struct EpiHasStore8 { static constexpr bool value = false; };
+template <class E> struct EpiHasStore8<E, typename std::enable_if<E::kStore8>::type> { static constexpr bool value = true; };
+template <class E, class = void> struct EpiHasTileSM { static constexpr bool value = false; };
+template <class E> struct EpiHasTileSM<E, typename std::enable_if<E::kTileSoftmax>::type> { static constexpr bool value = true; };
+template <class E, class = void> struct EpiHasFold { static constexpr bool value = false; };
+template <class E> struct EpiHasFold<E, typename std::enable_if<E::kFold>::type> { static constexpr bool value = true; };
 template <class E, class = void> struct EpiHasLate { static constexpr bool value = false; };
 template <class E> struct EpiHasLate<E, typename std::enable_if<E::kLate>::type> { static constexpr bool value = true; };
 template <class E, bool P = EpiHasLate<E>::value> struct EpiLateT { struct type {}; };
@@ -422,6 +486,13 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
       }
   }
 
+  // tile softmax: the key-bias values of this tile are requested before the k-loop
+  float4 tsm_kb[EpiHasTileSM<Epi>::value ? TI : 1];
+  if constexpr (EpiHasTileSM<Epi>::value) {
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+      tsm_kb[ti] = *reinterpret_cast<const float4*>(epi.key_bias + min(i0 + wi * TI * 16 + ti * 16 + q4 * 4, Ig - 4));   // (keys >= S are dead anyway)
+  }
   // residual rows requested before the last k-step (EpiResid::kLate)
   constexpr bool LATE = CFD_LATE_RESID && WIDE && EpiHasLate<Epi>::value && NSTAGE == 2 && TI * TJ <= 16;
   typename EpiLateT<Epi, LATE>::type late[LATE ? NIT : 1][LATE ? TJ : 1];
@@ -436,6 +507,39 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
           late[it][tj] = epi.late_load(g, b, z, min(i, Ig - 4), min(j, a.J - 1));
         }
       asm volatile("" ::: "memory");   // keep the requests ahead of the last k-step's LDS reads / MFMAs
+    }
+  };
+
+  // tile-relative P.V (EpiResidFold): acc holds the partial sum of the current 128-key score tile
+  constexpr bool FOLD = EpiHasFold<Epi>::value;
+  constexpr int FOLD_STEPS = 4;
+  static_assert(!FOLD || NSTAGE == 2, "the alpha fold is implemented for the 2-stage loop");
+  f32x4 tot[FOLD ? TI : 1][FOLD ? TJ : 1];
+  float al[FOLD ? TJ : 1];
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) tot[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  auto fold_request = [&](int tile) __attribute__((always_inline)) {
+    if constexpr (FOLD) {
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        const int j = min(j0 + (wj * TJ + tj) * 16 + l15, a.J - 1);
+        al[tj] = epi.alpha[(long long)j * epi.ntiles + tile];
+      }
+    }
+  };
+  auto fold_apply = [&]() __attribute__((always_inline)) {
+    if constexpr (FOLD) {
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) {
+          tot[ti][tj] += al[tj] * acc[ti][tj];
+          acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
   };
 
@@ -478,7 +582,13 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
       const int buf = kt & 1;
       if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);
       else late_issue();
+      if constexpr (FOLD) {
+        if ((kt & (FOLD_STEPS - 1)) == 0) fold_request(kt / FOLD_STEPS);   // consumed FOLD_STEPS k-steps later
+      }
       compute(buf);
+      if constexpr (FOLD) {
+        if ((kt & (FOLD_STEPS - 1)) == FOLD_STEPS - 1 || kt + 1 == nkt) fold_apply();
+      }
       if (!LATE || kt + 1 < nkt) __syncthreads();   // (LATE: the epilogue's own barrier follows, without a vmcnt drain)
     }
   } else if constexpr (NSTAGE == 3) {
@@ -578,6 +688,85 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
     }
   }
 
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) acc[ti][tj] = tot[ti][tj];
+  }
+  if constexpr (EpiHasTileSM<Epi>::value) {
+    static_assert(WI == 2 && WJ == 2 && TI == 4 && TJ == 4 && MODE == MODE_PLAIN, "tile softmax: 128-key x 128-token tiles");
+    // acc[ti][tj][r]: key i = i0 + wi*64 + ti*16 + q4*4 + r, token j = j0 + wj*64 + tj*16 + l15.
+    // Each wave first works relative to the maximum of ITS 64 keys; one LDS exchange of (max, sum) with the wave
+    // that holds the tile's other 64 keys then gives the tile statistics and the factor exp(m_wave - m_tile) that
+    // moves this wave's probabilities to the tile maximum (one barrier instead of one per reduction).
+    float2* red = reinterpret_cast<float2*>(smem + 32768);   // [wj][wi][tj][l15]  (the WIDE strips use < 20 KB)
+    float mw[TJ], lw[TJ];
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) mw[tj] = -INFINITY;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+      const int i = i0 + wi * 64 + ti * 16 + q4 * 4;
+      const float4 kb = tsm_kb[ti];
+      bool dead[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dead[r] = i + r >= epi.S;
+        if (epi.has_mask) dead[r] |= epi.mask[min(i + r, epi.S - 1)] != 0;   // wave-uniform condition
+      }
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        f32x4 v = acc[ti][tj];
+        v[0] = dead[0] ? -INFINITY : v[0] + kb.x;
+        v[1] = dead[1] ? -INFINITY : v[1] + kb.y;
+        v[2] = dead[2] ? -INFINITY : v[2] + kb.z;
+        v[3] = dead[3] ? -INFINITY : v[3] + kb.w;
+        acc[ti][tj] = v;
+        mw[tj] = fmaxf(mw[tj], fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+      }
+    }
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      float m = mw[tj];
+      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      mw[tj] = m;
+      float sum = 0.f;
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) {
+        f32x4 v = acc[ti][tj];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = (m == -INFINITY) ? 0.f : __expf(v[r] - m);   // keys that are all masked contribute nothing
+          sum += v[r];
+        }
+        acc[ti][tj] = v;
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      lw[tj] = sum;
+    }
+    __syncthreads();   // every wave is done with the last k-tile: smem is free
+    if (q4 == 0) {
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) red[((wj * 2 + wi) * TJ + tj) * 16 + l15] = make_float2(mw[tj], lw[tj]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      const float2 o = red[((wj * 2 + (wi ^ 1)) * TJ + tj) * 16 + l15];
+      const float m = fmaxf(mw[tj], o.x);
+      const float fs = (mw[tj] == -INFINITY) ? 0.f : __expf(mw[tj] - m);   // this wave's probabilities -> tile maximum
+      const float fo = (o.x == -INFINITY) ? 0.f : __expf(o.x - m);
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) acc[ti][tj] *= fs;
+      if (wi == 0 && q4 == 0) {
+        const int j = j0 + (wj * TJ + tj) * 16 + l15;
+        if (j < a.J) epi.stats[(long long)j * epi.ntiles + ti_blk] = make_float2(m, lw[tj] * fs + o.y * fo);
+      }
+    }
+    // (the WIDE path below starts with its own barrier before it reuses smem)
+  }
   if constexpr (WIDE) {
     static_assert(NIT == TI, "one epilogue instruction per MFMA tile");
     // every wave re-lays its tile band by band through a private LDS strip (the staging ring is free now)
@@ -595,6 +784,22 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
       for (int ti = 0; ti < TI; ++ti)
         *reinterpret_cast<f32x4*>(strip + l15 * RS + (ti * 16 + q4 * 4) * 4) = acc[ti][tj];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private strip: no barrier needed
+      if constexpr (EpiHasStore8<Epi>::value) {
+        // split-pair outputs: LPR8 lanes per row, 8 consecutive i per lane
+        constexpr int LPR8 = TI * 2, RPI8 = 64 / LPR8, NIT8 = 16 / RPI8;
+#pragma unroll
+        for (int it = 0; it < NIT8; ++it) {
+          const int i = i0 + wi * TI * 16 + (lane % LPR8) * 8;
+          const int j = j0 + (wj * TJ + tj) * 16 + it * RPI8 + lane / LPR8;
+          const char* sp = strip + (it * RPI8 + lane / LPR8) * RS + (lane % LPR8) * 32;
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + 16);
+          if (j < a.J) {
+            if (i + 4 < Ig) epi.store8(g, b, z, i, j, v0, v1);
+            else if (i < Ig) epi(g, b, z, i, j, v0);
+          }
+        }
+      } else {
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         int i, j;
@@ -605,6 +810,7 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
           else if constexpr (LATE) epi(g, b, z, i, j, v, late[it][tj]);
           else epi(g, b, z, i, j, v);
         }
+      }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next band overwrites the strip
     }
@@ -689,6 +895,13 @@ static hipError_t launch_cfg(GemmArgs a, const Epi& epi, int nb, int nz, hipStre
   }
   hipLaunchKernelGGL((gemm_sp_kernel<WI, WJ, TI, TJ, NSTAGE, MODE, Epi>), dim3(total, nb, nz), dim3(WI * WJ * 64), lds, st, a, epi);
   return hipGetLastError();
+}
+
+// the one configuration the tile-softmax epilogues (EpiTileSoftmax / EpiResidFold) are written for
+template <class Epi>
+static hipError_t launch_gemm_128(GemmArgs a, const Epi& epi, hipStream_t st) {
+  if (a.nslot < 1) a.nslot = 1;
+  return launch_cfg<2, 2, 4, 4, 2, MODE_PLAIN, Epi>(a, epi, 1, 1, st);
 }
 
 // cfg: 0 = auto, 1 = 128x128 (4 waves, 2-stage), 2 = 64x64, 3 = 128x16, 4 = 128x256 (8 waves, 3-stage), 5 = 128x128 3-stage,

@@ -123,6 +123,8 @@ struct SoftmaxArgs {
   const int* map[CFD_NMEM];       // b -> u, or null (u = b)
   float* att[CFD_NMEM];           // [Be][nl][L][S] or null
   int layer, nl;
+  int skip_seg;                   // segment whose softmax was done by the score product itself (EpiTileSoftmax) ...
+  const uint8_t* skip_rows;       // ... for the batch rows flagged here ([Be] bytes), or null
 };
 
 // Segments of <= 64 keys (text / activity-bit / listener-id memories) are handled TOGETHER, one 8-lane group per
@@ -205,6 +207,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const SoftmaxArgs a) 
     if (g >= a.nseg) break;
     const int S = a.S[g], Sp = a.Sp[g], off = a.off[g];
     if (Sp <= 64) continue;
+    if (a.skip_rows && g == a.skip_seg && a.skip_rows[b]) continue;   // wave-uniform
     const uint8_t* mk = a.mask[g] + (long long)(a.map[g] ? a.map[g][b] : b) * S;
     float v[SM_MAX_CHUNKS][8];
     float mx = -INFINITY;
@@ -250,6 +253,20 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const SoftmaxArgs a) 
       }
     }
   }
+}
+
+// Per-tile softmax statistics (EpiTileSoftmax) -> fold weights of the tile-relative P.V product:
+//   m = max_t m_t ;  l = sum_t l_t exp(m_t - m) ;  alpha_t = exp(m_t - m) / l
+// (a row whose keys are all masked gives 0 / 0 = NaN, as the reference's softmax does)
+__global__ void attn_alpha_kernel(const float2* stats, float* alpha, long long rows, int ntiles) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const float2* st = stats + row * ntiles;
+  float m = -INFINITY;
+  for (int t = 0; t < ntiles; ++t) m = fmaxf(m, st[t].x);
+  float l = 0.f;
+  for (int t = 0; t < ntiles; ++t) l += (st[t].x == -INFINITY) ? 0.f : st[t].y * __expf(st[t].x - m);
+  for (int t = 0; t < ntiles; ++t) alpha[row * ntiles + t] = (st[t].x == -INFINITY) ? 0.f / l : __expf(st[t].x - m) / l;
 }
 
 // ------------------------------------------------------------------------------------------------

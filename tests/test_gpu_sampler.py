@@ -162,14 +162,19 @@ def test_device_rng_stream_matches_oracle():
     assert e < TRAJ_TOL
 
 
-def test_shared_memory_run_path_matches_oracle():
+@pytest.mark.parametrize("S_audio,audio_pad", [(256, 0), (300, 37)])
+def test_shared_memory_run_path_matches_oracle(S_audio, audio_pad):
     """Long latents + a long audio memory switch on the un-batched attention products for rows that share the
-    unconditional memory (cfd_api.hip 'runs'); check that path end-to-end against the oracle."""
+    unconditional memory (cfd_api.hip 'runs'; with CFD_TILE_SM=1 -- test_developer_knobs_keep_parity -- their softmax
+    is done per 128-key tile inside the two products); check that path end-to-end against the oracle -- also with a key count that is
+    not a multiple of the tile (300 = 2 x 128 + 44, padded to 320) and a key-padding mask on the shared memory that
+    blanks the whole last tile's valid keys."""
     from convofusion_amd.sampler import sample
     from tests.gpu_helpers import hip_denoiser, to_dev
-    B, L, S, n = 2, 64, (8, 256, 8, 8, 1), 2
+    B, L, S, n = 2, 64, (8, S_audio, 8, 8, 1), 2
     seed = 31
-    cb = inputs.make_cfg_batch(seed=12, B=B, L=L, S=S, pad_tail=(2, 0, 1, 0, 0))
+    cb = inputs.make_cfg_batch(seed=12, B=B, L=L, S=S, pad_tail=(2, audio_pad, 1, 0, 0),
+                               uncond_pad_tail=(3, 44 if audio_pad else 0, 2, 0, 0))
     sd = state_dict()
     want, _, _ = sampler_ref.diffusion_reverse(
         lambda x, t, e, mk: denoiser_ref.denoiser_forward(sd, x, t, e, mk), scheduler_ref.DDPMSchedulerRef(),
@@ -252,7 +257,7 @@ def test_ddim_with_eta_matches_oracle():
 
 
 @pytest.mark.parametrize("env", [{"CFD_NAIVE_GEMM": "1"}, {"CFD_GEMM_CFG": "2"}, {"CFD_CHUNKS": "3"},
-                                 {"CFD_FUSED_SELF": "0"}, {"CFD_RUNS": "0"}, {"CFD_BRANCHES": "1"}, {"CFD_SHARE0": "0"}, {"CFD_PERMUTE": "0"}])
+                                 {"CFD_FUSED_SELF": "0"}, {"CFD_RUNS": "0"}, {"CFD_BRANCHES": "1"}, {"CFD_SHARE0": "0"}, {"CFD_PERMUTE": "0"}, {"CFD_TILE_SM": "1"}])
 def test_developer_knobs_keep_parity(env):
     """The debug / tuning switches (read once at cfd_create) must not change results: run the golden forward and
     the 20-step trajectory test in a child process under each of them."""
