@@ -142,11 +142,34 @@ __global__ void __launch_bounds__(SELF_ATTN_WAVES * 64, 4) self_attn_fused_kerne
       }
     }
   }
-  if (qvalid) {
+  // Epilogue.  The MFMA layout gives a lane 4 features of one query: 8-byte stores in 32-byte row segments.  Each
+  // wave re-lays its 16 x 128 block through a private LDS strip instead (the K / V^T tiles are free now) and stores
+  // 8 consecutive features per lane, 64 features per pass: 8 lanes cover a query, 8 queries per instruction.
+  __syncthreads();   // every wave is done with the last K / V^T tile
+  {
+    constexpr int RS = 64 * 4 + 16;   // strip row stride in bytes (+16: conflict-free 16-byte writes); 64 features per pass
+    char* strip = smem + wid * (16 * RS);
     const float inv = 1.0f / lsum;
-    char* orow = a.o + ((long long)b * a.L + q) * (CFD_D * 4);
 #pragma unroll
-    for (int f = 0; f < 8; ++f)
-      sp_store4(orow, h * 128 + f * 16 + q4 * 4, o[f][0] * inv, o[f][1] * inv, o[f][2] * inv, o[f][3] * inv);
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const f32x4 src = o[half * 4 + f];
+        *reinterpret_cast<f32x4*>(strip + l15 * RS + (f * 16 + q4 * 4) * 4) = f32x4{src[0] * inv, src[1] * inv, src[2] * inv, src[3] * inv};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private strip: no barrier needed
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+        const int qq = blockIdx.x * (SELF_ATTN_WAVES * 16) + wid * 16 + row;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(strip + row * RS + c8 * 4);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(strip + row * RS + c8 * 4 + 16);
+        if (qq < a.L) {
+          const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          sp_store8(a.o + ((long long)b * a.L + qq) * (CFD_D * 4), h * 128 + half * 64 + c8, v);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the second half overwrites the strip
+    }
   }
 }

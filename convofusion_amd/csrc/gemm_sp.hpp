@@ -243,6 +243,17 @@ struct EpiMemK {  // i < nfeat: K_layer[i/512][j][i%512] = split(v)  (one contig
   float* cbias;
   int nfeat, nl;
   static constexpr bool kPrefetch = false;
+  static constexpr bool kStore8 = true;
+  __device__ __forceinline__ void store8(int g, int b, int z, int i, int j, f32x4 v0, f32x4 v1) const {
+    if (i + 8 <= nfeat) {   // (nfeat is a multiple of 512: 8 consecutive features never straddle a layer)
+      const int layer = i >> 9, o = i & (CFD_D - 1);
+      const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      sp_store8(kall + ((long long)layer * rows + j) * (CFD_D * 4), o, v);
+    } else {
+      (*this)(g, b, z, i, j, v0);
+      (*this)(g, b, z, i + 4, j, v1);
+    }
+  }
   __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
     if (i < nfeat) {
       const int layer = i >> 9, o = i & (CFD_D - 1);
@@ -259,6 +270,13 @@ struct EpiMemV {  // V^T_layer_u[j/512][i/Sp][j%512][i%Sp] = split(v): one conti
   char* vt;
   int Sp, U;
   static constexpr bool kPrefetch = false;
+  static constexpr bool kStore8 = true;
+  __device__ __forceinline__ void store8(int g, int b, int z, int i, int j, f32x4 v0, f32x4 v1) const {
+    const int layer = j >> 9, f = j & (CFD_D - 1);
+    const int u = i / Sp, s = i - u * Sp;   // (Sp is a multiple of 32: 8 consecutive rows belong to one memory)
+    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    sp_store8(vt + (((long long)layer * U + u) * CFD_D + f) * ((long long)Sp * 4), s, v);
+  }
   __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
     const int layer = j >> 9, f = j & (CFD_D - 1);
     const int u = i / Sp, s = i - u * Sp;
