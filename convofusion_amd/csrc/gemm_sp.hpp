@@ -890,6 +890,7 @@ struct GemmCfgSel { int wi, wj, ti, tj; };
 
 extern int g_cfd_naive_gemm;  // set from CFD_NAIVE_GEMM env at cfd_create
 extern int g_cfd_gemm_cfg;    // CFD_GEMM_CFG env: force one tile configuration (tuning / A-B runs)
+extern int g_cfd_small3;      // CFD_SMALL3 env (default 1): 3-stage loop for the small-tile classes
 
 template <int WI, int WJ, int TI, int TJ, int NSTAGE, int MODE, class Epi>
 static hipError_t launch_cfg(GemmArgs a, const Epi& epi, int nb, int nz, hipStream_t st) {
@@ -945,11 +946,14 @@ static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStr
     big_tiles *= (long long)nb * nz;
     int imax = 0;
     for (int g = 0; g < ng; ++g) imax = a.I[g] > imax ? a.I[g] : imax;
+    // (the small-tile classes run few workgroups per CU and their k-loop is latency-bound: they use the 3-stage
+    //  counted-vmcnt loop -- two k-tiles in flight -- which is worth +3.4 % of a step at the product shape L = 16;
+    //  CFD_SMALL3=0 restores the 2-stage variants)
     if (a.J <= 16) cfg = 3;
-    else if (imax <= 64 && a.J >= 96) cfg = 7;
+    else if (imax <= 64 && a.J >= 96) cfg = g_cfd_small3 ? 20 : 7;
     else if (a.J > 128 && a.J <= 224 && big_tiles * 2 >= 256) cfg = 6;
     else if (big_tiles * 2 >= 384 && a.J >= 96) cfg = 1;
-    else cfg = 2;
+    else cfg = g_cfd_small3 ? 19 : 2;
   }
   switch (cfg) {
     case 1: return launch_cfg<2, 2, 4, 4, 2, MODE, Epi>(a, epi, nb, nz, st);
@@ -962,6 +966,8 @@ static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStr
     case 14: return launch_cfg<2, 2, 4, 8, 4, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 256, 4 waves x (64 x 128), software-pipelined
     case 15: return launch_cfg<2, 2, 4, 2, 2, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 64 (48 KB LDS: 3 blocks / CU)
     case 16: return launch_cfg<2, 2, 2, 4, 2, MODE, Epi>(a, epi, nb, nz, st);  // 64 x 128
+    case 19: return launch_cfg<2, 2, 2, 2, 3, MODE, Epi>(a, epi, nb, nz, st);   // 64 x 64, 3-stage counted-vmcnt loop
+    case 20: return launch_cfg<1, 4, 2, 2, 3, MODE, Epi>(a, epi, nb, nz, st);   // 32 x 128, 3-stage
     case 17: return launch_cfg<4, 1, 2, 11, 2, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 176: 43904 rows = 250 x 176 - 96
     case 18: return launch_cfg<8, 1, 2, 11, 2, MODE, Epi>(a, epi, nb, nz, st);  // 256 x 176, 8 waves
     case 12: return launch_cfg<2, 2, 4, 4, 1, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 128, single LDS buffer, 3+ blocks / CU

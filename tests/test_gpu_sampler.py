@@ -257,7 +257,7 @@ def test_ddim_with_eta_matches_oracle():
 
 
 @pytest.mark.parametrize("env", [{"CFD_NAIVE_GEMM": "1"}, {"CFD_GEMM_CFG": "2"}, {"CFD_CHUNKS": "3"},
-                                 {"CFD_FUSED_SELF": "0"}, {"CFD_RUNS": "0"}, {"CFD_BRANCHES": "1"}, {"CFD_SHARE0": "0"}, {"CFD_PERMUTE": "0"}, {"CFD_TILE_SM": "1"}])
+                                 {"CFD_FUSED_SELF": "0"}, {"CFD_RUNS": "0"}, {"CFD_BRANCHES": "1"}, {"CFD_SHARE0": "0"}, {"CFD_PERMUTE": "0"}, {"CFD_TILE_SM": "1"}, {"CFD_SMALL3": "0"}])
 def test_developer_knobs_keep_parity(env):
     """The debug / tuning switches (read once at cfd_create) must not change results: run the golden forward and
     the 20-step trajectory test in a child process under each of them."""

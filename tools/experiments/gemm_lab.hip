@@ -19,6 +19,7 @@
 
 int g_cfd_naive_gemm = 0;
 int g_cfd_gemm_cfg = 0;
+int g_cfd_small3 = 1;
 
 struct EpiResidOld : EpiResid {
   static constexpr bool kLate = false;
