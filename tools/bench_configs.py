@@ -1,0 +1,82 @@
+"""Timings of the BASELINE.json configurations that are not the bench.py line (developer tool; bench.py stays the
+contract).  Prints one JSON object:
+  C4  50-step DDIM, B=32, synthetic 196-token latents + 1500 audio tokens: end-to-end latency of the captured loop
+      (cfd_sample_begin .. cfd_sample_read, i.e. including table construction, warm-up iteration and capture)
+  C5  dyadic reactive path, B=16 per side, same shape (speaker memory = partner projection, 196 keys)
+  audio encoder: AudioConvEncoder over (B+1) x 1500 Mel frames (the conditioning producer of one batch)
+usage: python tools/bench_configs.py   (on the GPU box)"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from convofusion_amd import scheduler  # noqa: E402
+from convofusion_amd.conditioning import AudioConvEncoder, default_fuser  # noqa: E402
+from convofusion_amd.dyadic import DyadicRun  # noqa: E402
+from convofusion_amd.sampler import sample  # noqa: E402
+
+dev = torch.device("cuda:0")
+SCHED = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=True)
+out = {}
+
+
+def sync():
+    torch.cuda.synchronize(dev)
+
+
+model = bench.make_model(dev)
+mems, masks = bench.make_inputs(32, dev, 1234)
+L = bench.L
+
+# ---- C4: DDIM-50 latency
+sch = scheduler.DDIMScheduler(**SCHED, set_alpha_to_one=True, steps_offset=0)
+sample(model, sch, mems, masks, B=32, L=L, num_inference_steps=2, seed=0)   # first use: weight upload, kernel attributes
+sync()
+lat = []
+for r in range(3):
+    t0 = time.time()
+    x = sample(model, sch, mems, masks, B=32, L=L, num_inference_steps=50, eta=0.0, seed=r)
+    sync()
+    lat.append(time.time() - t0)
+out["C4_ddim50_B32"] = {"latency_s_end_to_end": min(lat), "all": lat, "steps_per_s": 50 / min(lat),
+                        "note": "sample(): de-duplication of the replicated batch, tables, warm-up iteration, capture, 50 replays, read"}
+
+# ---- C5: dyadic, B=16 per side
+B = 16
+g = torch.Generator().manual_seed(5)
+S = bench.S
+cond = lambda: [torch.randn(B, L if j == 0 else S[j], 512, generator=g).to(dev) for j in range(5)]
+uncond = [torch.randn(1, L if j == 0 else S[j], 512, generator=g).to(dev) for j in range(5)]
+model_b = bench.make_model(dev)
+fuser = default_fuser().to(dev).eval()
+run = DyadicRun(model, model_b, scheduler.DDPMScheduler(**SCHED), fuser, cond(), cond(), uncond, B, L, 1000, seed=3)
+run.steps(3)
+sync()
+t0 = time.time()
+n = 20
+run.steps(n)
+run.read()
+sync()
+dt = (time.time() - t0) / n
+out["C5_dyadic_B16x2"] = {"ms_per_lockstep_iteration": dt * 1e3, "iterations_per_s": 1 / dt,
+                          "note": "one iteration = both sides' guided denoising step + two partner projections (host-driven: "
+                                  "2 reads, 4 cfd_linear_act launches, 2 graph replays)"}
+run.read(close=True)
+
+# ---- audio encoder over one batch's Mel frames
+enc = AudioConvEncoder(input_size=80, hidden_size=256, latent_dim=512, max_seq_len=128, fps=25, sample_rate=16000, hop_length=160).to(dev).eval()
+mel = torch.randn(33, 1500, 80, device=dev)
+enc(mel)
+sync()
+t0 = time.time()
+for _ in range(10):
+    enc(mel)
+sync()
+dt = (time.time() - t0) / 10
+fl = 2.0 * 33 * 1500 * (80 * 256 + 256 * 512 + 512 * 512)
+out["audio_encoder_33x1500"] = {"ms": dt * 1e3, "tflops_fp32": fl / dt / 1e12}
+print(json.dumps(out))
