@@ -21,6 +21,7 @@ SYMBOLS = [
     "cfd_set_timestep_table", "cfd_forward", "cfd_sample_begin", "cfd_sample_steps", "cfd_sample_position",
     "cfd_sample_read", "cfd_scheduler_step", "cfd_add_noise", "cfd_philox_normal", "cfd_profile_forward",
     "cfd_test_gemm", "cfd_debug_stop_stage", "cfd_debug_read", "cfd_bench_gemm", "cfd_linear_act",
+    "cfd_layer_norm", "cfd_mha", "cfd_add", "cfd_zero_rows",
 ]
 
 
@@ -88,6 +89,11 @@ def load():
     lib.cfd_bench_gemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.cfd_linear_act.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p]
+    lib.cfd_layer_norm.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    lib.cfd_mha.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                            C.c_void_p, C.c_void_p]
+    lib.cfd_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.cfd_zero_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]
     lib.cfd_debug_stop_stage.argtypes = [C.c_void_p, C.c_int]
     lib.cfd_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
     for name in SYMBOLS:

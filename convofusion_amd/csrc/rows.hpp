@@ -571,3 +571,90 @@ __global__ void __launch_bounds__(256) linear_act_kernel(const float* __restrict
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Generic float32 row kernels for the small transformers either side of the loop (the VAE decoder, vae.py:268-372:
+// d_model 128, 2 heads, a few thousand rows, once per batch).  Plain and exact rather than fast.
+// ------------------------------------------------------------------------------------------------
+// out[r][:] = (x[r][:] - mean) * rstd * g + b   (nn.LayerNorm, eps 1e-5, biased variance); one wave per row, D <= 2048
+__global__ void __launch_bounds__(256) layernorm_f32_kernel(const float* x, const float* g, const float* b, float* out, long long rows, int D,
+                                                            float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * D;
+  float v[32];
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const int c = lane + 64 * q;
+    v[q] = c < D ? xr[c] : 0.f;
+    s += v[q];
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const int c = lane + 64 * q;
+    const float d = c < D ? v[q] - mean : 0.f;
+    v[q] = d;
+    ss += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + eps);
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const int c = lane + 64 * q;
+    if (c < D) out[row * D + c] = v[q] * rstd * g[c] + b[c];
+  }
+}
+
+// nn.MultiheadAttention core on projected inputs (F.multi_head_attention_forward after the in-projection):
+//   q [Lq][bs][E], k / v [Lk][bs][E] (sequence-major rows, as the reference's [L, N, E] tensors), H heads of hd = E / H <= 64,
+//   out[lq][b][h*hd + d] = sum_lk softmax_lk( scale * q.k  (+ -inf where key_padding_mask[b][lk]) ) v[lk][b][h*hd + d]
+// One wave per (lq, b, h): lanes <-> keys for the scores (kept in LDS), lanes <-> head features for the weighted sum.
+#define MHA_MAX_KEYS 1024
+__global__ void __launch_bounds__(256) mha_f32_kernel(const float* q, const float* k, const float* v, const uint8_t* key_padding_mask, float* out,
+                                                      int Lq, int Lk, int bs, int E, int H, float scale) {
+  __shared__ float sc[4][MHA_MAX_KEYS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long item = (long long)blockIdx.x * 4 + w;
+  if (item >= (long long)Lq * bs * H) return;
+  const int h = (int)(item % H);
+  const int b = (int)((item / H) % bs);
+  const int lq = (int)(item / ((long long)H * bs));
+  const int hd = E / H;
+  const float* qr = q + ((long long)lq * bs + b) * E + h * hd;
+  float mx = -INFINITY;
+  for (int lk = lane; lk < Lk; lk += 64) {
+    const float* kr = k + ((long long)lk * bs + b) * E + h * hd;
+    float s = 0.f;
+    for (int d = 0; d < hd; ++d) s = fmaf(qr[d] * scale, kr[d], s);   // q is scaled before the product (q_scaled @ k^T)
+    if (key_padding_mask && key_padding_mask[(long long)b * Lk + lk]) s = -INFINITY;
+    sc[w][lk] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int lk = lane; lk < Lk; lk += 64) {
+    const float p = expf(sc[w][lk] - mx);
+    sc[w][lk] = p;
+    sum += p;
+  }
+  sum = wave_sum(sum);
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes are visible to all of its lanes
+  if (lane < hd) {
+    float acc = 0.f;
+    for (int lk = 0; lk < Lk; ++lk) acc = fmaf(sc[w][lk] / sum, v[((long long)lk * bs + b) * E + h * hd + lane], acc);
+    out[((long long)lq * bs + b) * E + h * hd + lane] = acc;
+  }
+}
+
+// x[i] += y[i]  (residual connections); optional row mask: rows with keep[row] == 0 are set to zero afterwards
+__global__ void add_f32_kernel(float* x, const float* y, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = x[i] + y[i];
+}
+__global__ void zero_rows_f32_kernel(float* x, const uint8_t* keep, long long rows, int D) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows * D && !keep[i / D]) x[i] = 0.f;
+}

@@ -147,6 +147,21 @@ int cfd_add_noise(cfd_handle h, const float* alphas_cumprod_host, int t, const f
 int cfd_linear_act(cfd_handle h, const float* x, long long n_rows, int K, const float* W, const float* b, int N, int act,
                    float* out, void* stream);
 
+/* float32 building blocks of the small transformer that follows the loop -- ConvoFusionVae.decode
+ * (convofusion/models/architectures/vae.py:268-372: two SkipTransformerDecoders of d_model 128, 2 heads, 5 pre-norm layers,
+ * cross_attention.py:66-125,311-395) -- used by convofusion_amd/vae.py together with cfd_linear_act:
+ *   cfd_layer_norm  nn.LayerNorm over the last dimension (D <= 2048)
+ *   cfd_mha         the attention core of nn.MultiheadAttention on already projected q / k / v, sequence-major
+ *                   [L][bs][E] rows, key_padding_mask dev uint8 [bs][Lk] (1 = ignore) or NULL; head_dim <= 64, Lk <= 1024
+ *   cfd_add         x += y (residual connection)
+ *   cfd_zero_rows   rows with keep[row] == 0 are zeroed (vae.py:358 `output[~mask.T] = 0`) */
+int cfd_layer_norm(cfd_handle h, const float* x, long long rows, int D, const float* gamma, const float* beta, float eps,
+                   float* out, void* stream);
+int cfd_mha(cfd_handle h, const float* q, const float* k, const float* v, int Lq, int Lk, int bs, int E, int H,
+            const uint8_t* key_padding_mask, float* out, void* stream);
+int cfd_add(cfd_handle h, float* x, const float* y, size_t numel, void* stream);
+int cfd_zero_rows(cfd_handle h, float* x, const uint8_t* keep, long long rows, int D, void* stream);
+
 /* Device N(0,1) draws of the product's counter-based stream (DESIGN.md "RNG"): out dev [B][per_utt]. */
 int cfd_philox_normal(cfd_handle h, float* out, int B, int per_utt, uint64_t seed, uint32_t step,
                       uint32_t first_utterance, uint32_t stream_id, void* stream);
