@@ -4,6 +4,7 @@ contract).  Prints one JSON object:
       (cfd_sample_begin .. cfd_sample_read, i.e. including table construction, warm-up iteration and capture)
   C5  dyadic reactive path, B=16 per side, same shape (speaker memory = partner projection, 196 keys)
   audio encoder: AudioConvEncoder over (B+1) x 1500 Mel frames (the conditioning producer of one batch)
+  VAE decode: ConvoFusionVae.decode of one batch (B=32, 128 frames)
 usage: python tools/bench_configs.py   (on the GPU box)"""
 import json
 import os
@@ -79,4 +80,18 @@ sync()
 dt = (time.time() - t0) / 10
 fl = 2.0 * 33 * 1500 * (80 * 256 + 256 * 512 + 512 * 512)
 out["audio_encoder_33x1500"] = {"ms": dt * 1e3, "tflops_fp32": fl / dt / 1e12}
+# ---- VAE decode of one batch (the step after the loop): B=32, 8 chunks -> 128 frames
+from types import SimpleNamespace  # noqa: E402
+from convofusion_amd.vae import ConvoFusionVae  # noqa: E402
+vae = ConvoFusionVae(ablation=SimpleNamespace(MLP_DIST=False, PE_TYPE="convofusion"), nfeats=189, latent_dim=[1, 128], ff_size=1024,
+                     num_layers=5, num_heads=2, arch="encoder_decoder", normalize_before=True, activation="gelu",
+                     position_embedding="sine").to(dev).eval()
+z = torch.randn(2, 32, 8, 128, device=dev)
+vae.decode(z, [128] * 32)
+sync()
+t0 = time.time()
+for _ in range(5):
+    vae.decode(z, [128] * 32)
+sync()
+out["vae_decode_B32_128frames"] = {"ms": (time.time() - t0) / 5 * 1e3, "note": "~190 small float32 launches driven from Python"}
 print(json.dumps(out))
