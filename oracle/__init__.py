@@ -13,11 +13,15 @@ This package is a numpy (float32) restatement of the reference's hot path:
   * ``sampler_ref``   -- ``Convofusion._diffusion_reverse`` (convofusion.py:391-549), 7-way CFG
   * ``philox_ref``    -- CPU restatement of the product's device RNG (Philox4x32-10 + Box-Muller)
   * ``weights``       -- deterministic state-dict generator with the reference's 537 keys/shapes
+  * ``conditioning_ref`` -- AudioConvEncoder / TextAudioMotionFuser (audioenc.py:9-34, condfuser.py:8-50)
+  * ``dyadic_ref``    -- two loops in lock-step with partner-projected speaker memories (BASELINE configs[4])
+  * ``vae_ref``, ``vae_weights`` -- ``ConvoFusionVae.decode`` (vae.py:268-372) and its seeded 337-key state dict
 
 Parity pinning: the reference ships no tests or golden vectors.  The
 denoiser restatement is pinned against outputs of the reference ``Denoiser`` class itself,
 imported from /root/reference in the build container by ``tests/golden/make_golden.py`` and
-committed as fixtures under ``tests/golden/``.  The scheduler restatement (diffusers is absent
+committed as fixtures under ``tests/golden/``; the conditioning producers and the VAE decoder
+likewise (``make_golden_conditioning.py``, ``make_golden_vae.py``).  The scheduler restatement (diffusers is absent
 from the reference tree and from this image) is pinned by closed-form known-answer tests only:
 **scheduler parity unpinned** against the third-party package itself.
 
