@@ -36,16 +36,22 @@ def canonical_flops_per_step(Be, Lq, Ss, nl=NL):
     return 2.0 * macs_row * Be
 
 
-def executed_gemm_flops(Be, Lq, Ss, U, nl=NL):
+def executed_gemm_flops(Be, Lq, Ss, U, nl=NL, shared_rows=None):
     """Algorithmic (single-product) FLOPs of the GEMMs the HIP pipeline actually launches, per class.
-    Every product is issued as 3 bf16 MFMAs, so MFMA-issued FLOPs are 3x these."""
+    Every product is issued as 3 f16 MFMAs, so MFMA-issued FLOPs are 3x these.  ``shared_rows``: rows that run the
+    replica-independent head of the network (embedding, layer 0's self-attention and first time block) when the
+    batch is G replicas of them (cfd_api.hip Problem::share_B); the other rows do not launch those products."""
     M = Be * Lq
+    M0 = (shared_rows if shared_rows else Be) * Lq
+    B0 = shared_rows if shared_rows else Be
     Lp = (Lq + 31) // 32 * 32
     Sp = [(s + 31) // 32 * 32 for s in Ss]
-    tok = 2.0 * M * 512 * 128 + 2.0 * M * 128 * 512                       # embed + latent proj
+    tok = 2.0 * M0 * 512 * 128 + 2.0 * M * 128 * 512                      # embed (shared rows) + latent proj
     tok += nl * 2.0 * M * 512 * (1024 + 512 + 512 + 512 + 512 + 1024 + 1024)  # qk, v^T, Wo, TB1, TB2, FFN1, FFN2
+    tok -= 2.0 * (M - M0) * 512 * (1024 + 512 + 512 + 512)                # layer 0: qk, v^T, Wo, TB1 on the shared rows only
     mem = sum(2.0 * u * sp * 512 * (2 * nl * 512) for u, sp in zip(U, Sp))
     att = nl * (2.0 * Be * 4 * Lq * Lp * 128 * 2 + sum(2.0 * Be * Lq * sp * 512 * 2 for sp in Sp))
+    att -= 2.0 * (Be - B0) * 4 * Lq * Lp * 128 * 2                        # layer 0's self-attention
     return {"gemm_token": tok, "gemm_mem": mem, "gemm_attn": att}
 
 
@@ -195,7 +201,7 @@ def main():
         Be = G * B_PER_GPU
         U = [B_PER_GPU + 1] * 5
         canon = canonical_flops_per_step(Be, L, S)
-        ex = executed_gemm_flops(Be, L, S, U)
+        ex = executed_gemm_flops(Be, L, S, U, shared_rows=B_PER_GPU if os.environ.get("CFD_SHARE0", "1") != "0" else None)
         classes = {k: {"ms": round(v[0], 4), "launches": v[1]} for k, v in prof.items()}
         # dominant kernel = gemm_sp_kernel (every matrix product of the step); per-class split below
         gk = ("gemm_token", "gemm_mem", "gemm_attn")
