@@ -371,18 +371,19 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
   const int Iclamp_g = sel5(a.Iclamp, g);
 
   // X base for this (b, z): one slot in PLAIN / GROUPED mode, one per K segment in SEGK mode
-  const char* xb[GEMM_SLOTS];
+  // (five named scalars, not an array: hipcc turns a select chain over a small local array into an indexed SCRATCH
+  //  load in front of every k-step's requests)
+  static_assert(GEMM_SLOTS == 5, "the K-segment bases are five named scalars");
+  const char *xb0 = nullptr, *xb1 = nullptr, *xb2 = nullptr, *xb3 = nullptr, *xb4 = nullptr;
   const char* xbase_g = nullptr;
   long long ldx_g = 0;
   if (MODE == MODE_SEGK) {
-#pragma unroll
-    for (int s = 0; s < GEMM_SLOTS; ++s) {
-      xb[s] = nullptr;
-      if (s < a.nslot) {
-        const long long bi = a.xmap[s] ? a.xmap[s][b] : b;
-        xb[s] = a.X[s] + bi * a.xbs[s] + (long long)z * a.xzs;
-      }
-    }
+    auto seg_base = [&](int s) __attribute__((always_inline)) -> const char* {
+      if (s >= a.nslot) return nullptr;
+      const long long bi = a.xmap[s] ? a.xmap[s][b] : b;
+      return a.X[s] + bi * a.xbs[s] + (long long)z * a.xzs;
+    };
+    xb0 = seg_base(0); xb1 = seg_base(1); xb2 = seg_base(2); xb3 = seg_base(3); xb4 = seg_base(4);
   } else {
     const int* xm = sel5(a.xmap, g);
     const long long bi = xm ? xm[b] : b;
@@ -430,12 +431,12 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
 #pragma unroll
       for (int q = 0; q < GEMM_SLOTS - 1; ++q)
         if (s == q && q < a.nslot - 1 && ktl >= a.kt[q]) { ktl -= a.kt[q]; s = q + 1; }
-      const char* xs = xb[0];
+      const char* xs = s == 0 ? xb0 : s == 1 ? xb1 : s == 2 ? xb2 : s == 3 ? xb3 : xb4;
       long long ldx = a.ldx[0];
       int yk = a.yk0[0];
 #pragma unroll
       for (int q = 1; q < GEMM_SLOTS; ++q)
-        if (q == s) { xs = xb[q]; ldx = a.ldx[q]; yk = a.yk0[q]; }
+        if (q == s) { ldx = a.ldx[q]; yk = a.yk0[q]; }
       ykt = yk + ktl;
 #pragma unroll
       for (int n = 0; n < XPW; ++n) {
