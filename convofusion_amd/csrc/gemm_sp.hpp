@@ -29,6 +29,15 @@
 #ifndef CFD_WIDE_EPI
 #define CFD_WIDE_EPI 1
 #endif
+// hipcc moves part of a k-step's MFMAs below the barrier that ends the step (20 of 48 in the 128 x 128 kernel), i.e. in
+// front of the NEXT step's LDS-DMA requests: the requests are issued 320 cycles later and the vmcnt(0) wait at the barrier
+// is covered by fewer MFMAs.  A scheduling fence keeps the whole cluster in front of the barrier.
+#ifndef CFD_MFMA_FENCE
+#define CFD_MFMA_FENCE 1
+#endif
+#ifndef CFD_READS_FIRST
+#define CFD_READS_FIRST 1
+#endif
 #ifndef CFD_LATE_RESID
 #define CFD_LATE_RESID 0
 #endif
@@ -575,6 +584,9 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
       yh[tj] = *reinterpret_cast<const spx8*>(sb + yoff_h + tj * 2048);
       yl[tj] = *reinterpret_cast<const spx8*>(sb + yoff_l + tj * 2048);
     }
+#if CFD_READS_FIRST
+    __builtin_amdgcn_sched_barrier(0);   // all fragment reads of the k-step are issued before its first MFMA
+#endif
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
@@ -605,6 +617,9 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
         if ((kt & (FOLD_STEPS - 1)) == 0) fold_request(kt / FOLD_STEPS);   // consumed FOLD_STEPS k-steps later
       }
       compute(buf);
+#if CFD_MFMA_FENCE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       if constexpr (FOLD) {
         if ((kt & (FOLD_STEPS - 1)) == FOLD_STEPS - 1 || kt + 1 == nkt) fold_apply();
       }
