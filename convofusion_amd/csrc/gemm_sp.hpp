@@ -175,6 +175,20 @@ struct EpiResid {  // x[(b*rows_per_b + j)][i] += v + bias[i]   (row length CFD_
     r.x += v[0]; r.y += v[1]; r.z += v[2]; r.w += v[3];
     *reinterpret_cast<float4*>(p) = r;
   }
+  // Band form used by the wide epilogue: the old values of a 16-row band are requested together and the bias is
+  // read once per tile.  (Written item by item, hipcc serialises load -> wait -> store for every 16 bytes -- a store
+  // to x may alias the next load from x -- and re-reads the bias behind every store: 32 dependent round trips a tile.)
+  static constexpr bool kBand = true;
+  __device__ __forceinline__ float4 tile_bias(int i) const {
+    return bias ? *reinterpret_cast<const float4*>(bias + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __device__ __forceinline__ float4 band_load(int g, int b, int z, int i, int j) const {
+    return *reinterpret_cast<const float4*>(x + (long long)b * obs + (long long)j * CFD_D + i);
+  }
+  __device__ __forceinline__ void band_store(int g, int b, int z, int i, int j, f32x4 v, float4 r, float4 t) const {
+    r.x = (r.x + t.x) + v[0]; r.y = (r.y + t.y) + v[1]; r.z = (r.z + t.z) + v[2]; r.w = (r.w + t.w) + v[3];   // same association as above
+    *reinterpret_cast<float4*>(x + (long long)b * obs + (long long)j * CFD_D + i) = r;
+  }
 };
 
 // Attention scores against ONE shared memory, softmax-ed per 128-key tile inside the epilogue ("tile softmax"):
@@ -293,6 +307,8 @@ struct EpiMemV {  // V^T_layer_u[j/512][i/Sp][j%512][i%Sp] = split(v): one conti
   }
 };
 
+template <class E, class = void> struct EpiHasBand { static constexpr bool value = false; };
+template <class E> struct EpiHasBand<E, typename std::enable_if<E::kBand>::type> { static constexpr bool value = true; };
 template <class E, class = void> struct EpiHasStore8 { static constexpr bool value = false; };
 template <class E> struct EpiHasStore8<E, typename std::enable_if<E::kStore8>::type> { static constexpr bool value = true; };
 template <class E, class = void> struct EpiHasTileSM { static constexpr bool value = false; };
@@ -832,6 +848,23 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
             if (i + 4 < Ig) epi.store8(g, b, z, i, j, v0, v1);
             else if (i < Ig) epi(g, b, z, i, j, v0);
           }
+        }
+      } else if constexpr (EpiHasBand<Epi>::value && !LATE) {
+        f32x4 bv[NIT];
+        float4 br[NIT];
+        const float4 bt = epi.tile_bias(min(i0 + wi * TI * 16 + (lane % LPR) * 4, Ig - 4));   // (i does not depend on the band)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          int i, j;
+          epi_ij(tj, it, i, j);
+          bv[it] = *reinterpret_cast<const f32x4*>(strip + (it * RPI + lane / LPR) * RS + (lane % LPR) * 16);
+          br[it] = epi.band_load(g, b, z, min(i, Ig - 4), min(j, a.J - 1));
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          int i, j;
+          epi_ij(tj, it, i, j);
+          if (i < Ig && j < a.J) epi.band_store(g, b, z, i, j, bv[it], br[it], bt);
         }
       } else {
 #pragma unroll
