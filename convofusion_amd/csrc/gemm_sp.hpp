@@ -122,23 +122,31 @@ struct EpiSplit {  // out_sp[j][coloff + i] = split(act(v + bias[i]))
     const int col = perm32 ? ((i & ~31) | (((i >> 2) & 3) << 3) | (((i >> 4) & 1) << 2)) : i;
     sp_store4(out + (long long)b * obs + (long long)z * ozs + (long long)j * ldo, col, v[0], v[1], v[2], v[3]);
   }
-  __device__ __forceinline__ void store8(int g, int b, int z, int i, int j, f32x4 v0, f32x4 v1) const {
-    if (perm32) {   // the k-slot permutation moves groups of 4: two 4-wide stores
-      (*this)(g, b, z, i, j, v0);
-      (*this)(g, b, z, i + 4, j, v1);
-      return;
-    }
-    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+  // the bias of a lane's 8 columns is read once per tile (kBias8): re-read behind every store, the load's wait also
+  // waits for the store before it
+  static constexpr bool kBias8 = true;
+  __device__ __forceinline__ void tile_bias8(int i, float4& t0, float4& t1) const {
+    t0 = t1 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias) {
-      const float4 t0 = *reinterpret_cast<const float4*>(bias + i);
-      const float4 t1 = *reinterpret_cast<const float4*>(bias + i + 4);
-      v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+      t0 = *reinterpret_cast<const float4*>(bias + i);
+      t1 = *reinterpret_cast<const float4*>(bias + i + 4);
     }
+  }
+  __device__ __forceinline__ void store8(int g, int b, int z, int i, int j, f32x4 v0, f32x4 v1, float4 t0, float4 t1) const {
+    float v[8] = {v0[0] + t0.x, v0[1] + t0.y, v0[2] + t0.z, v0[3] + t0.w, v1[0] + t1.x, v1[1] + t1.y, v1[2] + t1.z, v1[3] + t1.w};
     if (gelu) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
     }
-    sp_store8(out + (long long)b * obs + (long long)z * ozs + (long long)j * ldo, i, v);
+    char* row = out + (long long)b * obs + (long long)z * ozs + (long long)j * ldo;
+    if (perm32) {   // the k-slot permutation moves groups of 4: two 4-wide stores
+      const int c0 = (i & ~31) | (((i >> 2) & 3) << 3) | (((i >> 4) & 1) << 2);
+      const int c1 = ((i + 4) & ~31) | ((((i + 4) >> 2) & 3) << 3) | ((((i + 4) >> 4) & 1) << 2);
+      sp_store4(row, c0, v[0], v[1], v[2], v[3]);
+      sp_store4(row, c1, v[4], v[5], v[6], v[7]);
+    } else {
+      sp_store8(row, i, v);
+    }
   }
 };
 
@@ -307,6 +315,8 @@ struct EpiMemV {  // V^T_layer_u[j/512][i/Sp][j%512][i%Sp] = split(v): one conti
   }
 };
 
+template <class E, class = void> struct EpiHasBias8 { static constexpr bool value = false; };
+template <class E> struct EpiHasBias8<E, typename std::enable_if<E::kBias8>::type> { static constexpr bool value = true; };
 template <class E, class = void> struct EpiHasBand { static constexpr bool value = false; };
 template <class E> struct EpiHasBand<E, typename std::enable_if<E::kBand>::type> { static constexpr bool value = true; };
 template <class E, class = void> struct EpiHasStore8 { static constexpr bool value = false; };
@@ -828,6 +838,13 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
     } else {
       __syncthreads();
     }
+    float4 s8_t0 = make_float4(0.f, 0.f, 0.f, 0.f), s8_t1 = s8_t0;
+    if constexpr (EpiHasStore8<Epi>::value && EpiHasBias8<Epi>::value) {
+      const int i8 = i0 + wi * TI * 16 + (lane % (TI * 2)) * 8;   // (a lane's columns do not depend on the band)
+      if (i8 + 8 <= Ig) epi.tile_bias8(i8, s8_t0, s8_t1);
+    }
+    float4 late_bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (LATE) late_bias = epi.tile_bias(min(i0 + wi * TI * 16 + (lane % LPR) * 4, Ig - 4));
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
 #pragma unroll
@@ -845,8 +862,13 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
           const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp);
           const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + 16);
           if (j < a.J) {
-            if (i + 4 < Ig) epi.store8(g, b, z, i, j, v0, v1);
-            else if (i < Ig) epi(g, b, z, i, j, v0);
+            if constexpr (EpiHasBias8<Epi>::value) {
+              if (i + 4 < Ig) epi.store8(g, b, z, i, j, v0, v1, s8_t0, s8_t1);
+              else if (i < Ig) epi(g, b, z, i, j, v0);
+            } else {
+              if (i + 4 < Ig) epi.store8(g, b, z, i, j, v0, v1);
+              else if (i < Ig) epi(g, b, z, i, j, v0);
+            }
           }
         }
       } else if constexpr (EpiHasBand<Epi>::value && !LATE) {
@@ -874,7 +896,7 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(strip + (it * RPI + lane / LPR) * RS + (lane % LPR) * 16);
         if (i < Ig && j < a.J) {
           if constexpr (Epi::kPrefetch) epi(g, b, z, i, j, v, pre[it][tj]);
-          else if constexpr (LATE) epi(g, b, z, i, j, v, late[it][tj]);
+          else if constexpr (LATE) epi.band_store(g, b, z, i, j, v, late[it][tj], late_bias);
           else epi(g, b, z, i, j, v);
         }
       }
