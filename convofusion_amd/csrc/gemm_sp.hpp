@@ -838,6 +838,18 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
     } else {
       __syncthreads();
     }
+    constexpr bool BAND = EpiHasBand<Epi>::value && !LATE && !EpiHasStore8<Epi>::value;
+    float4 band_r[BAND ? NIT : 1];
+    float4 band_t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (BAND) {
+      band_t = epi.tile_bias(min(i0 + wi * TI * 16 + (lane % LPR) * 4, Ig - 4));   // (a lane's columns do not depend on the band)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        int i, j;
+        epi_ij(0, it, i, j);
+        band_r[it] = epi.band_load(g, b, z, min(i, Ig - 4), min(j, a.J - 1));
+      }
+    }
     float4 s8_t0 = make_float4(0.f, 0.f, 0.f, 0.f), s8_t1 = s8_t0;
     if constexpr (EpiHasStore8<Epi>::value && EpiHasBias8<Epi>::value) {
       const int i8 = i0 + wi * TI * 16 + (lane % (TI * 2)) * 8;   // (a lane's columns do not depend on the band)
@@ -872,22 +884,29 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
           }
         }
       } else if constexpr (EpiHasBand<Epi>::value && !LATE) {
+        // the old values of band tj were requested one band ago (band 0: before the loop); band tj+1's requests go out
+        // BEFORE this band's stores, which they must not be reordered with as far as hipcc knows
         f32x4 bv[NIT];
-        float4 br[NIT];
-        const float4 bt = epi.tile_bias(min(i0 + wi * TI * 16 + (lane % LPR) * 4, Ig - 4));   // (i does not depend on the band)
+        float4 brn[NIT];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          int i, j;
-          epi_ij(tj, it, i, j);
+        for (int it = 0; it < NIT; ++it)
           bv[it] = *reinterpret_cast<const f32x4*>(strip + (it * RPI + lane / LPR) * RS + (lane % LPR) * 16);
-          br[it] = epi.band_load(g, b, z, min(i, Ig - 4), min(j, a.J - 1));
+        if (tj + 1 < TJ) {
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            int i, j;
+            epi_ij(tj + 1, it, i, j);
+            brn[it] = epi.band_load(g, b, z, min(i, Ig - 4), min(j, a.J - 1));
+          }
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
           int i, j;
           epi_ij(tj, it, i, j);
-          if (i < Ig && j < a.J) epi.band_store(g, b, z, i, j, bv[it], br[it], bt);
+          if (i < Ig && j < a.J) epi.band_store(g, b, z, i, j, bv[it], band_r[it], band_t);
         }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) band_r[it] = brn[it];
       } else {
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
