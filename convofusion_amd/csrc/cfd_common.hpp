@@ -91,3 +91,14 @@ __device__ __forceinline__ float wave_max(float v) {
 // v_exp_f32-based exponential (__expf): ~1e-7 relative near 0, grows with |x| only where the result is negligible
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+// GELU for the FFN epilogue (45 M evaluations per launch; erff's two-range code costs 41 of the launch's 188 us).
+// erf by Abramowitz & Stegun 7.1.26: erfc(a) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-a^2), t = 1 / (1 + p a),
+// |error| <= 1.5e-7 -- the float32 noise level of the reference's own erf; 1 + erf(x) is formed as erfc(|x|) for x < 0,
+// so the negative tail does not cancel.  |gelu error| <= 0.75e-7 |x|.
+__device__ __forceinline__ float gelu_fast_f(float x) {
+  const float a = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, a, 1.0f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float erfc_a = poly * __expf(-a * a);
+  return 0.5f * x * (x >= 0.f ? 2.0f - erfc_a : erfc_a);
+}

@@ -118,7 +118,7 @@ struct EpiSplit {  // out_sp[j][coloff + i] = split(act(v + bias[i]))
       const float4 t = *reinterpret_cast<const float4*>(bias + i);
       v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
     }
-    if (gelu) { v[0] = gelu_f(v[0]); v[1] = gelu_f(v[1]); v[2] = gelu_f(v[2]); v[3] = gelu_f(v[3]); }
+    if (gelu) { v[0] = gelu_fast_f(v[0]); v[1] = gelu_fast_f(v[1]); v[2] = gelu_fast_f(v[2]); v[3] = gelu_fast_f(v[3]); }
     const int col = perm32 ? ((i & ~31) | (((i >> 2) & 3) << 3) | (((i >> 4) & 1) << 2)) : i;
     sp_store4(out + (long long)b * obs + (long long)z * ozs + (long long)j * ldo, col, v[0], v[1], v[2], v[3]);
   }
@@ -136,7 +136,7 @@ struct EpiSplit {  // out_sp[j][coloff + i] = split(act(v + bias[i]))
     float v[8] = {v0[0] + t0.x, v0[1] + t0.y, v0[2] + t0.z, v0[3] + t0.w, v1[0] + t1.x, v1[1] + t1.y, v1[2] + t1.z, v1[3] + t1.w};
     if (gelu) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+      for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
     }
     char* row = out + (long long)b * obs + (long long)z * ozs + (long long)j * ldo;
     if (perm32) {   // the k-slot permutation moves groups of 4: two 4-wide stores

@@ -99,6 +99,7 @@ int main(int argc, char** argv) {
       case 'o': return launch_gemm<MODE_PLAIN, EpiResidOld>(a, eo, 1, 1, nullptr, v.cfg);
       case 'n': return launch_gemm<MODE_PLAIN, EpiNull>(a, en, 1, 1, nullptr, v.cfg);
       case 's': return launch_gemm<MODE_PLAIN, EpiSplit>(a, es, 1, 1, nullptr, v.cfg);
+      case 'G': { EpiSplit eg = es; eg.gelu = 1; return launch_gemm<MODE_PLAIN, EpiSplit>(a, eg, 1, 1, nullptr, v.cfg); }
       default: return launch_gemm<MODE_PLAIN, EpiF32>(a, ef, 1, 1, nullptr, v.cfg);
     }
   };
@@ -115,7 +116,7 @@ int main(int argc, char** argv) {
   std::vector<float> href((size_t)J * I), hout((size_t)J * I);
   CK(hipMemcpy(href.data(), ref, (size_t)J * I * 4, hipMemcpyDeviceToHost));
   for (auto& v : vs) {
-    if (v.epi == 'n' || v.epi == 's' || v.epi == 'g') continue;
+    if (v.epi == 'n' || v.epi == 's' || v.epi == 'g' || v.epi == 'G') continue;
     CK(hipMemset(out, 0, (size_t)J * I * 4));
     CK(go(v));
     CK(hipDeviceSynchronize());
