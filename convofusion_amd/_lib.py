@@ -21,7 +21,8 @@ SYMBOLS = [
     "cfd_set_timestep_table", "cfd_forward", "cfd_sample_begin", "cfd_sample_steps", "cfd_sample_position",
     "cfd_sample_read", "cfd_scheduler_step", "cfd_add_noise", "cfd_philox_normal", "cfd_profile_forward",
     "cfd_test_gemm", "cfd_debug_stop_stage", "cfd_debug_read", "cfd_bench_gemm", "cfd_linear_act",
-    "cfd_layer_norm", "cfd_mha", "cfd_add", "cfd_zero_rows",
+    "cfd_layer_norm", "cfd_mha", "cfd_add", "cfd_zero_rows", "cfd_gemm_f32", "cfd_softmax", "cfd_softmax_bwd",
+    "cfd_layer_norm_bwd", "cfd_ew", "cfd_weg_focus", "cfd_sample_write",
 ]
 
 
@@ -39,6 +40,11 @@ class Config(C.Structure):
 class Memory(C.Structure):
     _fields_ = [("data", C.c_void_p), ("row_map", C.c_void_p), ("key_padding_mask", C.c_void_p),
                 ("U", C.c_int), ("S", C.c_int)]
+
+
+class Mat(C.Structure):
+    """cfd_mat: element (z1, z2, r, c) = p[z1*b1 + z2*b2 + r*rs + c*cs]."""
+    _fields_ = [("p", C.c_void_p), ("rs", C.c_longlong), ("cs", C.c_longlong), ("b1", C.c_longlong), ("b2", C.c_longlong)]
 
 
 class SampleArgs(C.Structure):
@@ -94,6 +100,17 @@ def load():
                             C.c_void_p, C.c_void_p]
     lib.cfd_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.cfd_zero_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]
+    lib.cfd_gemm_f32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Mat), C.POINTER(Mat), C.POINTER(Mat),
+                                 C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+    lib.cfd_softmax.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
+    lib.cfd_softmax_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]
+    lib.cfd_layer_norm_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_float,
+                                       C.c_int, C.c_void_p]
+    lib.cfd_ew.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_longlong,
+                           C.c_longlong, C.c_float, C.c_void_p]
+    lib.cfd_weg_focus.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                  C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.cfd_sample_write.argtypes = [C.c_void_p, C.c_void_p]
     lib.cfd_debug_stop_stage.argtypes = [C.c_void_p, C.c_int]
     lib.cfd_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
     for name in SYMBOLS:

@@ -16,6 +16,7 @@
 #include "gemm_sp.hpp"
 #include "rows.hpp"
 #include "attn_fused.hpp"
+#include "grad.hpp"
 
 int g_cfd_naive_gemm = 0;
 int g_cfd_gemm_cfg = 0;
@@ -1335,6 +1336,82 @@ extern "C" int cfd_zero_rows(cfd_handle c, float* x, const uint8_t* keep, long l
   const long long n = rows * D;
   hipLaunchKernelGGL(zero_rows_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, keep, rows, D);
   HIPCHK(hipGetLastError());
+  return CFD_OK;
+}
+
+// ---- float32 pieces of the WEG gradient path (grad.hpp) ---------------------------------------------------------
+extern "C" int cfd_gemm_f32(cfd_handle c, int M, int N, int K, int nb1, int nb2, const cfd_mat* A, const cfd_mat* B, const cfd_mat* Cm,
+                            const float* bias, float alpha, int accumulate, void* stream) {
+  if (!c || !A || !B || !Cm || !A->p || !B->p || !Cm->p || M < 1 || N < 1 || K < 1 || nb1 < 1 || nb2 < 1) return fail(CFD_E_ARG, "bad argument");
+  if ((long long)nb1 * nb2 > 65535) return fail(CFD_E_SHAPE, "cfd_gemm_f32: at most 65535 batch entries");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  MatView a{A->p, A->rs, A->cs, A->b1, A->b2}, b{B->p, B->rs, B->cs, B->b1, B->b2};
+  hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)(nb1 * nb2)), dim3(256), 0,
+                     (hipStream_t)stream, a, b, const_cast<float*>(Cm->p), Cm->rs, Cm->cs, Cm->b1, Cm->b2, M, N, K, nb2, bias, alpha, accumulate);
+  HIPCHK(hipGetLastError());
+  return CFD_OK;
+}
+
+extern "C" int cfd_softmax(cfd_handle c, float* scores, long long rows, int Lk, const uint8_t* key_padding_mask, long long rows_per_batch,
+                           void* stream) {
+  if (!c || !scores || rows < 1 || Lk < 1 || rows_per_batch < 1) return fail(CFD_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  hipLaunchKernelGGL(softmax_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, scores, key_padding_mask, rows, Lk,
+                     rows_per_batch);
+  HIPCHK(hipGetLastError());
+  return CFD_OK;
+}
+
+extern "C" int cfd_softmax_bwd(cfd_handle c, const float* p, float* dp, const float* extra, long long rows, int Lk, void* stream) {
+  if (!c || !p || !dp || rows < 1 || Lk < 1) return fail(CFD_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  hipLaunchKernelGGL(softmax_bwd_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, dp, extra, rows, Lk);
+  HIPCHK(hipGetLastError());
+  return CFD_OK;
+}
+
+extern "C" int cfd_layer_norm_bwd(cfd_handle c, const float* x, const float* gamma, const float* dy, float* dx, long long rows, int D, float eps,
+                                  int accumulate, void* stream) {
+  if (!c || !x || !gamma || !dy || !dx || rows < 1 || D < 1 || D > 2048) return fail(CFD_E_ARG, "bad argument (D <= 2048)");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  hipLaunchKernelGGL(layernorm_bwd_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, dx, rows, D, eps,
+                     accumulate);
+  HIPCHK(hipGetLastError());
+  return CFD_OK;
+}
+
+extern "C" int cfd_ew(cfd_handle c, int op, const float* a, const float* b, float* out, size_t numel, int D, int R1, long long s0, long long s1,
+                      float alpha, void* stream) {
+  if (!c || !a || !out || numel < 1 || op < 0 || op >= EW_NOPS) return fail(CFD_E_ARG, "bad argument");
+  if (op >= EW_SILU_BWD && !b) return fail(CFD_E_ARG, "cfd_ew: this op needs the second operand");
+  if (op >= EW_ADD_BCAST && (D < 1 || R1 < 1)) return fail(CFD_E_ARG, "cfd_ew: D and R1 must be positive");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  hipLaunchKernelGGL(ew_f32_kernel, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, a, b, out, (long long)numel,
+                     D > 0 ? D : 1, R1 > 0 ? R1 : 1, s0, s1, alpha);
+  HIPCHK(hipGetLastError());
+  return CFD_OK;
+}
+
+extern "C" int cfd_weg_focus(cfd_handle c, const float* att, int B, int NL, int L, int S, const int32_t* tok_off, const int32_t* tok_idx, int last,
+                             int nt_max, const float kernel3[3], float* workspace, float* losses, float* max_att, float* d_att, void* stream) {
+  if (!c || !att || !tok_off || !tok_idx || !kernel3 || !workspace || !losses || !max_att || !d_att || B < 1 || NL < 1 || nt_max < 1)
+    return fail(CFD_E_ARG, "bad argument");
+  // F.pad(..., mode='reflect') with pad 1 needs at least 2 entries per axis (word_excitation_guidance.py:35)
+  if (L < 2 || last - 1 < 2 || last > S) return fail(CFD_E_SHAPE, "text slice [1, %d) of %d keys / %d frames is too short for the 3x3 reflect-padded smoothing", last, S, L);
+  HIPCHK(hipSetDevice(c->cfg.device));
+  hipLaunchKernelGGL(weg_focus_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, att, tok_off, tok_idx, B, NL, L, S, last, nt_max,
+                     kernel3[0], kernel3[1], kernel3[2], workspace, losses, max_att, d_att);
+  HIPCHK(hipGetLastError());
+  return CFD_OK;
+}
+
+extern "C" int cfd_sample_write(cfd_handle c, const float* latents) {
+  if (!c || !latents) return fail(CFD_E_ARG, "null argument");
+  if (!c->run_open) return fail(CFD_E_STATE, "no sampling run open");
+  HIPCHK(hipSetDevice(c->cfg.device));
+  const size_t lat_bytes = (size_t)c->sargs.B * c->sargs.L * CFD_LAT * 4;
+  HIPCHK(hipMemcpyAsync(c->latents.p, latents, lat_bytes, hipMemcpyDeviceToDevice, c->run_stream));
+  HIPCHK(hipStreamSynchronize(c->run_stream));
   return CFD_OK;
 }
 

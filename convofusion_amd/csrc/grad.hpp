@@ -1,0 +1,323 @@
+// float32 kernels of the word-excitation-guidance (WEG) gradient path: d(loss)/d(latents) through the denoiser
+// (reference: torch autograd over Denoiser.forward, convofusion/models/modeltype/convofusion.py:437-496 and
+// convofusion/models/tools/word_excitation_guidance.py:11-81).  WEG runs on the text-only guidance chunk with
+// test batch size 1 (word_excitation_guidance.py:25), i.e. 16 tokens x 512 features: launch-latency work, so the
+// kernels are general (arbitrary strides: every transpose of the backward pass is a view) and exact rather than tuned.
+#pragma once
+#include "cfd_common.hpp"
+
+// element (z1, z2, r, c) = p[z1 * b1 + z2 * b2 + r * rs + c * cs]   (mirrors cfd_mat in include/cfdenoise.h)
+struct MatView {
+  const float* p;
+  long long rs, cs, b1, b2;
+};
+
+// C(z; m, n) = alpha * sum_k A(z; m, k) B(z; k, n) + bias[n] (+ C(z; m, n) when accumulate); ascending-k FMA chain per
+// output.  64 x 64 output tile per 256-thread workgroup (4 x 4 per thread), K-step 16 through LDS.
+__global__ void __launch_bounds__(256) gemm_f32_kernel(MatView A, MatView B, float* C, long long c_rs, long long c_cs, long long c_b1,
+                                                       long long c_b2, int M, int N, int K, int nb2, const float* bias, float alpha,
+                                                       int accumulate) {
+  __shared__ float As[16][68];
+  __shared__ float Bs[16][68];
+  const int z1 = blockIdx.z / nb2, z2 = blockIdx.z % nb2;
+  const float* a = A.p + z1 * A.b1 + z2 * A.b2;
+  const float* b = B.p + z1 * B.b1 + z2 * B.b2;
+  float* c = C + z1 * c_b1 + z2 * c_b2;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const bool a_k_fast = A.cs == 1, b_n_fast = B.cs == 1;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      int mm, kk;
+      if (a_k_fast) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }
+      As[kk][mm] = (m0 + mm < M && k0 + kk < K) ? a[(long long)(m0 + mm) * A.rs + (long long)(k0 + kk) * A.cs] : 0.f;
+      int nn, kb;
+      if (b_n_fast) { nn = e & 63; kb = e >> 6; } else { kb = e & 15; nn = e >> 4; }
+      Bs[kb][nn] = (n0 + nn < N && k0 + kb < K) ? b[(long long)(k0 + kb) * B.rs + (long long)(n0 + nn) * B.cs] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[i] = As[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx * 4 + j;
+      if (n >= N) continue;
+      float v = alpha * acc[i][j];
+      if (bias) v += bias[n];
+      float* dst = c + (long long)m * c_rs + (long long)n * c_cs;
+      if (accumulate) v += *dst;
+      *dst = v;
+    }
+  }
+}
+
+// In-place softmax over the last axis of scores [rows][Lk]; key_padding_mask [batch][Lk] (1 = ignore), the batch of a
+// row is row / rows_per_batch.  One wave per row.
+__global__ void __launch_bounds__(256) softmax_f32_kernel(float* s, const uint8_t* kpm, long long rows, int Lk, long long rows_per_batch) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* r = s + row * Lk;
+  const uint8_t* mk = kpm ? kpm + (row / rows_per_batch) * Lk : nullptr;
+  float mx = -INFINITY;
+  for (int c = lane; c < Lk; c += 64)
+    if (!mk || !mk[c]) mx = fmaxf(mx, r[c]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int c = lane; c < Lk; c += 64) {
+    const float e = (!mk || !mk[c]) ? expf(r[c] - mx) : 0.f;
+    r[c] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  for (int c = lane; c < Lk; c += 64) r[c] = r[c] / sum;
+}
+
+// ds = p * ((dp + extra) - sum_k (dp + extra) p)   (softmax backward), in place on dp; one wave per row
+__global__ void __launch_bounds__(256) softmax_bwd_f32_kernel(const float* p, float* dp, const float* extra, long long rows, int Lk) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* pr = p + row * Lk;
+  float* dr = dp + row * Lk;
+  const float* er = extra ? extra + row * Lk : nullptr;
+  float dot = 0.f;
+  for (int c = lane; c < Lk; c += 64) {
+    const float d = dr[c] + (er ? er[c] : 0.f);
+    dr[c] = d;
+    dot = fmaf(d, pr[c], dot);
+  }
+  dot = wave_sum(dot);
+  for (int c = lane; c < Lk; c += 64) dr[c] = pr[c] * (dr[c] - dot);
+}
+
+// dx (+)= rstd * (dh - mean(dh) - xh * mean(dh * xh)),  dh = dy * gamma,  xh = (x - mean) * rstd   (nn.LayerNorm backward
+// with respect to its input); one wave per row, D <= 2048
+__global__ void __launch_bounds__(256) layernorm_bwd_f32_kernel(const float* x, const float* g, const float* dy, float* dx, long long rows, int D,
+                                                                float eps, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * D;
+  const float* dr = dy + row * D;
+  float v[32], dh[32];
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const int c = lane + 64 * q;
+    v[q] = c < D ? xr[c] : 0.f;
+    s += v[q];
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const int c = lane + 64 * q;
+    const float d = c < D ? v[q] - mean : 0.f;
+    v[q] = d;
+    ss += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + eps);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const int c = lane + 64 * q;
+    v[q] *= rstd;
+    dh[q] = c < D ? dr[c] * g[c] : 0.f;
+    s1 += dh[q];
+    s2 = fmaf(dh[q], v[q], s2);
+  }
+  const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const int c = lane + 64 * q;
+    if (c < D) {
+      float r = rstd * (dh[q] - m1 - v[q] * m2);
+      if (accumulate) r += dx[row * D + c];
+      dx[row * D + c] = r;
+    }
+  }
+}
+
+enum { EW_SILU = 0, EW_GELU = 1, EW_SILU_BWD = 2, EW_GELU_BWD = 3, EW_AXPY = 4, EW_ADD_BCAST = 5, EW_MODULATE = 6, EW_MODULATE_BWD = 7, EW_NOPS = 8 };
+
+// Element-wise pieces of the forward / backward pass over a [R0][R1][D] tensor (index i -> d = i % D, r1 = (i / D) % R1,
+// r0 = i / (D R1)):
+//   SILU / GELU          out = act(a)                                  (nn.SiLU, exact-erf nn.GELU)
+//   SILU_BWD / GELU_BWD  out = a * act'(b)                             (a upstream gradient, b pre-activation)
+//   AXPY                 out = a + alpha * b                           (weg.update_latent: latents - lr * grad)
+//   ADD_BCAST            out = a + b[r0 * s0 + r1 * s1 + d]            (temb / condition id / position rows)
+//   MODULATE             out = a * (1 + b[r1][d]) + b[r1][D + d]       (TimeBlock: b = emb_layers output [R1][2 D], scale first)
+//   MODULATE_BWD         out = a * (1 + b[r1][d])
+__global__ void __launch_bounds__(256) ew_f32_kernel(int op, const float* a, const float* b, float* out, long long n, int D, int R1, long long s0,
+                                                     long long s1, float alpha) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = a[i];
+  float r = 0.f;
+  switch (op) {
+    case EW_SILU: r = x / (1.0f + expf(-x)); break;
+    case EW_GELU: r = gelu_f(x); break;
+    case EW_SILU_BWD: {
+      const float y = b[i], sg = 1.0f / (1.0f + expf(-y));
+      r = x * (sg * (1.0f + y * (1.0f - sg)));
+      break;
+    }
+    case EW_GELU_BWD: {
+      const float y = b[i];
+      r = x * (0.5f * (1.0f + erff(y * 0.70710678118654752440f)) + y * expf(-0.5f * y * y) * 0.39894228040143267794f);
+      break;
+    }
+    case EW_AXPY: r = x + alpha * b[i]; break;
+    case EW_ADD_BCAST: {
+      const long long row = i / D;
+      r = x + b[(row / R1) * s0 + (row % R1) * s1 + (i % D)];
+      break;
+    }
+    case EW_MODULATE: {
+      const long long r1 = (i / D) % R1;
+      const int d = (int)(i % D);
+      r = x * (1.0f + b[r1 * 2 * D + d]) + b[r1 * 2 * D + D + d];
+      break;
+    }
+    case EW_MODULATE_BWD: {
+      const long long r1 = (i / D) % R1;
+      r = x * (1.0f + b[r1 * 2 * D + (i % D)]);
+      break;
+    }
+  }
+  out[i] = r;
+}
+
+// The attend-and-excite objective on the listener-text attention maps and its gradient with respect to them
+// (word_excitation_guidance.py:11-81; GaussianSmoothing 3 x 3, sigma 0.5, reflect padding: gaussian_smoothing.py:21-72).
+//   att     [B][NL][L][S]  probabilities of the tlsn cross-attention of every layer (Denoiser.forward's att_mats[2])
+//   tok_off [B + 1], tok_idx [tok_off[B]]  focus token indices of each sample (text positions, BOS = 0)
+//   last    exclusive end of the text slice [1, last) (eot index when normalize_eot, else S - 1)
+//   ws      workspace >= B * (3 * L * W + 3 * nt_max) 4-byte words, W = last - 1, nt_max >= tokens of any sample
+// outputs: losses [B] (mean over the sample's tokens of max(0, 1 - max attention)), max_att [tok_off[B]],
+//          d_att [B][NL][L][S] = d(mean_b losses[b]) / d att.  One workgroup per sample; phases separated by barriers.
+__global__ void __launch_bounds__(256) weg_focus_kernel(const float* att, const int* tok_off, const int* tok_idx, int B, int NL, int L, int S,
+                                                        int last, int nt_max, float k00, float k01, float k11, float* ws, float* losses,
+                                                        float* max_att, float* d_att) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int W = last - 1;
+  const long long LW = (long long)L * W;
+  float* sm = ws + (long long)b * (3 * LW + 3 * nt_max);
+  float* sg = sm + LW;
+  float* dsm = sg + LW;
+  float* tok_g = dsm + LW;            // [nt_max] upstream gradient at the token's arg-max cell
+  int* tok_l = (int*)(tok_g + nt_max);     // [nt_max] arg-max frame
+  int* tok_w = tok_l + nt_max;             // [nt_max] column in the slice
+  const float* ab = att + (long long)b * NL * L * S;
+  // 1. layer mean, slice [1, last), softmax over the slice
+  for (int l = tid; l < L; l += 256) {
+    float mx = -INFINITY;
+    for (int w = 0; w < W; ++w) {
+      float m = 0.f;
+      for (int n = 0; n < NL; ++n) m += ab[((long long)n * L + l) * S + 1 + w];
+      m = m / (float)NL;
+      sm[(long long)l * W + w] = m;
+      mx = fmaxf(mx, m);
+    }
+    float sum = 0.f;
+    for (int w = 0; w < W; ++w) {
+      const float e = expf(sm[(long long)l * W + w] - mx);
+      sm[(long long)l * W + w] = e;
+      sum += e;
+    }
+    for (int w = 0; w < W; ++w) sm[(long long)l * W + w] /= sum;
+  }
+  __syncthreads();
+  // 2. 3 x 3 Gaussian correlation over the reflect-padded map
+  const float kk[3][3] = {{k00, k01, k00}, {k01, k11, k01}, {k00, k01, k00}};
+  for (long long e = tid; e < LW; e += 256) {
+    const int l = (int)(e / W), w = (int)(e % W);
+    float v = 0.f;
+    for (int a = 0; a < 3; ++a)
+      for (int c = 0; c < 3; ++c) {
+        int ll = l + a - 1, ww = w + c - 1;
+        ll = ll < 0 ? 1 : (ll >= L ? L - 2 : ll);
+        ww = ww < 0 ? 1 : (ww >= W ? W - 2 : ww);
+        v += kk[a][c] * sm[(long long)ll * W + ww];
+      }
+    sg[e] = v;
+  }
+  __syncthreads();
+  // 3. per focus token: max over frames, hinge
+  const int t0 = tok_off[b], nt = tok_off[b + 1] - t0;
+  for (int t = tid; t < nt; t += 256) {
+    const int w = tok_idx[t0 + t] - 1;
+    float best = -INFINITY;
+    int bl = 0;
+    for (int l = 0; l < L; ++l) {
+      const float v = sg[(long long)l * W + w];
+      if (v > best) { best = v; bl = l; }
+    }
+    max_att[t0 + t] = best;
+    tok_l[t] = bl;
+    tok_w[t] = w;
+    tok_g[t] = (1.0f - best > 0.f) ? -1.0f / ((float)nt * (float)B) : 0.f;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+    for (int t = 0; t < nt; ++t) s += fmaxf(0.f, 1.0f - max_att[t0 + t]);
+    losses[b] = nt > 0 ? s / (float)nt : 0.f;
+  }
+  // 4. adjoint of the padded correlation, gathered per cell over the (few) tokens: deterministic, no atomics
+  for (long long e = tid; e < LW; e += 256) {
+    const int l = (int)(e / W), w = (int)(e % W);
+    float v = 0.f;
+    for (int t = 0; t < nt; ++t) {
+      const float g = tok_g[t];
+      if (g == 0.f) continue;
+      for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) {
+          int ll = tok_l[t] + a - 1, ww = tok_w[t] + c - 1;
+          ll = ll < 0 ? 1 : (ll >= L ? L - 2 : ll);
+          ww = ww < 0 ? 1 : (ww >= W ? W - 2 : ww);
+          if (ll == l && ww == w) v += kk[a][c] * g;
+        }
+    }
+    dsm[e] = v;
+  }
+  __syncthreads();
+  // 5. softmax backward, spread over the layers (mean) and written into the full-width maps
+  float* db = d_att + (long long)b * NL * L * S;
+  for (int l = tid; l < L; l += 256) {
+    float dot = 0.f;
+    for (int w = 0; w < W; ++w) dot = fmaf(dsm[(long long)l * W + w], sm[(long long)l * W + w], dot);
+    for (int s = 0; s < S; ++s) {
+      float v = 0.f;
+      if (s >= 1 && s < last) {
+        const int w = s - 1;
+        v = sm[(long long)l * W + w] * (dsm[(long long)l * W + w] - dot) / (float)NL;
+      }
+      for (int n = 0; n < NL; ++n) db[((long long)n * L + l) * S + s] = v;
+    }
+  }
+}

@@ -179,6 +179,15 @@ class SamplingRun:
             self.open = False
         return out
 
+    def write(self, latents):
+        """Overwrite the current latents of the open run (the WEG update between two iterations)."""
+        if tuple(latents.shape) != (self.B, self.L, 128):
+            raise ValueError(f"latents must be [{self.B}, {self.L}, 128]")
+        lat = latents.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        with torch.cuda.device(self.device):
+            torch.cuda.current_stream(self.device).synchronize()
+            _lib.check(self.lib.cfd_sample_write(self.handle, C.c_void_p(lat.data_ptr())))
+
     def profile(self):
         ms = (C.c_float * len(_lib.PROF_CLASSES))()
         n = (C.c_int * len(_lib.PROF_CLASSES))()
@@ -209,9 +218,6 @@ def sample(denoiser, scheduler, encoder_hidden_states, cond_masks=None, *, B, L=
 
 
 def _loop_from_model(model, encoder_hidden_states, cond_masks, preseq, focus_indices, init_latents, seed):
-    if len(focus_indices) > 0:
-        raise NotImplementedError("word-excitation guidance (focus_indices) needs gradients through the denoiser; "
-                                  "out of scope of the HIP path (SURVEY.md section 8f rank 3)")
     if not model.do_classifier_free_guidance:
         # the reference itself raises NameError here (guidance_bs_mulitplier undefined, convofusion.py:517)
         raise NameError("guidance_bs_mulitplier: the reference loop requires classifier-free guidance")
@@ -229,12 +235,47 @@ def _loop_from_model(model, encoder_hidden_states, cond_masks, preseq, focus_ind
         eta = model.cfg.model.scheduler.eta
     if seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())   # per-step noise stream keyed off torch's global generator
-    return sample(model.denoiser, model.scheduler, encoder_hidden_states, cond_masks, B=bsz, L=L,
-                  num_inference_steps=n_steps, guidance_scale=model.guidance_scale, guidance_chunks=G, eta=eta,
-                  init_latents=init_latents, seed=seed, preseq=preseq,
-                  # the full-conditioning chunk has guidance weight 0 (convofusion.py:538) and the fused loop keeps no
-                  # attention maps, so its forward is dead work: identical latents without it
-                  skip_zero_weight_chunks=True)
+    kw = dict(B=bsz, L=L, num_inference_steps=n_steps, guidance_scale=model.guidance_scale, guidance_chunks=G, eta=eta,
+              init_latents=init_latents, seed=seed, preseq=preseq,
+              # the full-conditioning chunk has guidance weight 0 (convofusion.py:538) and the fused loop keeps no
+              # attention maps, so its forward is dead work: identical latents without it
+              skip_zero_weight_chunks=True)
+    if len(focus_indices) == 0:
+        return sample(model.denoiser, model.scheduler, encoder_hidden_states, cond_masks, **kw)
+    if preseq is not None:
+        raise NotImplementedError("word-excitation guidance inside the in-painting rollout (the WEG update would have to land "
+                                  "between the fused in-paint overwrite and the replication of the same graph node)")
+    return sample_with_weg(model.denoiser, model.scheduler, encoder_hidden_states, cond_masks, focus_indices,
+                           model.weg_parameters, **kw)
+
+
+def sample_with_weg(denoiser, scheduler, encoder_hidden_states, cond_masks, focus_indices, weg_parameters, *, B, L=16,
+                    num_inference_steps=1000, guidance_chunks=CFG_CHUNKS, **kw):
+    """The loop with its word-excitation-guidance branch (convofusion.py:437-496): before iteration i the latents are
+    moved down the gradient of the attention-focus objective of the text-only chunk (``convofusion_amd.weg``), then the
+    captured guided step runs as usual.  ``weg_parameters``: scale_factor, scale_range, max_iter_to_alter, thresholds,
+    max_refinement_steps (configs/assets.yaml:18-23)."""
+    from . import weg
+    G = guidance_chunks
+    scheduler.set_timesteps(num_inference_steps)
+    run = SamplingRun(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
+                      guidance_chunks=G, **kw)
+    text_states = [enc.chunk(G)[1] for enc in encoder_hidden_states]                               # :447
+    text_masks = {k: (v.chunk(G)[1] if v is not None else v) for k, v in (cond_masks or {}).items()}  # :448
+    thresholds = dict(weg_parameters["thresholds"])
+    timesteps = [int(t) for t in scheduler.timesteps]
+    for i, t in enumerate(timesteps):
+        # past max_iter_to_alter the reference still evaluates the objective but only acts on it at a threshold step
+        if i >= weg_parameters["max_iter_to_alter"] and i not in thresholds:
+            if not any(k > i for k in thresholds):
+                break
+            run.steps(1)
+            continue
+        lat, _ = weg.weg_update(denoiser, run.read(), i, t, text_states, text_masks, focus_indices, weg_parameters, len(timesteps))
+        run.write(lat)
+        run.steps(1)
+    run.steps(num_inference_steps - run.position)
+    return run.read(close=True)
 
 
 def diffusion_reverse(model, encoder_hidden_states, lengths=None, cond_masks=dict(), focus_indices=[], *,

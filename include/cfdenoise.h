@@ -162,6 +162,41 @@ int cfd_mha(cfd_handle h, const float* q, const float* k, const float* v, int Lq
 int cfd_add(cfd_handle h, float* x, const float* y, size_t numel, void* stream);
 int cfd_zero_rows(cfd_handle h, float* x, const uint8_t* keep, long long rows, int D, void* stream);
 
+/* float32 pieces of word-excitation guidance (WEG): the attend-and-excite objective on the listener-text attention
+ * maps and d(loss)/d(latents) through the denoiser -- what the reference gets from torch autograd over
+ * Denoiser.forward (convofusion/models/modeltype/convofusion.py:437-496, iterative_refinement_step :298-388;
+ * convofusion/models/tools/word_excitation_guidance.py:11-81).  convofusion_amd/weg.py strings them into the
+ * forward-with-saved-activations and the hand-written backward pass; every transpose there is a strided view.
+ *   cfd_mat             element (z1, z2, r, c) = p[z1*b1 + z2*b2 + r*rs + c*cs]
+ *   cfd_gemm_f32        C(z; m, n) = alpha * sum_k A(z; m, k) B(z; k, n) + bias[n] (+ C when accumulate); nb1 x nb2 batch
+ *   cfd_softmax         in-place softmax over [rows][Lk]; key_padding_mask [batch][Lk], batch = row / rows_per_batch
+ *   cfd_softmax_bwd     dp <- p * ((dp + extra) - sum_k (dp + extra) p); extra (may be NULL) = gradient arriving at p directly
+ *   cfd_layer_norm_bwd  nn.LayerNorm backward with respect to the input; accumulate != 0: dx += result
+ *   cfd_ew              element-wise: 0 SiLU, 1 GELU, 2 a*SiLU'(b), 3 a*GELU'(b), 4 a + alpha*b (weg.update_latent),
+ *                       5 a + b[r0*s0 + r1*s1 + d] (broadcast add over a [R0][R1][D] tensor), 6 TimeBlock modulate
+ *                       a*(1 + b[r1][d]) + b[r1][D + d] (cross_attention.py:433-436), 7 its backward a*(1 + b[r1][d])
+ *   cfd_weg_focus       aggregate_attentions + get_max_attention_at_indices (softmax over text[1:last), 3x3 Gaussian sigma 0.5
+ *                       on the reflect-padded map, max over frames) + compute_attention_focus_loss, and the gradient with
+ *                       respect to att: att / d_att dev [B][NL][L][S], tok_off dev int32 [B+1], tok_idx dev int32 (text
+ *                       positions), kernel3 HOST {corner, edge, centre} of the normalised 3x3 kernel, workspace dev
+ *                       >= B*(3*L*(last-1) + 3*nt_max) floats, losses dev [B], max_att dev [tok_off[B]]
+ *   cfd_sample_write    overwrite the current latents of the open sampling run (the WEG update between two iterations) */
+typedef struct {
+  const float* p;
+  long long rs, cs, b1, b2;
+} cfd_mat;
+int cfd_gemm_f32(cfd_handle h, int M, int N, int K, int nb1, int nb2, const cfd_mat* A, const cfd_mat* B, const cfd_mat* C, const float* bias,
+                 float alpha, int accumulate, void* stream);
+int cfd_softmax(cfd_handle h, float* scores, long long rows, int Lk, const uint8_t* key_padding_mask, long long rows_per_batch, void* stream);
+int cfd_softmax_bwd(cfd_handle h, const float* p, float* dp, const float* extra, long long rows, int Lk, void* stream);
+int cfd_layer_norm_bwd(cfd_handle h, const float* x, const float* gamma, const float* dy, float* dx, long long rows, int D, float eps,
+                       int accumulate, void* stream);
+int cfd_ew(cfd_handle h, int op, const float* a, const float* b, float* out, size_t numel, int D, int R1, long long s0, long long s1, float alpha,
+           void* stream);
+int cfd_weg_focus(cfd_handle h, const float* att, int B, int NL, int L, int S, const int32_t* tok_off, const int32_t* tok_idx, int last, int nt_max,
+                  const float kernel3[3], float* workspace, float* losses, float* max_att, float* d_att, void* stream);
+int cfd_sample_write(cfd_handle h, const float* latents);
+
 /* Device N(0,1) draws of the product's counter-based stream (DESIGN.md "RNG"): out dev [B][per_utt]. */
 int cfd_philox_normal(cfd_handle h, float* out, int B, int per_utt, uint64_t seed, uint32_t step,
                       uint32_t first_utterance, uint32_t stream_id, void* stream);

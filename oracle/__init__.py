@@ -15,6 +15,9 @@ This package is a numpy (float32) restatement of the reference's hot path:
   * ``weights``       -- deterministic state-dict generator with the reference's 537 keys/shapes
   * ``conditioning_ref`` -- AudioConvEncoder / TextAudioMotionFuser (audioenc.py:9-34, condfuser.py:8-50)
   * ``dyadic_ref``    -- two loops in lock-step with partner-projected speaker memories (BASELINE configs[4])
+  * ``weg_ref``       -- word-excitation guidance: the attention-focus objective and a hand-written backward pass through
+                         the denoiser (word_excitation_guidance.py:11-81, convofusion.py:298-388,437-496), pinned against
+                         torch autograd through the imported reference (``make_golden_weg.py`` -> ``weg.npz``)
   * ``vae_ref``, ``vae_weights`` -- ``ConvoFusionVae.decode`` (vae.py:268-372) and its seeded 337-key state dict
 
 Parity pinning: the reference ships no tests or golden vectors.  The

@@ -3,7 +3,7 @@
 Reference: convofusion/models/modeltype/convofusion.py:391-549 (loop), :499-501 (7x replication),
 :527-541 (modality guidance combine), :544 (scheduler step), :548 (permute on return); in-painting
 variant unbounded_synthesis.py:28-187 (:70-76 overwrite of the first ``preseq_len`` tokens).
-The WEG branch (:437-496) is out of scope and not restated.
+The WEG branch (:437-496) enters through ``pre_step`` (restated in oracle/weg_ref.py).
 
 The reference module itself cannot be imported here (pytorch_lightning, torchmetrics, omegaconf ...
 are missing), so the loop is restated and drives either ``oracle.denoiser_ref`` or -- in
@@ -31,7 +31,7 @@ def cfg_combine(noise_pred, guidance_scale):
 
 def diffusion_reverse(denoise_fn, scheduler, encoder_hidden_states, cond_masks, init_latents,
                       step_noise, guidance_scale=7.5, num_inference_steps=1000, eta=0.0,
-                      preseq=None, keep_steps=(), return_att=False):
+                      preseq=None, keep_steps=(), return_att=False, pre_step=None):
     """denoise_fn(sample[7B,L,128], t, enc, masks) -> (eps[7B,L,128], att_mats).
     ``step_noise(i, t)`` returns the [B,L,128] N(0,1) draw for loop index i (used when t > 0
     for DDPM, when eta > 0 for DDIM).  Returns (latents [L,B,128], snapshots, att dict)."""
@@ -51,6 +51,8 @@ def diffusion_reverse(denoise_fn, scheduler, encoder_hidden_states, cond_masks, 
                 # the SAME tensor at i == 0, so the overwrite at :76 also rewrites the noise that
                 # every later iteration re-clones at :72.
                 init_noise[:, :pl] = noised
+        if pre_step is not None:  # the WEG branch (:437-496): latents = pre_step(i, t, latents)
+            latents = pre_step(i, int(t), latents)
         model_in = np.concatenate([latents] * CFG_CHUNKS, axis=0)
         noise_pred, att = denoise_fn(model_in, int(t), encoder_hidden_states, cond_masks)
         if return_att:

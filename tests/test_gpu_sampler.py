@@ -203,8 +203,20 @@ def test_model_level_drop_in():
     torch.manual_seed(0)
     lat, atts = diffusion_reverse(model, [to_dev(x) for x in cb["memories"]], None, {k: to_dev(v) for k, v in cb["masks"].items()})
     assert tuple(lat.shape) == (L, B, 128) and torch.isfinite(lat).all() and atts == {}
+    # the WEG branch (focus_indices) through the same entry point: batch size 1 as the reference requires
+    # (word_excitation_guidance.py:25); it must change the result and stay finite
+    from convofusion_amd.sampler import diffusion_reverse_forecast
+    cb1 = inputs.make_cfg_batch(seed=4, B=1, L=L, S=(6, 20, 12, 8, 1), pad_tail=(2, 0, 3, 0, 0))
+    enc1, masks1 = [to_dev(x) for x in cb1["memories"]], {k: to_dev(v) for k, v in cb1["masks"].items()}
+    model.weg_parameters = dict(scale_factor=1000, scale_range=[1.0, 0.5], max_iter_to_alter=2, thresholds={0: 0.05}, max_refinement_steps=1)
+    init = torch.randn((1, L, 128), device="cuda")
+    plain, _ = diffusion_reverse(model, enc1, None, masks1, init_latents=init, seed=5)
+    steered, _ = diffusion_reverse(model, enc1, None, masks1, focus_indices=[[2, 4]], init_latents=init, seed=5)
+    again, _ = diffusion_reverse(model, enc1, None, masks1, focus_indices=[[2, 4]], init_latents=init, seed=5)
+    assert torch.isfinite(steered).all() and torch.equal(steered, again)
+    assert (steered - plain).norm() / plain.norm() > 1e-3
     with pytest.raises(NotImplementedError):
-        diffusion_reverse(model, [to_dev(x) for x in cb["memories"]], None, {}, focus_indices=[1])
+        diffusion_reverse_forecast(model, enc1, None, torch.zeros((1, 8, 128), device="cuda"), masks1, focus_indices=[[2]])
 
 
 @pytest.mark.parametrize("shape", ["C2"])

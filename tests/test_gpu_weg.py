@@ -1,0 +1,189 @@
+"""-m gpu: word-excitation guidance on the HIP path (convofusion_amd/weg.py + csrc/grad.hpp) against the oracle
+(oracle/weg_ref.py) and against gradients from torch autograd through the REFERENCE (tests/golden/weg.npz).
+
+Tolerances: the objective 2e-6 absolute; the gradient 1e-3 relative L2 (BASELINE.json north_star), observed ~1e-5."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from oracle import denoiser_ref, inputs, philox_ref, sampler_ref, scheduler_ref, weg_ref
+from tests.helpers import load_golden, rel_l2, state_dict
+from tests.test_oracle_weg import CASES, weg_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    import torch
+    from convofusion_amd import weg
+    from convofusion_amd.conditioning import _engine_handle
+    dev = torch.device("cuda", 0)
+    return weg._Ops(_engine_handle(dev), dev)
+
+
+def test_gemm_f32_strided_views():
+    import torch
+    from tests.gpu_helpers import to_dev
+    ops = _ops()
+    rng = np.random.Generator(np.random.PCG64(1))
+    # plain, transposed operands, ragged sizes
+    for M, N, K in [(16, 512, 512), (70, 33, 129), (1, 5, 7), (130, 64, 16)]:
+        a, b = rng.standard_normal((M, K), dtype=np.float32), rng.standard_normal((N, K), dtype=np.float32)
+        bias = rng.standard_normal(N, dtype=np.float32)
+        ref = 0.5 * (a.astype(np.float64) @ b.astype(np.float64).T) + bias
+        out = ops.new(M, N)
+        ops.gemm(to_dev(a), to_dev(b).t(), out, to_dev(bias), alpha=0.5)
+        assert rel_l2(out.cpu().numpy(), ref) < 1e-6
+        out2 = ops.new(N, M).t()                     # transposed output view, accumulate
+        out2.zero_()
+        ops.gemm(to_dev(a), to_dev(b).t(), out2, None, 1.0, True)
+        ops.gemm(to_dev(a), to_dev(b).t(), out2, None, 1.0, True)
+        assert rel_l2(out2.cpu().numpy(), 2 * (a.astype(np.float64) @ b.astype(np.float64).T)) < 1e-6
+    # two-level batch over head views of sequence-major tensors
+    T, S, B, H, hd = 6, 9, 3, 4, 32
+    q, k = rng.standard_normal((T, B, H * hd), dtype=np.float32), rng.standard_normal((S, B, H * hd), dtype=np.float32)
+    sc = ops.new(B, H, T, S)
+    ops.gemm(to_dev(q).view(T, B, H, hd).permute(1, 2, 0, 3), to_dev(k).view(S, B, H, hd).permute(1, 2, 3, 0), sc)
+    ref = np.einsum("tbhd,sbhd->bhts", q.reshape(T, B, H, hd).astype(np.float64), k.reshape(S, B, H, hd).astype(np.float64))
+    assert rel_l2(sc.cpu().numpy(), ref) < 1e-6
+
+
+def test_row_kernels_match_oracle():
+    import torch
+    from convofusion_amd import weg
+    from tests.gpu_helpers import to_dev
+    ops = _ops()
+    rng = np.random.Generator(np.random.PCG64(2))
+    x = rng.standard_normal((37, 512), dtype=np.float32) * 2 + 0.3
+    g = (1 + 0.1 * rng.standard_normal(512, dtype=np.float32)).astype(np.float32)
+    dy = rng.standard_normal((37, 512), dtype=np.float32)
+    dx = ops.new(37, 512)
+    ops.layer_norm_bwd(to_dev(x), to_dev(g), to_dev(dy), dx, accumulate=False)
+    assert rel_l2(dx.cpu().numpy(), weg_ref.layer_norm_bwd(x, g, dy)) < 1e-5
+    ops.layer_norm_bwd(to_dev(x), to_dev(g), to_dev(dy), dx, accumulate=True)
+    assert rel_l2(dx.cpu().numpy(), 2 * weg_ref.layer_norm_bwd(x, g, dy)) < 1e-5
+    # softmax forward with a ragged key-padding mask, and its backward with a direct term
+    B, H, T, S = 3, 2, 5, 70
+    sc = rng.standard_normal((B, H, T, S), dtype=np.float32) * 3
+    mask = np.zeros((B, S), dtype=bool)
+    mask[1, 60:] = True
+    mask[2, 1:] = True
+    p = ops.softmax_(to_dev(sc), to_dev(mask.astype(np.uint8)), H * T).cpu().numpy()
+    m = np.where(mask[:, None, None, :], -np.inf, sc.astype(np.float64))
+    e = np.exp(m - m.max(-1, keepdims=True))
+    pref = e / e.sum(-1, keepdims=True)
+    assert np.abs(p - pref).max() < 1e-6 and (p[1, :, :, 60:] == 0).all()
+    dp, ex = rng.standard_normal(p.shape, dtype=np.float32), rng.standard_normal(p.shape, dtype=np.float32)
+    ds = ops.softmax_bwd_(to_dev(p), to_dev(dp), to_dev(ex)).cpu().numpy()
+    d = (dp + ex).astype(np.float64)
+    assert rel_l2(ds, pref * (d - (d * pref).sum(-1, keepdims=True))) < 1e-5
+    # element-wise pieces
+    a, b = rng.standard_normal((4, 3, 512), dtype=np.float32) * 2, rng.standard_normal((4, 3, 512), dtype=np.float32) * 2
+    assert rel_l2(ops.ew(weg.EW_SILU, to_dev(a)).cpu().numpy(), denoiser_ref.silu(a)) < 1e-6
+    assert rel_l2(ops.ew(weg.EW_GELU, to_dev(a)).cpu().numpy(), denoiser_ref.gelu(a)) < 1e-6
+    assert rel_l2(ops.ew(weg.EW_SILU_BWD, to_dev(a), to_dev(b)).cpu().numpy(), a * weg_ref.silu_grad(b)) < 1e-6
+    assert rel_l2(ops.ew(weg.EW_GELU_BWD, to_dev(a), to_dev(b)).cpu().numpy(), a * weg_ref.gelu_grad(b)) < 1e-6
+    assert rel_l2(ops.ew(weg.EW_AXPY, to_dev(a), to_dev(b), alpha=-2.5).cpu().numpy(), a - np.float32(2.5) * b) < 1e-7
+    e2 = rng.standard_normal((3, 1024), dtype=np.float32)
+    assert rel_l2(ops.ew(weg.EW_MODULATE, to_dev(a), to_dev(e2), D=512, R1=3).cpu().numpy(), a * (1 + e2[None, :, :512]) + e2[None, :, 512:]) < 1e-6
+    assert rel_l2(ops.ew(weg.EW_MODULATE_BWD, to_dev(a), to_dev(e2), D=512, R1=3).cpu().numpy(), a * (1 + e2[None, :, :512])) < 1e-6
+    pe = rng.standard_normal((4, 512), dtype=np.float32)
+    assert rel_l2(ops.ew(weg.EW_ADD_BCAST, to_dev(a), to_dev(pe), D=512, R1=3, s0=512, s1=0).cpu().numpy(), a + pe[:, None, :]) < 1e-7
+
+
+@pytest.mark.parametrize("case", ["rand_b2", "rand_eot", "golden"])
+def test_focus_objective_matches_oracle(case):
+    import torch
+    from convofusion_amd import weg
+    from tests.gpu_helpers import hip_denoiser, to_dev
+    m = hip_denoiser(1234, 1.0)
+    rng = np.random.Generator(np.random.PCG64(5))
+    todo = []
+    if case == "golden":
+        g = load_golden("weg")
+        for name in CASES:
+            _, _, _, focus, neot, eot = weg_case(name)
+            todo.append((g[name + ".att_tlsn"], focus, neot, eot))
+    else:
+        B, NL, L, S = (2, 9, 16, 24) if case == "rand_b2" else (1, 9, 196, 32)
+        att = rng.random((B, NL, L, S)).astype(np.float32) ** 4
+        att /= att.sum(-1, keepdims=True)
+        if case == "rand_b2":
+            todo.append((att, [[1, 2, 22], [7, 7]], False, ()))       # first / last column of the slice, a repeated token
+            todo.append((att, [[], [3]], False, ()))
+        else:
+            todo.append((att, [[1, 5, 20]], True, np.array([22])))
+    for att, focus, neot, eot in todo:
+        loss, losses, mx, datt = weg_ref.focus_loss(att, focus, neot, eot)
+        l2, ls2, mx2, d2 = weg.attention_focus_loss(m, to_dev(att), focus, neot, eot)
+        assert abs(float(l2) - float(loss)) < 2e-6
+        np.testing.assert_allclose(ls2.cpu().numpy(), losses, atol=2e-6)
+        np.testing.assert_allclose([float(v) for s in mx2 for v in s], [float(v) for s in mx for v in s], rtol=1e-5)
+        assert rel_l2(d2.cpu().numpy(), datt) < 1e-5
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_gradient_matches_oracle_and_reference_autograd(name):
+    import torch
+    from convofusion_amd import weg
+    from tests.gpu_helpers import dev_inputs, hip_denoiser, to_dev
+    g = load_golden("weg")
+    sd, inp, t, focus, neot, eot = weg_case(name)
+    m = hip_denoiser(CASES[name][0], CASES[name][1])
+    mems, masks = dev_inputs(inp)
+    loss, losses, mx, grad = weg.loss_and_grad(m, to_dev(inp["sample"]), t, mems, masks, focus, neot, to_dev(eot))
+    lo, _, _, go = weg_ref.loss_and_grad(sd, inp["sample"], t, inp["memories"], inp["masks"], focus, neot, eot)
+    grad = grad.cpu().numpy()
+    e_or, e_ref = rel_l2(grad, go), rel_l2(grad, g[name + ".grad"])
+    print(name, f"loss {float(loss):.6f} (oracle {float(lo):.6f}, reference {float(g[name + '.loss']):.6f})  grad vs oracle {e_or:.2e}  vs reference autograd {e_ref:.2e}")
+    assert abs(float(loss) - float(g[name + ".loss"])) < 2e-6
+    np.testing.assert_allclose([float(v) for s in mx for v in s], g[name + ".max_att"], rtol=2e-5)
+    assert e_or < 1e-3 and e_ref < 1e-3
+    upd = weg.update_latent(to_dev(inp["sample"]), to_dev(grad), 1000 * np.sqrt(0.9), m).cpu().numpy()
+    assert rel_l2(upd, g[name + ".updated"]) < 1e-4
+    # attention maps of the saved-activation forward against the reference's
+    att, _ = weg.forward_saved(m, to_dev(inp["sample"]), t, mems, masks)
+    assert np.abs(att.cpu().numpy() - g[name + ".att_tlsn"]).max() < (2e-4 if "sharp" in name else 1e-5)   # sharp: logits of +-40
+
+
+def test_loop_with_weg_matches_oracle():
+    """Five iterations of the loop with its WEG branch (one threshold step that triggers the iterative refinement)
+    against the oracle loop driven by the oracle denoiser."""
+    import torch
+    from convofusion_amd import scheduler
+    from convofusion_amd.sampler import sample_with_weg
+    from tests.gpu_helpers import SCHED_KW, hip_denoiser, to_dev
+    B, L, S, pad, n_steps, seed = 1, 16, (6, 20, 12, 8, 1), (2, 0, 3, 0, 0), 5, 11
+    cb = inputs.make_cfg_batch(seed=seed, B=B, L=L, S=S, pad_tail=pad)
+    init = philox_ref.normal_tensor(seed, 0, range(B), 1, L)
+    noise = np.stack([philox_ref.normal_tensor(seed, i, range(B), 0, L) for i in range(n_steps)])
+    focus = [[2, 5]]
+    params = dict(scale_factor=1000, scale_range=[1.0, 0.5], max_iter_to_alter=3, thresholds={1: 0.16}, max_refinement_steps=2)
+    sd = state_dict(1234, 1.0)
+    text_states = [np.split(x, 7, axis=0)[1] for x in cb["memories"]]
+    text_masks = {k: (np.split(v, 7, axis=0)[1] if v is not None else None) for k, v in cb["masks"].items()}
+    log = []
+
+    def pre_step(i, t, lat):
+        new, loss = weg_ref.weg_update(sd, lat, i, t, text_states, text_masks, focus, params, n_steps)
+        log.append(loss)
+        return new
+
+    ref, _, _ = sampler_ref.diffusion_reverse(
+        lambda x, t, enc, masks: denoiser_ref.denoiser_forward(sd, x, t, enc, masks), scheduler_ref.DDPMSchedulerRef(), cb["memories"],
+        cb["masks"], init, lambda i, t: noise[i], guidance_scale=7.5, num_inference_steps=n_steps, pre_step=pre_step)
+    plain, _, _ = sampler_ref.diffusion_reverse(
+        lambda x, t, enc, masks: denoiser_ref.denoiser_forward(sd, x, t, enc, masks), scheduler_ref.DDPMSchedulerRef(), cb["memories"],
+        cb["masks"], init, lambda i, t: noise[i], guidance_scale=7.5, num_inference_steps=n_steps)
+    m = hip_denoiser(1234, 1.0)
+    sch = scheduler.DDPMScheduler(variance_type="fixed_small", **SCHED_KW)
+    mems = [to_dev(x) for x in cb["memories"]]
+    masks = {k: to_dev(v) for k, v in cb["masks"].items()}
+    lat = sample_with_weg(m, sch, mems, masks, focus, params, B=B, L=L, num_inference_steps=n_steps, guidance_scale=7.5,
+                          init_latents=to_dev(init), step_noise=to_dev(noise))
+    lat = lat.permute(1, 0, 2).cpu().numpy()
+    err, moved = rel_l2(lat, ref), rel_l2(plain, ref)
+    print(f"loop with WEG: vs oracle {err:.2e}; WEG moved the result by {moved:.2e}; oracle objective per step {log}")
+    assert moved > 10 * err and err < 1e-3
