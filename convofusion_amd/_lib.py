@@ -22,7 +22,7 @@ SYMBOLS = [
     "cfd_sample_read", "cfd_scheduler_step", "cfd_add_noise", "cfd_philox_normal", "cfd_profile_forward",
     "cfd_test_gemm", "cfd_debug_stop_stage", "cfd_debug_read", "cfd_bench_gemm", "cfd_linear_act",
     "cfd_layer_norm", "cfd_mha", "cfd_add", "cfd_zero_rows", "cfd_gemm_f32", "cfd_softmax", "cfd_softmax_bwd",
-    "cfd_layer_norm_bwd", "cfd_ew", "cfd_weg_focus", "cfd_sample_write",
+    "cfd_layer_norm_bwd", "cfd_ew", "cfd_weg_focus", "cfd_sample_write", "cfd_sample_inpaint",
 ]
 
 
@@ -111,6 +111,7 @@ def load():
     lib.cfd_weg_focus.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                   C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.cfd_sample_write.argtypes = [C.c_void_p, C.c_void_p]
+    lib.cfd_sample_inpaint.argtypes = [C.c_void_p]
     lib.cfd_debug_stop_stage.argtypes = [C.c_void_p, C.c_int]
     lib.cfd_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
     for name in SYMBOLS:

@@ -1405,6 +1405,20 @@ extern "C" int cfd_weg_focus(cfd_handle c, const float* att, int B, int NL, int 
   return CFD_OK;
 }
 
+extern "C" int cfd_sample_inpaint(cfd_handle c) {
+  if (!c) return fail(CFD_E_ARG, "null handle");
+  if (!c->run_open) return fail(CFD_E_STATE, "no sampling run open");
+  const cfd_sample_args& s = c->sargs;
+  if (!s.preseq || s.preseq_len < 1) return CFD_OK;
+  HIPCHK(hipSetDevice(c->cfg.device));
+  BeginArgs ba{c->latents.as<float>(), c->sample_sp.as<char>(), s.B, s.L, s.G, s.preseq, c->inoise.as<float>(), s.preseq_len,
+               c->coef.as<StepCoef>(), c->d_step.as<int>()};
+  const long long n = (long long)s.B * s.preseq_len * CFD_LAT;
+  hipLaunchKernelGGL(inpaint_now_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->run_stream, ba, c->d_step.as<int>());
+  HIPCHK(hipGetLastError());
+  return CFD_OK;
+}
+
 extern "C" int cfd_sample_write(cfd_handle c, const float* latents) {
   if (!c || !latents) return fail(CFD_E_ARG, "null argument");
   if (!c->run_open) return fail(CFD_E_STATE, "no sampling run open");

@@ -427,7 +427,7 @@ __global__ void begin_step_kernel(const BeginArgs a) {
   const int l = (int)(bl % a.L), b = (int)(bl / a.L);
   float* lp = a.latents + bl * CFD_LAT + c;
   float v[8];
-  if (a.preseq && l < a.pl) {
+  if (a.preseq && l < a.pl && a.d_step[2] == 0) {   // d_step[2] != 0: cfd_sample_inpaint already did this iteration's overwrite
     const int i = *a.d_step;
     const float sa = a.coef[i].sa, sb = a.coef[i].sb;
     const long long po = ((long long)b * a.pl + l) * CFD_LAT + c;
@@ -513,7 +513,26 @@ __global__ void cfg_step_kernel(const CfgStepArgs a) {
   *reinterpret_cast<float4*>(a.latents + e0) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
-__global__ void advance_step_kernel(int* d_step) { *d_step += 1; }
+__global__ void advance_step_kernel(int* d_step) {
+  *d_step += 1;
+  d_step[2] = 0;
+}
+
+// The in-painting overwrite of begin_step_kernel alone, ahead of the captured iteration (cfd_sample_inpaint): the WEG
+// branch of the rollout alters the latents AFTER the overwrite and BEFORE the replication (unbounded_synthesis.py:70-143).
+__global__ void inpaint_now_kernel(const BeginArgs a, int* d_step) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = (long long)a.B * a.pl * CFD_LAT;
+  if (idx == 0) d_step[2] = 1;
+  if (idx >= n) return;
+  const int c = (int)(idx % CFD_LAT);
+  const long long bl = idx / CFD_LAT;
+  const int l = (int)(bl % a.pl), b = (int)(bl / a.pl);
+  const int i = *a.d_step;
+  const float v = a.coef[i].sa * a.preseq[idx] + a.coef[i].sb * a.inoise[idx];
+  a.latents[((long long)b * a.L + l) * CFD_LAT + c] = v;
+  if (i == 0) a.inoise[idx] = v;
+}
 
 // ------------------------------------------------------------------------------------------------
 // out[r][n] = act( b[n] + sum_k x[r][k] W[n][k] ), float32 FMA chain in ascending k (nn.Linear + activation).

@@ -188,6 +188,11 @@ class SamplingRun:
             torch.cuda.current_stream(self.device).synchronize()
             _lib.check(self.lib.cfd_sample_write(self.handle, C.c_void_p(lat.data_ptr())))
 
+    def inpaint(self):
+        """Do the next iteration's in-painting overwrite now (the captured iteration then skips it)."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.cfd_sample_inpaint(self.handle))
+
     def profile(self):
         ms = (C.c_float * len(_lib.PROF_CLASSES))()
         n = (C.c_int * len(_lib.PROF_CLASSES))()
@@ -217,7 +222,12 @@ def sample(denoiser, scheduler, encoder_hidden_states, cond_masks=None, *, B, L=
     return run.read(close=True)
 
 
-def _loop_from_model(model, encoder_hidden_states, cond_masks, preseq, focus_indices, init_latents, seed):
+# the WEG constants diffusion_reverse_forecast hard-codes instead of reading cfg.model.weg_parameters (unbounded_synthesis.py:80-84)
+FORECAST_WEG_PARAMETERS = dict(scale_factor=100, scale_range=(1.0, 0.5), max_iter_to_alter=800,
+                               thresholds={0: 0.05, 200: 0.4, 400: 0.6, 600: 0.8}, max_refinement_steps=300)
+
+
+def _loop_from_model(model, encoder_hidden_states, cond_masks, preseq, focus_indices, init_latents, seed, weg_parameters=None):
     if not model.do_classifier_free_guidance:
         # the reference itself raises NameError here (guidance_bs_mulitplier undefined, convofusion.py:517)
         raise NameError("guidance_bs_mulitplier: the reference loop requires classifier-free guidance")
@@ -242,11 +252,8 @@ def _loop_from_model(model, encoder_hidden_states, cond_masks, preseq, focus_ind
               skip_zero_weight_chunks=True)
     if len(focus_indices) == 0:
         return sample(model.denoiser, model.scheduler, encoder_hidden_states, cond_masks, **kw)
-    if preseq is not None:
-        raise NotImplementedError("word-excitation guidance inside the in-painting rollout (the WEG update would have to land "
-                                  "between the fused in-paint overwrite and the replication of the same graph node)")
     return sample_with_weg(model.denoiser, model.scheduler, encoder_hidden_states, cond_masks, focus_indices,
-                           model.weg_parameters, **kw)
+                           weg_parameters if weg_parameters is not None else model.weg_parameters, **kw)
 
 
 def sample_with_weg(denoiser, scheduler, encoder_hidden_states, cond_masks, focus_indices, weg_parameters, *, B, L=16,
@@ -271,6 +278,7 @@ def sample_with_weg(denoiser, scheduler, encoder_hidden_states, cond_masks, focu
                 break
             run.steps(1)
             continue
+        run.inpaint()   # rollout: the re-noised previous window goes in before the WEG update (unbounded_synthesis.py:70-76)
         lat, _ = weg.weg_update(denoiser, run.read(), i, t, text_states, text_masks, focus_indices, weg_parameters, len(timesteps))
         run.write(lat)
         run.steps(1)
@@ -293,5 +301,6 @@ def diffusion_reverse_forecast(model, encoder_hidden_states, lengths=None, prese
                                focus_indices=[], *, init_latents=None, seed=None):
     """``unbounded_synthesis.diffusion_reverse_forecast`` (reference unbounded_synthesis.py:28-187): the same
     loop with the first ``preseq.shape[1]`` tokens re-noised from the previous window every step (:70-76)."""
-    lat = _loop_from_model(model, encoder_hidden_states, cond_masks, preseq, focus_indices, init_latents, seed)
+    lat = _loop_from_model(model, encoder_hidden_states, cond_masks, preseq, focus_indices, init_latents, seed,
+                           weg_parameters=FORECAST_WEG_PARAMETERS)
     return lat.permute(1, 0, 2), dict()

@@ -180,7 +180,10 @@ int cfd_zero_rows(cfd_handle h, float* x, const uint8_t* keep, long long rows, i
  *                       respect to att: att / d_att dev [B][NL][L][S], tok_off dev int32 [B+1], tok_idx dev int32 (text
  *                       positions), kernel3 HOST {corner, edge, centre} of the normalised 3x3 kernel, workspace dev
  *                       >= B*(3*L*(last-1) + 3*nt_max) floats, losses dev [B], max_att dev [tok_off[B]]
- *   cfd_sample_write    overwrite the current latents of the open sampling run (the WEG update between two iterations) */
+ *   cfd_sample_write    overwrite the current latents of the open sampling run (the WEG update between two iterations)
+ *   cfd_sample_inpaint  do the next iteration's in-painting overwrite of the first preseq_len tokens now (the captured
+ *                       iteration then skips it): in the rollout the WEG update lands between the overwrite and the
+ *                       replication (unbounded_synthesis.py:70-143); no-op without preseq */
 typedef struct {
   const float* p;
   long long rs, cs, b1, b2;
@@ -196,6 +199,7 @@ int cfd_ew(cfd_handle h, int op, const float* a, const float* b, float* out, siz
 int cfd_weg_focus(cfd_handle h, const float* att, int B, int NL, int L, int S, const int32_t* tok_off, const int32_t* tok_idx, int last, int nt_max,
                   const float kernel3[3], float* workspace, float* losses, float* max_att, float* d_att, void* stream);
 int cfd_sample_write(cfd_handle h, const float* latents);
+int cfd_sample_inpaint(cfd_handle h);
 
 /* Device N(0,1) draws of the product's counter-based stream (DESIGN.md "RNG"): out dev [B][per_utt]. */
 int cfd_philox_normal(cfd_handle h, float* out, int B, int per_utt, uint64_t seed, uint32_t step,

@@ -215,8 +215,11 @@ def test_model_level_drop_in():
     again, _ = diffusion_reverse(model, enc1, None, masks1, focus_indices=[[2, 4]], init_latents=init, seed=5)
     assert torch.isfinite(steered).all() and torch.equal(steered, again)
     assert (steered - plain).norm() / plain.norm() > 1e-3
-    with pytest.raises(NotImplementedError):
-        diffusion_reverse_forecast(model, enc1, None, torch.zeros((1, 8, 128), device="cuda"), masks1, focus_indices=[[2]])
+    # the rollout entry point with its hard-coded WEG constants (unbounded_synthesis.py:80-84)
+    pre = 0.3 * torch.randn((1, 8, 128), device="cuda")
+    f_plain, _ = diffusion_reverse_forecast(model, enc1, None, pre, masks1, init_latents=init, seed=5)
+    f_weg, _ = diffusion_reverse_forecast(model, enc1, None, pre, masks1, focus_indices=[[2]], init_latents=init, seed=5)
+    assert torch.isfinite(f_weg).all() and (f_weg - f_plain).norm() / f_plain.norm() > 1e-4
 
 
 @pytest.mark.parametrize("shape", ["C2"])

@@ -148,9 +148,11 @@ def test_gradient_matches_oracle_and_reference_autograd(name):
     assert np.abs(att.cpu().numpy() - g[name + ".att_tlsn"]).max() < (2e-4 if "sharp" in name else 1e-5)   # sharp: logits of +-40
 
 
-def test_loop_with_weg_matches_oracle():
+@pytest.mark.parametrize("rollout", [False, True])
+def test_loop_with_weg_matches_oracle(rollout):
     """Five iterations of the loop with its WEG branch (one threshold step that triggers the iterative refinement)
-    against the oracle loop driven by the oracle denoiser."""
+    against the oracle loop driven by the oracle denoiser; ``rollout``: the in-painting variant, where the update
+    lands between the overwrite of the first 8 tokens and the replication (unbounded_synthesis.py:70-143)."""
     import torch
     from convofusion_amd import scheduler
     from convofusion_amd.sampler import sample_with_weg
@@ -159,6 +161,7 @@ def test_loop_with_weg_matches_oracle():
     cb = inputs.make_cfg_batch(seed=seed, B=B, L=L, S=S, pad_tail=pad)
     init = philox_ref.normal_tensor(seed, 0, range(B), 1, L)
     noise = np.stack([philox_ref.normal_tensor(seed, i, range(B), 0, L) for i in range(n_steps)])
+    preseq = (0.5 * philox_ref.normal_tensor(seed, 7, range(B), 2, 8)).astype(np.float32) if rollout else None
     focus = [[2, 5]]
     params = dict(scale_factor=1000, scale_range=[1.0, 0.5], max_iter_to_alter=3, thresholds={1: 0.16}, max_refinement_steps=2)
     sd = state_dict(1234, 1.0)
@@ -173,16 +176,16 @@ def test_loop_with_weg_matches_oracle():
 
     ref, _, _ = sampler_ref.diffusion_reverse(
         lambda x, t, enc, masks: denoiser_ref.denoiser_forward(sd, x, t, enc, masks), scheduler_ref.DDPMSchedulerRef(), cb["memories"],
-        cb["masks"], init, lambda i, t: noise[i], guidance_scale=7.5, num_inference_steps=n_steps, pre_step=pre_step)
+        cb["masks"], init, lambda i, t: noise[i], guidance_scale=7.5, num_inference_steps=n_steps, pre_step=pre_step, preseq=preseq)
     plain, _, _ = sampler_ref.diffusion_reverse(
         lambda x, t, enc, masks: denoiser_ref.denoiser_forward(sd, x, t, enc, masks), scheduler_ref.DDPMSchedulerRef(), cb["memories"],
-        cb["masks"], init, lambda i, t: noise[i], guidance_scale=7.5, num_inference_steps=n_steps)
+        cb["masks"], init, lambda i, t: noise[i], guidance_scale=7.5, num_inference_steps=n_steps, preseq=preseq)
     m = hip_denoiser(1234, 1.0)
     sch = scheduler.DDPMScheduler(variance_type="fixed_small", **SCHED_KW)
     mems = [to_dev(x) for x in cb["memories"]]
     masks = {k: to_dev(v) for k, v in cb["masks"].items()}
     lat = sample_with_weg(m, sch, mems, masks, focus, params, B=B, L=L, num_inference_steps=n_steps, guidance_scale=7.5,
-                          init_latents=to_dev(init), step_noise=to_dev(noise))
+                          init_latents=to_dev(init), step_noise=to_dev(noise), preseq=to_dev(preseq))
     lat = lat.permute(1, 0, 2).cpu().numpy()
     err, moved = rel_l2(lat, ref), rel_l2(plain, ref)
     print(f"loop with WEG: vs oracle {err:.2e}; WEG moved the result by {moved:.2e}; oracle objective per step {log}")
