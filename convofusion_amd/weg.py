@@ -215,7 +215,11 @@ def forward_saved(denoiser, sample, timestep, encoder_hidden_states, mem_mask_di
         x = ops.linear(sample.detach().to(torch.float32).permute(1, 0, 2).contiguous(), _w(denoiser.latent_embd.weight, dev),
                        _w(denoiser.latent_embd.bias, dev))                             # [L, B, D]  denoiser.py:183-187
         te = denoiser.time_embedding
-        trow = sinusoid_table(int(timestep) + 1, D)[int(timestep):].to(dev)            # get_timestep_embedding row (load-time table op)
+        tab = getattr(denoiser, "_weg_time_table", None)                                # get_timestep_embedding rows (load-time table)
+        if tab is None or tab.device != dev or tab.shape[0] <= int(timestep):
+            tab = sinusoid_table(max(1000, int(timestep) + 1), D).to(dev)
+            denoiser._weg_time_table = tab
+        trow = tab[int(timestep):int(timestep) + 1]
         temb = ops.linear(ops.ew(EW_SILU, ops.linear(trow, _w(te.linear_1.weight, dev), _w(te.linear_1.bias, dev))),
                           _w(te.linear_2.weight, dev), _w(te.linear_2.bias, dev))      # [1, D]  :195-199
         silu_temb = ops.ew(EW_SILU, temb)

@@ -5,6 +5,7 @@ contract).  Prints one JSON object:
   C5  dyadic reactive path, B=16 per side, same shape (speaker memory = partner projection, 196 keys)
   audio encoder: AudioConvEncoder over (B+1) x 1500 Mel frames (the conditioning producer of one batch)
   VAE decode: ConvoFusionVae.decode of one batch (B=32, 128 frames)
+  WEG: one objective + gradient evaluation (convofusion_amd.weg.loss_and_grad) at the product shape, B=1
 usage: python tools/bench_configs.py   (on the GPU box)"""
 import json
 import os
@@ -94,4 +95,27 @@ for _ in range(5):
     vae.decode(z, [128] * 32)
 sync()
 out["vae_decode_B32_128frames"] = {"ms": (time.time() - t0) / 5 * 1e3, "note": "~190 small float32 launches driven from Python"}
+# ---- word-excitation guidance: one objective + gradient evaluation on the text-only chunk, product shape (B=1, L=16)
+from convofusion_amd import weg  # noqa: E402
+gw = torch.Generator().manual_seed(9)
+Sw = (24, 161, 24, 8, 1)
+enc_w = [torch.randn(1, s, 512, generator=gw).to(dev) for s in Sw]
+mask_w = {"spkemb": None, "alsn": None, "apb": None, "lsnemb": None, "tlsn": (torch.arange(24) >= 17)[None].to(dev)}
+lat_w = torch.randn(1, 16, 128, generator=gw).to(dev)
+focus_w = [[3, 9, 14]]
+weg.loss_and_grad(model, lat_w, 500, enc_w, mask_w, focus_w)
+sync()
+t0 = time.time()
+for _ in range(10):
+    att_w, saved_w = weg.forward_saved(model, lat_w, 500, enc_w, mask_w)
+sync()
+t_fwd = (time.time() - t0) / 10
+t0 = time.time()
+for _ in range(10):
+    weg.loss_and_grad(model, lat_w, 500, enc_w, mask_w, focus_w)
+sync()
+t_all = (time.time() - t0) / 10
+out["weg_loss_and_grad_B1_L16"] = {"ms": t_all * 1e3, "forward_saved_ms": t_fwd * 1e3,
+                                   "note": "~1200 small float32 launches driven from Python (forward with saved activations, objective, "
+                                           "backward sweep); the reference runs the same evaluation through torch autograd"}
 print(json.dumps(out))
