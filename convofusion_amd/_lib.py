@@ -22,7 +22,7 @@ SYMBOLS = [
     "cfd_sample_read", "cfd_scheduler_step", "cfd_add_noise", "cfd_philox_normal", "cfd_profile_forward",
     "cfd_test_gemm", "cfd_debug_stop_stage", "cfd_debug_read", "cfd_bench_gemm", "cfd_linear_act",
     "cfd_layer_norm", "cfd_mha", "cfd_add", "cfd_zero_rows", "cfd_gemm_f32", "cfd_softmax", "cfd_softmax_bwd",
-    "cfd_layer_norm_bwd", "cfd_ew", "cfd_weg_focus", "cfd_sample_write", "cfd_sample_inpaint",
+    "cfd_layer_norm_bwd", "cfd_ew", "cfd_weg_focus", "cfd_sample_write", "cfd_sample_inpaint", "cfd_weg_eval",
 ]
 
 
@@ -55,6 +55,11 @@ class SampleArgs(C.Structure):
                 ("step_noise", C.c_void_p), ("seed", C.c_uint64), ("first_utterance", C.c_uint32),
                 ("preseq", C.c_void_p), ("preseq_len", C.c_int), ("mem", Memory * NUM_MEM),
                 ("skip_zero_weight_chunks", C.c_int)]
+
+
+class WegArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("L", C.c_int), ("timestep", C.c_int), ("latents", C.c_void_p), ("mem", Memory * NUM_MEM),
+                ("tok_off", C.c_void_p), ("tok_idx", C.c_void_p), ("last", C.c_int), ("kernel3", C.c_float * 3)]
 
 
 _lib = None
@@ -112,6 +117,7 @@ def load():
                                   C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.cfd_sample_write.argtypes = [C.c_void_p, C.c_void_p]
     lib.cfd_sample_inpaint.argtypes = [C.c_void_p]
+    lib.cfd_weg_eval.argtypes = [C.c_void_p, C.POINTER(WegArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_void_p]
     lib.cfd_debug_stop_stage.argtypes = [C.c_void_p, C.c_int]
     lib.cfd_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
     for name in SYMBOLS:

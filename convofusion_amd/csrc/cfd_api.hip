@@ -119,7 +119,8 @@ struct cfd_handle_s {
   bool tile_sm = false;
   DBuf sm_stats, sm_alpha, run_flags;
   bool share0 = true;       // CFD_SHARE0=0: evaluate the pre-cross-attention part of layer 0 for every guidance replica
-  DBuf d_step;  // [0] = loop index, [1] = constant 0
+  DBuf d_step;  // [0] = loop index, [1] = constant 0, [2] = "this iteration's in-painting overwrite is done" (cfd_sample_inpaint)
+  DBuf weg_ws, weg_tok;   // cfd_weg_eval: activation arena, focus-token tables
   Problem pb;
   // profiling
   bool prof = false;
@@ -271,7 +272,7 @@ extern "C" void cfd_destroy(cfd_handle c) {
   for (auto& kv : c->raw) kv.second.release();
   DBuf* all[] = {&c->we_sp, &c->wp_sp, &c->we_all, &c->be_all, &c->tsin, &c->x, &c->h_sp, &c->qk_sp, &c->vts_sp,
                  &c->ssc, &c->sp_sp, &c->o_sp, &c->u_sp, &c->sc, &c->p_sp, &c->eps, &c->sample_sp, &c->temb_tab,
-                 &c->h1_tab, &c->ss_tab, &c->trows, &c->d_step, &c->latents, &c->coef, &c->inoise, &c->sm_stats, &c->sm_alpha,
+                 &c->h1_tab, &c->ss_tab, &c->trows, &c->d_step, &c->weg_ws, &c->weg_tok, &c->latents, &c->coef, &c->inoise, &c->sm_stats, &c->sm_alpha,
                  &c->run_flags};
   for (DBuf* b : all) b->release();
   for (int j = 0; j < CFD_NMEM; ++j) {
@@ -1339,15 +1340,16 @@ extern "C" int cfd_zero_rows(cfd_handle c, float* x, const uint8_t* keep, long l
   return CFD_OK;
 }
 
-// ---- float32 pieces of the WEG gradient path (grad.hpp) ---------------------------------------------------------
+// ---- float32 pieces of the WEG gradient path (grad.hpp) and the whole evaluation (weg_eval.hpp) --------------------------
+#include "weg_eval.hpp"
+
 extern "C" int cfd_gemm_f32(cfd_handle c, int M, int N, int K, int nb1, int nb2, const cfd_mat* A, const cfd_mat* B, const cfd_mat* Cm,
                             const float* bias, float alpha, int accumulate, void* stream) {
   if (!c || !A || !B || !Cm || !A->p || !B->p || !Cm->p || M < 1 || N < 1 || K < 1 || nb1 < 1 || nb2 < 1) return fail(CFD_E_ARG, "bad argument");
   if ((long long)nb1 * nb2 > 65535) return fail(CFD_E_SHAPE, "cfd_gemm_f32: at most 65535 batch entries");
   HIPCHK(hipSetDevice(c->cfg.device));
   MatView a{A->p, A->rs, A->cs, A->b1, A->b2}, b{B->p, B->rs, B->cs, B->b1, B->b2};
-  hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)(nb1 * nb2)), dim3(256), 0,
-                     (hipStream_t)stream, a, b, const_cast<float*>(Cm->p), Cm->rs, Cm->cs, Cm->b1, Cm->b2, M, N, K, nb2, bias, alpha, accumulate);
+  launch_gemm_f32((hipStream_t)stream, a, b, const_cast<float*>(Cm->p), Cm->rs, Cm->cs, Cm->b1, Cm->b2, M, N, K, nb1, nb2, bias, alpha, accumulate);
   HIPCHK(hipGetLastError());
   return CFD_OK;
 }
@@ -1402,6 +1404,60 @@ extern "C" int cfd_weg_focus(cfd_handle c, const float* att, int B, int NL, int 
   hipLaunchKernelGGL(weg_focus_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, att, tok_off, tok_idx, B, NL, L, S, last, nt_max,
                      kernel3[0], kernel3[1], kernel3[2], workspace, losses, max_att, d_att);
   HIPCHK(hipGetLastError());
+  return CFD_OK;
+}
+
+extern "C" int cfd_weg_eval(cfd_handle c, const cfd_weg_args* a, float* losses, float* max_att, float* grad, float* loss_host, void* stream) {
+  if (!c || !a || !a->latents || !a->tok_off || !losses || !max_att || !grad) return fail(CFD_E_ARG, "null argument");
+  if (!c->finalized) return fail(CFD_E_STATE, "weights not finalized");
+  const int B = a->B, L = a->L, D = c->cfg.text_encoded_dim;
+  if (B < 1 || L < 2) return fail(CFD_E_ARG, "bad batch / length");
+  if (L % 2) return fail(CFD_E_SHAPE, "latent length %d is odd (reference: broadcasting error at position_encoding.py:160-161)", L);
+  if (L / 2 > c->qpe_rows) return fail(CFD_E_SHAPE, "L/2 = %d exceeds the query PE buffer (%d rows)", L / 2, c->qpe_rows);
+  if (a->timestep < 0 || a->timestep >= c->tsin_rows) return fail(CFD_E_ARG, "timestep %d outside the timestep table (%d rows)", a->timestep, c->tsin_rows);
+  if (D > 2048) return fail(CFD_E_SHAPE, "model width above 2048");
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    if (!a->mem[j].data || a->mem[j].S < 1) return fail(CFD_E_ARG, "memory %s missing", MEM_NAMES[j]);
+    if (a->mem[j].U != B || a->mem[j].row_map) return fail(CFD_E_ARG, "cfd_weg_eval takes one memory per row (U == B, no row map)");
+    if (a->mem[j].S > c->mpe_rows) return fail(CFD_E_SHAPE, "memory %s has %d tokens, the memory PE buffer %d rows", MEM_NAMES[j], a->mem[j].S, c->mpe_rows);
+  }
+  const int St = a->mem[2].S, n_tok = a->tok_off[B];
+  if (a->tok_off[0] != 0 || n_tok < 0 || (n_tok > 0 && !a->tok_idx)) return fail(CFD_E_ARG, "bad focus-token table");
+  // F.pad(..., mode='reflect') with pad 1 needs at least 2 entries per axis (word_excitation_guidance.py:35)
+  if (a->last - 1 < 2 || a->last > St) return fail(CFD_E_SHAPE, "text slice [1, %d) of %d keys is too short for the 3x3 reflect-padded smoothing", a->last, St);
+  int nt_max = 1;
+  for (int b = 0; b < B; ++b) {
+    if (a->tok_off[b + 1] < a->tok_off[b]) return fail(CFD_E_ARG, "bad focus-token table");
+    nt_max = std::max(nt_max, a->tok_off[b + 1] - a->tok_off[b]);
+  }
+  for (int t = 0; t < n_tok; ++t)
+    if (a->tok_idx[t] < 1 || a->tok_idx[t] > a->last - 1) return fail(CFD_E_ARG, "focus index %d is outside the text slice [1, %d)", a->tok_idx[t], a->last);
+  HIPCHK(hipSetDevice(c->cfg.device));
+  hipStream_t st = (hipStream_t)stream;
+  // focus-token tables to the device (the stream may still read the previous call's copy)
+  HIPCHK(hipStreamSynchronize(st));
+  CHK(c->weg_tok.ensure((size_t)(B + 1 + std::max(1, n_tok)) * 4));
+  HIPCHK(hipMemcpy(c->weg_tok.p, a->tok_off, (size_t)(B + 1) * 4, hipMemcpyHostToDevice));
+  if (n_tok > 0) HIPCHK(hipMemcpy(c->weg_tok.as<int32_t>() + B + 1, a->tok_idx, (size_t)n_tok * 4, hipMemcpyHostToDevice));
+  weg::Args wa{a->latents, a->timestep, a->mem, c->weg_tok.as<int32_t>(), c->weg_tok.as<int32_t>() + B + 1, a->last, nt_max, n_tok,
+               {a->kernel3[0], a->kernel3[1], a->kernel3[2]}, losses, max_att, grad};
+  weg::Ctx x{c, st, true, reinterpret_cast<char*>(256), 0, B, L, D, D, CFD_OK, std::string()};
+  weg::run(x, wa);                                   // sizing pass
+  if (x.err) return fail(x.err, "missing tensor '%s' (state-dict key denoiser.%s)", x.missing.c_str(), x.missing.c_str());
+  CHK(c->weg_ws.ensure(x.off));
+  x.dry = false;
+  x.base = c->weg_ws.as<char>();
+  x.off = 0;
+  weg::run(x, wa);
+  HIPCHK(hipGetLastError());
+  if (loss_host) {                                   // torch.mean(losses) over the batch (word_excitation_guidance.py:80)
+    std::vector<float> l(B);
+    HIPCHK(hipMemcpyAsync(l.data(), losses, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += l[b];
+    *loss_host = s / (float)B;
+  }
   return CFD_OK;
 }
 

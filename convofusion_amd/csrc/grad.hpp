@@ -74,6 +74,80 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(MatView A, MatView B, flo
   }
 }
 
+// The same product for few output rows (the WEG problem: 16 latent tokens, <= a few hundred memory tokens), where the
+// tiled kernel above would run 8 workgroups of 32 dependent k-steps: one workgroup = 16 rows x 16 columns, its 256
+// threads = 16 columns x 16 k-slices (thread (tn, tk) accumulates k = tk, tk + 16, ... for all 16 rows; A goes through
+// LDS in k-chunks of 512, B streams from global memory once), partial sums meet in LDS and are added in ascending tk.
+// N / 16 x M / 16 workgroups instead of N / 64 x M / 64, and no barrier inside a k-chunk.
+#define R16_KC 512
+__global__ void __launch_bounds__(256) gemm_f32_rows16_kernel(MatView A, MatView B, float* C, long long c_rs, long long c_cs, long long c_b1,
+                                                              long long c_b2, int M, int N, int K, int nb2, const float* bias, float alpha,
+                                                              int accumulate) {
+  __shared__ __attribute__((aligned(16))) float As[R16_KC][20];   // [k][row], rows padded to 20 (16-byte aligned float4 reads)
+  __shared__ float red[16][16][17];                                // [tk][tn][row]
+  const int z1 = blockIdx.z / nb2, z2 = blockIdx.z % nb2;
+  const float* a = A.p + z1 * A.b1 + z2 * A.b2;
+  const float* b = B.p + z1 * B.b1 + z2 * B.b2;
+  float* c = C + z1 * c_b1 + z2 * c_b2;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+  const int tid = threadIdx.x;
+  const bool b_n_fast = B.cs == 1, a_k_fast = A.cs == 1;
+  const int tn = b_n_fast ? (tid & 15) : (tid >> 4), tk = b_n_fast ? (tid >> 4) : (tid & 15);
+  const int n = n0 + tn;
+  const bool n_ok = n < N;
+  float acc[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) acc[m] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += R16_KC) {
+    const int kc = min(R16_KC, K - k0);
+    for (int e = tid; e < 16 * kc; e += 256) {
+      int m, kk;
+      if (a_k_fast) { kk = e % kc; m = e / kc; } else { m = e & 15; kk = e >> 4; }
+      As[kk][m] = (m0 + m < M) ? a[(long long)(m0 + m) * A.rs + (long long)(k0 + kk) * A.cs] : 0.f;
+    }
+    __syncthreads();
+    if (n_ok) {
+      const float* bp = b + (long long)k0 * B.rs + (long long)n * B.cs;
+#pragma unroll 4
+      for (int kk = tk; kk < kc; kk += 16) {
+        const float bv = bp[(long long)kk * B.rs];
+        const float4* ar = reinterpret_cast<const float4*>(&As[kk][0]);
+        const float4 a0 = ar[0], a1 = ar[1], a2 = ar[2], a3 = ar[3];
+        acc[0] = fmaf(a0.x, bv, acc[0]); acc[1] = fmaf(a0.y, bv, acc[1]); acc[2] = fmaf(a0.z, bv, acc[2]); acc[3] = fmaf(a0.w, bv, acc[3]);
+        acc[4] = fmaf(a1.x, bv, acc[4]); acc[5] = fmaf(a1.y, bv, acc[5]); acc[6] = fmaf(a1.z, bv, acc[6]); acc[7] = fmaf(a1.w, bv, acc[7]);
+        acc[8] = fmaf(a2.x, bv, acc[8]); acc[9] = fmaf(a2.y, bv, acc[9]); acc[10] = fmaf(a2.z, bv, acc[10]); acc[11] = fmaf(a2.w, bv, acc[11]);
+        acc[12] = fmaf(a3.x, bv, acc[12]); acc[13] = fmaf(a3.y, bv, acc[13]); acc[14] = fmaf(a3.z, bv, acc[14]); acc[15] = fmaf(a3.w, bv, acc[15]);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int m = 0; m < 16; ++m) red[tk][tn][m] = acc[m];
+  __syncthreads();
+  const int om = tid >> 4, on = tid & 15;
+  if (m0 + om < M && n0 + on < N) {
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v += red[t][on][om];
+    v *= alpha;
+    if (bias) v += bias[n0 + on];
+    float* dst = c + (long long)(m0 + om) * c_rs + (long long)(n0 + on) * c_cs;
+    if (accumulate) v += *dst;
+    *dst = v;
+  }
+}
+
+// launch the product with the kernel that fits its shape
+static inline void launch_gemm_f32(hipStream_t st, const MatView& a, const MatView& b, float* C, long long c_rs, long long c_cs, long long c_b1,
+                                   long long c_b2, int M, int N, int K, int nb1, int nb2, const float* bias, float alpha, int accumulate) {
+  if (M <= 256)
+    hipLaunchKernelGGL(gemm_f32_rows16_kernel, dim3((unsigned)((N + 15) / 16), (unsigned)((M + 15) / 16), (unsigned)(nb1 * nb2)), dim3(256), 0, st, a, b,
+                       C, c_rs, c_cs, c_b1, c_b2, M, N, K, nb2, bias, alpha, accumulate);
+  else
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)(nb1 * nb2)), dim3(256), 0, st, a, b, C,
+                       c_rs, c_cs, c_b1, c_b2, M, N, K, nb2, bias, alpha, accumulate);
+}
+
 // In-place softmax over the last axis of scores [rows][Lk]; key_padding_mask [batch][Lk] (1 = ignore), the batch of a
 // row is row / rows_per_batch.  One wave per row.
 __global__ void __launch_bounds__(256) softmax_f32_kernel(float* s, const uint8_t* kpm, long long rows, int Lk, long long rows_per_batch) {

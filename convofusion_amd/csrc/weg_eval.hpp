@@ -1,0 +1,334 @@
+// cfd_weg_eval: one evaluation of the word-excitation-guidance objective on the text-only chunk and its gradient with
+// respect to the latents, enqueued from C++ (no per-launch host language overhead).  What the reference does with
+//   latents.requires_grad_(True); _, att = denoiser(latents, t, text_only_states, ...); loss = focus(att[2]);
+//   torch.autograd.grad(loss, latents)                       (convofusion.py:447-471,490-495; weg.py:11-81)
+// Forward in the reference's own float32 formulation (denoiser.py:173-386, cross_attention.py:556-664, 426-439) keeping
+// the activations the backward needs, the objective (weg_focus_kernel), then the reverse sweep; only the query side
+// carries gradient (memories, time embedding, weights are constants).  Batch-major rows (r = b * L + l) so latents,
+// memories and the gradient need no permutation; every head split / transpose is a strided view of gemm_f32_kernel.
+// Included by cfd_api.hip after the handle definition.
+#pragma once
+
+namespace weg {
+
+struct View {           // element (z1, z2, r, c) = p[z1*b1 + z2*b2 + r*rs + c*cs]
+  float* p;
+  long long rs, cs, b1, b2;
+};
+
+struct AttnSaved {
+  float *q, *k, *v, *p;      // q / k / v batch-major [B][T or S][E]; p: probabilities of (b, h) at p + b*pb1 + h*T*S
+  long long pb1;
+  const float *W, *Wo;       // in_proj_weight [3E][E], out_proj.weight [E][E]
+  int T, S, H;
+  float scale;
+};
+
+struct TbSaved {
+  float *x, *h, *e;
+  const float *g, *Wout;
+};
+
+struct LayerSaved {
+  float *x0, *x2, *x4, *ffn_pre;
+  AttnSaved self, cross[CFD_NMEM];
+  TbSaved tb1, tb2;
+};
+
+struct Ctx {
+  cfd_handle c;
+  hipStream_t st;
+  bool dry;            // sizing pass: count workspace bytes, launch nothing
+  char* base;
+  size_t off;
+  int B, L, D, E;
+  int err;
+  std::string missing;
+
+  float* alloc(size_t n) {
+    const size_t bytes = (n * 4 + 255) & ~(size_t)255;
+    float* p = reinterpret_cast<float*>(base + off);   // sizing pass: a fake non-null base, never dereferenced (same control flow)
+    off += bytes;
+    return p;
+  }
+  const float* W(const std::string& name) {
+    auto it = c->raw.find(name);
+    if (it == c->raw.end()) {
+      if (missing.empty()) missing = name;
+      err = CFD_E_STATE;
+      return nullptr;
+    }
+    return it->second.as<float>();
+  }
+  void gemm(int M, int N, int K, int nb1, int nb2, View A, View Bv, View Cv, const float* bias, float alpha, int accumulate) {
+    if (dry || err) return;
+    MatView a{A.p, A.rs, A.cs, A.b1, A.b2}, b{Bv.p, Bv.rs, Bv.cs, Bv.b1, Bv.b2};
+    launch_gemm_f32(st, a, b, Cv.p, Cv.rs, Cv.cs, Cv.b1, Cv.b2, M, N, K, nb1, nb2, bias, alpha, accumulate);
+  }
+  // F.linear on [rows][K] -> [rows][N]; w [N][K]
+  float* linear(const float* x, long long rows, int K, const float* w, const float* bias, int N, float* out = nullptr) {
+    if (!out) out = alloc((size_t)rows * N);
+    gemm((int)rows, N, K, 1, 1, View{const_cast<float*>(x), K, 1, 0, 0}, View{const_cast<float*>(w), 1, K, 0, 0}, View{out, N, 1, 0, 0}, bias, 1.0f, 0);
+    return out;
+  }
+  // gradient of F.linear(x, w) with respect to x: dy [rows][N] @ w [N][K]
+  float* linear_bwd(const float* dy, long long rows, int N, const float* w, int K, float* out = nullptr, int accumulate = 0) {
+    if (!out) out = alloc((size_t)rows * K);
+    gemm((int)rows, K, N, 1, 1, View{const_cast<float*>(dy), N, 1, 0, 0}, View{const_cast<float*>(w), K, 1, 0, 0}, View{out, K, 1, 0, 0}, nullptr, 1.0f,
+         accumulate);
+    return out;
+  }
+  void softmax(float* s, long long rows, int Lk, const uint8_t* kpm, long long rows_per_batch) {
+    if (dry || err) return;
+    hipLaunchKernelGGL(softmax_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, s, kpm, rows, Lk, rows_per_batch);
+  }
+  void softmax_bwd(const float* p, float* dp, const float* extra, long long rows, int Lk) {
+    if (dry || err) return;
+    hipLaunchKernelGGL(softmax_bwd_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, dp, extra, rows, Lk);
+  }
+  float* ln(const float* x, long long rows, const float* g, const float* b) {
+    float* out = alloc((size_t)rows * D);
+    if (!dry && !err) hipLaunchKernelGGL(layernorm_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, g, b, out, rows, D, 1e-5f);
+    return out;
+  }
+  void ln_bwd(const float* x, const float* g, const float* dy, float* dx, long long rows, int accumulate) {
+    if (dry || err) return;
+    hipLaunchKernelGGL(layernorm_bwd_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, g, dy, dx, rows, D, 1e-5f, accumulate);
+  }
+  void ew(int op, const float* a, const float* b, float* out, long long n, int Dd = 1, int R1 = 1, long long s0 = 0, long long s1 = 0, float alpha = 0.f) {
+    if (dry || err) return;
+    hipLaunchKernelGGL(ew_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, op, a, b, out, n, Dd, R1, s0, s1, alpha);
+  }
+  void add(float* x, const float* y, long long n) {
+    if (dry || err) return;
+    hipLaunchKernelGGL(add_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
+  }
+  void zero(float* x, size_t n) {
+    if (dry || err) return;
+    (void)hipMemsetAsync(x, 0, n * 4, st);
+  }
+};
+
+// head view of a batch-major [B][n][E] tensor: (b, h; t, d)
+static inline View heads(float* t, int n, int E, int hd) { return View{t, E, 1, (long long)n * E, hd}; }
+static inline View heads_T(float* t, int n, int E, int hd) { return View{t, 1, E, (long long)n * E, hd}; }   // (b, h; d, t)
+
+// nn.MultiheadAttention(query, memory, memory, key_padding_mask) on batch-major rows.  `p_out`: where the probabilities go
+// ([B] blocks of H*T*S floats, pb1 apart), or null to allocate [B][H][T][S].
+static float* mha_fwd(Ctx& x, const std::string& pfx, const float* query, int T, const float* memory, int S, int H, const uint8_t* kpm,
+                      bool use_p_out, float* p_out, long long pb1, AttnSaved& sv) {
+  const int E = x.E, hd = E / H, B = x.B;
+  const float* W = x.W(pfx + ".in_proj_weight");
+  const float* Bi = x.W(pfx + ".in_proj_bias");
+  const float* Wo = x.W(pfx + ".out_proj.weight");
+  const float* bo = x.W(pfx + ".out_proj.bias");
+  if (x.err) return nullptr;
+  float* q = x.linear(query, (long long)B * T, E, W, Bi, E);
+  float* k = x.linear(memory, (long long)B * S, E, W + (size_t)E * E, Bi + E, E);
+  float* v = x.linear(memory, (long long)B * S, E, W + (size_t)2 * E * E, Bi + 2 * E, E);
+  float* p = p_out;
+  if (!use_p_out) {
+    p = x.alloc((size_t)B * H * T * S);
+    pb1 = (long long)H * T * S;
+  }
+  const float scale = (float)std::sqrt(1.0 / (double)hd);
+  x.gemm(T, S, hd, B, H, heads(q, T, E, hd), heads_T(k, S, E, hd), View{p, S, 1, pb1, (long long)T * S}, nullptr, scale, 0);
+  if (pb1 == (long long)H * T * S) x.softmax(p, (long long)B * H * T, S, kpm, (long long)H * T);
+  else
+    for (int b = 0; b < B; ++b) x.softmax(p + b * pb1, (long long)H * T, S, kpm ? kpm + (size_t)b * S : nullptr, (long long)H * T);
+  float* o = x.alloc((size_t)B * T * E);
+  x.gemm(T, hd, S, B, H, View{p, S, 1, pb1, (long long)T * S}, heads(v, S, E, hd), heads(o, T, E, hd), nullptr, 1.0f, 0);
+  float* out = x.linear(o, (long long)B * T, E, Wo, bo, E);
+  sv = AttnSaved{q, k, v, p, pb1, W, Wo, T, S, H, scale};
+  return out;
+}
+
+// Gradient with respect to the query input (self-attention: the sum of the query / key / value paths).  `dout` may be
+// null (nothing arrives through the output); `d_prob` (same layout as p, blocks dpb1 apart) arrives at the probabilities.
+static float* mha_bwd(Ctx& x, const AttnSaved& sv, const float* dout, const float* d_prob, long long dpb1, bool self_attention) {
+  const int E = x.E, H = sv.H, hd = E / H, B = x.B, T = sv.T, S = sv.S;
+  const long long blk = (long long)H * T * S;
+  float* dp = x.alloc((size_t)B * blk);
+  float* d_o = nullptr;
+  if (dout) {
+    d_o = x.linear_bwd(dout, (long long)B * T, E, sv.Wo, E);
+    x.gemm(T, S, hd, B, H, heads(d_o, T, E, hd), heads_T(sv.v, S, E, hd), View{dp, S, 1, blk, (long long)T * S}, nullptr, 1.0f, 0);
+  } else {
+    x.zero(dp, (size_t)B * blk);
+  }
+  if (sv.pb1 == blk && (!d_prob || dpb1 == blk)) x.softmax_bwd(sv.p, dp, d_prob, (long long)B * H * T, S);
+  else
+    for (int b = 0; b < B; ++b) x.softmax_bwd(sv.p + b * sv.pb1, dp + b * blk, d_prob ? d_prob + b * dpb1 : nullptr, (long long)H * T, S);
+  float* dq = x.alloc((size_t)B * T * E);
+  x.gemm(T, hd, S, B, H, View{dp, S, 1, blk, (long long)T * S}, heads(sv.k, S, E, hd), heads(dq, T, E, hd), nullptr, sv.scale, 0);
+  float* dx = x.linear_bwd(dq, (long long)B * T, E, sv.W, E);
+  if (self_attention) {
+    float* dk = x.alloc((size_t)B * S * E);
+    x.gemm(S, hd, T, B, H, View{dp, 1, S, blk, (long long)T * S}, heads(sv.q, T, E, hd), heads(dk, S, E, hd), nullptr, sv.scale, 0);
+    x.linear_bwd(dk, (long long)B * S, E, sv.W + (size_t)E * E, E, dx, 1);
+    float* dv = x.alloc((size_t)B * S * E);
+    x.gemm(S, hd, T, B, H, View{sv.p, 1, S, sv.pb1, (long long)T * S}, heads(d_o, T, E, hd), heads(dv, S, E, hd), nullptr, 1.0f, 0);
+    x.linear_bwd(dv, (long long)B * S, E, sv.W + (size_t)2 * E * E, E, dx, 1);
+  }
+  return dx;
+}
+
+// TimeBlock.forward (cross_attention.py:426-439) for one shared time-embedding row
+static float* time_block_fwd(Ctx& x, const std::string& pfx, float* in, const float* silu_temb, TbSaved& sv) {
+  const int D = x.D;
+  const long long rows = (long long)x.B * x.L;
+  const float *We = x.W(pfx + ".emb_layers.1.weight"), *be = x.W(pfx + ".emb_layers.1.bias"), *g = x.W(pfx + ".norm.weight"),
+              *bn = x.W(pfx + ".norm.bias"), *Wout = x.W(pfx + ".out_layers.2.weight"), *bout = x.W(pfx + ".out_layers.2.bias");
+  if (x.err) return nullptr;
+  float* e = x.linear(silu_temb, 1, D, We, be, 2 * D);                     // [1][2 D], scale first
+  float* n = x.ln(in, rows, g, bn);
+  float* h = x.alloc((size_t)rows * D);
+  x.ew(EW_MODULATE, n, e, h, rows * D, D, 1);
+  float* s = x.alloc((size_t)rows * D);
+  x.ew(EW_SILU, h, nullptr, s, rows * D);
+  sv = TbSaved{in, h, e, g, Wout};
+  return x.linear(s, rows, D, Wout, bout, D);
+}
+
+// g += d TimeBlock(x)/dx applied to g
+static void time_block_bwd(Ctx& x, const TbSaved& sv, float* g) {
+  const int D = x.D;
+  const long long rows = (long long)x.B * x.L;
+  float* dh = x.linear_bwd(g, rows, D, sv.Wout, D);
+  x.ew(EW_SILU_BWD, dh, sv.h, dh, rows * D);
+  x.ew(EW_MODULATE_BWD, dh, sv.e, dh, rows * D, D, 1);
+  x.ln_bwd(sv.x, sv.g, dh, g, rows, 1);
+}
+
+struct Args {
+  const float* latents;        // dev [B][L][latent]
+  int timestep;
+  const cfd_memory* mem;       // 5 memories, U == B, batch-major [B][S][D]
+  const int32_t *tok_off, *tok_idx;   // dev
+  int last, nt_max, n_tok;
+  float k3[3];
+  float *losses, *max_att, *grad;    // dev outputs
+};
+
+// One pass over the whole evaluation; with x.dry it only sizes the workspace.
+static void run(Ctx& x, const Args& a) {
+  cfd_handle c = x.c;
+  const int B = x.B, L = x.L, D = x.D, NL = c->nl, LAT = c->cfg.latent_dim, FF = c->cfg.ff_size;
+  const long long rows = (long long)B * L;
+  // ---- embedding, time embedding, memories (denoiser.py:183-353)
+  float* xx = x.linear(a.latents, rows, LAT, x.W("latent_embd.weight"), x.W("latent_embd.bias"), D);
+  const float* trow = c->tsin.as<float>() + (size_t)a.timestep * D;
+  float* t1 = x.linear(trow, 1, D, x.W("time_embedding.linear_1.weight"), x.W("time_embedding.linear_1.bias"), D);
+  x.ew(EW_SILU, t1, nullptr, t1, D);
+  float* temb = x.linear(t1, 1, D, x.W("time_embedding.linear_2.weight"), x.W("time_embedding.linear_2.bias"), D);
+  float* silu_temb = x.alloc(D);
+  x.ew(EW_SILU, temb, nullptr, silu_temb, D);
+  x.ew(EW_ADD_BCAST, xx, x.W("bh_embedding.weight"), xx, rows * D, D, 2, 0, D);                 // token l gets bh[l % 2] (:316-317)
+  const float* qpe = x.W("query_pos.pe");
+  for (int b = 0; b < B; ++b)                                                                      // and pe[l / 2] (SineBH)
+    x.ew(EW_ADD_BCAST, xx + (size_t)b * L * D, qpe, xx + (size_t)b * L * D, (long long)L * D, D, 2, D, 0);
+  float* mems[CFD_NMEM];
+  const float *ce = x.W("condition_embedding.weight"), *mpe = x.W("mem_pos.pe");
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    const int S = a.mem[j].S;
+    const long long n = (long long)B * S * D;
+    mems[j] = x.alloc((size_t)n);
+    x.ew(EW_ADD_BCAST, a.mem[j].data, temb, mems[j], n, D, S, 0, 0);                            // + temb (:223-261)
+    x.ew(EW_ADD_BCAST, mems[j], ce ? ce + (size_t)j * D : nullptr, mems[j], n, D, S, 0, 0);       // + condition id (:332-353)
+    x.ew(EW_ADD_BCAST, mems[j], mpe, mems[j], n, D, S, 0, D);                                   // + pe[s]
+  }
+  if (x.err) return;
+  // ---- layers, keeping what the backward needs
+  const int St = a.mem[2].S;
+  float* att = x.alloc((size_t)B * NL * L * St);                 // [B][NL][L][S_text]: Denoiser.forward's att_mats[2]
+  std::vector<LayerSaved> sv(NL);
+  for (int i = 0; i < NL; ++i) {
+    const std::string p = "decoder.layers." + std::to_string(i) + ".";
+    LayerSaved& s = sv[i];
+    s.x0 = xx;
+    float* t2 = x.ln(xx, rows, x.W(p + "norm1.weight"), x.W(p + "norm1.bias"));
+    float* o = mha_fwd(x, p + "self_attn", t2, L, t2, L, c->cfg.num_heads, nullptr, false, nullptr, 0, s.self);
+    if (x.err) return;
+    x.add(o, xx, rows * D);
+    xx = o;
+    o = time_block_fwd(x, p + "time_block1", xx, silu_temb, s.tb1);
+    if (x.err) return;
+    x.add(o, xx, rows * D);
+    xx = o;
+    s.x2 = xx;
+    t2 = x.ln(xx, rows, x.W(p + "norm2.weight"), x.W(p + "norm2.bias"));
+    float* cat = x.alloc((size_t)rows * CFD_NMEM * D);
+    for (int j = 0; j < CFD_NMEM; ++j) {
+      const std::string nm = MEM_NAMES[j];
+      const int S = a.mem[j].S;
+      float* m = x.ln(mems[j], (long long)B * S, x.W(p + nm + "_norm.weight"), x.W(p + nm + "_norm.bias"));
+      o = mha_fwd(x, p + "multihead_attn_" + nm, t2, L, m, S, 1, a.mem[j].key_padding_mask, j == 2, att + (size_t)i * L * St,
+                  (long long)NL * L * St, s.cross[j]);
+      if (x.err) return;
+      // torch.cat (cross_attention.py:629): column block j of [rows][5 D]
+      if (!x.dry) (void)hipMemcpy2DAsync(cat + (size_t)j * D, (size_t)CFD_NMEM * D * 4, o, (size_t)D * 4, (size_t)D * 4, (size_t)rows, hipMemcpyDeviceToDevice, x.st);
+    }
+    if (i == NL - 1) break;                                      // nothing above the last cross-attention reaches the objective
+    o = x.linear(cat, rows, CFD_NMEM * D, x.W(p + "att_fuser.weight"), x.W(p + "att_fuser.bias"), D);
+    x.add(o, xx, rows * D);
+    xx = o;
+    o = time_block_fwd(x, p + "time_block2", xx, silu_temb, s.tb2);
+    if (x.err) return;
+    x.add(o, xx, rows * D);
+    xx = o;
+    s.x4 = xx;
+    t2 = x.ln(xx, rows, x.W(p + "norm3.weight"), x.W(p + "norm3.bias"));
+    s.ffn_pre = x.linear(t2, rows, D, x.W(p + "linear1.weight"), x.W(p + "linear1.bias"), FF);
+    float* ge = x.alloc((size_t)rows * FF);
+    x.ew(EW_GELU, s.ffn_pre, nullptr, ge, rows * FF);
+    o = x.linear(ge, rows, FF, x.W(p + "linear2.weight"), x.W(p + "linear2.bias"), D);
+    x.add(o, xx, rows * D);
+    xx = o;
+  }
+  if (x.err) return;
+  // ---- the objective and its gradient with respect to the nine maps
+  const int W = a.last - 1;
+  float* ws = x.alloc((size_t)B * (3 * (size_t)L * W + 3 * (size_t)a.nt_max));
+  float* d_att = x.alloc((size_t)B * NL * L * St);
+  if (!x.dry)
+    hipLaunchKernelGGL(weg_focus_kernel, dim3((unsigned)B), dim3(256), 0, x.st, att, a.tok_off, a.tok_idx, B, NL, L, St, a.last, a.nt_max, a.k3[0],
+                       a.k3[1], a.k3[2], ws, a.losses, a.max_att, d_att);
+  // ---- reverse sweep
+  float* g = nullptr;
+  for (int i = NL - 1; i >= 0; --i) {
+    const std::string p = "decoder.layers." + std::to_string(i) + ".";
+    const LayerSaved& s = sv[i];
+    float* dcat = nullptr;
+    if (g) {
+      float* d1 = x.linear_bwd(g, rows, D, x.W(p + "linear2.weight"), FF);
+      x.ew(EW_GELU_BWD, d1, s.ffn_pre, d1, rows * FF);
+      float* d2 = x.linear_bwd(d1, rows, FF, x.W(p + "linear1.weight"), D);
+      x.ln_bwd(s.x4, x.W(p + "norm3.weight"), d2, g, rows, 1);
+      time_block_bwd(x, s.tb2, g);
+      dcat = x.linear_bwd(g, rows, D, x.W(p + "att_fuser.weight"), CFD_NMEM * D);
+    }
+    float* dt2 = nullptr;
+    for (int j = 0; j < CFD_NMEM; ++j) {
+      if (!dcat && j != 2) continue;
+      float* dout = nullptr;
+      if (dcat) {
+        dout = x.alloc((size_t)rows * D);
+        if (!x.dry) (void)hipMemcpy2DAsync(dout, (size_t)D * 4, dcat + (size_t)j * D, (size_t)CFD_NMEM * D * 4, (size_t)D * 4, (size_t)rows, hipMemcpyDeviceToDevice, x.st);
+      }
+      float* d = mha_bwd(x, s.cross[j], dout, j == 2 ? d_att + (size_t)i * L * St : nullptr, (long long)NL * L * St, false);
+      if (!dt2) dt2 = d;
+      else x.add(dt2, d, rows * D);
+    }
+    if (!g) {
+      g = x.alloc((size_t)rows * D);
+      x.zero(g, (size_t)rows * D);
+    }
+    x.ln_bwd(s.x2, x.W(p + "norm2.weight"), dt2, g, rows, 1);
+    time_block_bwd(x, s.tb1, g);
+    dt2 = mha_bwd(x, s.self, g, nullptr, 0, true);
+    x.ln_bwd(s.x0, x.W(p + "norm1.weight"), dt2, g, rows, 1);
+  }
+  x.linear_bwd(g, rows, D, x.W("latent_embd.weight"), LAT, a.grad);
+}
+
+}  // namespace weg

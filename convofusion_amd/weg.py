@@ -6,8 +6,11 @@ attend-and-excite objective on the listener-text attention maps of the text-only
 convofusion/models/tools/word_excitation_guidance.py:11-81).  It gets d(loss)/d(latents) from torch autograd over
 ``Denoiser.forward``; here the backward pass is written out: a float32 forward that keeps its activations and the
 reverse sweep, both strings of libcfdenoise launches (``cfd_gemm_f32`` on strided views -- every transpose is a view --
-``cfd_softmax(_bwd)``, ``cfd_layer_norm(_bwd)``, ``cfd_ew``, ``cfd_weg_focus``).  torch allocates, slices and permutes;
-it does no arithmetic.  There is no CPU fallback.
+``cfd_softmax(_bwd)``, ``cfd_layer_norm(_bwd)``, ``cfd_ew``, ``cfd_weg_focus``).  The product path is ``loss_and_grad`` =
+``cfd_weg_eval``: the library enqueues the whole evaluation itself (csrc/weg_eval.hpp; ~7x faster than one C call per
+kernel from Python).  ``forward_saved`` / ``attention_focus_loss`` / ``backward_to_sample`` string the same kernels
+together from here, one launch per call -- the inspectable form (``loss_and_grad_stepwise``) the tests compare against.
+torch allocates, slices and permutes; it does no arithmetic.  There is no CPU fallback.
 
 The gradient only flows through the query side: memories, time embedding and weights are constants, so the sweep
 needs no key / value gradients for the five cross-attentions and no weight gradients at all.
@@ -17,6 +20,7 @@ Public names follow the reference module (``aggregate_attentions`` + ``get_max_a
 instead of a graph) and the loop branch is ``weg_update`` / ``iterative_refinement_step``.
 """
 import ctypes as C
+import functools
 import math
 
 import numpy as np
@@ -310,6 +314,7 @@ def backward_to_sample(denoiser, saved, d_att_tlsn):
 
 
 # ----------------------------------------------------------------------------- the objective
+@functools.lru_cache(maxsize=4)
 def gaussian_kernel3(sigma=0.5):
     """GaussianSmoothing(channels=1, kernel_size=3, sigma=0.5, dim=2).weight with the reference's own float32 torch ops
     (gaussian_smoothing.py:28-43; a load-time table).  Returns (corner, edge, centre)."""
@@ -328,23 +333,9 @@ def attention_focus_loss(denoiser, att_tlsn, focus_indices, normalize_eot=False,
     Returns (loss 0-d tensor, losses [B], max_attention_at_indices list of lists of 0-d tensors, d_att [B, layers, L, S])."""
     dev = att_tlsn.device
     B, NL, L, S = att_tlsn.shape
-    if len(focus_indices) != B:
-        raise ValueError("focus_indices needs one list per batch row")
-    last = S - 1                                                                          # att_mat[:, :, 1:-1]
-    if normalize_eot:
-        assert len(eot_indices) > 0, "Need to provide eot indices for normalization"     # :24
-        assert B == 1, "EOS/BOS normalization only works for test batch size 1 currently"  # :25
-        last = int(eot_indices[0])
-        if last < 0:
-            last += S
+    last, off, flat = _focus_tables(B, S, focus_indices, normalize_eot, eot_indices)
     W = last - 1
-    for s in focus_indices:
-        for i in s:
-            if not 1 <= int(i) <= W:
-                raise IndexError(f"focus index {i} is outside the text slice [1, {last})")
-    off = np.cumsum([0] + [len(s) for s in focus_indices]).astype(np.int32)
     nt_max = max(1, int(max(len(s) for s in focus_indices)))
-    flat = np.array([int(i) for s in focus_indices for i in s] or [0], dtype=np.int32)
     tok_off = torch.from_numpy(off).to(dev)
     tok_idx = torch.from_numpy(flat).to(dev)
     ws = torch.empty(B * (3 * L * W + 3 * nt_max), dtype=torch.float32, device=dev)
@@ -363,11 +354,65 @@ def attention_focus_loss(denoiser, att_tlsn, focus_indices, normalize_eot=False,
     return loss, losses, mx, d_att
 
 
+def _focus_tables(B, S, focus_indices, normalize_eot, eot_indices):
+    """(last, offsets int32 [B + 1], flat indices int32) of the text slice and the focus tokens (weg.py:19-28,40-49)."""
+    if len(focus_indices) != B:
+        raise ValueError("focus_indices needs one list per batch row")
+    last = S - 1                                                                          # att_mat[:, :, 1:-1]
+    if normalize_eot:
+        assert len(eot_indices) > 0, "Need to provide eot indices for normalization"     # :24
+        assert B == 1, "EOS/BOS normalization only works for test batch size 1 currently"  # :25
+        last = int(eot_indices[0])
+        if last < 0:
+            last += S
+    for s in focus_indices:
+        for i in s:
+            if not 1 <= int(i) <= last - 1:
+                raise IndexError(f"focus index {i} is outside the text slice [1, {last})")
+    off = np.cumsum([0] + [len(s) for s in focus_indices]).astype(np.int32)
+    flat = np.array([int(i) for s in focus_indices for i in s] or [0], dtype=np.int32)
+    return last, off, flat
+
+
 def loss_and_grad(denoiser, latents, timestep, encoder_hidden_states, cond_masks, focus_indices, normalize_eot=True, eot_indices=None):
-    """One evaluation of the WEG objective on the text-only chunk (convofusion.py:447-471) and d(loss)/d(latents):
-    returns (loss, losses, max_attention_at_indices, grad [B, L, 128])."""
+    """One evaluation of the WEG objective on the text-only chunk (convofusion.py:447-471) and d(loss)/d(latents) --
+    ``cfd_weg_eval``: forward with saved activations, objective and backward sweep enqueued by the library.
+    Returns (loss 0-d tensor, losses [B], max_attention_at_indices, grad [B, L, 128])."""
+    if not isinstance(denoiser, Denoiser):
+        raise TypeError("denoiser must be a convofusion_amd.denoiser.Denoiser")
+    dev = latents.device
+    if dev.type != "cuda":
+        raise RuntimeError("WEG runs on an MI355X only (tensors must be on 'cuda'); no CPU fallback")
     if eot_indices is None:
         eot_indices = torch.argmax(cond_masks["tlsn"].int(), dim=1) - 1                   # :460 (index look-up)
+    B, L, _ = latents.shape
+    if encoder_hidden_states[0].shape[0] != B:
+        raise ValueError("the conditioning tuple must have one row per latent row (the text-only chunk)")
+    last, off, flat = _focus_tables(B, int(encoder_hidden_states[TLSN].shape[1]), focus_indices, normalize_eot, eot_indices)
+    lat = latents.detach().to(torch.float32).contiguous()
+    handle = denoiser.engine(dev, mem_len=max(int(m.shape[1]) for m in encoder_hidden_states))
+    marr, keep = Denoiser.pack_memories(encoder_hidden_states, cond_masks)
+    a = _lib.WegArgs()
+    a.B, a.L, a.timestep, a.latents, a.mem = B, L, int(timestep), lat.data_ptr(), marr
+    a.tok_off, a.tok_idx, a.last = off.ctypes.data, flat.ctypes.data, last
+    a.kernel3 = (C.c_float * 3)(*gaussian_kernel3())
+    losses = torch.empty(B, dtype=torch.float32, device=dev)
+    max_att = torch.empty(max(1, int(off[-1])), dtype=torch.float32, device=dev)
+    grad = torch.empty_like(lat)
+    loss = C.c_float()
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().cfd_weg_eval(handle, C.byref(a), C.c_void_p(losses.data_ptr()), C.c_void_p(max_att.data_ptr()),
+                                            C.c_void_p(grad.data_ptr()), C.byref(loss), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    mx = [[max_att[off[b] + k] for k in range(len(focus_indices[b]))] for b in range(B)]
+    return torch.tensor(loss.value), losses, mx, grad
+
+
+def loss_and_grad_stepwise(denoiser, latents, timestep, encoder_hidden_states, cond_masks, focus_indices, normalize_eot=True,
+                           eot_indices=None):
+    """The same evaluation strung together from this module's launch wrappers (one C call per kernel): the inspectable
+    form the tests use to look at intermediate tensors; ``loss_and_grad`` is the product path."""
+    if eot_indices is None:
+        eot_indices = torch.argmax(cond_masks["tlsn"].int(), dim=1) - 1
     att, saved = forward_saved(denoiser, latents, timestep, encoder_hidden_states, cond_masks)
     loss, losses, mx, d_att = attention_focus_loss(denoiser, att, focus_indices, normalize_eot, eot_indices)
     grad = backward_to_sample(denoiser, saved, d_att)

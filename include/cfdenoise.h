@@ -198,6 +198,23 @@ int cfd_ew(cfd_handle h, int op, const float* a, const float* b, float* out, siz
            void* stream);
 int cfd_weg_focus(cfd_handle h, const float* att, int B, int NL, int L, int S, const int32_t* tok_off, const int32_t* tok_idx, int last, int nt_max,
                   const float kernel3[3], float* workspace, float* losses, float* max_att, float* d_att, void* stream);
+/* One evaluation of the WEG objective on the text-only guidance chunk and d(loss)/d(latents), all launches enqueued from
+ * C++: replaces  latents.requires_grad_(True); _, att = denoiser(latents, t, text_only_states, ...);
+ * loss = compute_attention_focus_loss(get_max_attention_at_indices(aggregate_attentions(att[2]), ...));
+ * torch.autograd.grad(loss, latents)   (convofusion.py:447-471,490-495; iterative_refinement_step :322-346,372-386).
+ *   losses dev [B], max_att dev [tok_off[B]] (>= 1 float), grad dev [B][L][128]; loss_host (may be NULL): mean of losses,
+ *   copied back after a stream synchronise (the loop branches on it: `loss > 1 - threshold`, `loss != 0`). */
+typedef struct {
+  int B, L;                      /* rows of the text-only chunk (the reference requires B == 1 with normalize_eot) */
+  int timestep;
+  const float* latents;          /* dev [B][L][128] */
+  cfd_memory mem[CFD_NUM_MEM];   /* chunk 1 of the guidance batch: U == B, row_map NULL, masks as in cfd_forward */
+  const int32_t* tok_off;        /* HOST [B + 1] offsets into tok_idx */
+  const int32_t* tok_idx;        /* HOST focus token positions (text positions, BOS = 0), each in [1, last) */
+  int last;                      /* text slice [1, last): eot index (normalize_eot) or S_text - 1 */
+  float kernel3[3];              /* {corner, edge, centre} of GaussianSmoothing(1, 3, 0.5, dim=2).weight */
+} cfd_weg_args;
+int cfd_weg_eval(cfd_handle h, const cfd_weg_args* args, float* losses, float* max_att, float* grad, float* loss_host, void* stream);
 int cfd_sample_write(cfd_handle h, const float* latents);
 int cfd_sample_inpaint(cfd_handle h);
 

@@ -29,7 +29,7 @@ def test_gemm_f32_strided_views():
     ops = _ops()
     rng = np.random.Generator(np.random.PCG64(1))
     # plain, transposed operands, ragged sizes
-    for M, N, K in [(16, 512, 512), (70, 33, 129), (1, 5, 7), (130, 64, 16)]:
+    for M, N, K in [(16, 512, 512), (70, 33, 129), (1, 5, 7), (130, 64, 16), (16, 40, 1100), (300, 40, 50)]:   # > 256 rows: the tiled kernel
         a, b = rng.standard_normal((M, K), dtype=np.float32), rng.standard_normal((N, K), dtype=np.float32)
         bias = rng.standard_normal(N, dtype=np.float32)
         ref = 0.5 * (a.astype(np.float64) @ b.astype(np.float64).T) + bias
@@ -143,6 +143,9 @@ def test_gradient_matches_oracle_and_reference_autograd(name):
     assert e_or < 1e-3 and e_ref < 1e-3
     upd = weg.update_latent(to_dev(inp["sample"]), to_dev(grad), 1000 * np.sqrt(0.9), m).cpu().numpy()
     assert rel_l2(upd, g[name + ".updated"]) < 1e-4
+    # the launch-by-launch form of the same evaluation
+    l3, _, _, g3 = weg.loss_and_grad_stepwise(m, to_dev(inp["sample"]), t, mems, masks, focus, neot, to_dev(eot))
+    assert abs(float(l3) - float(loss)) < 1e-6 and rel_l2(g3.cpu().numpy(), grad) < 1e-5
     # attention maps of the saved-activation forward against the reference's
     att, _ = weg.forward_saved(m, to_dev(inp["sample"]), t, mems, masks)
     assert np.abs(att.cpu().numpy() - g[name + ".att_tlsn"]).max() < (2e-4 if "sharp" in name else 1e-5)   # sharp: logits of +-40
