@@ -121,6 +121,8 @@ struct cfd_handle_s {
   bool share0 = true;       // CFD_SHARE0=0: evaluate the pre-cross-attention part of layer 0 for every guidance replica
   DBuf d_step;  // [0] = loop index, [1] = constant 0, [2] = "this iteration's in-painting overwrite is done" (cfd_sample_inpaint)
   DBuf weg_ws, weg_tok;   // cfd_weg_eval: activation arena, focus-token tables
+  std::vector<int32_t> weg_tok_host;
+  int weg_launches = 0;
   Problem pb;
   // profiling
   bool prof = false;
@@ -1434,29 +1436,35 @@ extern "C" int cfd_weg_eval(cfd_handle c, const cfd_weg_args* a, float* losses, 
     if (a->tok_idx[t] < 1 || a->tok_idx[t] > a->last - 1) return fail(CFD_E_ARG, "focus index %d is outside the text slice [1, %d)", a->tok_idx[t], a->last);
   HIPCHK(hipSetDevice(c->cfg.device));
   hipStream_t st = (hipStream_t)stream;
-  // focus-token tables to the device (the stream may still read the previous call's copy)
-  HIPCHK(hipStreamSynchronize(st));
-  CHK(c->weg_tok.ensure((size_t)(B + 1 + std::max(1, n_tok)) * 4));
-  HIPCHK(hipMemcpy(c->weg_tok.p, a->tok_off, (size_t)(B + 1) * 4, hipMemcpyHostToDevice));
-  if (n_tok > 0) HIPCHK(hipMemcpy(c->weg_tok.as<int32_t>() + B + 1, a->tok_idx, (size_t)n_tok * 4, hipMemcpyHostToDevice));
-  weg::Args wa{a->latents, a->timestep, a->mem, c->weg_tok.as<int32_t>(), c->weg_tok.as<int32_t>() + B + 1, a->last, nt_max, n_tok,
-               {a->kernel3[0], a->kernel3[1], a->kernel3[2]}, losses, max_att, grad};
-  weg::Ctx x{c, st, true, reinterpret_cast<char*>(256), 0, B, L, D, D, CFD_OK, std::string()};
+  std::vector<int32_t> tok(a->tok_off, a->tok_off + B + 1);
+  tok.insert(tok.end(), a->tok_idx, a->tok_idx + n_tok);
+  if (tok != c->weg_tok_host) {                       // focus-token tables to the device (the stream may still read the old copy)
+    HIPCHK(hipStreamSynchronize(st));
+    CHK(c->weg_tok.ensure((size_t)(B + 1 + std::max(1, n_tok)) * 4));
+    HIPCHK(hipMemcpy(c->weg_tok.p, tok.data(), tok.size() * 4, hipMemcpyHostToDevice));
+    c->weg_tok_host = tok;
+  }
+  weg::Args wa{a->latents, c->tsin.as<float>() + (size_t)a->timestep * D, a->mem, c->weg_tok.as<int32_t>(), c->weg_tok.as<int32_t>() + B + 1,
+               a->last, nt_max, {a->kernel3[0], a->kernel3[1], a->kernel3[2]}, losses, max_att, grad};
+  weg::Ctx x{c, st, true, reinterpret_cast<char*>(256), 0, B, L, D, D, CFD_OK, std::string(), 0};
   weg::run(x, wa);                                   // sizing pass
   if (x.err) return fail(x.err, "missing tensor '%s' (state-dict key denoiser.%s)", x.missing.c_str(), x.missing.c_str());
+  if (x.off > c->weg_ws.bytes) HIPCHK(hipStreamSynchronize(st));
   CHK(c->weg_ws.ensure(x.off));
   x.dry = false;
   x.base = c->weg_ws.as<char>();
   x.off = 0;
+  x.launches = 0;
   weg::run(x, wa);
   HIPCHK(hipGetLastError());
+  c->weg_launches = x.launches;
   if (loss_host) {                                   // torch.mean(losses) over the batch (word_excitation_guidance.py:80)
     std::vector<float> l(B);
     HIPCHK(hipMemcpyAsync(l.data(), losses, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += l[b];
-    *loss_host = s / (float)B;
+    float sum = 0.f;
+    for (int b = 0; b < B; ++b) sum += l[b];
+    *loss_host = sum / (float)B;
   }
   return CFD_OK;
 }

@@ -14,9 +14,14 @@ struct MatView {
 
 // C(z; m, n) = alpha * sum_k A(z; m, k) B(z; k, n) + bias[n] (+ C(z; m, n) when accumulate); ascending-k FMA chain per
 // output.  64 x 64 output tile per 256-thread workgroup (4 x 4 per thread), K-step 16 through LDS.
+__device__ __forceinline__ float act_f32(float x, int act) {   // 0 none, 1 nn.SiLU, 2 nn.GELU (erf form)
+  return act == 1 ? x / (1.0f + expf(-x)) : (act == 2 ? gelu_f(x) : x);
+}
+
+// + resid(z; m, n) (same strides as C; the residual connection) ; a_act: activation applied to A's elements as they are read
 __global__ void __launch_bounds__(256) gemm_f32_kernel(MatView A, MatView B, float* C, long long c_rs, long long c_cs, long long c_b1,
                                                        long long c_b2, int M, int N, int K, int nb2, const float* bias, float alpha,
-                                                       int accumulate) {
+                                                       int accumulate, const float* resid, int a_act) {
   __shared__ float As[16][68];
   __shared__ float Bs[16][68];
   const int z1 = blockIdx.z / nb2, z2 = blockIdx.z % nb2;
@@ -37,7 +42,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(MatView A, MatView B, flo
       const int e = tid + 256 * i;
       int mm, kk;
       if (a_k_fast) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }
-      As[kk][mm] = (m0 + mm < M && k0 + kk < K) ? a[(long long)(m0 + mm) * A.rs + (long long)(k0 + kk) * A.cs] : 0.f;
+      As[kk][mm] = (m0 + mm < M && k0 + kk < K) ? act_f32(a[(long long)(m0 + mm) * A.rs + (long long)(k0 + kk) * A.cs], a_act) : 0.f;
       int nn, kb;
       if (b_n_fast) { nn = e & 63; kb = e >> 6; } else { kb = e & 15; nn = e >> 4; }
       Bs[kb][nn] = (n0 + nn < N && k0 + kb < K) ? b[(long long)(k0 + kb) * B.rs + (long long)(n0 + nn) * B.cs] : 0.f;
@@ -67,9 +72,10 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(MatView A, MatView B, flo
       if (n >= N) continue;
       float v = alpha * acc[i][j];
       if (bias) v += bias[n];
-      float* dst = c + (long long)m * c_rs + (long long)n * c_cs;
-      if (accumulate) v += *dst;
-      *dst = v;
+      const long long o = (long long)m * c_rs + (long long)n * c_cs;
+      if (resid) v += resid[z1 * c_b1 + z2 * c_b2 + o];
+      if (accumulate) v += c[o];
+      c[o] = v;
     }
   }
 }
@@ -78,11 +84,11 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(MatView A, MatView B, flo
 // tiled kernel above would run 8 workgroups of 32 dependent k-steps: one workgroup = 16 rows x 16 columns, its 256
 // threads = 16 columns x 16 k-slices (thread (tn, tk) accumulates k = tk, tk + 16, ... for all 16 rows; A goes through
 // LDS in k-chunks of 512, B streams from global memory once), partial sums meet in LDS and are added in ascending tk.
-// N / 16 x M / 16 workgroups instead of N / 64 x M / 64, and no barrier inside a k-chunk.
+// N / 16 x M / 16 workgroups instead of N / 64 x M / 64, and one memory round trip per k-chunk.
 #define R16_KC 512
 __global__ void __launch_bounds__(256) gemm_f32_rows16_kernel(MatView A, MatView B, float* C, long long c_rs, long long c_cs, long long c_b1,
                                                               long long c_b2, int M, int N, int K, int nb2, const float* bias, float alpha,
-                                                              int accumulate) {
+                                                              int accumulate, const float* resid, int a_act) {
   __shared__ __attribute__((aligned(16))) float As[R16_KC][20];   // [k][row], rows padded to 20 (16-byte aligned float4 reads)
   __shared__ float red[16][16][17];                                // [tk][tn][row]
   const int z1 = blockIdx.z / nb2, z2 = blockIdx.z % nb2;
@@ -98,28 +104,42 @@ __global__ void __launch_bounds__(256) gemm_f32_rows16_kernel(MatView A, MatView
   float acc[16];
 #pragma unroll
   for (int m = 0; m < 16; ++m) acc[m] = 0.f;
+  // This is latency-bound work (one workgroup owns a 512-deep dependent chain): every global load of a k-chunk -- the
+  // thread's 32 B values and its 32 A values -- is issued before anything waits, so a chunk costs one memory round trip.
+  const int am = a_k_fast ? (tid >> 4) : (tid & 15), ak = a_k_fast ? (tid & 15) : (tid >> 4);   // A element (am, ak + 16 i)
+  const bool am_ok = m0 + am < M;
   for (int k0 = 0; k0 < K; k0 += R16_KC) {
     const int kc = min(R16_KC, K - k0);
-    for (int e = tid; e < 16 * kc; e += 256) {
-      int m, kk;
-      if (a_k_fast) { kk = e % kc; m = e / kc; } else { m = e & 15; kk = e >> 4; }
-      As[kk][m] = (m0 + m < M) ? a[(long long)(m0 + m) * A.rs + (long long)(k0 + kk) * A.cs] : 0.f;
+    const float* bp = b + (long long)k0 * B.rs + (long long)n * B.cs;
+    const float* ap = a + (long long)(m0 + am) * A.rs + (long long)k0 * A.cs;
+    float bv[R16_KC / 16], av[R16_KC / 16];
+#pragma unroll
+    for (int i = 0; i < R16_KC / 16; ++i) {
+      const int kb = tk + 16 * i, ka = ak + 16 * i;
+      bv[i] = (n_ok && kb < kc) ? bp[(long long)kb * B.rs] : 0.f;
+      av[i] = (am_ok && ka < kc) ? ap[(long long)ka * A.cs] : 0.f;
     }
+    if (a_act) {
+#pragma unroll
+      for (int i = 0; i < R16_KC / 16; ++i) av[i] = (am_ok && ak + 16 * i < kc) ? act_f32(av[i], a_act) : 0.f;
+    }
+    if (k0) __syncthreads();          // the previous chunk's LDS reads are done
+#pragma unroll
+    for (int i = 0; i < R16_KC / 16; ++i) As[ak + 16 * i][am] = av[i];
     __syncthreads();
-    if (n_ok) {
-      const float* bp = b + (long long)k0 * B.rs + (long long)n * B.cs;
-#pragma unroll 4
-      for (int kk = tk; kk < kc; kk += 16) {
-        const float bv = bp[(long long)kk * B.rs];
+#pragma unroll
+    for (int i = 0; i < R16_KC / 16; ++i) {
+      const int kk = tk + 16 * i;
+      if (kk < kc) {
         const float4* ar = reinterpret_cast<const float4*>(&As[kk][0]);
         const float4 a0 = ar[0], a1 = ar[1], a2 = ar[2], a3 = ar[3];
-        acc[0] = fmaf(a0.x, bv, acc[0]); acc[1] = fmaf(a0.y, bv, acc[1]); acc[2] = fmaf(a0.z, bv, acc[2]); acc[3] = fmaf(a0.w, bv, acc[3]);
-        acc[4] = fmaf(a1.x, bv, acc[4]); acc[5] = fmaf(a1.y, bv, acc[5]); acc[6] = fmaf(a1.z, bv, acc[6]); acc[7] = fmaf(a1.w, bv, acc[7]);
-        acc[8] = fmaf(a2.x, bv, acc[8]); acc[9] = fmaf(a2.y, bv, acc[9]); acc[10] = fmaf(a2.z, bv, acc[10]); acc[11] = fmaf(a2.w, bv, acc[11]);
-        acc[12] = fmaf(a3.x, bv, acc[12]); acc[13] = fmaf(a3.y, bv, acc[13]); acc[14] = fmaf(a3.z, bv, acc[14]); acc[15] = fmaf(a3.w, bv, acc[15]);
+        const float w = bv[i];
+        acc[0] = fmaf(a0.x, w, acc[0]); acc[1] = fmaf(a0.y, w, acc[1]); acc[2] = fmaf(a0.z, w, acc[2]); acc[3] = fmaf(a0.w, w, acc[3]);
+        acc[4] = fmaf(a1.x, w, acc[4]); acc[5] = fmaf(a1.y, w, acc[5]); acc[6] = fmaf(a1.z, w, acc[6]); acc[7] = fmaf(a1.w, w, acc[7]);
+        acc[8] = fmaf(a2.x, w, acc[8]); acc[9] = fmaf(a2.y, w, acc[9]); acc[10] = fmaf(a2.z, w, acc[10]); acc[11] = fmaf(a2.w, w, acc[11]);
+        acc[12] = fmaf(a3.x, w, acc[12]); acc[13] = fmaf(a3.y, w, acc[13]); acc[14] = fmaf(a3.z, w, acc[14]); acc[15] = fmaf(a3.w, w, acc[15]);
       }
     }
-    __syncthreads();
   }
 #pragma unroll
   for (int m = 0; m < 16; ++m) red[tk][tn][m] = acc[m];
@@ -131,21 +151,23 @@ __global__ void __launch_bounds__(256) gemm_f32_rows16_kernel(MatView A, MatView
     for (int t = 0; t < 16; ++t) v += red[t][on][om];
     v *= alpha;
     if (bias) v += bias[n0 + on];
-    float* dst = c + (long long)(m0 + om) * c_rs + (long long)(n0 + on) * c_cs;
-    if (accumulate) v += *dst;
-    *dst = v;
+    const long long o = (long long)(m0 + om) * c_rs + (long long)(n0 + on) * c_cs;
+    if (resid) v += resid[z1 * c_b1 + z2 * c_b2 + o];
+    if (accumulate) v += c[o];
+    c[o] = v;
   }
 }
 
 // launch the product with the kernel that fits its shape
 static inline void launch_gemm_f32(hipStream_t st, const MatView& a, const MatView& b, float* C, long long c_rs, long long c_cs, long long c_b1,
-                                   long long c_b2, int M, int N, int K, int nb1, int nb2, const float* bias, float alpha, int accumulate) {
+                                   long long c_b2, int M, int N, int K, int nb1, int nb2, const float* bias, float alpha, int accumulate,
+                                   const float* resid = nullptr, int a_act = 0) {
   if (M <= 256)
     hipLaunchKernelGGL(gemm_f32_rows16_kernel, dim3((unsigned)((N + 15) / 16), (unsigned)((M + 15) / 16), (unsigned)(nb1 * nb2)), dim3(256), 0, st, a, b,
-                       C, c_rs, c_cs, c_b1, c_b2, M, N, K, nb2, bias, alpha, accumulate);
+                       C, c_rs, c_cs, c_b1, c_b2, M, N, K, nb2, bias, alpha, accumulate, resid, a_act);
   else
     hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)(nb1 * nb2)), dim3(256), 0, st, a, b, C,
-                       c_rs, c_cs, c_b1, c_b2, M, N, K, nb2, bias, alpha, accumulate);
+                       c_rs, c_cs, c_b1, c_b2, M, N, K, nb2, bias, alpha, accumulate, resid, a_act);
 }
 
 // In-place softmax over the last axis of scores [rows][Lk]; key_padding_mask [batch][Lk] (1 = ignore), the batch of a
@@ -237,6 +259,16 @@ __global__ void __launch_bounds__(256) layernorm_bwd_f32_kernel(const float* x, 
 }
 
 enum { EW_SILU = 0, EW_GELU = 1, EW_SILU_BWD = 2, EW_GELU_BWD = 3, EW_AXPY = 4, EW_ADD_BCAST = 5, EW_MODULATE = 6, EW_MODULATE_BWD = 7, EW_NOPS = 8 };
+
+// TimeBlock backward between its output projection and its LayerNorm in one pass: out = a * SiLU'(h) * (1 + e[d])
+// (h the modulated LayerNorm output kept by the forward, e the block's [scale | shift] row)
+__global__ void __launch_bounds__(256) tb_bwd_f32_kernel(const float* a, const float* h, const float* e, float* out, long long n, int D) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float y = h[i], sg = 1.0f / (1.0f + expf(-y));
+  out[i] = a[i] * (sg * (1.0f + y * (1.0f - sg))) * (1.0f + e[i % D]);
+}
+
 
 // Element-wise pieces of the forward / backward pass over a [R0][R1][D] tensor (index i -> d = i % D, r1 = (i / D) % R1,
 // r0 = i / (D R1)):

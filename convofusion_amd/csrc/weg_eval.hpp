@@ -17,8 +17,8 @@ struct View {           // element (z1, z2, r, c) = p[z1*b1 + z2*b2 + r*rs + c*c
 };
 
 struct AttnSaved {
-  float *q, *k, *v, *p;      // q / k / v batch-major [B][T or S][E]; p: probabilities of (b, h) at p + b*pb1 + h*T*S
-  long long pb1;
+  float *q, *k, *v, *p;      // q rows q_rs apart ([B][T] rows), k / v rows kv_rs apart ([B][S] rows); probabilities of (b, h) at p + b*pb1 + h*T*S
+  long long q_rs, kv_rs, pb1;
   const float *W, *Wo;       // in_proj_weight [3E][E], out_proj.weight [E][E]
   int T, S, H;
   float scale;
@@ -44,6 +44,7 @@ struct Ctx {
   int B, L, D, E;
   int err;
   std::string missing;
+  int launches;
 
   float* alloc(size_t n) {
     const size_t bytes = (n * 4 + 255) & ~(size_t)255;
@@ -60,152 +61,166 @@ struct Ctx {
     }
     return it->second.as<float>();
   }
-  void gemm(int M, int N, int K, int nb1, int nb2, View A, View Bv, View Cv, const float* bias, float alpha, int accumulate) {
-    if (dry || err) return;
-    MatView a{A.p, A.rs, A.cs, A.b1, A.b2}, b{Bv.p, Bv.rs, Bv.cs, Bv.b1, Bv.b2};
-    launch_gemm_f32(st, a, b, Cv.p, Cv.rs, Cv.cs, Cv.b1, Cv.b2, M, N, K, nb1, nb2, bias, alpha, accumulate);
+  bool skip() {
+    ++launches;
+    return dry || err;
   }
-  // F.linear on [rows][K] -> [rows][N]; w [N][K]
-  float* linear(const float* x, long long rows, int K, const float* w, const float* bias, int N, float* out = nullptr) {
-    if (!out) out = alloc((size_t)rows * N);
-    gemm((int)rows, N, K, 1, 1, View{const_cast<float*>(x), K, 1, 0, 0}, View{const_cast<float*>(w), 1, K, 0, 0}, View{out, N, 1, 0, 0}, bias, 1.0f, 0);
+  void gemm(int M, int N, int K, int nb1, int nb2, View A, View Bv, View Cv, const float* bias, float alpha, int accumulate,
+            const float* resid = nullptr, int a_act = 0) {
+    if (skip()) return;
+    MatView a{A.p, A.rs, A.cs, A.b1, A.b2}, b{Bv.p, Bv.rs, Bv.cs, Bv.b1, Bv.b2};
+    launch_gemm_f32(st, a, b, Cv.p, Cv.rs, Cv.cs, Cv.b1, Cv.b2, M, N, K, nb1, nb2, bias, alpha, accumulate, resid, a_act);
+  }
+  // F.linear: x rows x_rs apart, [rows][K] -> out rows out_rs apart [rows][N]; w [N][K]; + resid (out's layout); a_act on x
+  float* linear(const float* x, long long x_rs, long long rows, int K, const float* w, const float* bias, int N, float* out = nullptr,
+                long long out_rs = 0, const float* resid = nullptr, int a_act = 0) {
+    if (!out) {
+      out = alloc((size_t)rows * N);
+      out_rs = N;
+    }
+    gemm((int)rows, N, K, 1, 1, View{const_cast<float*>(x), x_rs, 1, 0, 0}, View{const_cast<float*>(w), 1, K, 0, 0}, View{out, out_rs, 1, 0, 0}, bias,
+         1.0f, 0, resid, a_act);
     return out;
   }
-  // gradient of F.linear(x, w) with respect to x: dy [rows][N] @ w [N][K]
-  float* linear_bwd(const float* dy, long long rows, int N, const float* w, int K, float* out = nullptr, int accumulate = 0) {
+  // gradient of F.linear(x, w) with respect to x: dy (rows dy_rs apart) [rows][N] @ w [N][K]
+  float* linear_bwd(const float* dy, long long dy_rs, long long rows, int N, const float* w, int K, float* out = nullptr, int accumulate = 0) {
     if (!out) out = alloc((size_t)rows * K);
-    gemm((int)rows, K, N, 1, 1, View{const_cast<float*>(dy), N, 1, 0, 0}, View{const_cast<float*>(w), K, 1, 0, 0}, View{out, K, 1, 0, 0}, nullptr, 1.0f,
-         accumulate);
+    gemm((int)rows, K, N, 1, 1, View{const_cast<float*>(dy), dy_rs, 1, 0, 0}, View{const_cast<float*>(w), K, 1, 0, 0}, View{out, K, 1, 0, 0}, nullptr,
+         1.0f, accumulate);
     return out;
   }
   void softmax(float* s, long long rows, int Lk, const uint8_t* kpm, long long rows_per_batch) {
-    if (dry || err) return;
+    if (skip()) return;
     hipLaunchKernelGGL(softmax_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, s, kpm, rows, Lk, rows_per_batch);
   }
   void softmax_bwd(const float* p, float* dp, const float* extra, long long rows, int Lk) {
-    if (dry || err) return;
+    if (skip()) return;
     hipLaunchKernelGGL(softmax_bwd_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, dp, extra, rows, Lk);
   }
   float* ln(const float* x, long long rows, const float* g, const float* b) {
     float* out = alloc((size_t)rows * D);
-    if (!dry && !err) hipLaunchKernelGGL(layernorm_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, g, b, out, rows, D, 1e-5f);
+    if (!skip()) hipLaunchKernelGGL(layernorm_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, g, b, out, rows, D, 1e-5f);
     return out;
   }
   void ln_bwd(const float* x, const float* g, const float* dy, float* dx, long long rows, int accumulate) {
-    if (dry || err) return;
+    if (skip()) return;
     hipLaunchKernelGGL(layernorm_bwd_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, g, dy, dx, rows, D, 1e-5f, accumulate);
   }
   void ew(int op, const float* a, const float* b, float* out, long long n, int Dd = 1, int R1 = 1, long long s0 = 0, long long s1 = 0, float alpha = 0.f) {
-    if (dry || err) return;
+    if (skip()) return;
     hipLaunchKernelGGL(ew_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, op, a, b, out, n, Dd, R1, s0, s1, alpha);
-  }
-  void add(float* x, const float* y, long long n) {
-    if (dry || err) return;
-    hipLaunchKernelGGL(add_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
-  }
-  void zero(float* x, size_t n) {
-    if (dry || err) return;
-    (void)hipMemsetAsync(x, 0, n * 4, st);
   }
 };
 
-// head view of a batch-major [B][n][E] tensor: (b, h; t, d)
-static inline View heads(float* t, int n, int E, int hd) { return View{t, E, 1, (long long)n * E, hd}; }
-static inline View heads_T(float* t, int n, int E, int hd) { return View{t, 1, E, (long long)n * E, hd}; }   // (b, h; d, t)
+// head views of batch-major rows (row stride rs, n rows per batch entry): (b, h; t, d) and its transpose (b, h; d, t)
+static inline View heads(float* t, int n, long long rs, int hd) { return View{t, rs, 1, (long long)n * rs, hd}; }
+static inline View heads_T(float* t, int n, long long rs, int hd) { return View{t, 1, rs, (long long)n * rs, hd}; }
 
-// nn.MultiheadAttention(query, memory, memory, key_padding_mask) on batch-major rows.  `p_out`: where the probabilities go
-// ([B] blocks of H*T*S floats, pb1 apart), or null to allocate [B][H][T][S].
-static float* mha_fwd(Ctx& x, const std::string& pfx, const float* query, int T, const float* memory, int S, int H, const uint8_t* kpm,
-                      bool use_p_out, float* p_out, long long pb1, AttnSaved& sv) {
+// nn.MultiheadAttention(query, memory, memory, key_padding_mask) on batch-major rows; self-attention (memory == query) projects
+// q | k | v in one product, cross-attention k | v.  The output projection writes rows out_rs apart (a column block of the
+// concatenated tensor, cross_attention.py:629) and adds `resid` (the residual connection) when given.
+static float* mha_fwd(Ctx& x, const std::string& pfx, const float* query, int T, const float* memory, int S, int H, const uint8_t* kpm, bool self,
+                      bool use_p_out, float* p_out, long long pb1, float* out, long long out_rs, const float* resid, AttnSaved& sv) {
   const int E = x.E, hd = E / H, B = x.B;
   const float* W = x.W(pfx + ".in_proj_weight");
   const float* Bi = x.W(pfx + ".in_proj_bias");
   const float* Wo = x.W(pfx + ".out_proj.weight");
   const float* bo = x.W(pfx + ".out_proj.bias");
   if (x.err) return nullptr;
-  float* q = x.linear(query, (long long)B * T, E, W, Bi, E);
-  float* k = x.linear(memory, (long long)B * S, E, W + (size_t)E * E, Bi + E, E);
-  float* v = x.linear(memory, (long long)B * S, E, W + (size_t)2 * E * E, Bi + 2 * E, E);
+  float *q, *k, *v;
+  long long q_rs, kv_rs;
+  if (self) {
+    q = x.linear(query, E, (long long)B * T, E, W, Bi, 3 * E);
+    k = q + E;
+    v = q + 2 * E;
+    q_rs = kv_rs = 3 * E;
+  } else {
+    q = x.linear(query, E, (long long)B * T, E, W, Bi, E);
+    k = x.linear(memory, E, (long long)B * S, E, W + (size_t)E * E, Bi + E, 2 * E);
+    v = k + E;
+    q_rs = E;
+    kv_rs = 2 * E;
+  }
   float* p = p_out;
   if (!use_p_out) {
     p = x.alloc((size_t)B * H * T * S);
     pb1 = (long long)H * T * S;
   }
   const float scale = (float)std::sqrt(1.0 / (double)hd);
-  x.gemm(T, S, hd, B, H, heads(q, T, E, hd), heads_T(k, S, E, hd), View{p, S, 1, pb1, (long long)T * S}, nullptr, scale, 0);
+  x.gemm(T, S, hd, B, H, heads(q, T, q_rs, hd), heads_T(k, S, kv_rs, hd), View{p, S, 1, pb1, (long long)T * S}, nullptr, scale, 0);
   if (pb1 == (long long)H * T * S) x.softmax(p, (long long)B * H * T, S, kpm, (long long)H * T);
   else
     for (int b = 0; b < B; ++b) x.softmax(p + b * pb1, (long long)H * T, S, kpm ? kpm + (size_t)b * S : nullptr, (long long)H * T);
   float* o = x.alloc((size_t)B * T * E);
-  x.gemm(T, hd, S, B, H, View{p, S, 1, pb1, (long long)T * S}, heads(v, S, E, hd), heads(o, T, E, hd), nullptr, 1.0f, 0);
-  float* out = x.linear(o, (long long)B * T, E, Wo, bo, E);
-  sv = AttnSaved{q, k, v, p, pb1, W, Wo, T, S, H, scale};
+  x.gemm(T, hd, S, B, H, View{p, S, 1, pb1, (long long)T * S}, heads(v, S, kv_rs, hd), heads(o, T, E, hd), nullptr, 1.0f, 0);
+  out = x.linear(o, E, (long long)B * T, E, Wo, bo, E, out, out_rs, resid);
+  sv = AttnSaved{q, k, v, p, q_rs, kv_rs, pb1, W, Wo, T, S, H, scale};
   return out;
 }
 
-// Gradient with respect to the query input (self-attention: the sum of the query / key / value paths).  `dout` may be
-// null (nothing arrives through the output); `d_prob` (same layout as p, blocks dpb1 apart) arrives at the probabilities.
-static float* mha_bwd(Ctx& x, const AttnSaved& sv, const float* dout, const float* d_prob, long long dpb1, bool self_attention) {
+// Gradient with respect to the query input into dx (+= when accumulate); self-attention: the query / key / value paths in
+// one product against the packed in-projection.  `dout` (rows dout_rs apart) may be null: nothing arrives through the output;
+// `d_prob` (layout of p, blocks dpb1 apart) arrives at the probabilities.
+static void mha_bwd(Ctx& x, const AttnSaved& sv, const float* dout, long long dout_rs, const float* d_prob, long long dpb1, bool self, float* dx,
+                    int accumulate) {
   const int E = x.E, H = sv.H, hd = E / H, B = x.B, T = sv.T, S = sv.S;
   const long long blk = (long long)H * T * S;
   float* dp = x.alloc((size_t)B * blk);
   float* d_o = nullptr;
   if (dout) {
-    d_o = x.linear_bwd(dout, (long long)B * T, E, sv.Wo, E);
-    x.gemm(T, S, hd, B, H, heads(d_o, T, E, hd), heads_T(sv.v, S, E, hd), View{dp, S, 1, blk, (long long)T * S}, nullptr, 1.0f, 0);
-  } else {
-    x.zero(dp, (size_t)B * blk);
+    d_o = x.linear_bwd(dout, dout_rs, (long long)B * T, E, sv.Wo, E);
+    x.gemm(T, S, hd, B, H, heads(d_o, T, E, hd), heads_T(sv.v, S, sv.kv_rs, hd), View{dp, S, 1, blk, (long long)T * S}, nullptr, 1.0f, 0);
+  }
+  // without dout the gradient at the probabilities is d_prob alone: dp is read as zeros through the `extra`-only form below
+  if (!dout) {
+    if (!x.skip()) (void)hipMemsetAsync(dp, 0, (size_t)B * blk * 4, x.st);
   }
   if (sv.pb1 == blk && (!d_prob || dpb1 == blk)) x.softmax_bwd(sv.p, dp, d_prob, (long long)B * H * T, S);
   else
     for (int b = 0; b < B; ++b) x.softmax_bwd(sv.p + b * sv.pb1, dp + b * blk, d_prob ? d_prob + b * dpb1 : nullptr, (long long)H * T, S);
-  float* dq = x.alloc((size_t)B * T * E);
-  x.gemm(T, hd, S, B, H, View{dp, S, 1, blk, (long long)T * S}, heads(sv.k, S, E, hd), heads(dq, T, E, hd), nullptr, sv.scale, 0);
-  float* dx = x.linear_bwd(dq, (long long)B * T, E, sv.W, E);
-  if (self_attention) {
-    float* dk = x.alloc((size_t)B * S * E);
-    x.gemm(S, hd, T, B, H, View{dp, 1, S, blk, (long long)T * S}, heads(sv.q, T, E, hd), heads(dk, S, E, hd), nullptr, sv.scale, 0);
-    x.linear_bwd(dk, (long long)B * S, E, sv.W + (size_t)E * E, E, dx, 1);
-    float* dv = x.alloc((size_t)B * S * E);
-    x.gemm(S, hd, T, B, H, View{sv.p, 1, S, sv.pb1, (long long)T * S}, heads(d_o, T, E, hd), heads(dv, S, E, hd), nullptr, 1.0f, 0);
-    x.linear_bwd(dv, (long long)B * S, E, sv.W + (size_t)2 * E * E, E, dx, 1);
+  if (!self) {
+    float* dq = x.alloc((size_t)B * T * E);
+    x.gemm(T, hd, S, B, H, View{dp, S, 1, blk, (long long)T * S}, heads(sv.k, S, sv.kv_rs, hd), heads(dq, T, E, hd), nullptr, sv.scale, 0);
+    x.linear_bwd(dq, E, (long long)B * T, E, sv.W, E, dx, accumulate);
+    return;
   }
-  return dx;
+  float* dqkv = x.alloc((size_t)B * T * 3 * E);      // [rows][dq | dk | dv]
+  x.gemm(T, hd, S, B, H, View{dp, S, 1, blk, (long long)T * S}, heads(sv.k, S, sv.kv_rs, hd), heads(dqkv, T, 3 * E, hd), nullptr, sv.scale, 0);
+  x.gemm(S, hd, T, B, H, View{dp, 1, S, blk, (long long)T * S}, heads(sv.q, T, sv.q_rs, hd), heads(dqkv + E, S, 3 * E, hd), nullptr, sv.scale, 0);
+  x.gemm(S, hd, T, B, H, View{sv.p, 1, S, sv.pb1, (long long)T * S}, heads(d_o, T, E, hd), heads(dqkv + 2 * E, S, 3 * E, hd), nullptr, 1.0f, 0);
+  x.linear_bwd(dqkv, 3 * E, (long long)B * T, 3 * E, sv.W, E, dx, accumulate);
 }
 
-// TimeBlock.forward (cross_attention.py:426-439) for one shared time-embedding row
-static float* time_block_fwd(Ctx& x, const std::string& pfx, float* in, const float* silu_temb, TbSaved& sv) {
+// x + TimeBlock(x) (cross_attention.py:426-439, the caller's residual :575,:655) for one shared time-embedding row
+static float* time_block_fwd(Ctx& x, const std::string& pfx, float* in, const float* temb, TbSaved& sv) {
   const int D = x.D;
   const long long rows = (long long)x.B * x.L;
   const float *We = x.W(pfx + ".emb_layers.1.weight"), *be = x.W(pfx + ".emb_layers.1.bias"), *g = x.W(pfx + ".norm.weight"),
               *bn = x.W(pfx + ".norm.bias"), *Wout = x.W(pfx + ".out_layers.2.weight"), *bout = x.W(pfx + ".out_layers.2.bias");
   if (x.err) return nullptr;
-  float* e = x.linear(silu_temb, 1, D, We, be, 2 * D);                     // [1][2 D], scale first
+  float* e = x.linear(temb, D, 1, D, We, be, 2 * D, nullptr, 0, nullptr, 1);          // Linear(SiLU(temb)): [1][2 D], scale first
   float* n = x.ln(in, rows, g, bn);
   float* h = x.alloc((size_t)rows * D);
   x.ew(EW_MODULATE, n, e, h, rows * D, D, 1);
-  float* s = x.alloc((size_t)rows * D);
-  x.ew(EW_SILU, h, nullptr, s, rows * D);
   sv = TbSaved{in, h, e, g, Wout};
-  return x.linear(s, rows, D, Wout, bout, D);
+  return x.linear(h, D, rows, D, Wout, bout, D, nullptr, 0, in, 1);                   // in + Linear(SiLU(h))
 }
 
 // g += d TimeBlock(x)/dx applied to g
 static void time_block_bwd(Ctx& x, const TbSaved& sv, float* g) {
   const int D = x.D;
   const long long rows = (long long)x.B * x.L;
-  float* dh = x.linear_bwd(g, rows, D, sv.Wout, D);
-  x.ew(EW_SILU_BWD, dh, sv.h, dh, rows * D);
-  x.ew(EW_MODULATE_BWD, dh, sv.e, dh, rows * D, D, 1);
+  float* dh = x.linear_bwd(g, D, rows, D, sv.Wout, D);
+  if (!x.skip()) hipLaunchKernelGGL(tb_bwd_f32_kernel, dim3((unsigned)((rows * D + 255) / 256)), dim3(256), 0, x.st, dh, sv.h, sv.e, dh, rows * D, D);
   x.ln_bwd(sv.x, sv.g, dh, g, rows, 1);
 }
 
 struct Args {
   const float* latents;        // dev [B][L][latent]
-  int timestep;
+  const float* trow;           // dev: the timestep's row of the sinusoid table (get_timestep_embedding)
   const cfd_memory* mem;       // 5 memories, U == B, batch-major [B][S][D]
   const int32_t *tok_off, *tok_idx;   // dev
-  int last, nt_max, n_tok;
+  int last, nt_max;
   float k3[3];
   float *losses, *max_att, *grad;    // dev outputs
 };
@@ -216,13 +231,9 @@ static void run(Ctx& x, const Args& a) {
   const int B = x.B, L = x.L, D = x.D, NL = c->nl, LAT = c->cfg.latent_dim, FF = c->cfg.ff_size;
   const long long rows = (long long)B * L;
   // ---- embedding, time embedding, memories (denoiser.py:183-353)
-  float* xx = x.linear(a.latents, rows, LAT, x.W("latent_embd.weight"), x.W("latent_embd.bias"), D);
-  const float* trow = c->tsin.as<float>() + (size_t)a.timestep * D;
-  float* t1 = x.linear(trow, 1, D, x.W("time_embedding.linear_1.weight"), x.W("time_embedding.linear_1.bias"), D);
-  x.ew(EW_SILU, t1, nullptr, t1, D);
-  float* temb = x.linear(t1, 1, D, x.W("time_embedding.linear_2.weight"), x.W("time_embedding.linear_2.bias"), D);
-  float* silu_temb = x.alloc(D);
-  x.ew(EW_SILU, temb, nullptr, silu_temb, D);
+  float* xx = x.linear(a.latents, LAT, rows, LAT, x.W("latent_embd.weight"), x.W("latent_embd.bias"), D);
+  float* t1 = x.linear(a.trow, D, 1, D, x.W("time_embedding.linear_1.weight"), x.W("time_embedding.linear_1.bias"), D);
+  float* temb = x.linear(t1, D, 1, D, x.W("time_embedding.linear_2.weight"), x.W("time_embedding.linear_2.bias"), D, nullptr, 0, nullptr, 1);
   x.ew(EW_ADD_BCAST, xx, x.W("bh_embedding.weight"), xx, rows * D, D, 2, 0, D);                 // token l gets bh[l % 2] (:316-317)
   const float* qpe = x.W("query_pos.pe");
   for (int b = 0; b < B; ++b)                                                                      // and pe[l / 2] (SineBH)
@@ -247,88 +258,68 @@ static void run(Ctx& x, const Args& a) {
     LayerSaved& s = sv[i];
     s.x0 = xx;
     float* t2 = x.ln(xx, rows, x.W(p + "norm1.weight"), x.W(p + "norm1.bias"));
-    float* o = mha_fwd(x, p + "self_attn", t2, L, t2, L, c->cfg.num_heads, nullptr, false, nullptr, 0, s.self);
+    xx = mha_fwd(x, p + "self_attn", t2, L, t2, L, c->cfg.num_heads, nullptr, true, false, nullptr, 0, nullptr, 0, xx, s.self);
     if (x.err) return;
-    x.add(o, xx, rows * D);
-    xx = o;
-    o = time_block_fwd(x, p + "time_block1", xx, silu_temb, s.tb1);
+    xx = time_block_fwd(x, p + "time_block1", xx, temb, s.tb1);
     if (x.err) return;
-    x.add(o, xx, rows * D);
-    xx = o;
     s.x2 = xx;
     t2 = x.ln(xx, rows, x.W(p + "norm2.weight"), x.W(p + "norm2.bias"));
-    float* cat = x.alloc((size_t)rows * CFD_NMEM * D);
+    float* cat = x.alloc((size_t)rows * CFD_NMEM * D);           // torch.cat (cross_attention.py:629): column block j of [rows][5 D]
     for (int j = 0; j < CFD_NMEM; ++j) {
       const std::string nm = MEM_NAMES[j];
       const int S = a.mem[j].S;
       float* m = x.ln(mems[j], (long long)B * S, x.W(p + nm + "_norm.weight"), x.W(p + nm + "_norm.bias"));
-      o = mha_fwd(x, p + "multihead_attn_" + nm, t2, L, m, S, 1, a.mem[j].key_padding_mask, j == 2, att + (size_t)i * L * St,
-                  (long long)NL * L * St, s.cross[j]);
+      mha_fwd(x, p + "multihead_attn_" + nm, t2, L, m, S, 1, a.mem[j].key_padding_mask, false, j == 2, att + (size_t)i * L * St,
+              (long long)NL * L * St, cat + (size_t)j * D, (long long)CFD_NMEM * D, nullptr, s.cross[j]);
       if (x.err) return;
-      // torch.cat (cross_attention.py:629): column block j of [rows][5 D]
-      if (!x.dry) (void)hipMemcpy2DAsync(cat + (size_t)j * D, (size_t)CFD_NMEM * D * 4, o, (size_t)D * 4, (size_t)D * 4, (size_t)rows, hipMemcpyDeviceToDevice, x.st);
     }
     if (i == NL - 1) break;                                      // nothing above the last cross-attention reaches the objective
-    o = x.linear(cat, rows, CFD_NMEM * D, x.W(p + "att_fuser.weight"), x.W(p + "att_fuser.bias"), D);
-    x.add(o, xx, rows * D);
-    xx = o;
-    o = time_block_fwd(x, p + "time_block2", xx, silu_temb, s.tb2);
+    xx = x.linear(cat, CFD_NMEM * D, rows, CFD_NMEM * D, x.W(p + "att_fuser.weight"), x.W(p + "att_fuser.bias"), D, nullptr, 0, xx);
+    xx = time_block_fwd(x, p + "time_block2", xx, temb, s.tb2);
     if (x.err) return;
-    x.add(o, xx, rows * D);
-    xx = o;
     s.x4 = xx;
     t2 = x.ln(xx, rows, x.W(p + "norm3.weight"), x.W(p + "norm3.bias"));
-    s.ffn_pre = x.linear(t2, rows, D, x.W(p + "linear1.weight"), x.W(p + "linear1.bias"), FF);
-    float* ge = x.alloc((size_t)rows * FF);
-    x.ew(EW_GELU, s.ffn_pre, nullptr, ge, rows * FF);
-    o = x.linear(ge, rows, FF, x.W(p + "linear2.weight"), x.W(p + "linear2.bias"), D);
-    x.add(o, xx, rows * D);
-    xx = o;
+    s.ffn_pre = x.linear(t2, D, rows, D, x.W(p + "linear1.weight"), x.W(p + "linear1.bias"), FF);
+    xx = x.linear(s.ffn_pre, FF, rows, FF, x.W(p + "linear2.weight"), x.W(p + "linear2.bias"), D, nullptr, 0, xx, 2);   // x + W2 GELU(pre)
   }
   if (x.err) return;
   // ---- the objective and its gradient with respect to the nine maps
   const int W = a.last - 1;
   float* ws = x.alloc((size_t)B * (3 * (size_t)L * W + 3 * (size_t)a.nt_max));
   float* d_att = x.alloc((size_t)B * NL * L * St);
-  if (!x.dry)
+  if (!x.skip())
     hipLaunchKernelGGL(weg_focus_kernel, dim3((unsigned)B), dim3(256), 0, x.st, att, a.tok_off, a.tok_idx, B, NL, L, St, a.last, a.nt_max, a.k3[0],
                        a.k3[1], a.k3[2], ws, a.losses, a.max_att, d_att);
   // ---- reverse sweep
-  float* g = nullptr;
+  float* g = x.alloc((size_t)rows * D);                          // gradient at the current layer's output
+  float* dt2 = x.alloc((size_t)rows * D);
+  bool have_g = false;
   for (int i = NL - 1; i >= 0; --i) {
     const std::string p = "decoder.layers." + std::to_string(i) + ".";
     const LayerSaved& s = sv[i];
     float* dcat = nullptr;
-    if (g) {
-      float* d1 = x.linear_bwd(g, rows, D, x.W(p + "linear2.weight"), FF);
+    if (have_g) {
+      float* d1 = x.linear_bwd(g, D, rows, D, x.W(p + "linear2.weight"), FF);
       x.ew(EW_GELU_BWD, d1, s.ffn_pre, d1, rows * FF);
-      float* d2 = x.linear_bwd(d1, rows, FF, x.W(p + "linear1.weight"), D);
+      float* d2 = x.linear_bwd(d1, FF, rows, FF, x.W(p + "linear1.weight"), D);
       x.ln_bwd(s.x4, x.W(p + "norm3.weight"), d2, g, rows, 1);
       time_block_bwd(x, s.tb2, g);
-      dcat = x.linear_bwd(g, rows, D, x.W(p + "att_fuser.weight"), CFD_NMEM * D);
+      dcat = x.linear_bwd(g, D, rows, D, x.W(p + "att_fuser.weight"), CFD_NMEM * D);
     }
-    float* dt2 = nullptr;
+    int n_done = 0;
     for (int j = 0; j < CFD_NMEM; ++j) {
-      if (!dcat && j != 2) continue;
-      float* dout = nullptr;
-      if (dcat) {
-        dout = x.alloc((size_t)rows * D);
-        if (!x.dry) (void)hipMemcpy2DAsync(dout, (size_t)D * 4, dcat + (size_t)j * D, (size_t)CFD_NMEM * D * 4, (size_t)D * 4, (size_t)rows, hipMemcpyDeviceToDevice, x.st);
-      }
-      float* d = mha_bwd(x, s.cross[j], dout, j == 2 ? d_att + (size_t)i * L * St : nullptr, (long long)NL * L * St, false);
-      if (!dt2) dt2 = d;
-      else x.add(dt2, d, rows * D);
+      if (!have_g && j != 2) continue;
+      mha_bwd(x, s.cross[j], have_g ? dcat + (size_t)j * D : nullptr, (long long)CFD_NMEM * D, j == 2 ? d_att + (size_t)i * L * St : nullptr,
+              (long long)NL * L * St, false, dt2, n_done > 0);
+      ++n_done;
     }
-    if (!g) {
-      g = x.alloc((size_t)rows * D);
-      x.zero(g, (size_t)rows * D);
-    }
-    x.ln_bwd(s.x2, x.W(p + "norm2.weight"), dt2, g, rows, 1);
+    x.ln_bwd(s.x2, x.W(p + "norm2.weight"), dt2, g, rows, have_g ? 1 : 0);
+    have_g = true;
     time_block_bwd(x, s.tb1, g);
-    dt2 = mha_bwd(x, s.self, g, nullptr, 0, true);
+    mha_bwd(x, s.self, g, D, nullptr, 0, true, dt2, 0);
     x.ln_bwd(s.x0, x.W(p + "norm1.weight"), dt2, g, rows, 1);
   }
-  x.linear_bwd(g, rows, D, x.W("latent_embd.weight"), LAT, a.grad);
+  x.linear_bwd(g, D, rows, D, x.W("latent_embd.weight"), LAT, a.grad);
 }
 
 }  // namespace weg

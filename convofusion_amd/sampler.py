@@ -268,7 +268,7 @@ def sample_with_weg(denoiser, scheduler, encoder_hidden_states, cond_masks, focu
     run = SamplingRun(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
                       guidance_chunks=G, **kw)
     text_states = [enc.chunk(G)[1] for enc in encoder_hidden_states]                               # :447
-    text_masks = {k: (v.chunk(G)[1] if v is not None else v) for k, v in (cond_masks or {}).items()}  # :448
+    text_masks = {k: (v.chunk(G)[1].to(torch.uint8).contiguous() if v is not None else v) for k, v in (cond_masks or {}).items()}  # :448
     thresholds = dict(weg_parameters["thresholds"])
     timesteps = [int(t) for t in scheduler.timesteps]
     for i, t in enumerate(timesteps):
