@@ -35,6 +35,33 @@ def test_struct_layouts_match_header():
     assert _lib.SampleArgs.mem.offset % 8 == 0 and C.sizeof(_lib.SampleArgs) == _lib.SampleArgs.mem.offset + 5 * 32 + 8
 
 
+def test_weg_host_logic():
+    """Struct layout of cfd_weg_args / cfd_mat, the focus-token tables, the smoothing kernel and the CPU refusal."""
+    import ctypes as C
+    from convofusion_amd import _lib, weg
+    from oracle import weg_ref
+    assert C.sizeof(_lib.Mat) == 40
+    assert _lib.WegArgs.mem.offset == 24 and _lib.WegArgs.tok_off.offset == 24 + 5 * 32 and C.sizeof(_lib.WegArgs) == 24 + 160 + 16 + 16
+    last, off, flat = weg._focus_tables(2, 12, [[2, 5], []], False, ())
+    assert last == 11 and off.tolist() == [0, 2, 2] and flat.tolist() == [2, 5]                      # att[:, :, 1:-1]
+    last, off, flat = weg._focus_tables(1, 12, [[3]], True, torch.tensor([8]))
+    assert last == 8
+    with pytest.raises(AssertionError):      # "EOS/BOS normalization only works for test batch size 1 currently" (weg.py:25)
+        weg._focus_tables(2, 12, [[2], [3]], True, torch.tensor([8, 8]))
+    with pytest.raises(IndexError):          # the reference would index outside the sliced map
+        weg._focus_tables(1, 12, [[8]], True, torch.tensor([8]))
+    with pytest.raises(ValueError):
+        weg._focus_tables(2, 12, [[2]], False, ())
+    k = weg_ref.gaussian_kernel()
+    np.testing.assert_allclose(weg.gaussian_kernel3(), (k[0, 0], k[0, 1], k[1, 1]), rtol=1e-6)
+    from tests.gpu_helpers import ABL, DENOISER_KW
+    from convofusion_amd.denoiser import Denoiser
+    m = Denoiser(ablation=ABL, **DENOISER_KW)
+    enc = [torch.zeros(1, s, 512) for s in (4, 6, 12, 8, 1)]
+    with pytest.raises(RuntimeError):        # the product never computes on the CPU
+        weg.loss_and_grad(m, torch.zeros(1, 16, 128), 5, enc, {"tlsn": torch.zeros(1, 12, dtype=torch.bool)}, [[2]], True, torch.tensor([8]))
+
+
 def test_denoiser_mirror_state_dict_and_validation():
     from convofusion_amd.denoiser import Denoiser, sine_pe, sinusoid_table
     from oracle import denoiser_ref, weights

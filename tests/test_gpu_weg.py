@@ -193,3 +193,39 @@ def test_loop_with_weg_matches_oracle(rollout):
     err, moved = rel_l2(lat, ref), rel_l2(plain, ref)
     print(f"loop with WEG: vs oracle {err:.2e}; WEG moved the result by {moved:.2e}; oracle objective per step {log}")
     assert moved > 10 * err and err < 1e-3
+
+
+def test_gradient_at_the_synthetic_shape_matches_oracle():
+    """BASELINE's synthetic shape (196 latent tokens, 1500 audio tokens, extended memory PE): 13 row tiles per product on
+    the token side and the tiled GEMM (> 256 rows) on the audio memory."""
+    from convofusion_amd import weg
+    from tests.gpu_helpers import dev_inputs, hip_denoiser, to_dev
+    B, L, S, pad, t, focus = 1, 196, (32, 1500, 32, 8, 1), (8, 0, 8, 0, 0), 250, [[2, 11, 20]]
+    inp = inputs.make_plain_batch(seed=91, Be=B, L=L, S=S, pad_tail=pad)
+    eot = np.argmax(inp["masks"]["tlsn"].astype(np.int64), axis=1) - 1
+    sd = state_dict(1234, 1.0, 1536)
+    lo, _, mo, go = weg_ref.loss_and_grad(sd, inp["sample"], t, inp["memories"], inp["masks"], focus, True, eot)
+    mems, masks = dev_inputs(inp)
+    loss, _, mx, grad = weg.loss_and_grad(hip_denoiser(1234, 1.0), to_dev(inp["sample"]), t, mems, masks, focus, True, to_dev(eot))
+    e = rel_l2(grad.cpu().numpy(), go)
+    print(f"synthetic shape: loss {float(loss):.6f} (oracle {float(lo):.6f}), grad vs oracle {e:.2e}")
+    assert abs(float(loss) - float(lo)) < 2e-6 and e < 1e-3
+    np.testing.assert_allclose([float(v) for s in mx for v in s], [float(v) for s in mo for v in s], rtol=2e-5)
+
+
+def test_eval_rejects_what_the_reference_cannot_run():
+    import torch
+    from convofusion_amd import _lib, weg
+    from tests.gpu_helpers import hip_denoiser
+    m = hip_denoiser(1234, 1.0)
+    enc = [torch.zeros(1, s, 512, device="cuda") for s in (4, 6, 12, 8, 1)]
+    mask = {"tlsn": (torch.arange(12) >= 9)[None].cuda()}
+    lat = torch.zeros(1, 16, 128, device="cuda")
+    with pytest.raises(_lib.CfdError):       # text slice [1, 2): F.pad(mode='reflect') needs two entries (weg.py:35)
+        weg.loss_and_grad(m, lat, 5, enc, mask, [[1]], True, torch.tensor([2]))
+    with pytest.raises(_lib.CfdError):       # odd latent length: the reference's SineBH position encoding cannot broadcast
+        weg.loss_and_grad(m, torch.zeros(1, 15, 128, device="cuda"), 5, enc, mask, [[2]], True, torch.tensor([8]))
+    with pytest.raises(_lib.CfdError):       # timestep outside the 1000-row table
+        weg.loss_and_grad(m, lat, 1000, enc, mask, [[2]], True, torch.tensor([8]))
+    with pytest.raises(ValueError):          # the conditioning tuple must be the text-only chunk (one row per latent row)
+        weg.loss_and_grad(m, lat, 5, [e.expand(7, -1, -1) for e in enc], mask, [[2]], True, torch.tensor([8]))
