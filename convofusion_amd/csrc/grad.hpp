@@ -86,16 +86,16 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(MatView A, MatView B, flo
 // LDS in k-chunks of 512, B streams from global memory once), partial sums meet in LDS and are added in ascending tk.
 // N / 16 x M / 16 workgroups instead of N / 64 x M / 64, and one memory round trip per k-chunk.
 #define R16_KC 512
-__global__ void __launch_bounds__(256) gemm_f32_rows16_kernel(MatView A, MatView B, float* C, long long c_rs, long long c_cs, long long c_b1,
-                                                              long long c_b2, int M, int N, int K, int nb2, const float* bias, float alpha,
-                                                              int accumulate, const float* resid, int a_act) {
+__device__ __forceinline__ void gemm_f32_rows16_tile(const MatView& A, const MatView& B, float* C, long long c_rs, long long c_cs, long long c_b1,
+                                                     long long c_b2, int M, int N, int K, int nb2, const float* bias, float alpha, int accumulate,
+                                                     const float* resid, int a_act, int bx, int by, int bz) {
   __shared__ __attribute__((aligned(16))) float As[R16_KC][20];   // [k][row], rows padded to 20 (16-byte aligned float4 reads)
   __shared__ float red[16][16][17];                                // [tk][tn][row]
-  const int z1 = blockIdx.z / nb2, z2 = blockIdx.z % nb2;
+  const int z1 = bz / nb2, z2 = bz % nb2;
   const float* a = A.p + z1 * A.b1 + z2 * A.b2;
   const float* b = B.p + z1 * B.b1 + z2 * B.b2;
   float* c = C + z1 * c_b1 + z2 * c_b2;
-  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+  const int m0 = by * 16, n0 = bx * 16;
   const int tid = threadIdx.x;
   const bool b_n_fast = B.cs == 1, a_k_fast = A.cs == 1;
   const int tn = b_n_fast ? (tid & 15) : (tid >> 4), tk = b_n_fast ? (tid >> 4) : (tid & 15);
@@ -156,6 +156,50 @@ __global__ void __launch_bounds__(256) gemm_f32_rows16_kernel(MatView A, MatView
     if (accumulate) v += c[o];
     c[o] = v;
   }
+}
+
+__global__ void __launch_bounds__(256) gemm_f32_rows16_kernel(MatView A, MatView B, float* C, long long c_rs, long long c_cs, long long c_b1,
+                                                              long long c_b2, int M, int N, int K, int nb2, const float* bias, float alpha,
+                                                              int accumulate, const float* resid, int a_act) {
+  gemm_f32_rows16_tile(A, B, C, c_rs, c_cs, c_b1, c_b2, M, N, K, nb2, bias, alpha, accumulate, resid, a_act, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Up to five independent products in one launch (the five cross-attentions of a layer differ in weights and memory
+// length, not in structure): blockIdx.z walks the groups' batch entries, a workgroup outside its group's extent leaves.
+#define GEMM_MAX_GROUPS 5
+struct GemmGroup {
+  MatView A, B;
+  float* C;
+  long long c_rs, c_cs, c_b1, c_b2;
+  int M, N, K, nb1, nb2;
+  const float* bias;
+  const float* resid;
+  float alpha;
+  int accumulate, a_act;
+};
+struct GemmGroups {
+  GemmGroup g[GEMM_MAX_GROUPS];
+  int n;
+  int zoff[GEMM_MAX_GROUPS + 1];
+};
+__global__ void __launch_bounds__(256) gemm_f32_rows16_grouped_kernel(const GemmGroups gs) {
+  int gi = 0;
+  while (gi + 1 < gs.n && (int)blockIdx.z >= gs.zoff[gi + 1]) ++gi;
+  const GemmGroup& g = gs.g[gi];
+  if ((int)blockIdx.x * 16 >= g.N || (int)blockIdx.y * 16 >= g.M) return;
+  gemm_f32_rows16_tile(g.A, g.B, g.C, g.c_rs, g.c_cs, g.c_b1, g.c_b2, g.M, g.N, g.K, g.nb2, g.bias, g.alpha, g.accumulate, g.resid, g.a_act, blockIdx.x,
+                       blockIdx.y, blockIdx.z - gs.zoff[gi]);
+}
+static inline void launch_gemm_f32_grouped(hipStream_t st, GemmGroups& gs) {
+  int mx = 0, nx = 0;
+  gs.zoff[0] = 0;
+  for (int i = 0; i < gs.n; ++i) {
+    mx = gs.g[i].M > mx ? gs.g[i].M : mx;
+    nx = gs.g[i].N > nx ? gs.g[i].N : nx;
+    gs.zoff[i + 1] = gs.zoff[i] + gs.g[i].nb1 * gs.g[i].nb2;
+  }
+  hipLaunchKernelGGL(gemm_f32_rows16_grouped_kernel, dim3((unsigned)((nx + 15) / 16), (unsigned)((mx + 15) / 16), (unsigned)gs.zoff[gs.n]), dim3(256), 0, st,
+                     gs);
 }
 
 // launch the product with the kernel that fits its shape
@@ -256,6 +300,96 @@ __global__ void __launch_bounds__(256) layernorm_bwd_f32_kernel(const float* x, 
       dx[row * D + c] = r;
     }
   }
+}
+
+// Grouped forms of the row kernels above for the five cross-attentions of a layer (blockIdx.y = group).
+#define ROW_MAX_GROUPS 5
+struct LnGroups {
+  const float* x[ROW_MAX_GROUPS];
+  const float* g[ROW_MAX_GROUPS];
+  const float* b[ROW_MAX_GROUPS];
+  float* out[ROW_MAX_GROUPS];
+  long long rows[ROW_MAX_GROUPS];
+};
+__global__ void __launch_bounds__(256) layernorm_f32_grouped_kernel(const LnGroups gs, int D, float eps) {
+  const int gi = blockIdx.y, lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= gs.rows[gi]) return;
+  const float* xr = gs.x[gi] + row * D;
+  const float *g = gs.g[gi], *b = gs.b[gi];
+  float* out = gs.out[gi];
+  float v[32];
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const int c = lane + 64 * q;
+    v[q] = c < D ? xr[c] : 0.f;
+    s += v[q];
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const int c = lane + 64 * q;
+    const float d = c < D ? v[q] - mean : 0.f;
+    v[q] = d;
+    ss += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + eps);
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const int c = lane + 64 * q;
+    if (c < D) out[row * D + c] = v[q] * rstd * g[c] + b[c];
+  }
+}
+
+// softmax / softmax backward over rows that sit in per-batch blocks `bstride` floats apart (rows_per_batch rows of Lk each)
+struct SoftmaxGroups {
+  float* s[ROW_MAX_GROUPS];            // scores -> probabilities (forward); dp -> ds (backward)
+  const float* p[ROW_MAX_GROUPS];      // backward: probabilities
+  const float* extra[ROW_MAX_GROUPS];  // backward: gradient arriving at the probabilities directly (or null)
+  const uint8_t* kpm[ROW_MAX_GROUPS];  // forward: key padding mask [batch][Lk] (or null)
+  long long rows[ROW_MAX_GROUPS], rows_per_batch[ROW_MAX_GROUPS], s_bstride[ROW_MAX_GROUPS], p_bstride[ROW_MAX_GROUPS], e_bstride[ROW_MAX_GROUPS];
+  int Lk[ROW_MAX_GROUPS];
+};
+__global__ void __launch_bounds__(256) softmax_f32_grouped_kernel(const SoftmaxGroups gs) {
+  const int gi = blockIdx.y, lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= gs.rows[gi]) return;
+  const int Lk = gs.Lk[gi];
+  const long long bt = row / gs.rows_per_batch[gi], lr = row % gs.rows_per_batch[gi];
+  float* r = gs.s[gi] + bt * gs.s_bstride[gi] + lr * Lk;
+  const uint8_t* mk = gs.kpm[gi] ? gs.kpm[gi] + bt * Lk : nullptr;
+  float mx = -INFINITY;
+  for (int c = lane; c < Lk; c += 64)
+    if (!mk || !mk[c]) mx = fmaxf(mx, r[c]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int c = lane; c < Lk; c += 64) {
+    const float e = (!mk || !mk[c]) ? expf(r[c] - mx) : 0.f;
+    r[c] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  for (int c = lane; c < Lk; c += 64) r[c] = r[c] / sum;
+}
+__global__ void __launch_bounds__(256) softmax_bwd_f32_grouped_kernel(const SoftmaxGroups gs) {
+  const int gi = blockIdx.y, lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= gs.rows[gi]) return;
+  const int Lk = gs.Lk[gi];
+  const long long bt = row / gs.rows_per_batch[gi], lr = row % gs.rows_per_batch[gi];
+  const float* pr = gs.p[gi] + bt * gs.p_bstride[gi] + lr * Lk;
+  float* dr = gs.s[gi] + bt * gs.s_bstride[gi] + lr * Lk;
+  const float* er = gs.extra[gi] ? gs.extra[gi] + bt * gs.e_bstride[gi] + lr * Lk : nullptr;
+  float dot = 0.f;
+  for (int c = lane; c < Lk; c += 64) {
+    const float d = dr[c] + (er ? er[c] : 0.f);
+    dr[c] = d;
+    dot = fmaf(d, pr[c], dot);
+  }
+  dot = wave_sum(dot);
+  for (int c = lane; c < Lk; c += 64) dr[c] = pr[c] * (dr[c] - dot);
 }
 
 enum { EW_SILU = 0, EW_GELU = 1, EW_SILU_BWD = 2, EW_GELU_BWD = 3, EW_AXPY = 4, EW_ADD_BCAST = 5, EW_MODULATE = 6, EW_MODULATE_BWD = 7, EW_NOPS = 8 };

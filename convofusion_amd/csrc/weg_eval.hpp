@@ -106,6 +106,23 @@ struct Ctx {
     if (skip()) return;
     hipLaunchKernelGGL(layernorm_bwd_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, g, dy, dx, rows, D, 1e-5f, accumulate);
   }
+  void gemm_grouped(GemmGroups& gs) {
+    if (skip()) return;
+    launch_gemm_f32_grouped(st, gs);
+  }
+  void ln_grouped(const LnGroups& gs, int n) {
+    if (skip()) return;
+    long long mx = 0;
+    for (int i = 0; i < n; ++i) mx = std::max(mx, gs.rows[i]);
+    hipLaunchKernelGGL(layernorm_f32_grouped_kernel, dim3((unsigned)((mx + 3) / 4), (unsigned)n), dim3(256), 0, st, gs, D, 1e-5f);
+  }
+  void softmax_grouped(const SoftmaxGroups& gs, int n, bool backward) {
+    if (skip()) return;
+    long long mx = 0;
+    for (int i = 0; i < n; ++i) mx = std::max(mx, gs.rows[i]);
+    if (backward) hipLaunchKernelGGL(softmax_bwd_f32_grouped_kernel, dim3((unsigned)((mx + 3) / 4), (unsigned)n), dim3(256), 0, st, gs);
+    else hipLaunchKernelGGL(softmax_f32_grouped_kernel, dim3((unsigned)((mx + 3) / 4), (unsigned)n), dim3(256), 0, st, gs);
+  }
   void ew(int op, const float* a, const float* b, float* out, long long n, int Dd = 1, int R1 = 1, long long s0 = 0, long long s1 = 0, float alpha = 0.f) {
     if (skip()) return;
     hipLaunchKernelGGL(ew_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, op, a, b, out, n, Dd, R1, s0, s1, alpha);
@@ -191,6 +208,95 @@ static void mha_bwd(Ctx& x, const AttnSaved& sv, const float* dout, long long do
   x.linear_bwd(dqkv, 3 * E, (long long)B * T, 3 * E, sv.W, E, dx, accumulate);
 }
 
+static inline GemmGroup group(View A, View Bv, View Cv, int M, int N, int K, int nb1, int nb2, const float* bias, float alpha) {
+  GemmGroup g;
+  g.A = MatView{A.p, A.rs, A.cs, A.b1, A.b2};
+  g.B = MatView{Bv.p, Bv.rs, Bv.cs, Bv.b1, Bv.b2};
+  g.C = Cv.p; g.c_rs = Cv.rs; g.c_cs = Cv.cs; g.c_b1 = Cv.b1; g.c_b2 = Cv.b2;
+  g.M = M; g.N = N; g.K = K; g.nb1 = nb1; g.nb2 = nb2;
+  g.bias = bias; g.resid = nullptr; g.alpha = alpha; g.accumulate = 0; g.a_act = 0;
+  return g;
+}
+
+// The five single-head cross-attentions of a layer (cross_attention.py:581-629) with one launch per stage instead of five:
+// memory LayerNorms, query projections, key|value projections, scores, softmax, P.V, output projections into the column
+// blocks of `cat`.  The tlsn probabilities go to `att_i` (blocks att_b1 apart: Denoiser.forward's att_mats[2] of this layer).
+static void cross_fwd_grouped(Ctx& x, const std::string& p, const float* t2, float* const mems[CFD_NMEM], const cfd_memory* mem, float* att_i,
+                              long long att_b1, float* cat, AttnSaved sv[CFD_NMEM]) {
+  const int E = x.E, B = x.B, T = x.L;
+  const long long rows = (long long)B * T;
+  const float *W[CFD_NMEM], *Bi[CFD_NMEM], *Wo[CFD_NMEM], *bo[CFD_NMEM];
+  LnGroups ln;
+  float *mn[CFD_NMEM], *q[CFD_NMEM], *kv[CFD_NMEM], *pr[CFD_NMEM], *o[CFD_NMEM];
+  long long pb1[CFD_NMEM];
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    const std::string nm = MEM_NAMES[j], a = p + "multihead_attn_" + nm;
+    W[j] = x.W(a + ".in_proj_weight"); Bi[j] = x.W(a + ".in_proj_bias"); Wo[j] = x.W(a + ".out_proj.weight"); bo[j] = x.W(a + ".out_proj.bias");
+    const int S = mem[j].S;
+    mn[j] = x.alloc((size_t)B * S * E);
+    ln.x[j] = mems[j]; ln.g[j] = x.W(p + nm + "_norm.weight"); ln.b[j] = x.W(p + nm + "_norm.bias"); ln.out[j] = mn[j]; ln.rows[j] = (long long)B * S;
+    q[j] = x.alloc((size_t)rows * E);
+    kv[j] = x.alloc((size_t)B * S * 2 * E);
+    if (j == 2) { pr[j] = att_i; pb1[j] = att_b1; }
+    else { pr[j] = x.alloc((size_t)B * T * S); pb1[j] = (long long)T * S; }
+    o[j] = x.alloc((size_t)rows * E);
+  }
+  if (x.err) return;
+  x.ln_grouped(ln, CFD_NMEM);
+  const float scale = (float)std::sqrt(1.0 / (double)E);
+  GemmGroups gq, gkv, gs, gpv, go;
+  SoftmaxGroups sm;
+  gq.n = gkv.n = gs.n = gpv.n = go.n = CFD_NMEM;
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    const int S = mem[j].S;
+    gq.g[j] = group(View{const_cast<float*>(t2), E, 1, 0, 0}, View{const_cast<float*>(W[j]), 1, E, 0, 0}, View{q[j], E, 1, 0, 0}, (int)rows, E, E, 1, 1, Bi[j], 1.0f);
+    gkv.g[j] = group(View{mn[j], E, 1, 0, 0}, View{const_cast<float*>(W[j]) + (size_t)E * E, 1, E, 0, 0}, View{kv[j], 2 * E, 1, 0, 0}, B * S, 2 * E, E, 1, 1,
+                     Bi[j] + E, 1.0f);
+    gs.g[j] = group(heads(q[j], T, E, E), heads_T(kv[j], S, 2 * E, E), View{pr[j], S, 1, pb1[j], (long long)T * S}, T, S, E, B, 1, nullptr, scale);
+    sm.s[j] = pr[j]; sm.p[j] = nullptr; sm.extra[j] = nullptr; sm.kpm[j] = mem[j].key_padding_mask; sm.rows[j] = rows; sm.rows_per_batch[j] = T;
+    sm.s_bstride[j] = pb1[j]; sm.p_bstride[j] = 0; sm.e_bstride[j] = 0; sm.Lk[j] = S;
+    gpv.g[j] = group(View{pr[j], S, 1, pb1[j], (long long)T * S}, heads(kv[j] + E, S, 2 * E, E), heads(o[j], T, E, E), T, E, S, B, 1, nullptr, 1.0f);
+    go.g[j] = group(View{o[j], E, 1, 0, 0}, View{const_cast<float*>(Wo[j]), 1, E, 0, 0}, View{cat + (size_t)j * E, (long long)CFD_NMEM * E, 1, 0, 0}, (int)rows, E, E,
+                    1, 1, bo[j], 1.0f);
+    sv[j] = AttnSaved{q[j], kv[j], kv[j] + E, pr[j], E, 2 * E, pb1[j], W[j], Wo[j], T, S, 1, scale};
+  }
+  x.gemm_grouped(gq);
+  x.gemm_grouped(gkv);
+  x.gemm_grouped(gs);
+  x.softmax_grouped(sm, CFD_NMEM, false);
+  x.gemm_grouped(gpv);
+  x.gemm_grouped(go);
+}
+
+// Their backward with respect to the shared query input: dt2 = sum_j dq_j Wq_j.  `dcat` [rows][5 E] arrives through the
+// outputs, `d_att_i` (blocks d_b1 apart) at the tlsn probabilities.
+static void cross_bwd_grouped(Ctx& x, const AttnSaved sv[CFD_NMEM], const float* dcat, const float* d_att_i, long long d_b1, float* dt2) {
+  const int E = x.E, B = x.B, T = x.L;
+  const long long rows = (long long)B * T;
+  float *d_o[CFD_NMEM], *dp[CFD_NMEM], *dq[CFD_NMEM];
+  GemmGroups g1, g2, g3;
+  SoftmaxGroups sm;
+  g1.n = g2.n = g3.n = CFD_NMEM;
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    const int S = sv[j].S;
+    const long long blk = (long long)T * S;
+    d_o[j] = x.alloc((size_t)rows * E);
+    dp[j] = x.alloc((size_t)B * blk);
+    dq[j] = x.alloc((size_t)rows * E);
+    g1.g[j] = group(View{const_cast<float*>(dcat) + (size_t)j * E, (long long)CFD_NMEM * E, 1, 0, 0}, View{const_cast<float*>(sv[j].Wo), E, 1, 0, 0},
+                    View{d_o[j], E, 1, 0, 0}, (int)rows, E, E, 1, 1, nullptr, 1.0f);
+    g2.g[j] = group(heads(d_o[j], T, E, E), heads_T(sv[j].v, S, sv[j].kv_rs, E), View{dp[j], S, 1, blk, blk}, T, S, E, B, 1, nullptr, 1.0f);
+    sm.s[j] = dp[j]; sm.p[j] = sv[j].p; sm.extra[j] = j == 2 ? d_att_i : nullptr; sm.kpm[j] = nullptr; sm.rows[j] = rows; sm.rows_per_batch[j] = T;
+    sm.s_bstride[j] = blk; sm.p_bstride[j] = sv[j].pb1; sm.e_bstride[j] = d_b1; sm.Lk[j] = S;
+    g3.g[j] = group(View{dp[j], S, 1, blk, blk}, heads(sv[j].k, S, sv[j].kv_rs, E), heads(dq[j], T, E, E), T, E, S, B, 1, nullptr, sv[j].scale);
+  }
+  x.gemm_grouped(g1);
+  x.gemm_grouped(g2);
+  x.softmax_grouped(sm, CFD_NMEM, true);
+  x.gemm_grouped(g3);
+  for (int j = 0; j < CFD_NMEM; ++j) x.linear_bwd(dq[j], E, rows, E, sv[j].W, E, dt2, j > 0);
+}
+
 // x + TimeBlock(x) (cross_attention.py:426-439, the caller's residual :575,:655) for one shared time-embedding row
 static float* time_block_fwd(Ctx& x, const std::string& pfx, float* in, const float* temb, TbSaved& sv) {
   const int D = x.D;
@@ -265,14 +371,8 @@ static void run(Ctx& x, const Args& a) {
     s.x2 = xx;
     t2 = x.ln(xx, rows, x.W(p + "norm2.weight"), x.W(p + "norm2.bias"));
     float* cat = x.alloc((size_t)rows * CFD_NMEM * D);           // torch.cat (cross_attention.py:629): column block j of [rows][5 D]
-    for (int j = 0; j < CFD_NMEM; ++j) {
-      const std::string nm = MEM_NAMES[j];
-      const int S = a.mem[j].S;
-      float* m = x.ln(mems[j], (long long)B * S, x.W(p + nm + "_norm.weight"), x.W(p + nm + "_norm.bias"));
-      mha_fwd(x, p + "multihead_attn_" + nm, t2, L, m, S, 1, a.mem[j].key_padding_mask, false, j == 2, att + (size_t)i * L * St,
-              (long long)NL * L * St, cat + (size_t)j * D, (long long)CFD_NMEM * D, nullptr, s.cross[j]);
-      if (x.err) return;
-    }
+    cross_fwd_grouped(x, p, t2, mems, a.mem, att + (size_t)i * L * St, (long long)NL * L * St, cat, s.cross);
+    if (x.err) return;
     if (i == NL - 1) break;                                      // nothing above the last cross-attention reaches the objective
     xx = x.linear(cat, CFD_NMEM * D, rows, CFD_NMEM * D, x.W(p + "att_fuser.weight"), x.W(p + "att_fuser.bias"), D, nullptr, 0, xx);
     xx = time_block_fwd(x, p + "time_block2", xx, temb, s.tb2);
@@ -306,13 +406,8 @@ static void run(Ctx& x, const Args& a) {
       time_block_bwd(x, s.tb2, g);
       dcat = x.linear_bwd(g, D, rows, D, x.W(p + "att_fuser.weight"), CFD_NMEM * D);
     }
-    int n_done = 0;
-    for (int j = 0; j < CFD_NMEM; ++j) {
-      if (!have_g && j != 2) continue;
-      mha_bwd(x, s.cross[j], have_g ? dcat + (size_t)j * D : nullptr, (long long)CFD_NMEM * D, j == 2 ? d_att + (size_t)i * L * St : nullptr,
-              (long long)NL * L * St, false, dt2, n_done > 0);
-      ++n_done;
-    }
+    if (have_g) cross_bwd_grouped(x, s.cross, dcat, d_att + (size_t)i * L * St, (long long)NL * L * St, dt2);
+    else mha_bwd(x, s.cross[2], nullptr, 0, d_att + (size_t)i * L * St, (long long)NL * L * St, false, dt2, 0);   // top layer: the objective only
     x.ln_bwd(s.x2, x.W(p + "norm2.weight"), dt2, g, rows, have_g ? 1 : 0);
     have_g = true;
     time_block_bwd(x, s.tb1, g);
