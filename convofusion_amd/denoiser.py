@@ -152,45 +152,47 @@ class Denoiser(nn.Module):
         self.decoder = _Decoder(_Layer(d, num_heads, ff_size, dropout), num_layers, d)
         self._cfg = dict(num_layers=num_layers, latent_dim=latent_dim[-1], d_model=d, ff_size=ff_size, num_heads=num_heads)
         self.return_attention = True   # set False to skip materialising att_mats (returns [])
-        self._handle = None
-        self._handle_device = None
-        self._dirty = True
-        self._mem_len = 0
+        self._main = dict(handle=None, device=None, version=-1, mem_len=0)
+        self._side = dict(handle=None, device=None, version=-1, mem_len=0)
+        self._version = 0          # bumped whenever the parameters may have changed: engines re-upload lazily
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
 
     # ---- engine management ---------------------------------------------------------------------
     def _mark_dirty(self):
-        self._dirty = True
+        self._version += 1
 
     def _apply(self, fn, *a, **kw):
-        self._dirty = True
+        self._version = getattr(self, "_version", 0) + 1
         return super()._apply(fn, *a, **kw)
 
     def __del__(self):
         try:
-            if self._handle is not None:
-                _lib.load().cfd_destroy(self._handle)
+            for st in (self._main, self._side):
+                if st["handle"] is not None:
+                    _lib.load().cfd_destroy(st["handle"])
         except Exception:
             pass
 
-    def engine(self, device=None, mem_len=0):
+    def engine(self, device=None, mem_len=0, side=False):
         """The libcfdenoise handle with the current weights uploaded (re-uploaded after
         load_state_dict / .to()).  ``mem_len``: longest memory the call will pass; the closed-form
         memory PE is extended past the checkpoint's 1024 rows when needed (SURVEY.md fact 4 -- the
-        reference itself raises for S > 1024)."""
+        reference itself raises for S > 1024).  ``side=True``: a second handle with the same weights for forwards
+        issued while a sampling run is open on the first (the run owns its handle's workspace and captured graph)."""
         device = torch.device(device) if device is not None else self.latent_embd.weight.device
         if device.type != "cuda":
             raise RuntimeError("convofusion_amd.Denoiser runs on an MI355X only (move the module to 'cuda'); "
                                "there is no CPU fallback")
         lib = _lib.load()
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        if self._handle is None or self._handle_device != idx:
-            if self._handle is not None:
-                lib.cfd_destroy(self._handle)
-            self._handle = _lib.create_handle(idx, **self._cfg)
-            self._handle_device = idx
-            self._dirty = True
-        if self._dirty or mem_len > self._mem_len:
+        st = self._side if side else self._main
+        if st["handle"] is None or st["device"] != idx:
+            if st["handle"] is not None:
+                lib.cfd_destroy(st["handle"])
+            st["handle"] = _lib.create_handle(idx, **self._cfg)
+            st["device"] = idx
+            st["version"] = -1
+        if st["version"] != self._version or mem_len > st["mem_len"]:
             sd = self.state_dict()
             need = max(mem_len, sd["mem_pos.pe"].shape[0])
             for name, t in sd.items():
@@ -200,14 +202,18 @@ class Denoiser(nn.Module):
                     ext = sine_pe(need, self.text_encoded_dim).to(t.device, t.dtype)
                     t = torch.cat([t, ext[t.shape[0]:]], dim=0)
                 t = t.detach().to(torch.float32).contiguous()
-                _lib.check(lib.cfd_load_tensor(self._handle, name.encode(), C.c_void_p(t.data_ptr()), t.numel(),
+                _lib.check(lib.cfd_load_tensor(st["handle"], name.encode(), C.c_void_p(t.data_ptr()), t.numel(),
                                                1 if t.is_cuda else 0))
-            _lib.check(lib.cfd_finalize_weights(self._handle))
+            _lib.check(lib.cfd_finalize_weights(st["handle"]))
             tab = sinusoid_table(1000, self.text_encoded_dim)
-            _lib.check(lib.cfd_set_timestep_table(self._handle, C.c_void_p(tab.data_ptr()), tab.shape[0]))
-            self._dirty = False
-            self._mem_len = need
-        return self._handle
+            _lib.check(lib.cfd_set_timestep_table(st["handle"], C.c_void_p(tab.data_ptr()), tab.shape[0]))
+            st["version"] = self._version
+            st["mem_len"] = need
+        return st["handle"]
+
+    @property
+    def _handle(self):
+        return self._main["handle"]
 
     # ---- conditioning helpers ------------------------------------------------------------------
     @staticmethod
@@ -241,13 +247,15 @@ class Denoiser(nn.Module):
 
     # ---- forward -------------------------------------------------------------------------------
     def forward(self, sample, timestep, encoder_hidden_states, lengths=None, mem_mask_dict=dict(), **kwargs):
+        """``kwargs['side_engine']=True`` (extension): run on the second handle, for calls made while a sampling run is
+        open on the first; every other keyword (``return_dict`` ...) is ignored like the reference does."""
         if torch.is_grad_enabled() and sample.requires_grad:
             raise NotImplementedError("the HIP denoiser is inference-only: call it under torch.no_grad()")
         if sample.dim() != 3 or sample.shape[-1] != self.latent_dim:
             raise ValueError(f"sample must be [batch, tokens, {self.latent_dim}]")
         lib = _lib.load()
         Be, L, _ = sample.shape
-        h = self.engine(sample.device, mem_len=max(int(m.shape[1]) for m in encoder_hidden_states))
+        h = self.engine(sample.device, mem_len=max(int(m.shape[1]) for m in encoder_hidden_states), side=bool(kwargs.get("side_engine", False)))
         x = sample.detach().to(torch.float32).contiguous()
         t = torch.as_tensor(timestep)
         if t.numel() == 1:

@@ -116,6 +116,6 @@ def timeit(fn, n=20):
 out["weg_loss_and_grad_B1_L16"] = {
     "ms": timeit(lambda: weg.loss_and_grad(model, lat_w, 500, enc_w, mask_w, focus_w)),
     "stepwise_from_python_ms": timeit(lambda: weg.loss_and_grad_stepwise(model, lat_w, 500, enc_w, mask_w, focus_w), 5),
-    "note": "cfd_weg_eval: ~1200 small float32 launches (forward with saved activations, objective, backward sweep) enqueued by the "
+    "note": "cfd_weg_eval: ~510 small float32 launches (forward with saved activations, objective, backward sweep) enqueued by the "
             "library, one host sync for the loss; stepwise = the same kernels, one C call per launch from Python"}
 print(json.dumps(out))
