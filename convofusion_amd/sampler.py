@@ -211,15 +211,48 @@ class SamplingRun:
             pass
 
 
+def last_step_attention(run, denoiser, timestep, encoder_hidden_states, cond_masks, guidance_chunks=CFG_CHUNKS, row_maps=None):
+    """The attention maps the reference keeps from an iteration: ``att_mats`` of the LAST guidance chunk (full
+    conditioning) of the denoiser call (convofusion.py:517-523, unbounded_synthesis.py:159-161) -- 5 tensors
+    [B, layers, L, S_j].  Call it right before ``run.steps(1)`` of that iteration: the in-painting overwrite of the rollout
+    is pulled in front (``run.inpaint``), the maps come from one extra forward of the B full-conditioning rows on the
+    denoiser's second engine (the run owns the first), so a loop that skips the zero-weight chunk still returns them."""
+    B, G = run.B, guidance_chunks
+    run.inpaint()
+    lat = run.read()
+    if row_maps is not None:   # distinct memories + row maps: gather the last chunk's rows
+        idx = [m[(G - 1) * B:].long() for m in row_maps]
+        enc = [e.index_select(0, i.to(e.device)) for e, i in zip(encoder_hidden_states, idx)]
+        masks = {k: (v.index_select(0, idx[_lib.MEM_NAMES.index(k)].to(v.device)) if v is not None else None) for k, v in (cond_masks or {}).items()}
+    else:
+        enc = [e.chunk(G)[-1] for e in encoder_hidden_states]
+        masks = {k: (v.chunk(G)[-1] if v is not None else None) for k, v in (cond_masks or {}).items()}
+    keep = denoiser.return_attention
+    denoiser.return_attention = True
+    try:
+        with torch.no_grad():
+            _, att = denoiser(sample=lat, timestep=int(timestep), encoder_hidden_states=enc, mem_mask_dict=masks, side_engine=True)
+    finally:
+        denoiser.return_attention = keep
+    return att
+
+
 def sample(denoiser, scheduler, encoder_hidden_states, cond_masks=None, *, B, L=16, num_inference_steps=1000,
            guidance_scale=7.5, guidance_chunks=CFG_CHUNKS, eta=0.0, init_latents=None, step_noise=None, seed=0,
-           first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False, row_maps=None):
-    """Run the whole loop; returns latents [B, L, 128] (batch-first)."""
+           first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False, row_maps=None, return_attention=False):
+    """Run the whole loop; returns latents [B, L, 128] (batch-first), with ``return_attention`` also the last
+    iteration's attention maps (``last_step_attention``)."""
     run = SamplingRun(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
                       guidance_scale, guidance_chunks, eta, init_latents, step_noise, seed, first_utterance, preseq, dedup,
                       skip_zero_weight_chunks, row_maps)
-    run.steps(num_inference_steps)
-    return run.read(close=True)
+    if not return_attention:
+        run.steps(num_inference_steps)
+        return run.read(close=True)
+    scheduler.set_timesteps(num_inference_steps)
+    run.steps(num_inference_steps - 1)
+    att = last_step_attention(run, denoiser, scheduler.timesteps[-1], encoder_hidden_states, cond_masks, guidance_chunks, row_maps)
+    run.steps(1)
+    return run.read(close=True), att
 
 
 # the WEG constants diffusion_reverse_forecast hard-codes instead of reading cfg.model.weg_parameters (unbounded_synthesis.py:80-84)
@@ -250,6 +283,7 @@ def _loop_from_model(model, encoder_hidden_states, cond_masks, preseq, focus_ind
               # the full-conditioning chunk has guidance weight 0 (convofusion.py:538) and the fused loop keeps no
               # attention maps, so its forward is dead work: identical latents without it
               skip_zero_weight_chunks=True)
+    kw["return_attention"] = True
     if len(focus_indices) == 0:
         return sample(model.denoiser, model.scheduler, encoder_hidden_states, cond_masks, **kw)
     return sample_with_weg(model.denoiser, model.scheduler, encoder_hidden_states, cond_masks, focus_indices,
@@ -257,7 +291,7 @@ def _loop_from_model(model, encoder_hidden_states, cond_masks, preseq, focus_ind
 
 
 def sample_with_weg(denoiser, scheduler, encoder_hidden_states, cond_masks, focus_indices, weg_parameters, *, B, L=16,
-                    num_inference_steps=1000, guidance_chunks=CFG_CHUNKS, **kw):
+                    num_inference_steps=1000, guidance_chunks=CFG_CHUNKS, return_attention=False, **kw):
     """The loop with its word-excitation-guidance branch (convofusion.py:437-496): before iteration i the latents are
     moved down the gradient of the attention-focus objective of the text-only chunk (``convofusion_amd.weg``), then the
     captured guided step runs as usual.  ``weg_parameters``: scale_factor, scale_range, max_iter_to_alter, thresholds,
@@ -271,19 +305,26 @@ def sample_with_weg(denoiser, scheduler, encoder_hidden_states, cond_masks, focu
     text_masks = {k: (v.chunk(G)[1].to(torch.uint8).contiguous() if v is not None else v) for k, v in (cond_masks or {}).items()}  # :448
     thresholds = dict(weg_parameters["thresholds"])
     timesteps = [int(t) for t in scheduler.timesteps]
+    att = None
     for i, t in enumerate(timesteps):
+        last = i == len(timesteps) - 1
         # past max_iter_to_alter the reference still evaluates the objective but only acts on it at a threshold step
         if i >= weg_parameters["max_iter_to_alter"] and i not in thresholds:
             if not any(k > i for k in thresholds):
                 break
-            run.steps(1)
-            continue
-        run.inpaint()   # rollout: the re-noised previous window goes in before the WEG update (unbounded_synthesis.py:70-76)
-        lat, _ = weg.weg_update(denoiser, run.read(), i, t, text_states, text_masks, focus_indices, weg_parameters, len(timesteps))
-        run.write(lat)
+        else:
+            run.inpaint()   # rollout: the re-noised previous window goes in before the WEG update (unbounded_synthesis.py:70-76)
+            lat, _ = weg.weg_update(denoiser, run.read(), i, t, text_states, text_masks, focus_indices, weg_parameters, len(timesteps))
+            run.write(lat)
+        if last and return_attention:
+            att = last_step_attention(run, denoiser, t, encoder_hidden_states, cond_masks, G, kw.get("row_maps"))
         run.steps(1)
+    if return_attention and att is None:
+        run.steps(num_inference_steps - 1 - run.position)
+        att = last_step_attention(run, denoiser, timesteps[-1], encoder_hidden_states, cond_masks, G, kw.get("row_maps"))
     run.steps(num_inference_steps - run.position)
-    return run.read(close=True)
+    lat = run.read(close=True)
+    return (lat, att) if return_attention else lat
 
 
 def diffusion_reverse(model, encoder_hidden_states, lengths=None, cond_masks=dict(), focus_indices=[], *,
@@ -291,16 +332,18 @@ def diffusion_reverse(model, encoder_hidden_states, lengths=None, cond_masks=dic
     """``Convofusion._diffusion_reverse(self, encoder_hidden_states, lengths, cond_masks, focus_indices)``
     with ``self`` passed as ``model`` (reads model.denoiser / scheduler / cfg / guidance_scale /
     clf_guidance_drops / latent_dim / do_classifier_free_guidance exactly like the reference).
-    Returns (latents [L, B, 128], attention_matrices dict) -- the dict is empty: per-step attention maps
-    are only materialised by ``Denoiser.forward`` (the reference keeps 1000 x 5 tensors alive)."""
-    lat = _loop_from_model(model, encoder_hidden_states, cond_masks, None, focus_indices, init_latents, seed)
-    return lat.permute(1, 0, 2), dict()                                                            # :548-549
+    Returns (latents [L, B, 128], attention_matrices dict).  The reference fills the dict with the full-conditioning
+    chunk's ``att_mats`` of EVERY iteration (1000 x 5 tensors kept alive, written out as att_<t>.npy by base.py:252-259);
+    the fused loop keeps the last iteration's entry only: {t_last: att_mats} (``last_step_attention``)."""
+    lat, att = _loop_from_model(model, encoder_hidden_states, cond_masks, None, focus_indices, init_latents, seed)
+    return lat.permute(1, 0, 2), {int(model.scheduler.timesteps[-1]): att}                        # :523,548-549
 
 
 def diffusion_reverse_forecast(model, encoder_hidden_states, lengths=None, preseq=None, cond_masks=dict(),
                                focus_indices=[], *, init_latents=None, seed=None):
     """``unbounded_synthesis.diffusion_reverse_forecast`` (reference unbounded_synthesis.py:28-187): the same
-    loop with the first ``preseq.shape[1]`` tokens re-noised from the previous window every step (:70-76)."""
-    lat = _loop_from_model(model, encoder_hidden_states, cond_masks, preseq, focus_indices, init_latents, seed,
-                           weg_parameters=FORECAST_WEG_PARAMETERS)
-    return lat.permute(1, 0, 2), dict()
+    loop with the first ``preseq.shape[1]`` tokens re-noised from the previous window every step (:70-76).
+    Returns (latents [L, B, 128], att_mats of the last iteration's full-conditioning chunk) like the reference (:159,187)."""
+    lat, att = _loop_from_model(model, encoder_hidden_states, cond_masks, preseq, focus_indices, init_latents, seed,
+                                weg_parameters=FORECAST_WEG_PARAMETERS)
+    return lat.permute(1, 0, 2), att

@@ -200,9 +200,22 @@ def test_model_level_drop_in():
         denoiser=hip_denoiser(1234, 1.0), scheduler=_sched("ddpm"), guidance_scale=7.5, clf_guidance_drops=6,
         latent_dim=[1, 128], do_classifier_free_guidance=True,
         cfg=SimpleNamespace(model=SimpleNamespace(scheduler=SimpleNamespace(num_inference_timesteps=5, eta=0.0))))
-    torch.manual_seed(0)
-    lat, atts = diffusion_reverse(model, [to_dev(x) for x in cb["memories"]], None, {k: to_dev(v) for k, v in cb["masks"].items()})
-    assert tuple(lat.shape) == (L, B, 128) and torch.isfinite(lat).all() and atts == {}
+    init0 = philox_ref.normal_tensor(21, 0, range(B), 1, L)
+    lat, atts = diffusion_reverse(model, [to_dev(x) for x in cb["memories"]], None, {k: to_dev(v) for k, v in cb["masks"].items()},
+                                  init_latents=to_dev(init0), seed=21)
+    assert tuple(lat.shape) == (L, B, 128) and torch.isfinite(lat).all()
+    # the attention dict: the reference keeps the full-conditioning chunk's maps of every iteration (convofusion.py:517-523);
+    # the fused loop returns the last iteration's entry -- checked against the oracle loop's maps at that timestep
+    sd = state_dict()
+    want, _, ref_att = sampler_ref.diffusion_reverse(
+        lambda x, t, e, mk: denoiser_ref.denoiser_forward(sd, x, t, e, mk), scheduler_ref.DDPMSchedulerRef(), cb["memories"], cb["masks"],
+        init0, lambda i, t: philox_ref.normal_tensor(21, i, range(B), 0, L), num_inference_steps=5, return_att=True)
+    assert rel_l2(lat.cpu().numpy(), want) < TRAJ_TOL
+    t_last = int(model.scheduler.timesteps[-1])
+    assert list(atts.keys()) == [t_last] and len(atts[t_last]) == 5
+    for j in range(5):
+        a = atts[t_last][j].cpu().numpy()
+        assert a.shape == (B, 9, L, S[j]) and np.abs(a - ref_att[t_last][j]).max() < 5e-5
     # the WEG branch (focus_indices) through the same entry point: batch size 1 as the reference requires
     # (word_excitation_guidance.py:25); it must change the result and stay finite
     from convofusion_amd.sampler import diffusion_reverse_forecast
@@ -217,9 +230,13 @@ def test_model_level_drop_in():
     assert (steered - plain).norm() / plain.norm() > 1e-3
     # the rollout entry point with its hard-coded WEG constants (unbounded_synthesis.py:80-84)
     pre = 0.3 * torch.randn((1, 8, 128), device="cuda")
-    f_plain, _ = diffusion_reverse_forecast(model, enc1, None, pre, masks1, init_latents=init, seed=5)
-    f_weg, _ = diffusion_reverse_forecast(model, enc1, None, pre, masks1, focus_indices=[[2]], init_latents=init, seed=5)
+    f_plain, a_plain = diffusion_reverse_forecast(model, enc1, None, pre, masks1, init_latents=init, seed=5)
+    f_weg, a_weg = diffusion_reverse_forecast(model, enc1, None, pre, masks1, focus_indices=[[2]], init_latents=init, seed=5)
     assert torch.isfinite(f_weg).all() and (f_weg - f_plain).norm() / f_plain.norm() > 1e-4
+    # the rollout returns the last iteration's att_mats list itself (unbounded_synthesis.py:159,187)
+    for att in (a_plain, a_weg):
+        assert len(att) == 5 and all(tuple(a.shape) == (1, 9, L, s) for a, s in zip(att, (6, 20, 12, 8, 1)))
+        assert all(torch.allclose(a.sum(-1), torch.ones_like(a.sum(-1)), atol=1e-4) for a in att)
 
 
 @pytest.mark.parametrize("shape", ["C2"])
