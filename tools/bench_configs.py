@@ -5,6 +5,7 @@ contract).  Prints one JSON object:
   C5  dyadic reactive path, B=16 per side, same shape (speaker memory = partner projection, 196 keys)
   audio encoder: AudioConvEncoder over (B+1) x 1500 Mel frames (the conditioning producer of one batch)
   VAE decode: ConvoFusionVae.decode of one batch (B=32, 128 frames)
+  C1 on the GPU: one utterance at the product shape, 1000-step DDPM end to end, without / with WEG
   WEG: one objective + gradient evaluation (convofusion_amd.weg.loss_and_grad) at the product shape, B=1
 usage: python tools/bench_configs.py   (on the GPU box)"""
 import json
@@ -118,4 +119,28 @@ out["weg_loss_and_grad_B1_L16"] = {
     "stepwise_from_python_ms": timeit(lambda: weg.loss_and_grad_stepwise(model, lat_w, 500, enc_w, mask_w, focus_w), 5),
     "note": "cfd_weg_eval: ~510 small float32 launches (forward with saved activations, objective, backward sweep) enqueued by the "
             "library, one host sync for the loss; stepwise = the same kernels, one C call per launch from Python"}
+# ---- C1 on the GPU: ONE utterance at the product shape (B=1, L=16, 161 audio tokens), the full 1000-step DDPM loop end to end,
+#      without and with word-excitation guidance (the reference's defaults: 800 altered iterations, 4 threshold iterations)
+from convofusion_amd.sampler import sample_with_weg  # noqa: E402
+g1 = torch.Generator().manual_seed(11)
+cond1 = [torch.randn(1, s, 512, generator=g1) for s in Sw]
+unc1 = [torch.randn(1, s, 512, generator=g1) for s in Sw]
+pat = {0: (3, 6), 1: (2, 6), 2: (1, 6), 3: (4, 6), 4: (5, 6)}        # chunks that carry the conditional memory (convofusion.py:909-929)
+enc7 = [torch.cat([(cond1[j] if c in pat[j] else unc1[j]) for c in range(7)], 0).to(dev) for j in range(5)]
+mask7 = {"spkemb": None, "alsn": None, "apb": None, "lsnemb": None, "tlsn": (torch.arange(24) >= 17)[None].expand(7, 24).contiguous().to(dev)}
+sch1 = scheduler.DDPMScheduler(**SCHED)
+sample(model, sch1, enc7, mask7, B=1, L=16, num_inference_steps=3, seed=1)
+sync()
+t0 = time.time()
+sample(model, sch1, enc7, mask7, B=1, L=16, num_inference_steps=1000, seed=1)
+sync()
+t_plain = time.time() - t0
+wp = dict(scale_factor=1000, scale_range=[1.0, 0.5], max_iter_to_alter=800, thresholds={0: 0.05, 200: 0.4, 400: 0.6, 600: 0.8}, max_refinement_steps=300)
+t0 = time.time()
+sample_with_weg(model, sch1, enc7, mask7, [[3, 9, 14]], wp, B=1, L=16, num_inference_steps=1000, seed=1)
+sync()
+t_weg = time.time() - t0
+out["C1_single_utterance_ddpm1000"] = {"seconds_end_to_end": t_plain, "steps_per_s": 1000 / t_plain, "with_weg_seconds": t_weg,
+                                       "note": "B=1 product shape (L=16, S=(24,161,24,8,1)); WEG with configs/assets.yaml:18-23 parameters on random weights "
+                                               "(the threshold iterations run their refinement loops to the 300-evaluation cap or until the objective falls)"}
 print(json.dumps(out))
