@@ -1379,7 +1379,7 @@ extern "C" int cfd_layer_norm_bwd(cfd_handle c, const float* x, const float* gam
   if (!c || !x || !gamma || !dy || !dx || rows < 1 || D < 1 || D > 2048) return fail(CFD_E_ARG, "bad argument (D <= 2048)");
   HIPCHK(hipSetDevice(c->cfg.device));
   hipLaunchKernelGGL(layernorm_bwd_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, dx, rows, D, eps,
-                     accumulate);
+                     accumulate, (const float*)nullptr, (const float*)nullptr);
   HIPCHK(hipGetLastError());
   return CFD_OK;
 }

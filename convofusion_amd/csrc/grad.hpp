@@ -86,24 +86,40 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(MatView A, MatView B, flo
 // LDS in k-chunks of 512, B streams from global memory once), partial sums meet in LDS and are added in ascending tk.
 // N / 16 x M / 16 workgroups instead of N / 64 x M / 64, and one memory round trip per k-chunk.
 #define R16_KC 512
-__device__ __forceinline__ void gemm_f32_rows16_tile(const MatView& A, const MatView& B, float* C, long long c_rs, long long c_cs, long long c_b1,
-                                                     long long c_b2, int M, int N, int K, int nb2, const float* bias, float alpha, int accumulate,
-                                                     const float* resid, int a_act, int bx, int by, int bz) {
+struct GemmSeg {   // one more (A, B, K) term of the same output: C = alpha * sum_segments A_s B_s + ...
+  MatView A, B;
+  int K;
+};
+template <bool MULTI>
+__device__ __forceinline__ void gemm_f32_rows16_tile(const MatView& A0, const MatView& B0, float* C, long long c_rs, long long c_cs, long long c_b1,
+                                                     long long c_b2, int M, int N, int K0, int nb2, const float* bias, float alpha, int accumulate,
+                                                     const float* resid, int a_act, int bx, int by, int bz, const GemmSeg* more = nullptr,
+                                                     int n_more = 0) {
   __shared__ __attribute__((aligned(16))) float As[R16_KC][20];   // [k][row], rows padded to 20 (16-byte aligned float4 reads)
   __shared__ float red[16][16][17];                                // [tk][tn][row]
   const int z1 = bz / nb2, z2 = bz % nb2;
-  const float* a = A.p + z1 * A.b1 + z2 * A.b2;
-  const float* b = B.p + z1 * B.b1 + z2 * B.b2;
   float* c = C + z1 * c_b1 + z2 * c_b2;
   const int m0 = by * 16, n0 = bx * 16;
   const int tid = threadIdx.x;
-  const bool b_n_fast = B.cs == 1, a_k_fast = A.cs == 1;
+  // the thread layout follows the first segment's operand orientation (all segments of a launch share it)
+  const bool b_n_fast = B0.cs == 1, a_k_fast = A0.cs == 1;
   const int tn = b_n_fast ? (tid & 15) : (tid >> 4), tk = b_n_fast ? (tid >> 4) : (tid & 15);
   const int n = n0 + tn;
   const bool n_ok = n < N;
   float acc[16];
 #pragma unroll
   for (int m = 0; m < 16; ++m) acc[m] = 0.f;
+  bool first = true;
+  for (int sgi = 0; sgi <= (MULTI ? n_more : 0); ++sgi) {
+  MatView A = A0, B = B0;
+  int K = K0;
+  if (MULTI && sgi) {
+    A = more[sgi - 1].A;
+    B = more[sgi - 1].B;
+    K = more[sgi - 1].K;
+  }
+  const float* a = A.p + z1 * A.b1 + z2 * A.b2;
+  const float* b = B.p + z1 * B.b1 + z2 * B.b2;
   // This is latency-bound work (one workgroup owns a 512-deep dependent chain): every global load of a k-chunk -- the
   // thread's 32 B values and its 32 A values -- is issued before anything waits, so a chunk costs one memory round trip.
   const int am = a_k_fast ? (tid >> 4) : (tid & 15), ak = a_k_fast ? (tid & 15) : (tid >> 4);   // A element (am, ak + 16 i)
@@ -123,7 +139,8 @@ __device__ __forceinline__ void gemm_f32_rows16_tile(const MatView& A, const Mat
 #pragma unroll
       for (int i = 0; i < R16_KC / 16; ++i) av[i] = (am_ok && ak + 16 * i < kc) ? act_f32(av[i], a_act) : 0.f;
     }
-    if (k0) __syncthreads();          // the previous chunk's LDS reads are done
+    if (!first) __syncthreads();      // the previous chunk's LDS reads are done
+    first = false;
 #pragma unroll
     for (int i = 0; i < R16_KC / 16; ++i) As[ak + 16 * i][am] = av[i];
     __syncthreads();
@@ -140,6 +157,7 @@ __device__ __forceinline__ void gemm_f32_rows16_tile(const MatView& A, const Mat
         acc[12] = fmaf(a3.x, w, acc[12]); acc[13] = fmaf(a3.y, w, acc[13]); acc[14] = fmaf(a3.z, w, acc[14]); acc[15] = fmaf(a3.w, w, acc[15]);
       }
     }
+  }
   }
 #pragma unroll
   for (int m = 0; m < 16; ++m) red[tk][tn][m] = acc[m];
@@ -161,7 +179,7 @@ __device__ __forceinline__ void gemm_f32_rows16_tile(const MatView& A, const Mat
 __global__ void __launch_bounds__(256) gemm_f32_rows16_kernel(MatView A, MatView B, float* C, long long c_rs, long long c_cs, long long c_b1,
                                                               long long c_b2, int M, int N, int K, int nb2, const float* bias, float alpha,
                                                               int accumulate, const float* resid, int a_act) {
-  gemm_f32_rows16_tile(A, B, C, c_rs, c_cs, c_b1, c_b2, M, N, K, nb2, bias, alpha, accumulate, resid, a_act, blockIdx.x, blockIdx.y, blockIdx.z);
+  gemm_f32_rows16_tile<false>(A, B, C, c_rs, c_cs, c_b1, c_b2, M, N, K, nb2, bias, alpha, accumulate, resid, a_act, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Up to five independent products in one launch (the five cross-attentions of a layer differ in weights and memory
@@ -187,8 +205,8 @@ __global__ void __launch_bounds__(256) gemm_f32_rows16_grouped_kernel(const Gemm
   while (gi + 1 < gs.n && (int)blockIdx.z >= gs.zoff[gi + 1]) ++gi;
   const GemmGroup& g = gs.g[gi];
   if ((int)blockIdx.x * 16 >= g.N || (int)blockIdx.y * 16 >= g.M) return;
-  gemm_f32_rows16_tile(g.A, g.B, g.C, g.c_rs, g.c_cs, g.c_b1, g.c_b2, g.M, g.N, g.K, g.nb2, g.bias, g.alpha, g.accumulate, g.resid, g.a_act, blockIdx.x,
-                       blockIdx.y, blockIdx.z - gs.zoff[gi]);
+  gemm_f32_rows16_tile<false>(g.A, g.B, g.C, g.c_rs, g.c_cs, g.c_b1, g.c_b2, g.M, g.N, g.K, g.nb2, g.bias, g.alpha, g.accumulate, g.resid, g.a_act,
+                              blockIdx.x, blockIdx.y, blockIdx.z - gs.zoff[gi]);
 }
 static inline void launch_gemm_f32_grouped(hipStream_t st, GemmGroups& gs) {
   int mx = 0, nx = 0;
@@ -200,6 +218,26 @@ static inline void launch_gemm_f32_grouped(hipStream_t st, GemmGroups& gs) {
   }
   hipLaunchKernelGGL(gemm_f32_rows16_grouped_kernel, dim3((unsigned)((nx + 15) / 16), (unsigned)((mx + 15) / 16), (unsigned)gs.zoff[gs.n]), dim3(256), 0, st,
                      gs);
+}
+
+// C = alpha * (A_0 B_0 + A_1 B_1 + ...) + ...: the terms of one output summed inside the workgroup (the five cross-attention
+// query gradients that meet in one tensor: one launch and one pass over the output instead of five read-modify-writes)
+struct GemmSum {
+  GemmGroup g;                       // output, extents and the first term
+  GemmSeg more[GEMM_MAX_GROUPS - 1];
+  int n_more;
+};
+__global__ void __launch_bounds__(256) gemm_f32_rows16_sum_kernel(const GemmSum s) {
+  __shared__ GemmSeg more[GEMM_MAX_GROUPS - 1];        // the extra terms, out of the kernel-argument segment
+  if (threadIdx.x < (unsigned)s.n_more) more[threadIdx.x] = s.more[threadIdx.x];
+  __syncthreads();
+  const GemmGroup& g = s.g;
+  gemm_f32_rows16_tile<true>(g.A, g.B, g.C, g.c_rs, g.c_cs, g.c_b1, g.c_b2, g.M, g.N, g.K, g.nb2, g.bias, g.alpha, g.accumulate, g.resid, g.a_act, blockIdx.x,
+                             blockIdx.y, blockIdx.z, more, s.n_more);
+}
+static inline void launch_gemm_f32_sum(hipStream_t st, const GemmSum& s) {
+  hipLaunchKernelGGL(gemm_f32_rows16_sum_kernel, dim3((unsigned)((s.g.N + 15) / 16), (unsigned)((s.g.M + 15) / 16), (unsigned)(s.g.nb1 * s.g.nb2)),
+                     dim3(256), 0, st, s);
 }
 
 // launch the product with the kernel that fits its shape
@@ -256,8 +294,10 @@ __global__ void __launch_bounds__(256) softmax_bwd_f32_kernel(const float* p, fl
 
 // dx (+)= rstd * (dh - mean(dh) - xh * mean(dh * xh)),  dh = dy * gamma,  xh = (x - mean) * rstd   (nn.LayerNorm backward
 // with respect to its input); one wave per row, D <= 2048
+// With (tb_h, tb_e) the incoming gradient is first taken through the TimeBlock's SiLU and modulation:
+// dy <- dy * SiLU'(tb_h) * (1 + tb_e[d])   (tb_h the modulated LayerNorm output the forward kept, tb_e its [scale | shift] row).
 __global__ void __launch_bounds__(256) layernorm_bwd_f32_kernel(const float* x, const float* g, const float* dy, float* dx, long long rows, int D,
-                                                                float eps, int accumulate) {
+                                                                float eps, int accumulate, const float* tb_h, const float* tb_e) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -286,7 +326,12 @@ __global__ void __launch_bounds__(256) layernorm_bwd_f32_kernel(const float* x, 
   for (int q = 0; q < 32; ++q) {
     const int c = lane + 64 * q;
     v[q] *= rstd;
-    dh[q] = c < D ? dr[c] * g[c] : 0.f;
+    float dyv = c < D ? dr[c] : 0.f;
+    if (tb_h && c < D) {
+      const float y = tb_h[row * D + c], sg = 1.0f / (1.0f + expf(-y));
+      dyv *= (sg * (1.0f + y * (1.0f - sg))) * (1.0f + tb_e[c]);
+    }
+    dh[q] = c < D ? dyv * g[c] : 0.f;
     s1 += dh[q];
     s2 = fmaf(dh[q], v[q], s2);
   }
@@ -299,6 +344,38 @@ __global__ void __launch_bounds__(256) layernorm_bwd_f32_kernel(const float* x, 
       if (accumulate) r += dx[row * D + c];
       dx[row * D + c] = r;
     }
+  }
+}
+
+// h = LayerNorm(x) * (1 + e[d]) + e[D + d]: the TimeBlock's norm and modulation in one pass (cross_attention.py:433-436)
+__global__ void __launch_bounds__(256) layernorm_mod_f32_kernel(const float* x, const float* g, const float* b, const float* e, float* out, long long rows,
+                                                                int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * D;
+  float v[32];
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const int c = lane + 64 * q;
+    v[q] = c < D ? xr[c] : 0.f;
+    s += v[q];
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const int c = lane + 64 * q;
+    const float d = c < D ? v[q] - mean : 0.f;
+    v[q] = d;
+    ss += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + eps);
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const int c = lane + 64 * q;
+    if (c < D) out[row * D + c] = (v[q] * rstd * g[c] + b[c]) * (1.0f + e[c]) + e[D + c];
   }
 }
 

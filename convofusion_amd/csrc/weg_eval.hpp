@@ -102,9 +102,19 @@ struct Ctx {
     if (!skip()) hipLaunchKernelGGL(layernorm_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, g, b, out, rows, D, 1e-5f);
     return out;
   }
-  void ln_bwd(const float* x, const float* g, const float* dy, float* dx, long long rows, int accumulate) {
+  void ln_bwd(const float* x, const float* g, const float* dy, float* dx, long long rows, int accumulate, const float* tb_h = nullptr,
+              const float* tb_e = nullptr) {
     if (skip()) return;
-    hipLaunchKernelGGL(layernorm_bwd_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, g, dy, dx, rows, D, 1e-5f, accumulate);
+    hipLaunchKernelGGL(layernorm_bwd_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, g, dy, dx, rows, D, 1e-5f, accumulate, tb_h, tb_e);
+  }
+  float* ln_mod(const float* x, long long rows, const float* g, const float* b, const float* e) {
+    float* out = alloc((size_t)rows * D);
+    if (!skip()) hipLaunchKernelGGL(layernorm_mod_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, g, b, e, out, rows, D, 1e-5f);
+    return out;
+  }
+  void gemm_sum(const GemmSum& gs) {
+    if (skip()) return;
+    launch_gemm_f32_sum(st, gs);
   }
   void gemm_grouped(GemmGroups& gs) {
     if (skip()) return;
@@ -132,6 +142,8 @@ struct Ctx {
 // head views of batch-major rows (row stride rs, n rows per batch entry): (b, h; t, d) and its transpose (b, h; d, t)
 static inline View heads(float* t, int n, long long rs, int hd) { return View{t, rs, 1, (long long)n * rs, hd}; }
 static inline View heads_T(float* t, int n, long long rs, int hd) { return View{t, 1, rs, (long long)n * rs, hd}; }
+
+static inline GemmGroup group(View A, View Bv, View Cv, int M, int N, int K, int nb1, int nb2, const float* bias, float alpha);
 
 // nn.MultiheadAttention(query, memory, memory, key_padding_mask) on batch-major rows; self-attention (memory == query) projects
 // q | k | v in one product, cross-attention k | v.  The output projection writes rows out_rs apart (a column block of the
@@ -201,10 +213,13 @@ static void mha_bwd(Ctx& x, const AttnSaved& sv, const float* dout, long long do
     x.linear_bwd(dq, E, (long long)B * T, E, sv.W, E, dx, accumulate);
     return;
   }
-  float* dqkv = x.alloc((size_t)B * T * 3 * E);      // [rows][dq | dk | dv]
-  x.gemm(T, hd, S, B, H, View{dp, S, 1, blk, (long long)T * S}, heads(sv.k, S, sv.kv_rs, hd), heads(dqkv, T, 3 * E, hd), nullptr, sv.scale, 0);
-  x.gemm(S, hd, T, B, H, View{dp, 1, S, blk, (long long)T * S}, heads(sv.q, T, sv.q_rs, hd), heads(dqkv + E, S, 3 * E, hd), nullptr, sv.scale, 0);
-  x.gemm(S, hd, T, B, H, View{sv.p, 1, S, sv.pb1, (long long)T * S}, heads(d_o, T, E, hd), heads(dqkv + 2 * E, S, 3 * E, hd), nullptr, 1.0f, 0);
+  float* dqkv = x.alloc((size_t)B * T * 3 * E);      // [rows][dq | dk | dv]: three products, one launch
+  GemmGroups g3;
+  g3.n = 3;
+  g3.g[0] = group(View{dp, S, 1, blk, (long long)T * S}, heads(sv.k, S, sv.kv_rs, hd), heads(dqkv, T, 3 * E, hd), T, hd, S, B, H, nullptr, sv.scale);
+  g3.g[1] = group(View{dp, 1, S, blk, (long long)T * S}, heads(sv.q, T, sv.q_rs, hd), heads(dqkv + E, S, 3 * E, hd), S, hd, T, B, H, nullptr, sv.scale);
+  g3.g[2] = group(View{sv.p, 1, S, sv.pb1, (long long)T * S}, heads(d_o, T, E, hd), heads(dqkv + 2 * E, S, 3 * E, hd), S, hd, T, B, H, nullptr, 1.0f);
+  x.gemm_grouped(g3);
   x.linear_bwd(dqkv, 3 * E, (long long)B * T, 3 * E, sv.W, E, dx, accumulate);
 }
 
@@ -294,20 +309,22 @@ static void cross_bwd_grouped(Ctx& x, const AttnSaved sv[CFD_NMEM], const float*
   x.gemm_grouped(g2);
   x.softmax_grouped(sm, CFD_NMEM, true);
   x.gemm_grouped(g3);
-  for (int j = 0; j < CFD_NMEM; ++j) x.linear_bwd(dq[j], E, rows, E, sv[j].W, E, dt2, j > 0);
+  GemmSum sum;                                                   // dt2 = sum_j dq_j Wq_j
+  sum.g = group(View{dq[0], E, 1, 0, 0}, View{const_cast<float*>(sv[0].W), E, 1, 0, 0}, View{dt2, E, 1, 0, 0}, (int)rows, E, E, 1, 1, nullptr, 1.0f);
+  sum.n_more = CFD_NMEM - 1;
+  for (int j = 1; j < CFD_NMEM; ++j)
+    sum.more[j - 1] = GemmSeg{MatView{dq[j], E, 1, 0, 0}, MatView{sv[j].W, E, 1, 0, 0}, E};
+  x.gemm_sum(sum);
 }
 
-// x + TimeBlock(x) (cross_attention.py:426-439, the caller's residual :575,:655) for one shared time-embedding row
-static float* time_block_fwd(Ctx& x, const std::string& pfx, float* in, const float* temb, TbSaved& sv) {
+// x + TimeBlock(x) (cross_attention.py:426-439, the caller's residual :575,:655); `e` = emb_layers(temb) [1][2 D] (scale first),
+// computed for all blocks of the evaluation at once (time_block_embeddings)
+static float* time_block_fwd(Ctx& x, const std::string& pfx, float* in, float* e, TbSaved& sv) {
   const int D = x.D;
   const long long rows = (long long)x.B * x.L;
-  const float *We = x.W(pfx + ".emb_layers.1.weight"), *be = x.W(pfx + ".emb_layers.1.bias"), *g = x.W(pfx + ".norm.weight"),
-              *bn = x.W(pfx + ".norm.bias"), *Wout = x.W(pfx + ".out_layers.2.weight"), *bout = x.W(pfx + ".out_layers.2.bias");
+  const float *g = x.W(pfx + ".norm.weight"), *bn = x.W(pfx + ".norm.bias"), *Wout = x.W(pfx + ".out_layers.2.weight"), *bout = x.W(pfx + ".out_layers.2.bias");
   if (x.err) return nullptr;
-  float* e = x.linear(temb, D, 1, D, We, be, 2 * D, nullptr, 0, nullptr, 1);          // Linear(SiLU(temb)): [1][2 D], scale first
-  float* n = x.ln(in, rows, g, bn);
-  float* h = x.alloc((size_t)rows * D);
-  x.ew(EW_MODULATE, n, e, h, rows * D, D, 1);
+  float* h = x.ln_mod(in, rows, g, bn, e);                                            // LN(x) (1 + scale) + shift
   sv = TbSaved{in, h, e, g, Wout};
   return x.linear(h, D, rows, D, Wout, bout, D, nullptr, 0, in, 1);                   // in + Linear(SiLU(h))
 }
@@ -317,8 +334,27 @@ static void time_block_bwd(Ctx& x, const TbSaved& sv, float* g) {
   const int D = x.D;
   const long long rows = (long long)x.B * x.L;
   float* dh = x.linear_bwd(g, D, rows, D, sv.Wout, D);
-  if (!x.skip()) hipLaunchKernelGGL(tb_bwd_f32_kernel, dim3((unsigned)((rows * D + 255) / 256)), dim3(256), 0, x.st, dh, sv.h, sv.e, dh, rows * D, D);
-  x.ln_bwd(sv.x, sv.g, dh, g, rows, 1);
+  x.ln_bwd(sv.x, sv.g, dh, g, rows, 1, sv.h, sv.e);                                   // through SiLU', the modulation and the norm
+}
+
+// emb_layers of every TimeBlock of the evaluation: Linear(SiLU(temb)) -> e[2 * layer + {0, 1}] [1][2 D], five blocks per launch
+static void time_block_embeddings(Ctx& x, const float* temb, int n_layers, std::vector<float*>& e) {
+  const int D = x.D;
+  e.assign((size_t)2 * n_layers, nullptr);
+  GemmGroups gs;
+  gs.n = 0;
+  for (int i = 0; i < 2 * n_layers; ++i) {
+    const std::string pfx = "decoder.layers." + std::to_string(i / 2) + (i % 2 ? ".time_block2" : ".time_block1");
+    const float *We = x.W(pfx + ".emb_layers.1.weight"), *be = x.W(pfx + ".emb_layers.1.bias");
+    if (x.err) return;
+    e[i] = x.alloc((size_t)2 * D);
+    gs.g[gs.n] = group(View{const_cast<float*>(temb), D, 1, 0, 0}, View{const_cast<float*>(We), 1, D, 0, 0}, View{e[i], 2 * D, 1, 0, 0}, 1, 2 * D, D, 1, 1, be, 1.0f);
+    gs.g[gs.n].a_act = 1;
+    if (++gs.n == GEMM_MAX_GROUPS || i == 2 * n_layers - 1) {
+      x.gemm_grouped(gs);
+      gs.n = 0;
+    }
+  }
 }
 
 struct Args {
@@ -355,6 +391,9 @@ static void run(Ctx& x, const Args& a) {
     x.ew(EW_ADD_BCAST, mems[j], mpe, mems[j], n, D, S, 0, D);                                   // + pe[s]
   }
   if (x.err) return;
+  std::vector<float*> tb_e;
+  time_block_embeddings(x, temb, NL, tb_e);
+  if (x.err) return;
   // ---- layers, keeping what the backward needs
   const int St = a.mem[2].S;
   float* att = x.alloc((size_t)B * NL * L * St);                 // [B][NL][L][S_text]: Denoiser.forward's att_mats[2]
@@ -366,7 +405,7 @@ static void run(Ctx& x, const Args& a) {
     float* t2 = x.ln(xx, rows, x.W(p + "norm1.weight"), x.W(p + "norm1.bias"));
     xx = mha_fwd(x, p + "self_attn", t2, L, t2, L, c->cfg.num_heads, nullptr, true, false, nullptr, 0, nullptr, 0, xx, s.self);
     if (x.err) return;
-    xx = time_block_fwd(x, p + "time_block1", xx, temb, s.tb1);
+    xx = time_block_fwd(x, p + "time_block1", xx, tb_e[2 * i], s.tb1);
     if (x.err) return;
     s.x2 = xx;
     t2 = x.ln(xx, rows, x.W(p + "norm2.weight"), x.W(p + "norm2.bias"));
@@ -375,7 +414,7 @@ static void run(Ctx& x, const Args& a) {
     if (x.err) return;
     if (i == NL - 1) break;                                      // nothing above the last cross-attention reaches the objective
     xx = x.linear(cat, CFD_NMEM * D, rows, CFD_NMEM * D, x.W(p + "att_fuser.weight"), x.W(p + "att_fuser.bias"), D, nullptr, 0, xx);
-    xx = time_block_fwd(x, p + "time_block2", xx, temb, s.tb2);
+    xx = time_block_fwd(x, p + "time_block2", xx, tb_e[2 * i + 1], s.tb2);
     if (x.err) return;
     s.x4 = xx;
     t2 = x.ln(xx, rows, x.W(p + "norm3.weight"), x.W(p + "norm3.bias"));
