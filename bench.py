@@ -162,7 +162,9 @@ def main():
             dist.barrier()
 
     run.steps(args.warmup)
-    run.read()
+    warm = run.read()
+    if world > 1:
+        gather_latents(warm, world * B_PER_GPU)   # untimed: the collective's first use sets up its channels
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()

@@ -301,8 +301,15 @@ def sample_with_weg(denoiser, scheduler, encoder_hidden_states, cond_masks, focu
     scheduler.set_timesteps(num_inference_steps)
     run = SamplingRun(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
                       guidance_chunks=G, **kw)
-    text_states = [enc.chunk(G)[1] for enc in encoder_hidden_states]                               # :447
-    text_masks = {k: (v.chunk(G)[1].to(torch.uint8).contiguous() if v is not None else v) for k, v in (cond_masks or {}).items()}  # :448
+    rm = kw.get("row_maps")
+    if rm is not None:       # distinct memories + row maps (build_guidance_batch): gather the text-only chunk's rows
+        idx = [m[B:2 * B].long() for m in rm]
+        text_states = [e.index_select(0, i.to(e.device)).contiguous() for e, i in zip(encoder_hidden_states, idx)]
+        text_masks = {k: (v.index_select(0, idx[_lib.MEM_NAMES.index(k)].to(v.device)).to(torch.uint8).contiguous() if v is not None else v)
+                      for k, v in (cond_masks or {}).items()}
+    else:
+        text_states = [enc.chunk(G)[1] for enc in encoder_hidden_states]                           # :447
+        text_masks = {k: (v.chunk(G)[1].to(torch.uint8).contiguous() if v is not None else v) for k, v in (cond_masks or {}).items()}  # :448
     thresholds = dict(weg_parameters["thresholds"])
     timesteps = [int(t) for t in scheduler.timesteps]
     att = None

@@ -193,6 +193,21 @@ def test_loop_with_weg_matches_oracle(rollout):
     err, moved = rel_l2(lat, ref), rel_l2(plain, ref)
     print(f"loop with WEG: vs oracle {err:.2e}; WEG moved the result by {moved:.2e}; oracle objective per step {log}")
     assert moved > 10 * err and err < 1e-3
+    if not rollout:
+        # the same run from the structured guidance batch (B + 1 distinct memories and row maps instead of the 7x batch)
+        from convofusion_amd.sampler import build_guidance_batch
+        cond = [to_dev(u[1:]) for u in cb["unique"]]
+        unc = [to_dev(u[:1]) for u in cb["unique"]]
+        cm = {k: (to_dev(v)[B:2 * B] if v is not None else None) for k, v in cb["masks"].items()}     # placeholder rows, replaced below
+        um = {k: (to_dev(v)[:1] if v is not None else None) for k, v in cb["masks"].items()}          # chunk 0 = all dropped
+        for j, name in enumerate(inputs.MEM_NAMES):                                                    # the conditional rows' own masks
+            if cb["masks"][name] is not None:
+                c = inputs.COND_CHUNKS[j][0]
+                cm[name] = to_dev(cb["masks"][name])[c * B:(c + 1) * B]
+        u_mems, maps, u_masks = build_guidance_batch(cond, unc, cm, um)
+        lat2 = sample_with_weg(m, sch, u_mems, u_masks, focus, params, B=B, L=L, num_inference_steps=n_steps, guidance_scale=7.5,
+                               init_latents=to_dev(init), step_noise=to_dev(noise), row_maps=maps)
+        assert rel_l2(lat2.permute(1, 0, 2).cpu().numpy(), lat) < 1e-5
 
 
 def test_gradient_at_the_synthetic_shape_matches_oracle():
