@@ -21,6 +21,7 @@
 int g_cfd_naive_gemm = 0;
 int g_cfd_gemm_cfg = 0;
 int g_cfd_small3 = 1;
+int g_cfd_deep = 0;
 
 static thread_local char g_err[1024] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -249,6 +250,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   g_cfd_gemm_cfg = env ? atoi(env) : 0;
   env = getenv("CFD_SMALL3");
   g_cfd_small3 = (env && atoi(env) == 0) ? 0 : 1;
+  env = getenv("CFD_DEEP");
+  g_cfd_deep = (env && atoi(env) != 0) ? 1 : 0;
   if (c->d_step.ensure(16) != CFD_OK) { delete c; return CFD_E_HIP; }
   if (hipMemset(c->d_step.p, 0, 16) != hipSuccess) { delete c; return fail(CFD_E_HIP, "memset"); }
   (void)hipEventCreate(&c->pev[0]);

@@ -337,6 +337,10 @@ template <class E> struct EpiPre<E, true> { typedef typename E::Pre type; };
 // NSTAGE == 3: two k-tiles of prefetch kept in flight ACROSS the per-k-step barrier: counted
 //              s_waitcnt vmcnt(GPW) + raw s_barrier (a __syncthreads() would drain the LDS-DMA queue).
 //              Requires every wave to issue exactly GPW loads per stage.
+// NSTAGE >= 5: deep prefetch for SMALL problems (a few workgroups per CU, K = 512: the k-loop is a chain of dependent
+//              memory round trips, not a throughput problem): NSTAGE k-tiles are requested before the first one is
+//              consumed and each buffer is refilled as soon as every wave has read it, so K = 512 costs two round
+//              trips instead of eight.  One workgroup per CU (NSTAGE x tile bytes of LDS).
 template <int WI, int WJ, int TI, int TJ, int NSTAGE, int MODE, class Epi>
 __global__ void __launch_bounds__(WI * WJ * 64, (WI * WJ * 64) / 256 * ((WI * TI + WJ * TJ) * 16 * 128 * (NSTAGE == 4 ? 3 : NSTAGE) > 80 * 1024 ? 1 : ((NSTAGE == 1 || (WI * TI + WJ * TJ) * 16 * 128 * NSTAGE <= 52 * 1024) ? 3 : 2)))
 gemm_sp_kernel(const GemmArgs a, const Epi epi) {
@@ -673,6 +677,36 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
       __builtin_amdgcn_s_barrier();
       buf = (buf == 2) ? 0 : buf + 1;
     }
+  } else if constexpr (NSTAGE >= 5) {
+    constexpr int NB = NSTAGE;
+    static_assert((NB - 1) * GPW <= 63, "vmcnt is a 6-bit counter");
+    const int pre_n = nkt < NB ? nkt : NB;
+    for (int s = 0; s < pre_n; ++s) stage(s, s);
+    int buf = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+      // loads complete in order: tile kt has landed once at most `after` younger tiles are still outstanding
+      const int after = min(NB - 1, nkt - 1 - kt);
+      switch (after) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPW) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GPW) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * GPW) : "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * GPW) : "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * GPW > 63 ? 63 : 5 * GPW) : "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * GPW > 63 ? 63 : 6 * GPW) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 1) * GPW > 63 ? 63 : (NB - 1) * GPW) : "memory"); break;
+      }
+      __builtin_amdgcn_s_barrier();                           // ... and every other wave's share of it
+      compute(buf);
+      if (kt + NB < nkt) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's reads of `buf` are done
+        __builtin_amdgcn_s_barrier();                         // ... and everyone else's, before the refill lands on them
+        stage(kt + NB, buf);
+      }
+      buf = buf + 1 == NB ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   } else {
     // NSTAGE == 4 ("software-pipelined"): 3 LDS buffers + register double-buffered fragments.
     // While the MFMAs of tile kt run on one register set, the LDS reads of tile kt+1 fill the other set and the
@@ -981,6 +1015,7 @@ struct GemmCfgSel { int wi, wj, ti, tj; };
 extern int g_cfd_naive_gemm;  // set from CFD_NAIVE_GEMM env at cfd_create
 extern int g_cfd_gemm_cfg;    // CFD_GEMM_CFG env: force one tile configuration (tuning / A-B runs)
 extern int g_cfd_small3;      // CFD_SMALL3 env (default 1): 3-stage loop for the small-tile classes
+extern int g_cfd_deep;        // CFD_DEEP env: 8-deep prefetch for the small-tile classes when the launch has few workgroups per CU
 
 template <int WI, int WJ, int TI, int TJ, int NSTAGE, int MODE, class Epi>
 static hipError_t launch_cfg(GemmArgs a, const Epi& epi, int nb, int nz, hipStream_t st) {
@@ -1044,6 +1079,13 @@ static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStr
     else if (a.J > 128 && a.J <= 224 && big_tiles * 2 >= 256) cfg = 6;
     else if (big_tiles * 2 >= 384 && a.J >= 96) cfg = 1;
     else cfg = g_cfd_small3 ? 19 : 2;
+    if (g_cfd_deep && (cfg == 19 || cfg == 20) && MODE != MODE_SEGK) {
+      // few workgroups per CU (one fits anyway: 128 KB of LDS) and a k-loop of at least 8 tiles: latency-bound
+      long long wgs = 0;
+      for (int g = 0; g < ng; ++g) wgs += (long long)((a.I[g] + (cfg == 19 ? 63 : 31)) / (cfg == 19 ? 64 : 32)) * ((a.J + (cfg == 19 ? 63 : 127)) / (cfg == 19 ? 64 : 128));
+      wgs *= (long long)nb * nz;
+      if (wgs <= 3 * 256 && a.kt[0] >= 8) cfg = cfg == 19 ? 21 : 22;
+    }
   }
   switch (cfg) {
     case 1: return launch_cfg<2, 2, 4, 4, 2, MODE, Epi>(a, epi, nb, nz, st);
@@ -1058,6 +1100,8 @@ static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStr
     case 16: return launch_cfg<2, 2, 2, 4, 2, MODE, Epi>(a, epi, nb, nz, st);  // 64 x 128
     case 19: return launch_cfg<2, 2, 2, 2, 3, MODE, Epi>(a, epi, nb, nz, st);   // 64 x 64, 3-stage counted-vmcnt loop
     case 20: return launch_cfg<1, 4, 2, 2, 3, MODE, Epi>(a, epi, nb, nz, st);   // 32 x 128, 3-stage
+    case 21: return launch_cfg<2, 2, 2, 2, 8, MODE, Epi>(a, epi, nb, nz, st);   // 64 x 64, 8-deep prefetch (small problems)
+    case 22: return launch_cfg<1, 4, 2, 2, 8, MODE, Epi>(a, epi, nb, nz, st);   // 32 x 128, 8-deep prefetch
     case 17: return launch_cfg<4, 1, 2, 11, 2, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 176: 43904 rows = 250 x 176 - 96
     case 18: return launch_cfg<8, 1, 2, 11, 2, MODE, Epi>(a, epi, nb, nz, st);  // 256 x 176, 8 waves
     case 12: return launch_cfg<2, 2, 4, 4, 1, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 128, single LDS buffer, 3+ blocks / CU
