@@ -109,6 +109,13 @@ __device__ __forceinline__ void gemm_f32_rows16_tile(const MatView& A0, const Ma
   float acc[16];
 #pragma unroll
   for (int m = 0; m < 16; ++m) acc[m] = 0.f;
+  // the epilogue's own operands are requested now, so they are not a second memory round trip after the k-loop
+  const int om = tid >> 4, on = tid & 15;
+  const bool o_ok = m0 + om < M && n0 + on < N;
+  const long long o = (long long)(m0 + om) * c_rs + (long long)(n0 + on) * c_cs;
+  const float e_bias = (o_ok && bias) ? bias[n0 + on] : 0.f;
+  const float e_res = (o_ok && resid) ? resid[z1 * c_b1 + z2 * c_b2 + o] : 0.f;
+  const float e_old = (o_ok && accumulate) ? c[o] : 0.f;
   bool first = true;
   for (int sgi = 0; sgi <= (MULTI ? n_more : 0); ++sgi) {
   MatView A = A0, B = B0;
@@ -162,16 +169,14 @@ __device__ __forceinline__ void gemm_f32_rows16_tile(const MatView& A0, const Ma
 #pragma unroll
   for (int m = 0; m < 16; ++m) red[tk][tn][m] = acc[m];
   __syncthreads();
-  const int om = tid >> 4, on = tid & 15;
-  if (m0 + om < M && n0 + on < N) {
+  if (o_ok) {
     float v = 0.f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) v += red[t][on][om];
     v *= alpha;
-    if (bias) v += bias[n0 + on];
-    const long long o = (long long)(m0 + om) * c_rs + (long long)(n0 + on) * c_cs;
-    if (resid) v += resid[z1 * c_b1 + z2 * c_b2 + o];
-    if (accumulate) v += c[o];
+    if (bias) v += e_bias;
+    if (resid) v += e_res;
+    if (accumulate) v += e_old;
     c[o] = v;
   }
 }
@@ -305,10 +310,17 @@ __global__ void __launch_bounds__(256) layernorm_bwd_f32_kernel(const float* x, 
   const float* dr = dy + row * D;
   float v[32], dh[32];
   float s = 0.f;
+  // every operand is requested before the first reduction (one memory round trip for the whole row)
 #pragma unroll
   for (int q = 0; q < 32; ++q) {
     const int c = lane + 64 * q;
     v[q] = c < D ? xr[c] : 0.f;
+    float dyv = c < D ? dr[c] : 0.f;
+    if (tb_h && c < D) {
+      const float y = tb_h[row * D + c], sg = 1.0f / (1.0f + expf(-y));
+      dyv *= (sg * (1.0f + y * (1.0f - sg))) * (1.0f + tb_e[c]);
+    }
+    dh[q] = c < D ? dyv * g[c] : 0.f;
     s += v[q];
   }
   const float mean = wave_sum(s) / (float)D;
@@ -326,12 +338,6 @@ __global__ void __launch_bounds__(256) layernorm_bwd_f32_kernel(const float* x, 
   for (int q = 0; q < 32; ++q) {
     const int c = lane + 64 * q;
     v[q] *= rstd;
-    float dyv = c < D ? dr[c] : 0.f;
-    if (tb_h && c < D) {
-      const float y = tb_h[row * D + c], sg = 1.0f / (1.0f + expf(-y));
-      dyv *= (sg * (1.0f + y * (1.0f - sg))) * (1.0f + tb_e[c]);
-    }
-    dh[q] = c < D ? dyv * g[c] : 0.f;
     s1 += dh[q];
     s2 = fmaf(dh[q], v[q], s2);
   }
