@@ -19,14 +19,32 @@ from .denoiser import Denoiser
 CFG_CHUNKS = 7
 
 
+def _dedup_rows_exact(m, mk):
+    """Row-by-row grouping with exact comparisons (the fallback when two different rows share a hash)."""
+    Be = m.shape[0]
+    reps, rmap = [], []
+    for b in range(Be):
+        found = -1
+        for ui, rb in enumerate(reps):
+            if (mk is None or bool((mk[b] == mk[rb]).all())) and torch.equal(m[b], m[rb]):
+                found = ui
+                break
+        if found < 0:
+            reps.append(b)
+            found = len(reps) - 1
+        rmap.append(found)
+    return torch.tensor(reps, device=m.device), torch.tensor(rmap, dtype=torch.int32, device=m.device)
+
+
 def dedup_memories(encoder_hidden_states, cond_masks=None):
     """Exact de-duplication of the replicated conditioning batch.
 
     The reference materialises every memory 7x per utterance (convofusion.py:909-929) although each
-    takes only two values per utterance -- its own and one shared unconditional tensor.  Rows are
-    compared bit-exactly (hash candidates, then ``torch.equal`` verification, masks included), so any
-    input works; in the worst case nothing is shared.  Returns (unique 5x[U_j,S_j,512],
-    row_maps 5x int32[Be], unique masks dict)."""
+    takes only two values per utterance -- its own and one shared unconditional tensor.  Rows are grouped by a
+    cheap hash on the device (identical rows reduce identically) and every row is then compared bit for bit, masks
+    included, with its group's first row; a hash collision between different rows falls back to pairwise exact
+    comparisons, so any input works (in the worst case nothing is shared).  Distinct rows keep the order of their first
+    occurrence.  Returns (unique 5x[U_j,S_j,512], row_maps 5x int32[Be], unique masks dict)."""
     cond_masks = cond_masks or {}
     uniq, maps, umasks = [], [], {}
     for j, name in enumerate(_lib.MEM_NAMES):
@@ -34,24 +52,27 @@ def dedup_memories(encoder_hidden_states, cond_masks=None):
         mask = cond_masks.get(name)
         Be = m.shape[0]
         flat = m.reshape(Be, -1)
-        # cheap candidate hash (identical rows reduce identically); candidates are verified with torch.equal below
-        hsh = torch.stack([flat.sum(1), (flat * flat).sum(1), flat[:, ::97].sum(1)], dim=1).cpu()
-        mk = mask.to(torch.uint8).cpu() if mask is not None else None
-        reps, rmap = [], []
-        for b in range(Be):
-            found = -1
-            for ui, rb in enumerate(reps):
-                if bool((hsh[b] == hsh[rb]).all()) and (mk is None or bool((mk[b] == mk[rb]).all())) \
-                        and torch.equal(m[b], m[rb]):
-                    found = ui
-                    break
-            if found < 0:
-                reps.append(b)
-                found = len(reps) - 1
-            rmap.append(found)
-        idx = torch.tensor(reps, device=m.device)
+        mk = mask.to(device=m.device, dtype=torch.uint8).reshape(Be, -1) if mask is not None else None
+        cols = [flat.sum(1), (flat * flat).sum(1), flat[:, ::97].sum(1)]
+        if mk is not None:
+            w = torch.arange(1, mk.shape[1] + 1, device=m.device, dtype=torch.float32)
+            cols += [mk.to(torch.float32).sum(1), (mk.to(torch.float32) * w).sum(1)]
+        key = torch.stack(cols, dim=1)
+        _, inv = torch.unique(key, dim=0, return_inverse=True)
+        ar = torch.arange(Be, device=m.device)
+        first = torch.full((int(inv.max()) + 1,), Be, device=m.device, dtype=torch.long).scatter_reduce_(0, inv, ar, reduce="amin")
+        order = torch.argsort(first)                       # groups in the order of their first row
+        rank = torch.empty_like(order)
+        rank[order] = torch.arange(order.numel(), device=m.device)
+        idx, rmap = first[order], rank[inv]
+        rep_row = idx[rmap]                                # every row's group representative
+        same = (flat == flat[rep_row]).all(dim=1)
+        if mk is not None:
+            same &= (mk == mk[rep_row]).all(dim=1)
+        if not bool(same.all()):                           # two different rows with one hash: exact pairwise grouping
+            idx, rmap = _dedup_rows_exact(m, mk)
         uniq.append(m.index_select(0, idx).contiguous())
-        maps.append(torch.tensor(rmap, dtype=torch.int32, device=m.device))
+        maps.append(rmap.to(torch.int32))
         umasks[name] = mask.index_select(0, idx.to(mask.device)).contiguous() if mask is not None else None
     return uniq, maps, umasks
 

@@ -103,6 +103,28 @@ def test_scheduler_mirror_tables_and_timesteps():
         s.step(torch.zeros(1, 2, 128), 5, torch.zeros(1, 2, 128))  # CPU tensors: no fallback
 
 
+def test_dedup_memories_groups_exactly():
+    """The device-agnostic grouping logic of the sampler's de-duplication (hash groups + bitwise verification) against the
+    known structure of the guidance batch and against the pairwise exact path."""
+    from convofusion_amd import sampler
+    from oracle import inputs
+    for seed, B in [(1, 1), (2, 3), (3, 8)]:
+        cb = inputs.make_cfg_batch(seed=seed, B=B, L=16, S=(6, 20, 6, 8, 1), pad_tail=(2, 0, 1, 0, 0))
+        enc = [torch.from_numpy(x) for x in cb["memories"]]
+        masks = {k: (torch.from_numpy(v) if v is not None else None) for k, v in cb["masks"].items()}
+        u, maps, um = sampler.dedup_memories(enc, masks)
+        for j, name in enumerate(inputs.MEM_NAMES):
+            assert torch.equal(maps[j], torch.from_numpy(cb["row_map"][j])) and torch.equal(u[j], torch.from_numpy(cb["unique"][j]))
+            mk = masks[name].to(torch.uint8) if masks[name] is not None else None
+            assert torch.equal(sampler._dedup_rows_exact(enc[j], mk)[1], maps[j])
+    u, maps, _ = sampler.dedup_memories([torch.randn(5, 3, 512) for _ in range(5)], {})          # nothing shared
+    assert all(m.tolist() == [0, 1, 2, 3, 4] for m in maps)
+    e = torch.randn(1, 4, 512).expand(3, 4, 512).contiguous()                                     # equal data, different masks
+    mk = torch.tensor([[0, 0, 0, 1], [0, 0, 1, 1], [0, 0, 0, 1]], dtype=torch.bool)
+    _, maps, um = sampler.dedup_memories([e] * 5, {"tlsn": mk})
+    assert maps[2].tolist() == [0, 1, 0] and maps[0].tolist() == [0, 0, 0] and um["tlsn"].shape[0] == 2
+
+
 def test_shard_helpers():
     from convofusion_amd.distributed import shard_cfg_batch, shard_range
     assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
