@@ -59,7 +59,7 @@ class SampleArgs(C.Structure):
 
 class WegArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("L", C.c_int), ("timestep", C.c_int), ("latents", C.c_void_p), ("mem", Memory * NUM_MEM),
-                ("tok_off", C.c_void_p), ("tok_idx", C.c_void_p), ("last", C.c_int), ("kernel3", C.c_float * 3)]
+                ("tok_off", C.c_void_p), ("tok_idx", C.c_void_p), ("last", C.c_int), ("kernel3", C.c_float * 3), ("reuse_memory_side", C.c_int)]
 
 
 _lib = None

@@ -374,9 +374,12 @@ def _focus_tables(B, S, focus_indices, normalize_eot, eot_indices):
     return last, off, flat
 
 
-def loss_and_grad(denoiser, latents, timestep, encoder_hidden_states, cond_masks, focus_indices, normalize_eot=True, eot_indices=None):
+def loss_and_grad(denoiser, latents, timestep, encoder_hidden_states, cond_masks, focus_indices, normalize_eot=True, eot_indices=None,
+                  same_conditioning=False):
     """One evaluation of the WEG objective on the text-only chunk (convofusion.py:447-471) and d(loss)/d(latents) --
     ``cfd_weg_eval``: forward with saved activations, objective and backward sweep enqueued by the library.
+    ``same_conditioning``: timestep, memories and masks are those of the previous call (only the latents moved): the
+    memory-side LayerNorms / key-value projections and the time embeddings are reused.
     Returns (loss 0-d tensor, losses [B], max_attention_at_indices, grad [B, L, 128])."""
     if not isinstance(denoiser, Denoiser):
         raise TypeError("denoiser must be a convofusion_amd.denoiser.Denoiser")
@@ -396,6 +399,7 @@ def loss_and_grad(denoiser, latents, timestep, encoder_hidden_states, cond_masks
     a.B, a.L, a.timestep, a.latents, a.mem = B, L, int(timestep), lat.data_ptr(), marr
     a.tok_off, a.tok_idx, a.last = off.ctypes.data, flat.ctypes.data, last
     a.kernel3 = (C.c_float * 3)(*gaussian_kernel3())
+    a.reuse_memory_side = 1 if same_conditioning else 0
     losses = torch.empty(B, dtype=torch.float32, device=dev)
     max_att = torch.empty(max(1, int(off[-1])), dtype=torch.float32, device=dev)
     grad = torch.empty_like(lat)
@@ -433,14 +437,18 @@ def iterative_refinement_step(denoiser, latents, indices_to_alter, loss, thresho
     objective falls below ``1 - threshold``.  Returns (loss, latents, max_attention_at_indices, grad at the returned latents)."""
     iteration = 0
     target_loss = max(0, 1.0 - threshold)
+    same = False      # the loop stays at one timestep with the same memories: from the second evaluation on only the latents differ
     while loss > target_loss:
         iteration += 1
-        loss, _, _, grad = loss_and_grad(denoiser, latents, t, encoder_hidden_states, cond_masks, indices_to_alter, normalize_eot, eot_indices)
+        loss, _, _, grad = loss_and_grad(denoiser, latents, t, encoder_hidden_states, cond_masks, indices_to_alter, normalize_eot, eot_indices,
+                                         same_conditioning=same)
+        same = True
         if loss != 0:
             latents = update_latent(latents, grad, step_size, denoiser)
         if iteration >= max_refinement_steps:
             break
-    loss, _, mx, grad = loss_and_grad(denoiser, latents, t, encoder_hidden_states, cond_masks, indices_to_alter, normalize_eot, eot_indices)
+    loss, _, mx, grad = loss_and_grad(denoiser, latents, t, encoder_hidden_states, cond_masks, indices_to_alter, normalize_eot, eot_indices,
+                                      same_conditioning=same)
     return loss, latents, mx, grad
 
 

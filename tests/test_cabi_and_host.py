@@ -41,7 +41,7 @@ def test_weg_host_logic():
     from convofusion_amd import _lib, weg
     from oracle import weg_ref
     assert C.sizeof(_lib.Mat) == 40
-    assert _lib.WegArgs.mem.offset == 24 and _lib.WegArgs.tok_off.offset == 24 + 5 * 32 and C.sizeof(_lib.WegArgs) == 24 + 160 + 16 + 16
+    assert _lib.WegArgs.mem.offset == 24 and _lib.WegArgs.tok_off.offset == 24 + 5 * 32 and C.sizeof(_lib.WegArgs) == 24 + 160 + 16 + 4 + 12 + 4 + 4
     last, off, flat = weg._focus_tables(2, 12, [[2, 5], []], False, ())
     assert last == 11 and off.tolist() == [0, 2, 2] and flat.tolist() == [2, 5]                      # att[:, :, 1:-1]
     last, off, flat = weg._focus_tables(1, 12, [[3]], True, torch.tensor([8]))

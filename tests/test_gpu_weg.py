@@ -143,6 +143,12 @@ def test_gradient_matches_oracle_and_reference_autograd(name):
     assert e_or < 1e-3 and e_ref < 1e-3
     upd = weg.update_latent(to_dev(inp["sample"]), to_dev(grad), 1000 * np.sqrt(0.9), m).cpu().numpy()
     assert rel_l2(upd, g[name + ".updated"]) < 1e-4
+    # a second evaluation at moved latents that reuses the memory-side work of the first is bit-identical to a fresh one
+    lat2 = to_dev(inp["sample"] + np.float32(0.01))
+    fresh = weg.loss_and_grad(m, lat2, t, mems, masks, focus, neot, to_dev(eot))
+    weg.loss_and_grad(m, to_dev(inp["sample"]), t, mems, masks, focus, neot, to_dev(eot))
+    reused = weg.loss_and_grad(m, lat2, t, mems, masks, focus, neot, to_dev(eot), same_conditioning=True)
+    assert float(fresh[0]) == float(reused[0]) and torch.equal(fresh[3], reused[3])
     # the launch-by-launch form of the same evaluation
     l3, _, _, g3 = weg.loss_and_grad_stepwise(m, to_dev(inp["sample"]), t, mems, masks, focus, neot, to_dev(eot))
     assert abs(float(l3) - float(loss)) < 1e-6 and rel_l2(g3.cpu().numpy(), grad) < 1e-5
