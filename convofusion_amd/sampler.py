@@ -261,8 +261,9 @@ def last_step_attention(run, denoiser, timestep, encoder_hidden_states, cond_mas
 def sample(denoiser, scheduler, encoder_hidden_states, cond_masks=None, *, B, L=16, num_inference_steps=1000,
            guidance_scale=7.5, guidance_chunks=CFG_CHUNKS, eta=0.0, init_latents=None, step_noise=None, seed=0,
            first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False, row_maps=None, return_attention=False):
-    """Run the whole loop; returns latents [B, L, 128] (batch-first), with ``return_attention`` also the last
-    iteration's attention maps (``last_step_attention``)."""
+    """Run the whole loop; returns latents [B, L, 128] (batch-first); with ``return_attention=True`` also the last
+    iteration's attention maps (``last_step_attention``), with ``return_attention="all"`` a dict {timestep: maps} over every
+    iteration like the reference's (the loop then leaves the device once per step)."""
     run = SamplingRun(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
                       guidance_scale, guidance_chunks, eta, init_latents, step_noise, seed, first_utterance, preseq, dedup,
                       skip_zero_weight_chunks, row_maps)
@@ -270,6 +271,12 @@ def sample(denoiser, scheduler, encoder_hidden_states, cond_masks=None, *, B, L=
         run.steps(num_inference_steps)
         return run.read(close=True)
     scheduler.set_timesteps(num_inference_steps)
+    if return_attention == "all":   # the reference's full dict: one entry per iteration (convofusion.py:523); one extra forward + sync per step
+        atts = {}
+        for t in scheduler.timesteps:
+            atts[int(t)] = last_step_attention(run, denoiser, t, encoder_hidden_states, cond_masks, guidance_chunks, row_maps)
+            run.steps(1)
+        return run.read(close=True), atts
     run.steps(num_inference_steps - 1)
     att = last_step_attention(run, denoiser, scheduler.timesteps[-1], encoder_hidden_states, cond_masks, guidance_chunks, row_maps)
     run.steps(1)
@@ -281,7 +288,8 @@ FORECAST_WEG_PARAMETERS = dict(scale_factor=100, scale_range=(1.0, 0.5), max_ite
                                thresholds={0: 0.05, 200: 0.4, 400: 0.6, 600: 0.8}, max_refinement_steps=300)
 
 
-def _loop_from_model(model, encoder_hidden_states, cond_masks, preseq, focus_indices, init_latents, seed, weg_parameters=None):
+def _loop_from_model(model, encoder_hidden_states, cond_masks, preseq, focus_indices, init_latents, seed, weg_parameters=None,
+                     attention=True):
     if not model.do_classifier_free_guidance:
         # the reference itself raises NameError here (guidance_bs_mulitplier undefined, convofusion.py:517)
         raise NameError("guidance_bs_mulitplier: the reference loop requires classifier-free guidance")
@@ -304,7 +312,7 @@ def _loop_from_model(model, encoder_hidden_states, cond_masks, preseq, focus_ind
               # the full-conditioning chunk has guidance weight 0 (convofusion.py:538) and the fused loop keeps no
               # attention maps, so its forward is dead work: identical latents without it
               skip_zero_weight_chunks=True)
-    kw["return_attention"] = True
+    kw["return_attention"] = attention
     if len(focus_indices) == 0:
         return sample(model.denoiser, model.scheduler, encoder_hidden_states, cond_masks, **kw)
     return sample_with_weg(model.denoiser, model.scheduler, encoder_hidden_states, cond_masks, focus_indices,
@@ -356,13 +364,18 @@ def sample_with_weg(denoiser, scheduler, encoder_hidden_states, cond_masks, focu
 
 
 def diffusion_reverse(model, encoder_hidden_states, lengths=None, cond_masks=dict(), focus_indices=[], *,
-                      init_latents=None, seed=None):
+                      init_latents=None, seed=None, attention_steps="last"):
     """``Convofusion._diffusion_reverse(self, encoder_hidden_states, lengths, cond_masks, focus_indices)``
     with ``self`` passed as ``model`` (reads model.denoiser / scheduler / cfg / guidance_scale /
     clf_guidance_drops / latent_dim / do_classifier_free_guidance exactly like the reference).
     Returns (latents [L, B, 128], attention_matrices dict).  The reference fills the dict with the full-conditioning
     chunk's ``att_mats`` of EVERY iteration (1000 x 5 tensors kept alive, written out as att_<t>.npy by base.py:252-259);
-    the fused loop keeps the last iteration's entry only: {t_last: att_mats} (``last_step_attention``)."""
+    the fused loop keeps the last iteration's entry only: {t_last: att_mats} (``last_step_attention``);
+    ``attention_steps="all"`` (without focus_indices) fills the whole dict at the price of one extra forward and one host
+    round trip per iteration."""
+    if attention_steps == "all" and len(focus_indices) == 0:
+        lat, atts = _loop_from_model(model, encoder_hidden_states, cond_masks, None, focus_indices, init_latents, seed, attention="all")
+        return lat.permute(1, 0, 2), atts
     lat, att = _loop_from_model(model, encoder_hidden_states, cond_masks, None, focus_indices, init_latents, seed)
     return lat.permute(1, 0, 2), {int(model.scheduler.timesteps[-1]): att}                        # :523,548-549
 

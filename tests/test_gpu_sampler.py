@@ -216,6 +216,12 @@ def test_model_level_drop_in():
     for j in range(5):
         a = atts[t_last][j].cpu().numpy()
         assert a.shape == (B, 9, L, S[j]) and np.abs(a - ref_att[t_last][j]).max() < 5e-5
+    # every iteration's maps on request, like the reference's dict
+    lat_all, atts_all = diffusion_reverse(model, [to_dev(x) for x in cb["memories"]], None, {k: to_dev(v) for k, v in cb["masks"].items()},
+                                          init_latents=to_dev(init0), seed=21, attention_steps="all")
+    assert torch.equal(lat_all, lat) and sorted(atts_all.keys()) == sorted(ref_att.keys())
+    for t, maps in atts_all.items():
+        assert max(float(np.abs(maps[j].cpu().numpy() - ref_att[t][j]).max()) for j in range(5)) < 5e-5
     # the WEG branch (focus_indices) through the same entry point: batch size 1 as the reference requires
     # (word_excitation_guidance.py:25); it must change the result and stay finite
     from convofusion_amd.sampler import diffusion_reverse_forecast
