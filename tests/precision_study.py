@@ -4,6 +4,9 @@ Emulates on CPU, inside the numpy oracle, the split-precision products the HIP k
 (operands split into 2 x bf16 or 2 x fp16, 3 partial products, fp32 accumulate) and reports the
 per-forward and per-trajectory relative error against the plain-fp32 oracle.
 Usage: python tests/precision_study.py [scheme ...]      schemes: bf16x1 bf16x3 fp16x1 fp16x3
+                                                         fp16w2 : weight x activation products with the ACTIVATION as one fp16 and the
+                                                                  weight as an fp16 pair (2 partial products); activation x activation
+                                                                  products (attention) keep 3
 """
 import sys
 import os
@@ -33,7 +36,8 @@ WEIGHT_IDS = set()
 
 def make_mm(scheme):
     rnd = to_bf16 if scheme.startswith("bf16") else to_fp16
-    terms = int(scheme[-1])
+    mixed = scheme == "fp16w2"
+    terms = 3 if mixed else int(scheme[-1])
 
     cache = {}
 
@@ -44,16 +48,23 @@ def make_mm(scheme):
             r = r.base
         big = id(r) in WEIGHT_IDS  # only views of the persistent weight arrays are cached
         if big and key in cache:
-            return cache[key]
+            return (*cache[key], big) if mixed else cache[key]
         h = rnd(x)
         l = rnd(x - h) if terms == 3 else None
         if big:
             cache[key] = (h, l)
-        return h, l
+        return (h, l, big) if mixed else (h, l)
 
     def mm(a, b):
         a = np.asarray(a, dtype=F32)
         b = np.asarray(b, dtype=F32)
+        if mixed:
+            (ah, al, aw), (bh, bl, bw) = split(a), split(b)
+            if bw and not aw:      # activation x weight: a_h (w_h + w_l)
+                return (np.matmul(ah, bh) + np.matmul(ah, bl)).astype(F32)
+            if aw and not bw:
+                return (np.matmul(ah, bh) + np.matmul(al, bh)).astype(F32)
+            return (np.matmul(ah, bh) + (np.matmul(ah, bl) + np.matmul(al, bh))).astype(F32)
         (ah, al), (bh, bl) = split(a), split(b)
         if terms == 1:
             return np.matmul(ah, bh)
