@@ -94,7 +94,7 @@ def make_inputs(B, device, seed):
     return mems, masks
 
 
-def cpu_baseline(model, n_fwd=2):
+def cpu_baseline(model, n_fwd=3):
     """The CPU oracle (numpy restatement of the reference op sequence; kind = "port") timed on this box's
     host cores on a bounded sample: single-utterance steps (Be=7) of the same workload; a B=32 step is 32 of them."""
     from oracle import denoiser_ref, sampler_ref, weights
