@@ -2,7 +2,9 @@
 """Benchmark of the denoising loop (BASELINE.json metric: denoise-steps/sec, B=32 utterances per GPU,
 196-token latents, 1500 audio tokens, 1000-step DDPM schedule, 7-way guidance => denoiser batch 224).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+      N > 1 without a launcher environment: bench.py starts N worker processes itself (torch.distributed.run on
+      127.0.0.1, one rank per GPU, RCCL); under the driver's own torch.distributed.run launch it is a rank.
 
 One "step" = one iteration of the captured loop for the rank's 32 utterances: replicate latents x7,
 denoiser forward, guidance combine, scheduler step.  Inputs are resident in HBM before the timed region.
@@ -50,9 +52,10 @@ def executed_gemm_flops(Be, Lq, Ss, U, nl=NL, shared_rows=None):
     tok += nl * 2.0 * M * 512 * (1024 + 512 + 512 + 512 + 512 + 1024 + 1024)  # qk, v^T, Wo, TB1, TB2, FFN1, FFN2
     tok -= 2.0 * (M - M0) * 512 * (1024 + 512 + 512 + 512)                # layer 0: qk, v^T, Wo, TB1 on the shared rows only
     mem = sum(2.0 * u * sp * 512 * (2 * nl * 512) for u, sp in zip(U, Sp))
-    att = nl * (2.0 * Be * 4 * Lq * Lp * 128 * 2 + sum(2.0 * Be * Lq * sp * 512 * 2 for sp in Sp))
-    att -= 2.0 * (Be - B0) * 4 * Lq * Lp * 128 * 2                        # layer 0's self-attention
-    return {"gemm_token": tok, "gemm_mem": mem, "gemm_attn": att}
+    att = nl * 2.0 * Be * 4 * Lq * Lp * 128 * 2                           # self-attention (fused kernel), padded key axis
+    att -= 2.0 * (Be - B0) * 4 * Lq * Lp * 128 * 2                        # layer 0's self-attention on the shared rows only
+    xat = nl * sum(2.0 * Be * Lq * sp * 512 * 2 for sp in Sp)             # cross-attention: scores + P.V over the padded keys
+    return {"gemm_token": tok, "gemm_mem": mem, "gemm_attn": att, "xattn": xat}
 
 
 def make_model(device, seed=1234):
@@ -94,29 +97,104 @@ def make_inputs(B, device, seed):
     return mems, masks
 
 
-def cpu_baseline(model, n_fwd=3):
-    """The CPU oracle (numpy restatement of the reference op sequence; kind = "port") timed on this box's
-    host cores on a bounded sample: single-utterance steps (Be=7) of the same workload; a B=32 step is 32 of them."""
-    from oracle import denoiser_ref, sampler_ref, weights
+def _cpu_info():
+    """(model string, physical cores) from /proc/cpuinfo; falls back to os.cpu_count()."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return model, (len(cores) or os.cpu_count() or 1)
+
+
+def cpu_baseline(model, n_warm=3, n_timed=10, budget_s=30.0):
+    """The reference's own CPU path -- PyTorch eager float32 (oracle/denoiser_torch.py: the same torch op sequence
+    as ``Denoiser.forward``, pinned against the imported reference class by tests/test_oracle_denoiser.py) + the 7-way
+    guidance combine + the DDPM step -- timed on this box's host cores (kind = "port").  Bounded sample:
+    ``n_warm`` + ``n_timed`` single-utterance steps (Be=7) at timesteps spread over the schedule, one B=4 step (Be=28)
+    and, when the single-utterance time says it fits ``budget_s``, one full B=32 step (Be=224) -- the headline
+    workload itself; ``value`` is taken from the largest batch that was timed."""
+    from oracle import denoiser_torch, sampler_ref, scheduler_ref, weights
+    cpu_model, cores = _cpu_info()
+    torch.set_num_threads(cores)
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-    sd = weights.extend_pe(sd, 1536)
-    rng = np.random.default_rng(0)
-    x = rng.standard_normal((7, L, 128)).astype(np.float32)
-    mems = [rng.standard_normal((7, s, 512)).astype(np.float32) for s in S]
-    denoiser_ref.denoiser_forward(sd, x[:, :16], 10, [m[:, : min(s, 32)] for m, s in zip(mems, S)], {}, num_layers=1)  # warm BLAS
-    t0 = time.time()
-    for i in range(n_fwd):
-        eps, _ = denoiser_ref.denoiser_forward(sd, x, 999 - i, mems, {})
-        sampler_ref.cfg_combine(eps, 7.5)
-    dt = (time.time() - t0) / n_fwd
-    try:   # threads the BLAS behind numpy actually used (OpenBLAS caps at its build-time MAX_THREADS)
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
-    except Exception:
-        cores = os.cpu_count()
-    return {"value": 1.0 / (dt * B_PER_GPU), "unit": "denoise-steps/s (B=32)", "cores": cores, "kind": "port",
-            "sample": f"{n_fwd} single-utterance steps (Be=7, L={L}, S={S}) of the numpy oracle at {dt:.2f} s each; "
-                      f"a B=32 step counted as 32 of them"}
+    tsd = denoiser_torch.to_torch(weights.extend_pe(sd, 1536))
+    sch = scheduler_ref.DDPMSchedulerRef()
+    sch.set_timesteps(1000)
+    g = torch.Generator().manual_seed(0)
+
+    def step(B, t):
+        x = torch.randn(B, L, 128, generator=g)
+        mems = [torch.randn(7 * B, s, 512, generator=g) for s in S]
+        t0 = time.perf_counter()
+        eps, _ = denoiser_torch.denoiser_forward(tsd, torch.cat([x] * 7), int(t), mems, {})
+        e = sampler_ref.cfg_combine(eps.numpy(), 7.5)
+        sch.step(e, int(t), x.numpy(), noise=np.zeros_like(e))
+        return time.perf_counter() - t0
+
+    for i in range(n_warm):
+        step(1, 999 - i)
+    ts = [int(t) for t in np.linspace(999, 0, n_timed)]
+    t1 = float(np.mean([step(1, t) for t in ts]))
+    t4 = step(4, 500)
+    sample = (f"torch {torch.__version__} CPU eager fp32, {cores} threads on '{cpu_model}': {n_warm} warm-up + {n_timed} timed "
+              f"single-utterance steps (Be=7, L={L}, S={S}) at {t1:.3f} s each; one B=4 step (Be=28) {t4:.2f} s")
+    per_b32 = t4 * (B_PER_GPU / 4)
+    if min(t1 * B_PER_GPU, per_b32) <= budget_s:
+        t32 = step(B_PER_GPU, 500)
+        sample += f"; one full B=32 step (Be=224) {t32:.2f} s (value = 1 / this)"
+        per_b32 = t32
+    else:
+        sample += f"; a B=32 step counted as 8 B=4 steps (a timed Be=224 step would exceed the {budget_s:.0f} s sample budget)"
+    return {"value": 1.0 / per_b32, "unit": "denoise-steps/s (B=32)", "cores": cores, "kind": "port", "cpu": cpu_model,
+            "single_utterance_s": t1, "b4_step_s": t4, "sample": sample}
+
+
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` with N > 1 and no launcher environment: start N fresh worker processes (one per
+    GPU, torch.distributed.run on 127.0.0.1) BEFORE anything in this process touches the GPU, forward their output
+    and exit with their return code.  (Never exec from a process that has initialised HIP.)"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def selftest_cpu(args, world, rank):
+    """Launch-path self test on CPU (tests/test_cabi_and_host.py): rendezvous over gloo, the collate all_gather and the
+    single JSON line -- with NO denoiser work and no throughput value, so it cannot be mistaken for a measurement."""
+    import torch.distributed as dist
+    from convofusion_amd.distributed import gather_latents
+    seen = 1
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        local = torch.full((2, 4, 128), float(rank))
+        total = gather_latents(local, 2 * world)
+        seen = int(total[:, 0, 0].unique().numel())
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": True, "metric": None, "value": None, "n_gpus": world, "ranks_seen": seen,
+                          "steps": args.steps, "warmup": args.warmup}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -126,11 +204,21 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shape", default="C2", choices=["C2", "R"])
+    ap.add_argument("--no-full-loop", action="store_true", help="skip the secondary whole-1000-step-run wall time")
+    ap.add_argument("--selftest-cpu", action="store_true", help="exercise only the N-rank launch path on CPU (gloo); no measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)          # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: start it as `python bench.py --gpus N` "
+                         f"or under torch.distributed.run with --nproc-per-node N")
+    if args.selftest_cpu:
+        return selftest_cpu(args, world, rank)
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -174,12 +262,17 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    rank_ms = [1000.0 * dt / args.steps]
     if world > 1:
         import torch.distributed as dist
-        tmax = torch.tensor([dt], device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        tall = [torch.zeros(1, device=device) for _ in range(world)]
+        dist.all_gather(tall, torch.tensor([dt], device=device))      # a real RCCL collective: one entry per rank that answered
+        ranks_seen = len(tall)
+        assert ranks_seen == dist.get_world_size() == args.gpus
+        rank_ms = [1000.0 * float(t.item()) / args.steps for t in tall]
+        dt = max(float(t.item()) for t in tall)
     assert torch.isfinite(total).all()
+    assert total.shape[0] == world * B_PER_GPU
 
     # per-kernel-class timing with HIP events on the launch stream (one eager forward of the same problem)
     prof = run.profile()
@@ -199,14 +292,31 @@ def main():
     dt_skip = time.perf_counter() - t1
     run2.close()
 
+    # secondary measurement: the ENTIRE 1000-step run of the same job (set-up, capture, 1000 replays, read), wall clock;
+    # puts the sustained clock on record next to the short timed window above
+    full_loop_s = None
+    if not args.no_full_loop and args.shape == "C2":
+        torch.cuda.synchronize()
+        barrier()
+        t2 = time.perf_counter()
+        run3 = SamplingRun(model, sch, mems, masks, B_PER_GPU, L, n_sched, guidance_scale=7.5, seed=0,
+                           first_utterance=rank * B_PER_GPU)
+        run3.steps(n_sched)
+        fin = run3.read(close=True)
+        torch.cuda.synchronize()
+        full_loop_s = time.perf_counter() - t2
+        assert torch.isfinite(fin).all()
+        barrier()
+
     if rank == 0:
         Be = G * B_PER_GPU
         U = [B_PER_GPU + 1] * 5
         canon = canonical_flops_per_step(Be, L, S)
         ex = executed_gemm_flops(Be, L, S, U, shared_rows=B_PER_GPU if os.environ.get("CFD_SHARE0", "1") != "0" else None)
         classes = {k: {"ms": round(v[0], 4), "launches": v[1]} for k, v in prof.items()}
-        # dominant kernel = gemm_sp_kernel (every matrix product of the step); per-class split below
-        gk = ("gemm_token", "gemm_mem", "gemm_attn")
+        # dominant kernel = gemm_sp_kernel (the token-side and memory-side products: the largest share of a step); the fused
+        # attention kernels (self_attn_fused_kernel = class gemm_attn, xattn_fused_kernel = class xattn) are listed per class
+        gk = ("gemm_token", "gemm_mem")
         dom_ms = sum(prof[k][0] for k in gk)
         dom_n = sum(prof[k][1] for k in gk)
         achieved = sum(ex[k] for k in gk) / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -217,11 +327,15 @@ def main():
         for k in ex:
             classes[k]["algorithmic_tflop"] = round(ex[k] / 1e12, 4)
             classes[k]["tflops"] = round(ex[k] / (prof[k][0] * 1e-3) / 1e12, 1) if prof[k][0] > 0 else None
+            classes[k]["frac_of_peak"] = round(classes[k]["tflops"] / PEAK_BF16_TFLOPS, 4) if classes[k]["tflops"] else None
+        mfma_ms = sum(prof[k][0] for k in ex)
+        all_mfma = sum(ex.values()) / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
         out = {
             "metric": "denoise-steps/sec (B=32 per GPU, 196-token latent, 1500 audio tokens, 1000-step DDPM schedule)",
             "value": world * args.steps / dt,
             "unit": "denoise-steps/s (32-utterance batches, summed over GPUs)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks_seen": ranks_seen, "rank_ms_per_step": [round(x, 4) for x in rank_ms],
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16x3 (fp16 hi/lo split operands, 3 MFMAs per product, f32 accumulate; f32-equivalent)",
@@ -231,11 +345,15 @@ def main():
                        "shape": args.shape, "parallelism": f"batch-shard x{world}, one all_gather of latents"},
             "utterance_steps_per_s": world * B_PER_GPU * args.steps / dt,
             "value_without_zero_weight_chunk": args.steps / dt_skip,
+            "full_loop_s": full_loop_s,
+            "full_loop_steps_per_s": (n_sched / full_loop_s) if full_loop_s else None,
             "canonical_tflop_per_step": canon / 1e12,
             "canonical_tflops": world * canon * args.steps / dt / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "gemm_sp_kernel (all matrix products of one step)", "achieved": achieved,
-                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma", "kernel": "gemm_sp_kernel (token-side and memory-side matrix products of one step)", "achieved": achieved,
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+                         "frac_issued": 3.0 * achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "launches_per_step": dom_n, "avg_launch_ms": dom_ms / max(dom_n, 1),
+                         "all_mfma_kernels_achieved": all_mfma, "all_mfma_kernels_frac": all_mfma / PEAK_BF16_TFLOPS,
                          "note": "achieved = algorithmic (single-product) FLOPs of the launched GEMMs / their HIP-event time; "
                                  "each product is issued as 3 f16 MFMAs, so the MFMA pipe sees 3x this; traffic = mean HBM bytes "
                                  "per launch from rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE (profiles/)"},

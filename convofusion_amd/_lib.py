@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("CFD_LIB", os.path.join(HERE, "libcfdenoise.so"))  # C
 
 NUM_MEM = 5
 MEM_NAMES = ("spkemb", "alsn", "tlsn", "apb", "lsnemb")
-PROF_CLASSES = ("gemm_token", "gemm_mem", "gemm_attn", "rows", "other")
+PROF_CLASSES = ("gemm_token", "gemm_mem", "gemm_attn", "rows", "other", "xattn")
 
 SYMBOLS = [
     "cfd_create", "cfd_destroy", "cfd_last_error", "cfd_load_tensor", "cfd_finalize_weights",

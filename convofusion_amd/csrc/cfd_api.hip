@@ -16,12 +16,10 @@
 #include "gemm_sp.hpp"
 #include "rows.hpp"
 #include "attn_fused.hpp"
+#include "xattn_fused.hpp"
 #include "grad.hpp"
 
 int g_cfd_naive_gemm = 0;
-int g_cfd_gemm_cfg = 0;
-int g_cfd_small3 = 1;
-int g_cfd_deep = 0;
 
 static thread_local char g_err[1024] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -90,6 +88,8 @@ struct Problem {
   // un-batched product per run instead of a 196-row product per batch row.
   int jbig = -1, nruns = 0, nlong = 0, nshort = 0;
   int run_row0[8], run_len[8], run_u[8];
+  // fused cross-attention (xattn_fused.hpp): workgroups of the work list, 0 = the list was not built
+  int xa_nwg = 0;
 };
 
 struct cfd_handle_s {
@@ -110,15 +110,12 @@ struct cfd_handle_s {
   DBuf x, h_sp, qk_sp, vts_sp, ssc, sp_sp, o_sp, u_sp, sc, p_sp, eps, sample_sp;
   DBuf n_sp[CFD_NMEM], kall_sp[CFD_NMEM], cb[CFD_NMEM], vt_all[CFD_NMEM];
   DBuf temb_tab, h1_tab, ss_tab, trows, iota, long_rows, short_rows, zero_mask;
-  bool use_runs = true;   // CFD_RUNS=0 disables the shared-memory run optimisation
-  int nchunks_env = 0;
-  bool fused_self = true;   // CFD_FUSED_SELF=0 selects the GEMM -> softmax -> GEMM self-attention
-  // CFD_TILE_SM=1: the shared-memory runs do their softmax per 128-key tile inside the two attention products
-  // (EpiTileSoftmax / EpiResidFold, gemm_sp.hpp): no fp32 score matrix, 378 MB less HBM traffic per layer.  Parity-
-  // tested, but measured neutral on MI355X (57.1 vs 57.0 steps/s: the exp / reduction work added to the score
-  // product's epilogue costs what the lighter softmax launch saves), so the simpler path stays the default.
-  bool tile_sm = false;
-  DBuf sm_stats, sm_alpha, run_flags;
+  bool use_runs = true;   // CFD_RUNS=0 disables the shared-memory run optimisation of the three-launch attention path
+  // The cross-attention block is one fused kernel (xattn_fused.hpp) unless the caller wants att_mats, which only the
+  // three-launch path (score products -> softmax_rows_kernel -> P.V products) materialises.  CFD_FUSED_XATTN=0 forces
+  // the three-launch path everywhere (parity A/B of the two paths).
+  bool fused_xattn = true;
+  DBuf xa_wgs, xa_segs, xa_stamps;
   bool share0 = true;       // CFD_SHARE0=0: evaluate the pre-cross-attention part of layer 0 for every guidance replica
   DBuf d_step;  // [0] = loop index, [1] = constant 0, [2] = "this iteration's in-painting overwrite is done" (cfd_sample_inpaint)
   DBuf weg_ws, weg_tok;   // cfd_weg_eval: activation arena, focus-token tables
@@ -133,9 +130,6 @@ struct cfd_handle_s {
   int prof_n[CFD_PROF_NCLASS];
   int stop_stage = 0;  // test hook: leave enqueue_denoise after this tap point (0 = run everything)
   hipStream_t own_stream = nullptr;  // non-blocking stream the captured loop iteration replays on
-  hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // side streams for independent launches (graph branches)
-  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-  bool branches = false;              // CFD_BRANCHES=1: independent launches on side streams (measured gain 0.5 %: off)
   // sampling run
   bool run_open = false;
   cfd_sample_args sargs;
@@ -188,14 +182,6 @@ static int run_gemm(Ctx* c, int cls, const GemmArgs& a, const Epi& e, int nb, in
   return CFD_OK;
 }
 
-template <class Epi>
-static int run_gemm_128(Ctx* c, int cls, const GemmArgs& a, const Epi& e, hipStream_t st) {
-  Bracket br(c, cls, st);
-  hipError_t err = launch_gemm_128<Epi>(a, e, st);
-  if (err != hipSuccess) return fail(CFD_E_HIP, "gemm launch failed: %s", hipGetErrorString(err));
-  return CFD_OK;
-}
-
 static GemmArgs gemm_args() {
   GemmArgs a;
   memset(&a, 0, sizeof(a));
@@ -237,34 +223,17 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   g_cfd_naive_gemm = (env && atoi(env) != 0) ? 1 : 0;
   env = getenv("CFD_RUNS");
   c->use_runs = !(env && atoi(env) == 0);
-  env = getenv("CFD_FUSED_SELF");
-  c->fused_self = !(env && atoi(env) == 0);
-  env = getenv("CFD_TILE_SM");
-  c->tile_sm = env && atoi(env) != 0;
+  env = getenv("CFD_FUSED_XATTN");
+  c->fused_xattn = !(env && atoi(env) == 0);
   env = getenv("CFD_PERMUTE");
   c->permute = !(env && atoi(env) == 0);
   env = getenv("CFD_SHARE0");
   c->share0 = !(env && atoi(env) == 0);
-  env = getenv("CFD_CHUNKS");
-  c->nchunks_env = env ? atoi(env) : 0;
-  env = getenv("CFD_GEMM_CFG");
-  g_cfd_gemm_cfg = env ? atoi(env) : 0;
-  env = getenv("CFD_SMALL3");
-  g_cfd_small3 = (env && atoi(env) == 0) ? 0 : 1;
-  env = getenv("CFD_DEEP");
-  g_cfd_deep = (env && atoi(env) != 0) ? 1 : 0;
   if (c->d_step.ensure(16) != CFD_OK) { delete c; return CFD_E_HIP; }
   if (hipMemset(c->d_step.p, 0, 16) != hipSuccess) { delete c; return fail(CFD_E_HIP, "memset"); }
   (void)hipEventCreate(&c->pev[0]);
   (void)hipEventCreate(&c->pev[1]);
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(CFD_E_HIP, "stream create"); }
-  (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-  for (int k = 0; k < 3; ++k) {
-    if (hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking) != hipSuccess) { delete c; return fail(CFD_E_HIP, "stream create"); }
-    (void)hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming);
-  }
-  env = getenv("CFD_BRANCHES");
-  c->branches = env && atoi(env) != 0;
   *out = c;
   return CFD_OK;
 }
@@ -278,8 +247,8 @@ extern "C" void cfd_destroy(cfd_handle c) {
   for (auto& kv : c->raw) kv.second.release();
   DBuf* all[] = {&c->we_sp, &c->wp_sp, &c->we_all, &c->be_all, &c->tsin, &c->x, &c->h_sp, &c->qk_sp, &c->vts_sp,
                  &c->ssc, &c->sp_sp, &c->o_sp, &c->u_sp, &c->sc, &c->p_sp, &c->eps, &c->sample_sp, &c->temb_tab,
-                 &c->h1_tab, &c->ss_tab, &c->trows, &c->d_step, &c->weg_ws, &c->weg_tok, &c->latents, &c->coef, &c->inoise, &c->sm_stats, &c->sm_alpha,
-                 &c->run_flags};
+                 &c->h1_tab, &c->ss_tab, &c->trows, &c->d_step, &c->weg_ws, &c->weg_tok, &c->latents, &c->coef, &c->inoise, &c->xa_wgs, &c->xa_segs, &c->xa_stamps,
+                 &c->long_rows, &c->short_rows, &c->zero_mask, &c->iota};
   for (DBuf* b : all) b->release();
   for (int j = 0; j < CFD_NMEM; ++j) {
     c->wk_all_sp[j].release(); c->wv_all_sp[j].release(); c->n_sp[j].release(); c->kall_sp[j].release();
@@ -290,11 +259,6 @@ extern "C" void cfd_destroy(cfd_handle c) {
     for (DBuf* b : lb) b->release();
   }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
-  for (int k = 0; k < 3; ++k) {
-    if (c->aux[k]) (void)hipStreamDestroy(c->aux[k]);
-    if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
-  }
-  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->pev[0]) (void)hipEventDestroy(c->pev[0]);
   if (c->pev[1]) (void)hipEventDestroy(c->pev[1]);
   delete c;
@@ -507,6 +471,106 @@ extern "C" int cfd_set_timestep_table(cfd_handle c, const float* rows, int n_row
 }
 
 // ---- problem setup ----------------------------------------------------------------------------------
+// Work list of the fused cross-attention kernel (xattn_fused.hpp).  A wave owns one tile of 16 queries of one batch row;
+// the four waves of a workgroup share every K / V^T tile that passes through LDS, so
+//  * rows are grouped by the instance of the LARGEST memory they attend to (the guidance batch: 5 of 7 chunks share the
+//    unconditional audio memory; the other two chunks of an utterance share its own): a group's query tiles are dealt to
+//    workgroups four at a time, and the long key stream is read once per workgroup whatever the rows' other memories are;
+//  * per workgroup and memory, one segment per DISTINCT instance among its waves' rows (wave mask says who takes part);
+//  * memories longer than one 32-key tile come first (online softmax; a flush of the accumulator between two of them);
+//  * workgroups that read the same instance are placed on one XCD (block id % 8) next to each other so the stream is
+//    fetched into that XCD's L2 once; big groups are dealt over all XCDs.
+static int build_xattn_worklist(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
+  Problem& p = c->pb;
+  p.xa_nwg = 0;
+  if (!c->fused_xattn) return CFD_OK;
+  const int Be = p.Be, L = p.L, nqt = (L + 15) / 16;
+  std::vector<std::vector<int>> hm(CFD_NMEM, std::vector<int>(Be));
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    if (mem[j].row_map) HIPCHK(hipMemcpy(hm[j].data(), mem[j].row_map, (size_t)Be * 4, hipMemcpyDeviceToHost));
+    else for (int b = 0; b < Be; ++b) hm[j][b] = b;
+    for (int b = 0; b < Be; ++b)
+      if (hm[j][b] < 0 || hm[j][b] >= p.U[j]) return fail(CFD_E_ARG, "memory %s: row_map[%d] = %d outside [0, %d)", MEM_NAMES[j], b, hm[j][b], p.U[j]);
+  }
+  // memory order: long (online) memories first, longest first; then the single-tile ones
+  int order[CFD_NMEM], n_online = 0;
+  for (int j = 0; j < CFD_NMEM; ++j) order[j] = j;
+  std::stable_sort(order, order + CFD_NMEM, [&](int a, int b) { return p.Sp[a] > p.Sp[b]; });
+  for (int j = 0; j < CFD_NMEM; ++j) n_online += p.Sp[j] > XA_KEYS;
+  const int jg = order[0];
+  // groups of rows by instance of memory jg, in order of first appearance
+  std::vector<int> inst_group(p.U[jg], -1);
+  std::vector<std::vector<int>> groups;
+  for (int b = 0; b < Be; ++b) {
+    int& g = inst_group[hm[jg][b]];
+    if (g < 0) { g = (int)groups.size(); groups.emplace_back(); }
+    groups[g].push_back(b);
+  }
+  std::vector<XaSeg> segs;
+  std::vector<std::vector<XaWg>> group_wgs(groups.size());
+  for (size_t g = 0; g < groups.size(); ++g) {
+    std::vector<std::pair<int, int>> tiles;   // (row, first query)
+    for (int b : groups[g])
+      for (int t = 0; t < nqt; ++t) tiles.emplace_back(b, t * 16);
+    for (size_t t0 = 0; t0 < tiles.size(); t0 += XA_TILES) {
+      XaWg w;
+      memset(&w, 0, sizeof(w));
+      for (int k = 0; k < XA_TILES; ++k) {
+        const bool on = t0 + k < tiles.size();
+        w.row[k] = on ? tiles[t0 + k].first : -1;
+        w.q0[k] = on ? tiles[t0 + k].second : 0;
+      }
+      w.seg0 = (int)segs.size();
+      int online_seen = 0;
+      for (int oi = 0; oi < CFD_NMEM; ++oi) {
+        const int j = order[oi];
+        const bool online = p.Sp[j] > XA_KEYS;
+        online_seen += online;
+        int done = 0;
+        size_t first_seg = segs.size();
+        for (int k = 0; k < XA_TILES; ++k) {
+          if (w.row[k] < 0 || (done >> k) & 1) continue;
+          XaSeg sg;
+          sg.j = j; sg.u = hm[j][w.row[k]]; sg.wmask = 0; sg.flags = online ? XA_ONLINE : 0;
+          for (int k2 = k; k2 < XA_TILES; ++k2)
+            if (w.row[k2] >= 0 && hm[j][w.row[k2]] == sg.u) sg.wmask |= 1 << k2;
+          done |= sg.wmask;
+          segs.push_back(sg);
+        }
+        // one accumulator: a finished online memory is flushed to x before the next online memory starts
+        if (online && online_seen < n_online && segs.size() > first_seg) segs.back().flags |= XA_FLUSH;
+      }
+      w.nseg = (int)segs.size() - w.seg0;
+      group_wgs[g].push_back(w);
+    }
+  }
+  // XCD placement: queue x holds the workgroups with block id % 8 == x, in dispatch order
+  std::vector<std::vector<XaWg>> queue(8);
+  std::vector<size_t> gorder(groups.size());
+  for (size_t g = 0; g < groups.size(); ++g) gorder[g] = g;
+  std::stable_sort(gorder.begin(), gorder.end(), [&](size_t a, size_t b) { return group_wgs[a].size() > group_wgs[b].size(); });
+  auto shortest = [&]() { int q = 0; for (int x = 1; x < 8; ++x) if (queue[x].size() < queue[q].size()) q = x; return q; };
+  for (size_t g : gorder) {
+    if (group_wgs[g].size() > 32) { for (const XaWg& w : group_wgs[g]) queue[shortest()].push_back(w); }
+    else { const int q = shortest(); for (const XaWg& w : group_wgs[g]) queue[q].push_back(w); }
+  }
+  size_t qlen = 0;
+  for (int x = 0; x < 8; ++x) qlen = std::max(qlen, queue[x].size());
+  XaWg idle;
+  memset(&idle, 0, sizeof(idle));
+  for (int k = 0; k < XA_TILES; ++k) idle.row[k] = -1;
+  std::vector<XaWg> wgs(qlen * 8, idle);
+  for (int x = 0; x < 8; ++x)
+    for (size_t i = 0; i < queue[x].size(); ++i) wgs[i * 8 + x] = queue[x][i];
+  if (wgs.empty() || segs.empty()) return CFD_OK;
+  CHK(c->xa_wgs.ensure(wgs.size() * sizeof(XaWg)));
+  CHK(c->xa_segs.ensure(segs.size() * sizeof(XaSeg)));
+  HIPCHK(hipMemcpy(c->xa_wgs.p, wgs.data(), wgs.size() * sizeof(XaWg), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->xa_segs.p, segs.data(), segs.size() * sizeof(XaSeg), hipMemcpyHostToDevice));
+  p.xa_nwg = (int)wgs.size();
+  return CFD_OK;
+}
+
 static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], float* const att[CFD_NMEM], int tmode, int T) {
   if (!c->finalized) return fail(CFD_E_STATE, "weights not finalized");
   if (c->tsin_rows < 1) return fail(CFD_E_STATE, "timestep table not set");
@@ -573,15 +637,6 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
       }
       if (p.nruns > 0) {
         p.jbig = jb; p.nlong = (int)lrows.size(); p.nshort = (int)srows.size();
-        {   // tile-softmax path of the runs: per-token, per-128-key-tile statistics and fold weights; run-row flags
-          const size_t nt = (size_t)(p.Sp[jb] + 127) / 128;
-          CHK(c->sm_stats.ensure((size_t)Be * L * nt * 8));
-          CHK(c->sm_alpha.ensure((size_t)Be * L * nt * 4));
-          std::vector<uint8_t> fl(Be, 0);
-          for (int b : lrows) fl[b] = 1;
-          CHK(c->run_flags.ensure((size_t)Be));
-          HIPCHK(hipMemcpy(c->run_flags.p, fl.data(), (size_t)Be, hipMemcpyHostToDevice));
-        }
         CHK(c->long_rows.ensure(lrows.size() * 4 + 16));
         CHK(c->short_rows.ensure(srows.size() * 4 + 16));
         HIPCHK(hipMemcpy(c->long_rows.p, lrows.data(), lrows.size() * 4, hipMemcpyHostToDevice));
@@ -589,6 +644,7 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
       }
     }
   }
+  CHK(build_xattn_worklist(c, mem));
   const long long M = p.M;
   const int nl = c->nl;
   CHK(c->x.ensure((size_t)M * CFD_D * 4));
@@ -670,7 +726,7 @@ static int enqueue_memside(Ctx* c, hipStream_t st) {
       a.X[0] = c->wk_all_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = nl * CFD_D + 32; a.Iclamp[0] = nl * CFD_D + 32; a.kt[0] = CFD_D / 32;
       a.Y = c->n_sp[j].as<char>(); a.ldy = ROWB; a.J = rows; a.Jclamp = rows;
       a.super_i = 8; a.super_j = 8;
-      EpiMemK e{c->kall_sp[j].as<char>(), (long long)rows, c->cb[j].as<float>(), nl * CFD_D, nl};
+      EpiMemK e{c->kall_sp[j].as<char>(), (long long)rows, c->cb[j].as<float>(), nl * CFD_D, nl, p.mask[j], p.S[j], p.Sp[j]};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }
     {
@@ -686,56 +742,30 @@ static int enqueue_memside(Ctx* c, hipStream_t st) {
   return CFD_OK;
 }
 
-// Optional row chunking (CFD_CHUNKS=n): effective-batch rows are independent, so the token-side pipeline can
-// run chunk by chunk.  Measured on MI355X at the benchmark shape this is SLOWER (23.1 / 25.0 / 28.1 / 33.5 ms
-// per step for 1 / 2 / 4 / 8 chunks): the kernels are not HBM-bound enough for Infinity-Cache residency of
-// the intermediates to pay for the smaller grids.  Kept as a developer knob; default is one chunk.
-static int pick_chunks(Ctx* c) {
-  const Problem& p = c->pb;
-  if (c->stop_stage || c->nchunks_env <= 1) return 1;
-  return c->nchunks_env < p.Be ? c->nchunks_env : p.Be;
-}
-
 static int enqueue_denoise(Ctx* c, hipStream_t st) {
   CHK(enqueue_memside(c, st));
-  const int Be = c->pb.Be;
-  const int n = pick_chunks(c);
-  for (int k = 0; k < n; ++k) {
-    const int r0 = (int)((long long)Be * k / n), r1 = (int)((long long)Be * (k + 1) / n);
-    if (r1 > r0) CHK(enqueue_rows(c, st, r0, r1 - r0));
-  }
-  return CFD_OK;
+  return enqueue_rows(c, st, 0, c->pb.Be);
 }
 
 static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
   const Problem& p = c->pb;
-  const int nl = c->nl, L = p.L, Lp = p.Lp;
+  const int nl = c->nl, L = p.L;
   const long long M = (long long)Be * L;
   const int* dstep = p.tmode ? c->d_step.as<int>() + 1 : c->d_step.as<int>();
   const long long ROWB = CFD_D * 4;  // bytes per SP row of 512
   const dim3 blk(256);
-  // Independent launches (different rows / different outputs) go to side streams: under stream capture they become
-  // parallel graph branches, so one kernel's tail is filled by the next kernel's head.
-  const bool br = c->branches && !c->prof;
-  auto fork = [&](int k) -> hipStream_t {
-    if (!br) return st;
-    (void)hipEventRecord(c->ev_fork, st);
-    (void)hipStreamWaitEvent(c->aux[k], c->ev_fork, 0);
-    return c->aux[k];
-  };
-  auto join = [&](int k) {
-    if (!br) return;
-    (void)hipEventRecord(c->ev_join[k], c->aux[k]);
-    (void)hipStreamWaitEvent(st, c->ev_join[k], 0);
-  };
   const char* sample_sp = c->sample_sp.as<char>() + (size_t)row0 * L * CFD_LAT * 4;
   float* eps_out = c->eps.as<float>() + (size_t)row0 * L * CFD_LAT;
   const int* mapj[CFD_NMEM];
   float* attj[CFD_NMEM];
+  bool want_att = false;
   for (int j = 0; j < CFD_NMEM; ++j) {
     mapj[j] = p.map[j] + row0;
     attj[j] = p.att[j] ? p.att[j] + (size_t)row0 * nl * L * p.S[j] : nullptr;
+    want_att = want_att || p.att[j];
   }
+  // one fused kernel per layer for the cross-attention block, unless att_mats are wanted (or the naive debug GEMMs)
+  const bool fused_x = c->fused_xattn && p.xa_nwg > 0 && !want_att && !g_cfd_naive_gemm && row0 == 0 && Be == p.Be;
 
   // rows that run the replica-independent head of the network (see Problem::share_B)
   const bool share = p.share_B > 0 && row0 == 0 && Be == p.Be && Be % p.share_B == 0 && Be > p.share_B && !c->stop_stage;
@@ -763,6 +793,12 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     EpiResid e{c->x.as<float>(), 0, bias};
     return run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st);
   };
+  static bool attr = false;
+  if (!attr) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
+    attr = true;
+  }
 
   for (int l = 0; l < nl; ++l) {
     const LayerW& w = c->lw[l];
@@ -778,53 +814,19 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       EpiSplit e{c->qk_sp.as<char>(), 2 * ROWB, 0, 0, w.bqk.as<float>(), 0, 0};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
     }
-    const bool fused_self = c->fused_self;
-    const int Lv = fused_self ? (L + 63) / 64 * 64 : Lp;
+    const int Lv = (L + 63) / 64 * 64;
     {  // v^T per batch row: vts[b][f][l] (keys in P-fragment order for the fused kernel)
       GemmArgs a = gemm_args();
       a.X[0] = c->h_sp.as<char>(); a.ldx[0] = ROWB; a.xbs[0] = (long long)L * ROWB; a.I[0] = Lv; a.Iclamp[0] = L; a.kt[0] = CFD_D / 32;
       a.Y = w.wv_sp.as<char>(); a.ldy = ROWB; a.J = CFD_D; a.Jclamp = CFD_D;
-      EpiSplit e{c->vts_sp.as<char>(), (long long)Lv * 4, (long long)CFD_D * Lv * 4, 0, nullptr, 0, fused_self ? 1 : 0};
+      EpiSplit e{c->vts_sp.as<char>(), (long long)Lv * 4, (long long)CFD_D * Lv * 4, 0, nullptr, 0, 1};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, Ba, 1, st)));
     }
-    if (fused_self) {
+    {
       SelfAttnArgs a{c->qk_sp.as<char>(), c->vts_sp.as<char>(), c->o_sp.as<char>(), L, Lv};
-      static bool attr = false;
-      if (!attr) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        attr = true;
-      }
       Bracket br(c, CFD_PROF_GEMM_ATTN, st);
       hipLaunchKernelGGL(self_attn_fused_kernel, dim3((L + SELF_ATTN_WAVES * 16 - 1) / (SELF_ATTN_WAVES * 16), CFD_NHEAD, Ba), dim3(SELF_ATTN_WAVES * 64), 65536, st, a);
       HIPCHK(hipGetLastError());
-    } else {
-    {  // scores[b][h][lq][lk]
-      GemmArgs a = gemm_args();
-      a.X[0] = c->qk_sp.as<char>() + (CFD_D / 32) * 128; a.ldx[0] = 2 * ROWB; a.xbs[0] = (long long)L * 2 * ROWB; a.xzs = (CFD_HD / 32) * 128;
-      a.I[0] = Lp; a.Iclamp[0] = L; a.kt[0] = CFD_HD / 32;
-      a.Y = c->qk_sp.as<char>(); a.ldy = 2 * ROWB; a.ybs = (long long)L * 2 * ROWB; a.yzs = (CFD_HD / 32) * 128; a.J = L; a.Jclamp = L;
-      EpiF32 e;
-      memset(&e, 0, sizeof(e));
-      e.out = c->ssc.as<float>(); e.ldo = Lp; e.obs = (long long)CFD_NHEAD * L * Lp; e.ozs = (long long)L * Lp;
-      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_ATTN, a, e, Ba, CFD_NHEAD, st)));
-    }
-    {
-      SoftmaxArgs a;
-      memset(&a, 0, sizeof(a));
-      a.sc = c->ssc.as<float>(); a.P = c->sp_sp.as<char>(); a.ld = Lp; a.rows = (long long)Ba * CFD_NHEAD * L; a.rows_per_b = CFD_NHEAD * L;
-      a.nseg = 1; a.S[0] = L; a.Sp[0] = Lp; a.nl = nl;
-      for (int j = 0; j < CFD_NMEM; ++j) a.mask[j] = c->zero_mask.as<uint8_t>();
-      LAUNCH(CFD_PROF_ROWS, softmax_rows_kernel, dim3((unsigned)((a.rows + 3) / 4)), blk, st, a);
-    }
-    {  // o[b*L+l][h*128+d] = sum_lk P[lq][lk] v[lk][d]
-      GemmArgs a = gemm_args();
-      a.X[0] = c->vts_sp.as<char>(); a.ldx[0] = (long long)Lp * 4; a.xbs[0] = (long long)CFD_D * Lp * 4; a.xzs = (long long)CFD_HD * Lp * 4;
-      a.I[0] = CFD_HD; a.Iclamp[0] = CFD_HD; a.kt[0] = Lp / 32;
-      a.Y = c->sp_sp.as<char>(); a.ldy = (long long)Lp * 4; a.ybs = (long long)CFD_NHEAD * L * Lp * 4; a.yzs = (long long)L * Lp * 4;
-      a.J = L; a.Jclamp = L;
-      EpiSplit e{c->o_sp.as<char>(), ROWB, (long long)L * ROWB, (CFD_HD / 32) * 128, nullptr, 0, 0};
-      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_ATTN, a, e, Ba, CFD_NHEAD, st)));
-    }
     }
     CHK(token_gemm_resid(w.wo_sp, CFD_D, c->o_sp.as<char>(), w.bo2.as<float>(), Ma));
     if (c->stop_stage == 2 + 4 * l) return CFD_OK;
@@ -839,13 +841,31 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     }
     // ---- c-e. five cross attentions + fuser, folded                             (:578-652)
     CHK(ln(w.ln2g, w.ln2b, 0, 0, c->h_sp.as<char>(), M));
-    // scores against the folded keys of every memory.  Long memories and short (<= 64 keys) memories go to
-    // different tile shapes; rows in a shared-memory run of the largest memory use one un-batched product per run.
+    if (fused_x) {
+      XAttnArgs a;
+      memset(&a, 0, sizeof(a));
+      a.h = c->h_sp.as<char>(); a.x = c->x.as<float>(); a.bias = w.cross_bias.as<float>(); a.L = L;
+      for (int j = 0; j < CFD_NMEM; ++j) {
+        const size_t rows = (size_t)p.U[j] * p.Sp[j];
+        a.K[j] = c->kall_sp[j].as<char>() + (size_t)l * rows * ROWB;
+        a.cb[j] = c->cb[j].as<float>() + (size_t)l * rows;
+        a.VT[j] = c->vt_all[j].as<char>() + (size_t)l * rows * ROWB;
+        a.Sp[j] = p.Sp[j];
+      }
+      a.wgs = c->xa_wgs.as<XaWg>(); a.segs = c->xa_segs.as<XaSeg>();
+#if XA_STAMP
+      CHK(c->xa_stamps.ensure((size_t)p.xa_nwg * XA_WAVES * XA_NSTAMP * 8));
+      a.stamps = c->xa_stamps.as<long long>();
+#endif
+      Bracket br(c, CFD_PROF_XATTN, st);
+      hipLaunchKernelGGL(xattn_fused_kernel, dim3(p.xa_nwg), dim3(XA_WAVES * 64), XA_LDS, st, a);
+      HIPCHK(hipGetLastError());
+    } else {
+    // Three-launch path (att_mats wanted): scores against the folded keys of every memory.  Long memories and short
+    // (<= 64 keys) memories go to different tile shapes; rows in a shared-memory run of the largest memory use one
+    // un-batched product per run.
     const bool runs = p.nruns > 0 && row0 == 0 && Be == p.Be;
-    // runs: softmax per score tile inside the products (no fp32 score matrix) unless the caller wants the
-    // normalised attention maps of that memory
-    const bool tile_sm = runs && c->tile_sm && !g_cfd_naive_gemm && !p.att[p.jbig];
-    auto scores_grouped = [&](bool small, int skip_j, const int* brow, int nb, hipStream_t sst) -> int {
+    auto scores_grouped = [&](bool small, int skip_j, const int* brow, int nb) -> int {
       GemmArgs a = gemm_args();
       EpiF32 e;
       memset(&e, 0, sizeof(e));
@@ -862,47 +882,27 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       a.nslot = n; a.brow = brow;
       a.Y = c->h_sp.as<char>(); a.ldy = ROWB; a.ybs = (long long)L * ROWB; a.J = L; a.Jclamp = L;
       e.out = c->sc.as<float>(); e.ldo = p.Sp_tot; e.obs = (long long)L * p.Sp_tot;
-      return run_gemm<MODE_GROUPED>(c, CFD_PROF_GEMM_ATTN, a, e, nb, 1, sst);
+      return run_gemm<MODE_GROUPED>(c, CFD_PROF_GEMM_ATTN, a, e, nb, 1, st);
     };
-    // all score launches of a layer are independent: fork the side streams BEFORE queueing anything on `st`
-    hipStream_t sc_side[3] = {fork(0), fork(1), fork(2)};
-    CHK(scores_grouped(true, -1, nullptr, Be, sc_side[2]));   // short memories
+    CHK(scores_grouped(true, -1, nullptr, Be));   // short memories
     if (!runs) {
-      CHK(scores_grouped(false, -1, nullptr, Be, st));
+      CHK(scores_grouped(false, -1, nullptr, Be));
     } else {
-      CHK(scores_grouped(false, -1, c->short_rows.as<int>(), p.nshort, st));
-      CHK(scores_grouped(false, p.jbig, c->long_rows.as<int>(), p.nlong, st));
+      CHK(scores_grouped(false, -1, c->short_rows.as<int>(), p.nshort));
+      CHK(scores_grouped(false, p.jbig, c->long_rows.as<int>(), p.nlong));
       const int j = p.jbig;
       for (int r = 0; r < p.nruns; ++r) {
-        hipStream_t rs = sc_side[r & 1];   // runs touch disjoint rows
         GemmArgs a = gemm_args();
         a.X[0] = c->kall_sp[j].as<char>() + ((size_t)l * p.U[j] + p.run_u[r]) * p.Sp[j] * ROWB; a.ldx[0] = ROWB;
         a.I[0] = p.Sp[j]; a.Iclamp[0] = p.Sp[j]; a.kt[0] = CFD_D / 32;
         a.Y = c->h_sp.as<char>() + (size_t)p.run_row0[r] * L * ROWB; a.ldy = ROWB; a.J = p.run_len[r] * L; a.Jclamp = a.J;
-        if (tile_sm) {
-          // softmax per 128-key tile inside the product: tile-relative probabilities go straight to P
-          const int nt = (p.Sp[j] + 127) / 128;
-          const size_t tok0 = (size_t)p.run_row0[r] * L;
-          EpiTileSoftmax e;
-          e.out = c->p_sp.as<char>() + tok0 * p.Sp_tot * 4 + (size_t)(p.off[j] / 32) * 128; e.ldo = (long long)p.Sp_tot * 4;
-          e.key_bias = c->cb[j].as<float>() + ((size_t)l * p.U[j] + p.run_u[r]) * p.Sp[j];
-          e.mask = p.mask[j] + (size_t)p.run_u[r] * p.S[j]; e.has_mask = p.has_mask[j]; e.S = p.S[j];
-          e.stats = c->sm_stats.as<float2>() + tok0 * nt; e.ntiles = nt;
-          CHK(run_gemm_128(c, CFD_PROF_GEMM_ATTN, a, e, rs));
-          LAUNCH(CFD_PROF_ROWS, attn_alpha_kernel, dim3((unsigned)((a.J + 255) / 256)), blk, rs, c->sm_stats.as<float2>() + tok0 * nt,
-                 c->sm_alpha.as<float>() + tok0 * nt, (long long)a.J, nt);
-          continue;
-        }
         EpiF32 e;
         memset(&e, 0, sizeof(e));
         e.out = c->sc.as<float>() + (size_t)p.run_row0[r] * L * p.Sp_tot; e.ldo = p.Sp_tot; e.goff[0] = p.off[j];
         e.gbias[0] = c->cb[j].as<float>() + ((size_t)l * p.U[j] + p.run_u[r]) * p.Sp[j]; e.gstride[0] = 0;
-        CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_ATTN, a, e, 1, 1, rs)));
+        CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_ATTN, a, e, 1, 1, st)));
       }
-      join(0);
-      join(1);
     }
-    join(2);
     {
       SoftmaxArgs a;
       memset(&a, 0, sizeof(a));
@@ -911,11 +911,10 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
         a.off[j] = p.off[j]; a.S[j] = p.S[j]; a.Sp[j] = p.Sp[j]; a.mask[j] = p.mask[j]; a.has_mask[j] = p.has_mask[j]; a.map[j] = mapj[j]; a.att[j] = attj[j];
       }
       a.layer = l; a.nl = nl;
-      if (tile_sm) { a.skip_seg = p.jbig; a.skip_rows = c->run_flags.as<uint8_t>(); }
       LAUNCH(CFD_PROF_ROWS, softmax_rows_kernel, dim3((unsigned)((M + 3) / 4)), blk, st, a);
     }
     // x += sum_j P_j . VV_j(n_j) + folded bias
-    auto pv_segk = [&](int skip_j, const int* brow, int nb, hipStream_t sst) -> int {
+    auto pv_segk = [&](int skip_j, const int* brow, int nb) -> int {
       if (nb <= 0) return CFD_OK;
       GemmArgs a = gemm_args();
       int n = 0;
@@ -930,38 +929,24 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       a.nslot = n; a.brow = brow;
       a.Y = c->p_sp.as<char>(); a.ldy = (long long)p.Sp_tot * 4; a.ybs = (long long)L * p.Sp_tot * 4; a.J = L; a.Jclamp = L;
       EpiResid e{c->x.as<float>(), (long long)L * CFD_D, w.cross_bias.as<float>()};
-      return run_gemm<MODE_SEGK>(c, CFD_PROF_GEMM_ATTN, a, e, nb, 1, sst);
+      return run_gemm<MODE_SEGK>(c, CFD_PROF_GEMM_ATTN, a, e, nb, 1, st);
     };
     if (!runs) {
-      CHK(pv_segk(-1, nullptr, Be, st));
+      CHK(pv_segk(-1, nullptr, Be));
     } else {
-      {  // short rows (all segments) are independent of the long rows
-        hipStream_t s2 = fork(2);
-        CHK(pv_segk(-1, c->short_rows.as<int>(), p.nshort, s2));
-      }
-      CHK(pv_segk(p.jbig, c->long_rows.as<int>(), p.nlong, st));   // long rows: short segments first ...
+      CHK(pv_segk(-1, c->short_rows.as<int>(), p.nshort));   // short rows: all segments
+      CHK(pv_segk(p.jbig, c->long_rows.as<int>(), p.nlong));   // long rows: short segments first ...
       const int j = p.jbig;
       for (int r = 0; r < p.nruns; ++r) {   // ... then the shared audio memory, run by run (disjoint rows)
-        hipStream_t rs = fork(r & 1);
         GemmArgs a = gemm_args();
         a.X[0] = c->vt_all[j].as<char>() + ((size_t)l * p.U[j] + p.run_u[r]) * CFD_D * p.Sp[j] * 4; a.ldx[0] = (long long)p.Sp[j] * 4;
         a.I[0] = CFD_D; a.Iclamp[0] = CFD_D; a.kt[0] = p.Sp[j] / 32;
         a.Y = c->p_sp.as<char>() + (size_t)p.run_row0[r] * L * p.Sp_tot * 4 + (size_t)(p.off[j] / 32) * 128;
         a.ldy = (long long)p.Sp_tot * 4; a.J = p.run_len[r] * L; a.Jclamp = a.J;
-        if (tile_sm) {
-          const int nt = (p.Sp[j] + 127) / 128;
-          EpiResidFold e;
-          e.x = c->x.as<float>() + (size_t)p.run_row0[r] * L * CFD_D; e.obs = 0; e.bias = nullptr;
-          e.alpha = c->sm_alpha.as<float>() + (size_t)p.run_row0[r] * L * nt; e.ntiles = nt;
-          CHK(run_gemm_128(c, CFD_PROF_GEMM_ATTN, a, e, rs));
-          continue;
-        }
         EpiResid e{c->x.as<float>() + (size_t)p.run_row0[r] * L * CFD_D, 0, nullptr};
-        CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_ATTN, a, e, 1, 1, rs)));
+        CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_ATTN, a, e, 1, 1, st)));
       }
-      join(0);
-      join(1);
-      join(2);
+    }
     }
     if (c->stop_stage == 4 + 4 * l) return CFD_OK;
     // ---- f. time block 2                                                        (:655)
@@ -1527,6 +1512,7 @@ extern "C" int cfd_debug_read(cfd_handle c, const char* what, float* dst_dev, si
   else if (!strcmp(what, "eps")) b = &c->eps;
   else if (!strcmp(what, "sc")) b = &c->sc;
   else if (!strcmp(what, "ssc")) b = &c->ssc;
+  else if (!strcmp(what, "xa_stamps")) b = &c->xa_stamps;
   else return fail(CFD_E_ARG, "unknown buffer '%s'", what);
   if (numel * 4 > b->bytes) return fail(CFD_E_ARG, "buffer '%s' holds %zu bytes, asked for %zu", what, b->bytes, numel * 4);
   HIPCHK(hipDeviceSynchronize());

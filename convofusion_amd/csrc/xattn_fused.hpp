@@ -1,0 +1,497 @@
+// Fused cross-attention block of one decoder layer (cross_attention.py:578-652, folded form of DESIGN.md section 3):
+//
+//   x[token][:] += sum_j softmax_s( h[token] . Kf_j[u_j][s] + cb_j[u_j][s] ) Vf_j[u_j][s][:]  + cross_bias
+//
+// for the five memories j (one head of width 512 each), u_j = the memory instance the token's batch row maps to.
+// Scores, probabilities and the per-memory outputs never leave the chip: the kernel replaces the score products,
+// softmax_rows_kernel and the P.V products of the three-launch path (which stays for calls that want att_mats).
+//
+// Work decomposition.  A workgroup = 8 waves = 4 query tiles of 16 queries (each of ONE batch row) x 2 halves.  The two
+// waves of a pair (w, w + 4) share a query tile and split the two 512-long axes between them, so that a wave's resident
+// state -- its Q fragments (8 k-steps x hi/lo = 64 VGPRs) and its output accumulator O^T[256 features][16 queries]
+// (16 MFMA tiles = 64 VGPRs) -- leaves room for two waves per SIMD:
+//   phase A   partial S^T[32 keys][16 q] over ITS half of the 512-deep dot product: Kf tile (LDS, A operand) x Q
+//             (registers, B operand), 48 MFMAs; the two partial sums meet through 2 KB of LDS per wave
+//   phase B   O^T[its 256 features][16 q] += Vf^T tile (LDS, A operand) x P (registers), 48 MFMAs
+// Keys arrive in tiles of 32.  A K tile (32 keys x 2 KB) and a V^T tile (512 features x 128 B) are 64 KB each and LDS
+// holds exactly one of each, so the tiles are cut into four 32 KB sub-buffers that are consumed by four sub-phases:
+//   A0  scores of the tile's first 16-key MFMA tile   (Ka: LDS rows 0-15 of every k-step)
+//   A1  scores of the second                          (Kb: rows 16-31)
+//   B0  P.V for the first 128 features of each half   (Va)
+//   B1  P.V for the other 128 features of each half   (Vb)
+// Each sub-phase is 24 MFMAs fed by 16 fragment reads, done in two halves: the 8 reads of a half are issued BEFORE the 12
+// MFMAs of the previous half (two register sets), so the LDS latency hides under MFMAs instead of in front of them -- with
+// the reads issued only right behind a barrier, two waves per SIMD reach ~45 % of the MFMA rate even with every operand
+// resident.  For the reads of the next sub-phase to be issued early, its sub-buffer is declared ready in the MIDDLE of the
+// current one: barriers sit at mid-A0 (Kb ready), end of A1 (Va ready + the pair's partial scores exchanged), mid-B0 (Vb
+// ready) and mid-B1 (next Ka ready); behind each, the sub-buffer that every wave has finished with is refilled
+// (global_load_lds) with the data of its next use 1.5-2.5 sub-phases ahead.  The fills are waited for with COUNTED
+// s_waitcnt vmcnt(N) + raw s_barrier (a __syncthreads() would drain the queue); for the counts to hold there is no
+// ordinary global load inside the loop: the key bias of a tile arrives through LDS with its Ka fill, and the
+// workgroup's segment list is copied to LDS once.
+//
+// MFMA operand orientation (v_mfma_f32_16x16x32, split pairs, 3 MFMAs per product).  Phase A leaves lane (q = lane&15,
+// g = lane>>4) with S^T rows 4g..4g+3 of the two 16-key MFMA tiles.  The K tile's LDS row order is chosen at staging time
+// (the per-lane SOURCE address of the LDS-DMA) so that those 8 accumulator registers are keys 8g..8g+7: exactly the
+// k-slots lane (q, g) supplies as the B operand of phase B against a V^T tile in natural key order.  So P goes from
+// the softmax straight into the P.V MFMAs -- no LDS round trip, no permuted V layout.  Both waves of a pair form the
+// same sum of the two partial scores (a + b = b + a in floating point), hence bit-identical probabilities.
+//
+// Softmax.  A memory longer than one tile runs the online (flash) recurrence and is normalised in registers when its
+// last tile is done; a memory of <= 32 padded keys is normalised before its single P.V step, so its contribution is
+// simply accumulated on top.  With ONE accumulator only one online memory can be pending at a time: the host puts the
+// long memories first and asks for a flush (x += O, O = 0) between two of them (the shipped shapes have at most one
+// memory that is long at L = 196 -- the audio memory -- so the benchmark shape never flushes before the end).
+// Dead keys (padding, key-padding mask) carry cb = -inf (EpiMemK writes it), so the kernel needs no mask loads.
+// A row whose keys are all dead gives NaN like the reference's softmax.
+//
+// The segment list (which memory instance, which of the four waves take part) is built by the host per problem
+// (build_xattn_worklist, cfd_api.hip): waves of a workgroup share every LDS tile, so a segment whose instance differs
+// between the workgroup's batch rows is split into passes.
+#pragma once
+#include "cfd_common.hpp"
+
+#define XA_TILES 4     // query tiles (of 16 queries) per workgroup
+#define XA_WAVES 8     // two waves per query tile
+#define XA_KEYS 32
+// LDS map: K tile | V^T tile (the epilogue strips alias these two and 2 KB more) | partial-score exchange | key bias of
+// two steps | the workgroup's segment list
+#define XA_XOFF 133120
+#define XA_CBOFF (XA_XOFF + XA_WAVES * 2048)
+#define XA_SEGOFF (XA_CBOFF + 512)
+#define XA_MAXSEG 24
+#define XA_LDS (XA_SEGOFF + XA_MAXSEG * 16)
+
+struct XaSeg {
+  int j;        // memory 0..4
+  int u;        // memory instance
+  int wmask;    // query tiles (bit t) whose batch row uses this instance
+  int flags;    // XA_ONLINE | XA_FLUSH
+};
+enum { XA_ONLINE = 1, XA_FLUSH = 2 };
+
+struct XaWg {
+  int row[XA_TILES];   // effective-batch row of query tile t, or -1 (idle)
+  int q0[XA_TILES];    // first query (token index inside the row) of tile t
+  int seg0, nseg;
+  int pad0, pad1;
+};
+
+struct XAttnArgs {
+  const char* h;              // SP [M][512]: LayerNorm2(x)
+  float* x;                   // fp32 [M][512] residual stream (updated in place)
+  const float* bias;          // folded cross-attention bias [512]
+  const char* K[CFD_NMEM];    // this layer's folded keys: SP [U_j * Sp_j][512]
+  const float* cb[CFD_NMEM];  // this layer's key bias (+ -inf on dead keys): [U_j * Sp_j]
+  const char* VT[CFD_NMEM];   // this layer's folded values^T: SP [U_j][512][Sp_j]
+  int Sp[CFD_NMEM];
+  int L;
+  const XaWg* wgs;
+  const XaSeg* segs;
+  long long* stamps;          // XA_STAMP builds only (tools/xa_stamps.py): per wave, cycles per section of the kernel
+};
+
+template <class T>
+__device__ __forceinline__ T xa_sel(const T (&arr)[CFD_NMEM], int j) {
+  T v = arr[0];
+#pragma unroll
+  for (int q = 1; q < CFD_NMEM; ++q)
+    if (j == q) v = arr[q];
+  return v;
+}
+
+// s_waitcnt immediates (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt = 6:4, lgkmcnt = 11:8).  The waits are the BUILTIN,
+// not inline asm: hipcc's own wait-count bookkeeping then knows what has landed and adds no vmcnt(0) of its own in front
+// of the first use of a register that an older load filled (an asm wait is invisible to it).
+#ifndef XA_STAMP
+#define XA_STAMP 0    // developer build: s_memtime stamps around the sections of the kernel (adds ~10 % to its run time)
+#endif
+#define XA_NSTAMP 12
+#if XA_STAMP
+#define XA_T(k) do { asm volatile("" ::: "memory"); const long long t_ = __builtin_amdgcn_s_memtime(); acc_[k] += t_ - tprev_; tprev_ = t_; asm volatile("" ::: "memory"); } while (0)
+#else
+#define XA_T(k) do { } while (0)
+#endif
+#ifndef XA_ABLATE
+#define XA_ABLATE 0   // developer timing experiments, bit mask: 1 = no fills, 2 = no MFMAs, 4 = no fragment reads, 8 = no softmax (results are garbage)
+#endif
+#if XA_ABLATE & 2
+#define XA_MFMA(a_, b_, c_) ([&]() { asm volatile("" ::"v"(a_), "v"(b_)); return c_; }())
+#else
+#define XA_MFMA(a_, b_, c_) SP_MFMA(a_, b_, c_, 0, 0, 0)
+#endif
+#if XA_ABLATE & 4
+#define XA_FRAG(p_) ([&]() { spx8 z_; for (int e_ = 0; e_ < 8; ++e_) z_[e_] = (sp_t)(float)(lane + e_); asm volatile("" : "+v"(z_)); return z_; }())
+#else
+#define XA_FRAG(p_) (*reinterpret_cast<const spx8*>(p_))
+#endif
+#define XA_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | (0xF << 8) | ((((N) >> 4) & 3) << 14))
+#define XA_WAIT_VM_LGKM0(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | ((((N) >> 4) & 3) << 14))
+
+__global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KOFF = 0, VOFF = 65536;
+#if XA_STAMP
+  long long acc_[XA_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev_ = __builtin_amdgcn_s_memtime();
+#endif
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = wid & 3, half = wid >> 2;           // query tile of the pair; which half of the 512-long axes
+  const int l15 = lane & 15, q4 = lane >> 4, sw = l15 >> 1;
+  const int cpos = lane & 7, rsub = lane >> 3;
+
+  const XaWg* wgp = a.wgs + blockIdx.x;
+  const int my_row = wgp->row[tile];
+  const int my_q0 = wgp->q0[tile];
+  const int seg0 = wgp->seg0, nseg = wgp->nseg;
+  const bool active = my_row >= 0;                     // wave-uniform
+  const long long tok0 = active ? (long long)my_row * a.L + my_q0 : 0;
+  const int nq = active ? min(16, a.L - my_q0) : 0;    // valid queries of this wave's tile
+
+  // the segment list of this workgroup -> LDS (read back with ds_read: no vector-memory traffic inside the loop)
+  if (threadIdx.x < nseg) reinterpret_cast<int4*>(smem + XA_SEGOFF)[threadIdx.x] = reinterpret_cast<const int4*>(a.segs + seg0)[threadIdx.x];
+
+  // Q fragments (B operand) of this wave's half of the feature axis: lane holds d = 256 half + 32 ks + 8 q4 .. +7 of
+  // query l15 (clamped to a valid one)
+  spx8 qh[8], ql[8];
+  {
+    const char* qp = a.h + (tok0 + min(l15, max(nq - 1, 0))) * (CFD_D * 4) + half * 1024 + q4 * 16;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      qh[ks] = *reinterpret_cast<const spx8*>(qp + ks * 128);
+      ql[ks] = *reinterpret_cast<const spx8*>(qp + ks * 128 + 64);
+    }
+  }
+  f32x4 o[16];   // O^T tiles of features 256 half + 16 f .. +15
+#pragma unroll
+  for (int f = 0; f < 16; ++f) o[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+  XA_WAIT_VM_LGKM0(0);   // Q fragments have arrived: the counted waits of the loop start from an empty queue
+  __builtin_amdgcn_s_barrier();   // segment list visible
+
+  // ---- staging: one piece = one global_load_lds_dwordx4 wave-instruction = 8 tile rows x 128 B; a 32 KB sub-buffer is
+  //      32 pieces = 4 per wave.  K tile LDS image: [k-step 16][row 32][128 B]; LDS row rho = 16 t + i holds key
+  //      8 (i>>2) + 4 t + (i&3) of the tile (see header); chunk swizzle (rho>>1)&7 on the source address.
+  //      Sub-buffer Ka = rows 0-15, Kb = rows 16-31.  Piece n of wave `wid`: rows (wid&1)*8 .. +7 (+16 for Kb), k-step (wid>>1) + 4 n.
+  const int kr = (wid & 1) * 8 + rsub;                                   // row inside the 16-row half
+  const int kkey = 8 * (kr >> 2) + (kr & 3);                             // its key (+ 4 for the second half)
+  const int ksrc_lane = kkey * (CFD_D * 4) + (wid >> 1) * 128 + ((cpos ^ ((kr >> 1) & 7)) << 4);
+  const int kdst_wave = KOFF + (wid >> 1) * 4096 + (wid & 1) * 1024;
+  //      V^T tile LDS image: [feature 512][128 B]; Va = features [0,128) + [256,384), Vb = the rest.  Piece n of wave `wid`:
+  //      8-row group g = wid + 8 (n&1) + 32 (n>>1) (+16 for Vb); swizzle ((f>>1)&7) = ((wid&1)<<2) | (rsub>>1)
+  const int vsw = (cpos ^ (((wid & 1) << 2) | (rsub >> 1))) << 4;
+
+  // A tile = 32 keys of one memory instance: its K rows, its V^T column block, its key bias; rowb = bytes per V^T feature
+  // row of that memory; vlane = this lane's byte offset inside a V^T piece (depends on rowb).  All but vlane are wave-uniform.
+  struct Tile { const char* k; const char* v; const float* cb; long long rowb; unsigned vlane; };
+  auto seg_field = [&](int si, int fld) __attribute__((always_inline)) -> int {
+    return __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(smem + XA_SEGOFF)[si * 4 + fld]);
+  };
+  auto seg_tile = [&](int si, Tile& t, int& T, int& wm, int& fl) __attribute__((always_inline)) {   // first tile of segment si
+    const int j = seg_field(si, 0), u = seg_field(si, 1);
+    wm = seg_field(si, 2); fl = seg_field(si, 3);
+    const int Sp = xa_sel(a.Sp, j);
+    T = Sp / XA_KEYS;
+    t.k = xa_sel(a.K, j) + (long long)u * Sp * (CFD_D * 4);
+    t.v = xa_sel(a.VT, j) + (long long)u * CFD_D * Sp * 4;
+    t.cb = xa_sel(a.cb, j) + (long long)u * Sp;
+    t.rowb = (long long)Sp * 4;
+    t.vlane = (unsigned)((wid * 8 + rsub) * Sp * 4 + vsw);    // (512 rows x Sp x 4 B < 4 GiB)
+  };
+  // fills: K half `hb` (0: Ka, 1: Kb) of tile `t`; with Ka travels the key bias of the tile (1 piece: 64 x 4 B, the
+  // upper 32 lanes re-read the lower ones' words) into key-bias slot `slot`.  Every address is a wave-uniform 64-bit base
+  // (SGPRs) + a loop-invariant 32-bit lane offset: no vector arithmetic per fill.  (The operands are made opaque at every
+  // use: otherwise hipcc hoists base + lane offset out of the loop as a 64-bit per-lane pointer and pays vector adds per fill.)
+  const unsigned cb_lane = (lane & 31) * 4;
+  auto fill_k = [&](const Tile& t, int hb, int slot) __attribute__((always_inline)) {
+    if (XA_ABLATE & 1) return;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      unsigned kl = (unsigned)ksrc_lane;
+      const char* b = t.k + hb * (4 * CFD_D * 4) + n * 512;
+      asm volatile("" : "+v"(kl), "+s"(b));
+      __builtin_amdgcn_global_load_lds((gptr_t)(b + kl), (lptr_t)(smem + kdst_wave + hb * 2048 + n * 16384), 16, 0, 0);
+    }
+    if (hb == 0) {
+      unsigned cl = cb_lane;
+      asm volatile("" : "+v"(cl));
+      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(t.cb) + cl), (lptr_t)(smem + XA_CBOFF + slot * 256), 4, 0, 0);
+    }
+  };
+  auto fill_v = [&](const Tile& t, int hb) __attribute__((always_inline)) {
+    if (XA_ABLATE & 1) return;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      unsigned vl = t.vlane;
+      const int g = 8 * (n & 1) + 32 * (n >> 1) + 16 * hb;       // uniform part of the 8-row group index (+ wid per wave)
+      const char* b = t.v + (long long)g * 8 * t.rowb;
+      asm volatile("" : "+v"(vl), "+s"(b));
+      __builtin_amdgcn_global_load_lds((gptr_t)(b + vl), (lptr_t)(smem + VOFF + (wid + g) * 1024), 16, 0, 0);
+    }
+  };
+
+  // x[token][256 half ..] += O^T (+ bias) for this wave's queries, then O = 0.  Every wave re-lays its 256 x 16 tile
+  // through a private LDS strip (the caller has drained every fill and passed a barrier, so the tile buffers are free)
+  // and moves whole 1 KB row pieces.
+  auto flush = [&](bool add_bias) __attribute__((always_inline)) {
+    constexpr int RS = 256 * 4 + 16;
+    static_assert(XA_WAVES * 16 * RS <= XA_XOFF, "the epilogue strips must not reach the exchange / key-bias / segment areas");
+    char* strip = smem + wid * (16 * RS);
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+      *reinterpret_cast<f32x4*>(strip + l15 * RS + (f * 16 + q4 * 4) * 4) = o[f];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private strip: no barrier needed
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (add_bias) bv = *reinterpret_cast<const float4*>(a.bias + half * 256 + lane * 4);
+    float* xp = a.x + tok0 * CFD_D + half * 256 + lane * 4;
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += 4) {
+      float4 old[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (r0 + r < nq) old[r] = *reinterpret_cast<const float4*>(xp + (long long)(r0 + r) * CFD_D);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(strip + (r0 + r) * RS + lane * 16);
+        if (r0 + r < nq) {
+          float4 t = old[r];
+          t.x = (t.x + bv.x) + v[0]; t.y = (t.y + bv.y) + v[1]; t.z = (t.z + bv.z) + v[2]; t.w = (t.w + bv.w) + v[3];
+          *reinterpret_cast<float4*>(xp + (long long)(r0 + r) * CFD_D) = t;
+        }
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < 16; ++f) o[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    XA_WAIT_VM(0);                                       // the counted waits of the loop assume an empty queue
+  };
+
+  float m = -INFINITY, lsum = 0.f;
+  char* xch_mine = smem + XA_XOFF + wid * 2048 + lane * 16;
+  const char* xch_other = smem + XA_XOFF + (wid ^ 4) * 2048 + lane * 16;
+  // fragment reads: half `hf` (4 k-steps / 4 feature tiles) of a sub-phase -> 8 fragments (hi, lo alternating)
+  const char* kfrag = smem + KOFF + (8 * half) * 4096 + l15 * 128;
+  const char* vfrag = smem + VOFF + (16 * half * 16 + l15) * 128;
+  const int off_h = (q4 ^ sw) << 4, off_l = ((4 + q4) ^ sw) << 4;
+  auto read_k = [&](spx8 (&fr)[8], int t, int hf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const char* kp = kfrag + (4 * hf + i) * 4096 + t * 2048;
+      fr[2 * i] = XA_FRAG(kp + off_h);
+      fr[2 * i + 1] = XA_FRAG(kp + off_l);
+    }
+  };
+  auto read_v = [&](spx8 (&fr)[8], int qf) __attribute__((always_inline)) {   // qf = 0..3: feature tiles 4 qf .. 4 qf + 3 of this half
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const char* vp = vfrag + (4 * qf + i) * 2048;
+      fr[2 * i] = XA_FRAG(vp + off_h);
+      fr[2 * i + 1] = XA_FRAG(vp + off_l);
+    }
+  };
+  auto mfma_k = [&](f32x4& acc, const spx8 (&fr)[8], int hf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc = XA_MFMA(fr[2 * i + 1], qh[4 * hf + i], acc);
+      acc = XA_MFMA(fr[2 * i], ql[4 * hf + i], acc);
+      acc = XA_MFMA(fr[2 * i], qh[4 * hf + i], acc);
+    }
+  };
+  spx8 ph, pl;
+  auto mfma_v = [&](const spx8 (&fr)[8], int qf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[4 * qf + i] = XA_MFMA(fr[2 * i + 1], ph, o[4 * qf + i]);
+      o[4 * qf + i] = XA_MFMA(fr[2 * i], pl, o[4 * qf + i]);
+      o[4 * qf + i] = XA_MFMA(fr[2 * i], ph, o[4 * qf + i]);
+    }
+  };
+  spx8 fa[8], fb[8];   // the two fragment sets
+  // max / sum over the 4 lanes {l, l^16, l^32, l^48} that share a query, in the vector ALU (v_permlane32_swap /
+  // v_permlane16_swap: with both operands the same register, the two results hold the value of the lane's own and of its
+  // partner's half / row) -- four dependent ds_bpermute round trips per step otherwise
+  auto xlane = [&](float x, bool is_max) __attribute__((always_inline)) -> float {
+    unsigned xi = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+    const float a0 = __uint_as_float(r[0]), a1 = __uint_as_float(r[1]);
+    x = is_max ? fmaxf(a0, a1) : a0 + a1;
+    xi = __float_as_uint(x);
+    auto q = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+    const float b0 = __uint_as_float(q[0]), b1 = __uint_as_float(q[1]);
+    return is_max ? fmaxf(b0, b1) : b0 + b1;
+  };
+  bool primed = false;
+  int step = 0;
+  Tile cur, nseg_t;
+  int cT = 1, cmask = 0, cflags = 0, nT = 1, nmask = 0, nflags = 0;
+  if (nseg > 0) seg_tile(0, cur, cT, cmask, cflags);
+  XA_T(0);
+  for (int si = 0; si < nseg; ++si) {
+    const bool in_seg = active && ((cmask >> tile) & 1);   // wave-uniform, the same for both waves of a pair
+    const bool online = (cflags & XA_ONLINE) != 0;
+    const bool seg_follows = si + 1 < nseg;
+    // the first tile of the next segment (this segment's first tile again when there is none: the trailing fills then land
+    // in buffers nobody reads)
+    nseg_t = cur; nT = cT; nmask = cmask; nflags = cflags;
+    if (seg_follows) seg_tile(si + 1, nseg_t, nT, nmask, nflags);
+    XA_T(11);
+    for (int kt = 0; kt < cT; ++kt) {
+    const bool last_in_seg = kt + 1 == cT;
+    Tile nxt;   // the tile of the step after this one
+    nxt.k = last_in_seg ? nseg_t.k : cur.k + XA_KEYS * CFD_D * 4;
+    nxt.v = last_in_seg ? nseg_t.v : cur.v + 128;
+    nxt.cb = last_in_seg ? nseg_t.cb : cur.cb + XA_KEYS;
+    nxt.rowb = last_in_seg ? nseg_t.rowb : cur.rowb;
+    nxt.vlane = last_in_seg ? nseg_t.vlane : cur.vlane;
+    const int slot = step & 1;
+    if (!primed) {   // (re)start of the pipeline: Ka (+ key bias), Kb, Va of this step; Vb follows behind mid-A0
+      fill_k(cur, 0, slot);
+      fill_k(cur, 1, slot);
+      fill_v(cur, 0);
+      XA_WAIT_VM_LGKM0(8);               // Ka + key bias landed
+      __builtin_amdgcn_s_barrier();
+      read_k(fa, 0, 0);
+      primed = true;
+      XA_T(0);
+    }
+    // ---- A0 (fa holds its first half) --------------------------------------------------------------------------------
+    f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    read_k(fb, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_k(s0, fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    XA_T(1);
+    XA_WAIT_VM_LGKM0(4);                 // Kb landed (one fill of 4 pieces is younger); this wave's reads of Ka's first half are done
+    __builtin_amdgcn_s_barrier();        // mid-A0: Kb ready; every wave is done with Vb
+    XA_T(2);
+    fill_v(cur, 1);
+    read_k(fa, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) {
+      mfma_k(s0, fb, 1);
+      *reinterpret_cast<f32x4*>(xch_mine) = s0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- A1 ---------------------------------------------------------------------------------------------------------
+    read_k(fb, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_k(s1, fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) {
+      mfma_k(s1, fb, 1);
+      *reinterpret_cast<f32x4*>(xch_mine + 1024) = s1;
+    }
+    XA_T(3);
+    XA_WAIT_VM_LGKM0(4);                 // Va landed (Vb is younger); partial scores written
+    __builtin_amdgcn_s_barrier();        // end of A1: Va ready, partial scores visible, every wave is done with Ka and Kb
+    XA_T(4);
+    fill_k(nxt, 0, slot ^ 1);
+    read_v(fa, 0);
+    float scale = 1.0f;
+    if (in_seg && !(XA_ABLATE & 8)) {
+      // softmax of this tile: lane (q, g) holds keys 8 g + e, e = 0..7 (s0 = e 0..3, s1 = e 4..7)
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(xch_other);
+      const f32x4 t1 = *reinterpret_cast<const f32x4*>(xch_other + 1024);
+      const f32x4 kb0 = *reinterpret_cast<const f32x4*>(smem + XA_CBOFF + slot * 256 + q4 * 32);
+      const f32x4 kb1 = *reinterpret_cast<const f32x4*>(smem + XA_CBOFF + slot * 256 + q4 * 32 + 16);
+      float p[8];
+      p[0] = (s0[0] + t0[0]) + kb0[0]; p[1] = (s0[1] + t0[1]) + kb0[1]; p[2] = (s0[2] + t0[2]) + kb0[2]; p[3] = (s0[3] + t0[3]) + kb0[3];
+      p[4] = (s1[0] + t1[0]) + kb1[0]; p[5] = (s1[1] + t1[1]) + kb1[1]; p[6] = (s1[2] + t1[2]) + kb1[2]; p[7] = (s1[3] + t1[3]) + kb1[3];
+      const float mx = xlane(fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7]))), true);
+      if (online) {
+        const float m_new = fmaxf(m, mx);
+        const bool dead = m_new == -INFINITY;             // nothing but dead keys so far: contribute 0, keep m = -inf
+        scale = dead ? 1.0f : __expf(m - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          p[e] = dead ? 0.f : __expf(p[e] - m_new);
+          ps += p[e];
+        }
+        lsum = lsum * scale + xlane(ps, false);
+        m = m_new;
+      } else {
+        float ps = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          p[e] = __expf(p[e] - mx);                        // all keys dead: (-inf) - (-inf) = NaN, as in the reference
+          ps += p[e];
+        }
+        const float inv = 1.0f / xlane(ps, false);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p[e] *= inv;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sp_t hi, lo;
+        split_f32(p[e], hi, lo);
+        ph[e] = hi;
+        pl[e] = lo;
+      }
+      if (online && !__all(scale == 1.0f)) {
+#pragma unroll
+        for (int f = 0; f < 16; ++f) { o[f][0] *= scale; o[f][1] *= scale; o[f][2] *= scale; o[f][3] *= scale; }
+      }
+    }
+    // ---- B0 (fa holds its first half) --------------------------------------------------------------------------------
+    XA_T(10);
+    read_v(fb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    XA_T(5);
+    XA_WAIT_VM_LGKM0(5);                 // Vb landed (the next Ka + key bias = 5 pieces are younger)
+    __builtin_amdgcn_s_barrier();        // mid-B0: Vb ready
+    XA_T(6);
+    fill_k(nxt, 1, slot ^ 1);            // (Kb has been free since the end of A1)
+    read_v(fa, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- B1 ---------------------------------------------------------------------------------------------------------
+    read_v(fb, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fa, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    XA_T(7);
+    XA_WAIT_VM_LGKM0(4);                 // next Ka + key bias landed (the next Kb is younger)
+    __builtin_amdgcn_s_barrier();        // mid-B1: next Ka ready; every wave is done with Va
+    XA_T(8);
+    fill_v(nxt, 0);
+    read_k(fa, 0, 0);                    // first half of the next step's A0
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fb, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+    ++step;
+    XA_T(9);
+    }   // kt
+    if (in_seg && online) {   // normalise the finished online memory in registers (all keys dead: 0 * inf = NaN)
+      const float inv = 1.0f / lsum;
+#pragma unroll
+      for (int f = 0; f < 16; ++f) { o[f][0] *= inv; o[f][1] *= inv; o[f][2] *= inv; o[f][3] *= inv; }
+    }
+    if (cflags & XA_FLUSH) {   // one accumulator: hand the finished online memory to x before the next one starts
+      XA_WAIT_VM_LGKM0(0);
+      __builtin_amdgcn_s_barrier();   // every wave is done with Vb and every fill has landed: the strips may alias the tile buffers
+      flush(false);
+      XA_WAIT_VM_LGKM0(0);
+      __builtin_amdgcn_s_barrier();   // strips read back everywhere before the pipeline is primed again
+      primed = false;
+    }
+    m = -INFINITY;
+    lsum = 0.f;
+    cT = nT; cmask = nmask; cflags = nflags;   // (cur already points at the next segment's first tile)
+  }
+  XA_WAIT_VM_LGKM0(0);
+  __builtin_amdgcn_s_barrier();   // last B1 done everywhere and the trailing (unused) fills have landed: the tile buffers become the epilogue strips
+  XA_T(11);
+  flush(true);
+#if XA_STAMP
+  {
+    const long long t_ = __builtin_amdgcn_s_memtime();
+    acc_[0] += t_ - tprev_;   // epilogue goes with the prologue
+    if (a.stamps && lane == 0)
+      for (int k = 0; k < XA_NSTAMP; ++k) a.stamps[((long long)blockIdx.x * XA_WAVES + wid) * XA_NSTAMP + k] = acc_[k];
+  }
+#endif
+}

@@ -230,10 +230,11 @@ int cfd_philox_normal(cfd_handle h, float* out, int B, int per_utt, uint64_t see
  * and the number of launches per class.  Classes: see CFD_PROF_* below. */
 #define CFD_PROF_GEMM_TOKEN 0    /* token-side projections (QK, V^T, Wo, TimeBlocks, FFN, embed, proj) */
 #define CFD_PROF_GEMM_MEM 1      /* memory-side K / V^T projections */
-#define CFD_PROF_GEMM_ATTN 2     /* attention score and P.V products */
+#define CFD_PROF_GEMM_ATTN 2     /* fused self-attention; score and P.V products of the three-launch cross-attention path */
 #define CFD_PROF_ROWS 3          /* LayerNorm / AdaLN / softmax / memory prep */
 #define CFD_PROF_OTHER 4
-#define CFD_PROF_NCLASS 5
+#define CFD_PROF_XATTN 5         /* fused cross-attention kernel (scores + softmax + P.V + residual of the five memories) */
+#define CFD_PROF_NCLASS 6
 int cfd_profile_forward(cfd_handle h, float ms[CFD_PROF_NCLASS], int launches[CFD_PROF_NCLASS]);
 
 /* Test hook: D[j][i] = sum_k X[i][k] Y[j][k] through the split-bf16 MFMA kernel.

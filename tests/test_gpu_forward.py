@@ -128,3 +128,44 @@ def test_forward_does_not_mutate_inputs_and_is_deterministic():
         b, _ = m(x, torch.tensor(t), mems, mem_mask_dict=masks)
     assert torch.equal(a, b)
     assert torch.equal(x, x0) and all(torch.equal(p, q) for p, q in zip(mems, m0))
+
+
+def test_headline_shape_rows_match_reference():
+    """BASELINE configs[1] at FULL size (Be = 7 x 32 = 224 rows, L = 196, 1500 audio tokens): rows are independent, so the
+    7 guidance rows of utterances {0, 17, 31} are held against the REFERENCE Denoiser's outputs for exactly those rows
+    (tests/golden/denoiser_c2rows.npz, made by make_golden_c2rows.py) -- the hot MFMA path at the shape the metric is
+    quoted on (Lp = 224: a partial last key tile, 13 row tiles per batch row), with and without attention maps
+    (the two cross-attention paths)."""
+    import torch
+    from oracle import inputs
+    from tests.gpu_helpers import hip_denoiser, to_dev
+    from tests.helpers import load_golden
+    g = load_golden("denoiser_c2rows")
+    meta = [int(v) for v in g["meta"]]
+    B, L, S, pad, t, seed, utts = meta[0], meta[1], tuple(meta[2:7]), tuple(meta[7:12]), meta[12], meta[13], meta[14:]
+    cb = inputs.make_cfg_batch(seed=seed, B=B, L=L, S=S, pad_tail=pad, uncond_pad_tail=pad)
+    m = hip_denoiser(1234, 1.0)
+    x = to_dev(np.concatenate([cb["init"]] * 7))
+    mems = [to_dev(v) for v in cb["memories"]]
+    masks = {k: to_dev(v) for k, v in cb["masks"].items()}
+    keep = m.return_attention
+    try:
+        for want_att in (False, True):
+            m.return_attention = want_att
+            with torch.no_grad():
+                out, att = m(x, torch.tensor(t), mems, mem_mask_dict=masks)
+            out = out.cpu().numpy()
+            assert np.isfinite(out).all()
+            for u in utts:
+                idx = np.array([c * B + u for c in range(7)])
+                e = rel_l2(out[idx], g[f"out{u}"])
+                print(f"attention maps {want_att}: utterance {u} rows rel {e:.2e}")
+                assert e < FWD_TOL
+            if want_att:
+                a1 = att[1][2 * B + 17].cpu().numpy()       # audio attention of the audio-only chunk's row of utterance 17
+                assert max_abs(a1[:, :, :96], g["att1_u17_row2_head"]) < 1e-4
+                assert max_abs(a1.sum(-1), g["att1_u17_row2_rowsum"]) < 1e-4
+                assert max_abs(att[2][1 * B + 17].cpu().numpy(), g["att2_u17_row1"]) < 1e-4
+            del att
+    finally:
+        m.return_attention = keep

@@ -165,8 +165,9 @@ def test_device_rng_stream_matches_oracle():
 @pytest.mark.parametrize("S_audio,audio_pad", [(256, 0), (300, 37)])
 def test_shared_memory_run_path_matches_oracle(S_audio, audio_pad):
     """Long latents + a long audio memory switch on the un-batched attention products for rows that share the
-    unconditional memory (cfd_api.hip 'runs'; with CFD_TILE_SM=1 -- test_developer_knobs_keep_parity -- their softmax
-    is done per 128-key tile inside the two products); check that path end-to-end against the oracle -- also with a key count that is
+    unconditional memory in the three-launch path (cfd_api.hip 'runs'; CFD_FUSED_XATTN=0 leg of
+    test_developer_knobs_keep_parity) and give the fused cross-attention kernel a multi-tile online softmax with row-straddling
+    workgroups; check the loop end-to-end against the oracle -- also with a key count that is
     not a multiple of the tile (300 = 2 x 128 + 44, padded to 320) and a key-padding mask on the shared memory that
     blanks the whole last tile's valid keys."""
     from convofusion_amd.sampler import sample
@@ -294,19 +295,61 @@ def test_ddim_with_eta_matches_oracle():
     assert e < TRAJ_TOL
 
 
-@pytest.mark.parametrize("env", [{"CFD_NAIVE_GEMM": "1"}, {"CFD_GEMM_CFG": "2"}, {"CFD_CHUNKS": "3"},
-                                 {"CFD_FUSED_SELF": "0"}, {"CFD_RUNS": "0"}, {"CFD_BRANCHES": "1"}, {"CFD_SHARE0": "0"}, {"CFD_PERMUTE": "0"}, {"CFD_TILE_SM": "1"}, {"CFD_SMALL3": "0"}])
+@pytest.mark.parametrize("env", [{"CFD_NAIVE_GEMM": "1"}, {"CFD_RUNS": "0", "CFD_FUSED_XATTN": "0"}, {"CFD_FUSED_XATTN": "0"}])
 def test_developer_knobs_keep_parity(env):
-    """The debug / tuning switches (read once at cfd_create) must not change results: run the golden forward and
-    the 20-step trajectory test in a child process under each of them."""
+    """The debug switches that select another code path for the same arithmetic (read once at cfd_create) must not change
+    results: CFD_NAIVE_GEMM=1 (one-thread-per-output products instead of the MFMA kernels, three-launch attention),
+    CFD_FUSED_XATTN=0 (three-launch cross-attention everywhere, with its shared-memory runs) and the same with
+    CFD_RUNS=0 (per-row attention products only).  Each leg runs the golden forward, the 20-step trajectory, the run-path
+    test and the headline-shape loop rows in a child process."""
     import os
     import subprocess
     import sys
     e = dict(os.environ, **env)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x",
-                        "tests/test_gpu_forward.py::test_forward_matches_reference_golden",
-                        "tests/test_gpu_sampler.py::test_sampler_matches_reference_trajectory[ddpm20_b2]",
-                        "tests/test_gpu_sampler.py::test_shared_memory_run_path_matches_oracle"],
-                       cwd=root, env=e, capture_output=True, text=True, timeout=900)
+    tests = ["tests/test_gpu_forward.py::test_forward_matches_reference_golden",
+             "tests/test_gpu_sampler.py::test_sampler_matches_reference_trajectory[ddpm20_b2]",
+             "tests/test_gpu_sampler.py::test_shared_memory_run_path_matches_oracle"]
+    if "CFD_NAIVE_GEMM" not in env:   # (the one-thread-per-output products would take minutes at the headline size)
+        tests.append("tests/test_gpu_sampler.py::test_headline_shape_loop_row_matches_reference[b32-ddpm5]")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", *tests], cwd=root, env=e, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize("kind", ["ddpm5", "ddim5"])
+@pytest.mark.parametrize("variant", ["b32", "b32_skip_zero_weight_chunk", "b1_shard"])
+def test_headline_shape_loop_row_matches_reference(kind, variant):
+    """The captured loop at BASELINE configs[1]'s full size (B = 32, L = 196, 1500 audio tokens), 5 guided steps: utterance
+    17's latents against the trajectory the restated loop produced driving the REFERENCE denoiser for that utterance alone
+    (tests/golden/traj_c2_*.npz).  Utterances are independent and the Philox streams are keyed by global utterance id, so
+    the B = 32 run's row 17 (default path: shared-memory runs, chunk permutation, shared layer-0 head), the same with the
+    zero-weight chunk skipped, and a one-utterance shard with first_utterance = 17 must all reproduce it."""
+    from convofusion_amd.distributed import shard_cfg_batch
+    from convofusion_amd.sampler import SamplingRun
+    from tests.gpu_helpers import hip_denoiser, to_dev
+    g = load_golden("traj_c2_" + kind)
+    meta = [int(v) for v in g["meta"]]
+    B, L, S, pad, n, seed, u = meta[0], meta[1], tuple(meta[2:7]), tuple(meta[7:12]), meta[12], meta[13], meta[14]
+    cb = inputs.make_cfg_batch(seed=seed, B=B, L=L, S=S, pad_tail=pad, uncond_pad_tail=pad)
+    mems = [to_dev(x) for x in cb["memories"]]
+    masks = {k: to_dev(v) for k, v in cb["masks"].items()}
+    m = hip_denoiser(1234, 1.0)
+    sched = _sched("ddim" if "ddim" in kind else "ddpm")
+    if variant == "b1_shard":
+        mems = [shard_cfg_batch(x, u, u + 1, B) for x in mems]
+        masks = {k: shard_cfg_batch(v, u, u + 1, B) for k, v in masks.items()}
+        run = SamplingRun(m, sched, mems, masks, 1, L, n, guidance_scale=7.5, seed=seed, first_utterance=u)
+        row = 0
+    else:
+        run = SamplingRun(m, sched, mems, masks, B, L, n, guidance_scale=7.5, seed=seed,
+                          skip_zero_weight_chunks=variant.endswith("chunk"))
+        row = u
+    errs = {}
+    for k in sorted(int(f[4:]) for f in g.files if f.startswith("step")):
+        run.steps(k - run.position)
+        errs[k] = rel_l2(run.read().cpu().numpy()[row], g[f"step{k}"][0])
+    run.steps(n - run.position)
+    lat = run.read(close=True).cpu().numpy()
+    errs["final"] = rel_l2(lat[row], g["latents"][:, 0])
+    print(kind, variant, {k: f"{v:.2e}" for k, v in errs.items()})
+    assert np.isfinite(lat).all() and all(v < TRAJ_TOL for v in errs.values()), errs

@@ -55,3 +55,20 @@ def test_per_row_timesteps_equal_scalar():
     a, _ = denoiser_ref.denoiser_forward(sd, inp["sample"], t, inp["memories"], inp["masks"], num_layers=2)
     b, _ = denoiser_ref.denoiser_forward(sd, inp["sample"], np.full((7,), t), inp["memories"], inp["masks"], num_layers=2)
     np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_sharp", "real", "oddlen"])
+def test_torch_restatement_matches_reference_golden(name):
+    """oracle/denoiser_torch.py (bench.py's cpu_baseline leg: the reference's own torch CPU-eager op sequence driven
+    from a state dict) against the outputs of the imported reference class."""
+    import torch
+    from oracle import denoiser_torch
+    sd, inp, t, g = forward_case(name)
+    tsd = denoiser_torch.to_torch(sd)
+    mems = [torch.from_numpy(m) for m in inp["memories"]]
+    masks = {k: (torch.from_numpy(v) if v is not None else None) for k, v in inp["masks"].items()}
+    out, att = denoiser_torch.denoiser_forward(tsd, torch.from_numpy(inp["sample"]), t, mems, masks)
+    assert rel_l2(out.numpy(), g["out"]) < 2e-5
+    for j in range(5):
+        ref = g[f"att{j}"]
+        assert max_abs(att[j].numpy()[: ref.shape[0]], ref) < 2e-4

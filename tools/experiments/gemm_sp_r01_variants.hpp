@@ -38,6 +38,9 @@
 #ifndef CFD_READS_FIRST
 #define CFD_READS_FIRST 1
 #endif
+#ifndef CFD_LATE_RESID
+#define CFD_LATE_RESID 0
+#endif
 #define GEMM_SLOTS 5
 enum { MODE_PLAIN = 0, MODE_GROUPED = 1, MODE_SEGK = 2 };
 
@@ -154,6 +157,22 @@ struct EpiResid {  // x[(b*rows_per_b + j)][i] += v + bias[i]   (row length CFD_
   // (Reading the residual rows before the K loop was tried: +46 VGPRs and no gain -- 92 vs 86 us on the
   //  43904x512x512 product; the epilogue is bandwidth-, not latency-limited.)
   static constexpr bool kPrefetch = false;
+  // The residual rows of a tile are requested together, just before the last k-step's MFMAs (kLate): one exposed
+  // HBM round trip per tile instead of one per 16-row band of the epilogue.
+  static constexpr bool kLate = true;
+  typedef float4 Late;
+  __device__ __forceinline__ Late late_load(int g, int b, int z, int i, int j) const {
+    return *reinterpret_cast<const float4*>(x + (long long)b * obs + (long long)j * CFD_D + i);
+  }
+  __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v, Late r) const {
+    float* p = x + (long long)b * obs + (long long)j * CFD_D + i;
+    if (bias) {
+      const float4 t = *reinterpret_cast<const float4*>(bias + i);
+      r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+    }
+    r.x += v[0]; r.y += v[1]; r.z += v[2]; r.w += v[3];
+    *reinterpret_cast<float4*>(p) = r;
+  }
   __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
     float* p = x + (long long)b * obs + (long long)j * CFD_D + i;
     float4 r = *reinterpret_cast<const float4*>(p);
@@ -178,6 +197,43 @@ struct EpiResid {  // x[(b*rows_per_b + j)][i] += v + bias[i]   (row length CFD_
     r.x = (r.x + t.x) + v[0]; r.y = (r.y + t.y) + v[1]; r.z = (r.z + t.z) + v[2]; r.w = (r.w + t.w) + v[3];   // same association as above
     *reinterpret_cast<float4*>(x + (long long)b * obs + (long long)j * CFD_D + i) = r;
   }
+};
+
+// Attention scores against ONE shared memory, softmax-ed per 128-key tile inside the epilogue ("tile softmax"):
+//   P_rel[token][key] = exp(s - m_tile[token])  written as SP,   stats[token][tile] = (m_tile, sum_tile P_rel)
+// with s = D + key_bias[key], keys >= S or masked -> -inf.  attn_alpha_kernel turns the per-tile statistics into
+// alpha[token][tile] = exp(m_tile - m_row) / l_row, and the P.V product (EpiResidFold) accumulates
+// sum_tile alpha * (V^T P_rel) -- the softmax of the whole row without the fp32 score matrix ever reaching HBM.
+// Only for tile configuration 1 (128 keys x 128 tokens, 2 x 2 waves); the kernel body implements the reductions.
+struct EpiTileSoftmax {
+  static constexpr bool kPrefetch = false;
+  static constexpr bool kTileSoftmax = true;
+  char* out;                 // SP [tokens][ldo bytes]; column i = key
+  long long ldo;             // bytes
+  const float* key_bias;     // [>= I] (the folded q-bias term of this memory and layer)
+  const uint8_t* mask;       // [S] key-padding mask of the shared memory (never null)
+  int has_mask;              // 0: the mask is the all-zero stand-in (no byte loads)
+  int S;                     // valid keys
+  float2* stats;             // [tokens][ntiles]
+  int ntiles;
+  static constexpr bool kStore8 = true;
+  __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
+    sp_store4(out + (long long)j * ldo, i, v[0], v[1], v[2], v[3]);
+  }
+  __device__ __forceinline__ void store8(int g, int b, int z, int i, int j, f32x4 v0, f32x4 v1) const {
+    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    sp_store8(out + (long long)j * ldo, i, v);
+  }
+};
+
+// x[j][i] += sum_tile alpha[j][tile] * partial_tile[i][j]: EpiResid for a P.V product whose P is tile-relative
+// (EpiTileSoftmax); the kernel folds the running partial sum into the total every `kFoldSteps` k-steps.
+struct EpiResidFold : EpiResid {
+  static constexpr bool kLate = false;
+  static constexpr bool kFold = true;
+  static constexpr int kFoldSteps = 4;   // 128-key score tiles / 32-key k-steps
+  const float* alpha;        // [tokens][ntiles]
+  int ntiles;
 };
 
 struct EpiNull {  // timing experiments only: keeps the accumulators live, stores nothing
@@ -217,10 +273,6 @@ struct EpiMemK {  // i < nfeat: K_layer[i/512][j][i%512] = split(v)  (one contig
   long long rows;  // memory rows J (= cbias row length)
   float* cbias;
   int nfeat, nl;
-  // dead keys (padding rows s >= S of a memory, key-padding mask) get key bias -inf: the fused cross-attention kernel
-  // then needs no mask loads, and the three-launch path's softmax masks them (again) anyway
-  const uint8_t* mask;   // [U][S] (1 = padded key); never null
-  int S, Sp;
   static constexpr bool kPrefetch = false;
   static constexpr bool kStore8 = true;
   __device__ __forceinline__ void store8(int g, int b, int z, int i, int j, f32x4 v0, f32x4 v1) const {
@@ -238,11 +290,9 @@ struct EpiMemK {  // i < nfeat: K_layer[i/512][j][i%512] = split(v)  (one contig
       const int layer = i >> 9, o = i & (CFD_D - 1);
       sp_store4(kall + ((long long)layer * rows + j) * (CFD_D * 4), o, v[0], v[1], v[2], v[3]);
     } else {
-      const int u = j / Sp, sk = j - u * Sp;
-      const bool dead = sk >= S || mask[(long long)u * S + min(sk, S - 1)] != 0;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (i - nfeat + e < nl) cbias[(long long)(i - nfeat + e) * rows + j] = dead ? -INFINITY : v[e];
+        if (i - nfeat + e < nl) cbias[(long long)(i - nfeat + e) * rows + j] = v[e];
     }
   }
 };
@@ -271,6 +321,14 @@ template <class E, class = void> struct EpiHasBand { static constexpr bool value
 template <class E> struct EpiHasBand<E, typename std::enable_if<E::kBand>::type> { static constexpr bool value = true; };
 template <class E, class = void> struct EpiHasStore8 { static constexpr bool value = false; };
 template <class E> struct EpiHasStore8<E, typename std::enable_if<E::kStore8>::type> { static constexpr bool value = true; };
+template <class E, class = void> struct EpiHasTileSM { static constexpr bool value = false; };
+template <class E> struct EpiHasTileSM<E, typename std::enable_if<E::kTileSoftmax>::type> { static constexpr bool value = true; };
+template <class E, class = void> struct EpiHasFold { static constexpr bool value = false; };
+template <class E> struct EpiHasFold<E, typename std::enable_if<E::kFold>::type> { static constexpr bool value = true; };
+template <class E, class = void> struct EpiHasLate { static constexpr bool value = false; };
+template <class E> struct EpiHasLate<E, typename std::enable_if<E::kLate>::type> { static constexpr bool value = true; };
+template <class E, bool P = EpiHasLate<E>::value> struct EpiLateT { struct type {}; };
+template <class E> struct EpiLateT<E, true> { typedef typename E::Late type; };
 template <class E, bool P = E::kPrefetch> struct EpiPre { struct type {}; };
 template <class E> struct EpiPre<E, true> { typedef typename E::Pre type; };
 
@@ -279,8 +337,12 @@ template <class E> struct EpiPre<E, true> { typedef typename E::Pre type; };
 // NSTAGE == 3: two k-tiles of prefetch kept in flight ACROSS the per-k-step barrier: counted
 //              s_waitcnt vmcnt(GPW) + raw s_barrier (a __syncthreads() would drain the LDS-DMA queue).
 //              Requires every wave to issue exactly GPW loads per stage.
+// NSTAGE >= 5: deep prefetch for SMALL problems (a few workgroups per CU, K = 512: the k-loop is a chain of dependent
+//              memory round trips, not a throughput problem): NSTAGE k-tiles are requested before the first one is
+//              consumed and each buffer is refilled as soon as every wave has read it, so K = 512 costs two round
+//              trips instead of eight.  One workgroup per CU (NSTAGE x tile bytes of LDS).
 template <int WI, int WJ, int TI, int TJ, int NSTAGE, int MODE, class Epi>
-__global__ void __launch_bounds__(WI * WJ * 64, (WI * WJ * 64) / 256 * ((WI * TI + WJ * TJ) * 16 * 128 * NSTAGE <= 52 * 1024 ? 3 : 2))
+__global__ void __launch_bounds__(WI * WJ * 64, (WI * WJ * 64) / 256 * ((WI * TI + WJ * TJ) * 16 * 128 * (NSTAGE == 4 ? 3 : NSTAGE) > 80 * 1024 ? 1 : ((NSTAGE == 1 || (WI * TI + WJ * TJ) * 16 * 128 * NSTAGE <= 52 * 1024) ? 3 : 2)))
 gemm_sp_kernel(const GemmArgs a, const Epi epi) {
   constexpr int NW = WI * WJ;
   constexpr int BI = WI * TI * 16, BJ = WJ * TJ * 16;
@@ -288,7 +350,6 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
   constexpr int XG = BI / 8, YG = BJ / 8;                // 8-row load groups per operand tile
   constexpr int XPW = (XG + NW - 1) / NW, YPW = (YG + NW - 1) / NW;
   constexpr int GPW = XPW + YPW;
-  static_assert(NSTAGE == 2 || NSTAGE == 3, "2-stage (one barrier per k-step) or 3-stage (counted vmcnt) loop");
   static_assert(NSTAGE == 2 || (XG % NW == 0 && YG % NW == 0), "3-stage pipeline needs uniform load counts per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -483,6 +544,63 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
       }
   }
 
+  // tile softmax: the key-bias values of this tile are requested before the k-loop
+  float4 tsm_kb[EpiHasTileSM<Epi>::value ? TI : 1];
+  if constexpr (EpiHasTileSM<Epi>::value) {
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+      tsm_kb[ti] = *reinterpret_cast<const float4*>(epi.key_bias + min(i0 + wi * TI * 16 + ti * 16 + q4 * 4, Ig - 4));   // (keys >= S are dead anyway)
+  }
+  // residual rows requested before the last k-step (EpiResid::kLate)
+  constexpr bool LATE = CFD_LATE_RESID && WIDE && EpiHasLate<Epi>::value && NSTAGE == 2 && TI * TJ <= 16;
+  typename EpiLateT<Epi, LATE>::type late[LATE ? NIT : 1][LATE ? TJ : 1];
+  auto late_issue = [&]() __attribute__((always_inline)) {
+    if constexpr (LATE) {
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          int i, j;
+          epi_ij(tj, it, i, j);
+          late[it][tj] = epi.late_load(g, b, z, min(i, Ig - 4), min(j, a.J - 1));
+        }
+      asm volatile("" ::: "memory");   // keep the requests ahead of the last k-step's LDS reads / MFMAs
+    }
+  };
+
+  // tile-relative P.V (EpiResidFold): acc holds the partial sum of the current 128-key score tile
+  constexpr bool FOLD = EpiHasFold<Epi>::value;
+  constexpr int FOLD_STEPS = 4;
+  static_assert(!FOLD || NSTAGE == 2, "the alpha fold is implemented for the 2-stage loop");
+  f32x4 tot[FOLD ? TI : 1][FOLD ? TJ : 1];
+  float al[FOLD ? TJ : 1];
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) tot[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  auto fold_request = [&](int tile) __attribute__((always_inline)) {
+    if constexpr (FOLD) {
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        const int j = min(j0 + (wj * TJ + tj) * 16 + l15, a.J - 1);
+        al[tj] = epi.alpha[(long long)j * epi.ntiles + tile];
+      }
+    }
+  };
+  auto fold_apply = [&]() __attribute__((always_inline)) {
+    if constexpr (FOLD) {
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) {
+          tot[ti][tj] += al[tj] * acc[ti][tj];
+          acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+  };
+
   auto compute = [&](int buf) __attribute__((always_inline)) {
     const char* sb = smem + buf * STAGE;
     spx8 xh[TI], xl[TI], yh[TJ], yl[TJ];
@@ -509,19 +627,35 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
       }
   };
 
-  if constexpr (NSTAGE == 2) {
+  if constexpr (NSTAGE == 1) {
+    // single LDS buffer: no intra-block overlap at all, but only 32 KB per 128x128 block, so 3-4 blocks share a
+    // CU and cover each other's load / epilogue phases
+    for (int kt = 0; kt < nkt; ++kt) {
+      stage(kt, 0);
+      __syncthreads();
+      compute(0);
+      __syncthreads();
+    }
+  } else if constexpr (NSTAGE == 2) {
     stage(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
       const int buf = kt & 1;
       if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);
+      else late_issue();
+      if constexpr (FOLD) {
+        if ((kt & (FOLD_STEPS - 1)) == 0) fold_request(kt / FOLD_STEPS);   // consumed FOLD_STEPS k-steps later
+      }
       compute(buf);
 #if CFD_MFMA_FENCE
       __builtin_amdgcn_sched_barrier(0);
 #endif
-      __syncthreads();
+      if constexpr (FOLD) {
+        if ((kt & (FOLD_STEPS - 1)) == FOLD_STEPS - 1 || kt + 1 == nkt) fold_apply();
+      }
+      if (!LATE || kt + 1 < nkt) __syncthreads();   // (LATE: the epilogue's own barrier follows, without a vmcnt drain)
     }
-  } else {
+  } else if constexpr (NSTAGE == 3) {
     // tiles kt+1 and kt+2 are in flight while tile kt is consumed
     stage(0, 0);
     if (nkt > 1) {
@@ -543,15 +677,202 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
       __builtin_amdgcn_s_barrier();
       buf = (buf == 2) ? 0 : buf + 1;
     }
+  } else if constexpr (NSTAGE >= 5) {
+    constexpr int NB = NSTAGE;
+    static_assert((NB - 1) * GPW <= 63, "vmcnt is a 6-bit counter");
+    const int pre_n = nkt < NB ? nkt : NB;
+    for (int s = 0; s < pre_n; ++s) stage(s, s);
+    int buf = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+      // loads complete in order: tile kt has landed once at most `after` younger tiles are still outstanding
+      const int after = min(NB - 1, nkt - 1 - kt);
+      switch (after) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPW) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GPW) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * GPW) : "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * GPW) : "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * GPW > 63 ? 63 : 5 * GPW) : "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * GPW > 63 ? 63 : 6 * GPW) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 1) * GPW > 63 ? 63 : (NB - 1) * GPW) : "memory"); break;
+      }
+      __builtin_amdgcn_s_barrier();                           // ... and every other wave's share of it
+      compute(buf);
+      if (kt + NB < nkt) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's reads of `buf` are done
+        __builtin_amdgcn_s_barrier();                         // ... and everyone else's, before the refill lands on them
+        stage(kt + NB, buf);
+      }
+      buf = buf + 1 == NB ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  } else {
+    // NSTAGE == 4 ("software-pipelined"): 3 LDS buffers + register double-buffered fragments.
+    // While the MFMAs of tile kt run on one register set, the LDS reads of tile kt+1 fill the other set and the
+    // LDS-DMA of tiles kt+2 / kt+3 is in flight; one barrier per k-step.  Two waves that share a SIMD run in
+    // lock-step (they alternate on the matrix pipe), so without this their LDS-read phases coincide and the
+    // pipe idles ~40 % (measured: MFMA + LDS reads alone reach only 54 % of the 16-cycle issue rate).
+    struct Frags { spx8 xh[TI], xl[TI], yh[TJ], yl[TJ]; };
+    auto load_frags = [&](Frags& f, int buf) __attribute__((always_inline)) {
+      const char* sb = smem + buf * STAGE;
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) {
+        f.xh[ti] = *reinterpret_cast<const spx8*>(sb + xoff_h + ti * 2048);
+        f.xl[ti] = *reinterpret_cast<const spx8*>(sb + xoff_l + ti * 2048);
+      }
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        f.yh[tj] = *reinterpret_cast<const spx8*>(sb + yoff_h + tj * 2048);
+        f.yl[tj] = *reinterpret_cast<const spx8*>(sb + yoff_l + tj * 2048);
+      }
+    };
+    auto mfma_all = [&](const Frags& f) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) {
+          acc[ti][tj] = SP_MFMA(f.xl[ti], f.yh[tj], acc[ti][tj], 0, 0, 0);
+          acc[ti][tj] = SP_MFMA(f.xh[ti], f.yl[tj], acc[ti][tj], 0, 0, 0);
+          acc[ti][tj] = SP_MFMA(f.xh[ti], f.yh[tj], acc[ti][tj], 0, 0, 0);
+        }
+    };
+    // one k-step: `cur` holds tile kt (reads issued one step ago), `nxt` receives tile kt+1 (LAST = no next tile)
+    auto kstep = [&](Frags& cur, Frags& nxt, int kt, auto last_tag) __attribute__((always_inline)) {
+      constexpr bool LAST = decltype(last_tag)::value;
+      // my DMA share of tile kt+1 has landed (only tile kt+2's loads may still be in flight) and my reads of
+      // tile kt's buffer are complete; after the barrier both hold for every wave.  The waits are BUILTINS so
+      // that hipcc's own wait-count bookkeeping knows the fragments are ready and inserts no lgkmcnt(0) between
+      // the next tile's ds_reads and this tile's MFMAs (the reads must also be unconditional for that).
+      if (!LAST && kt + 2 < nkt) __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(GPW));
+      else __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(0));
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      int bk = kt % 3;
+      if (!LAST && kt + 3 < nkt) stage(kt + 3, bk);   // tile kt's buffer is free now
+      int bn = bk + 1;
+      if (bn == 3) bn = 0;
+      if (!LAST) load_frags(nxt, bn);                  // async LDS reads, consumed in the next k-step
+      __builtin_amdgcn_sched_barrier(0);               // reads are issued BEFORE the MFMAs they overlap with
+      mfma_all(cur);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    stage(0, 0);
+    if (nkt > 1) stage(1, 1);
+    if (nkt > 2) stage(2, 2);
+    if (nkt > 2) __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(2 * GPW));
+    else if (nkt > 1) __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(GPW));
+    else __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(0));
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    Frags fa, fb;
+    load_frags(fa, 0);
+    int kt = 0;
+    for (; kt + 2 < nkt; kt += 2) {
+      kstep(fa, fb, kt, std::false_type{});
+      kstep(fb, fa, kt + 1, std::false_type{});
+    }
+    if (nkt - kt == 2) {
+      kstep(fa, fb, kt, std::false_type{});
+      kstep(fb, fa, kt + 1, std::true_type{});
+    } else {
+      kstep(fa, fb, kt, std::true_type{});
+    }
   }
 
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) acc[ti][tj] = tot[ti][tj];
+  }
+  if constexpr (EpiHasTileSM<Epi>::value) {
+    static_assert(WI == 2 && WJ == 2 && TI == 4 && TJ == 4 && MODE == MODE_PLAIN, "tile softmax: 128-key x 128-token tiles");
+    // acc[ti][tj][r]: key i = i0 + wi*64 + ti*16 + q4*4 + r, token j = j0 + wj*64 + tj*16 + l15.
+    // Each wave first works relative to the maximum of ITS 64 keys; one LDS exchange of (max, sum) with the wave
+    // that holds the tile's other 64 keys then gives the tile statistics and the factor exp(m_wave - m_tile) that
+    // moves this wave's probabilities to the tile maximum (one barrier instead of one per reduction).
+    float2* red = reinterpret_cast<float2*>(smem + 32768);   // [wj][wi][tj][l15]  (the WIDE strips use < 20 KB)
+    float mw[TJ], lw[TJ];
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) mw[tj] = -INFINITY;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+      const int i = i0 + wi * 64 + ti * 16 + q4 * 4;
+      const float4 kb = tsm_kb[ti];
+      bool dead[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dead[r] = i + r >= epi.S;
+        if (epi.has_mask) dead[r] |= epi.mask[min(i + r, epi.S - 1)] != 0;   // wave-uniform condition
+      }
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        f32x4 v = acc[ti][tj];
+        v[0] = dead[0] ? -INFINITY : v[0] + kb.x;
+        v[1] = dead[1] ? -INFINITY : v[1] + kb.y;
+        v[2] = dead[2] ? -INFINITY : v[2] + kb.z;
+        v[3] = dead[3] ? -INFINITY : v[3] + kb.w;
+        acc[ti][tj] = v;
+        mw[tj] = fmaxf(mw[tj], fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+      }
+    }
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      float m = mw[tj];
+      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      mw[tj] = m;
+      float sum = 0.f;
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) {
+        f32x4 v = acc[ti][tj];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = (m == -INFINITY) ? 0.f : __expf(v[r] - m);   // keys that are all masked contribute nothing
+          sum += v[r];
+        }
+        acc[ti][tj] = v;
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      lw[tj] = sum;
+    }
+    __syncthreads();   // every wave is done with the last k-tile: smem is free
+    if (q4 == 0) {
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) red[((wj * 2 + wi) * TJ + tj) * 16 + l15] = make_float2(mw[tj], lw[tj]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      const float2 o = red[((wj * 2 + (wi ^ 1)) * TJ + tj) * 16 + l15];
+      const float m = fmaxf(mw[tj], o.x);
+      const float fs = (mw[tj] == -INFINITY) ? 0.f : __expf(mw[tj] - m);   // this wave's probabilities -> tile maximum
+      const float fo = (o.x == -INFINITY) ? 0.f : __expf(o.x - m);
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) acc[ti][tj] *= fs;
+      if (wi == 0 && q4 == 0) {
+        const int j = j0 + (wj * TJ + tj) * 16 + l15;
+        if (j < a.J) epi.stats[(long long)j * epi.ntiles + ti_blk] = make_float2(m, lw[tj] * fs + o.y * fo);
+      }
+    }
+    // (the WIDE path below starts with its own barrier before it reuses smem)
+  }
   if constexpr (WIDE) {
     static_assert(NIT == TI, "one epilogue instruction per MFMA tile");
     // every wave re-lays its tile band by band through a private LDS strip (the staging ring is free now)
     constexpr int RS = TI * 64 + 16;                 // row stride in bytes (+16: conflict-free 16-byte writes)
     char* strip = smem + wid * (16 * RS);
-    __syncthreads();
-    constexpr bool BAND = EpiHasBand<Epi>::value && !EpiHasStore8<Epi>::value;
+    if constexpr (LATE) {                             // all waves are done with the last k-tile; the residual
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // requests stay in flight across the barrier
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __syncthreads();
+    }
+    constexpr bool BAND = EpiHasBand<Epi>::value && !LATE && !EpiHasStore8<Epi>::value;
     float4 band_r[BAND ? NIT : 1];
     float4 band_t = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (BAND) {
@@ -568,6 +889,8 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
       const int i8 = i0 + wi * TI * 16 + (lane % (TI * 2)) * 8;   // (a lane's columns do not depend on the band)
       if (i8 + 8 <= Ig) epi.tile_bias8(i8, s8_t0, s8_t1);
     }
+    float4 late_bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (LATE) late_bias = epi.tile_bias(min(i0 + wi * TI * 16 + (lane % LPR) * 4, Ig - 4));
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
 #pragma unroll
@@ -594,7 +917,7 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
             }
           }
         }
-      } else if constexpr (EpiHasBand<Epi>::value) {
+      } else if constexpr (EpiHasBand<Epi>::value && !LATE) {
         // the old values of band tj were requested one band ago (band 0: before the loop); band tj+1's requests go out
         // BEFORE this band's stores, which they must not be reordered with as far as hipcc knows
         f32x4 bv[NIT];
@@ -626,6 +949,7 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(strip + (it * RPI + lane / LPR) * RS + (lane % LPR) * 16);
         if (i < Ig && j < a.J) {
           if constexpr (Epi::kPrefetch) epi(g, b, z, i, j, v, pre[it][tj]);
+          else if constexpr (LATE) epi.band_store(g, b, z, i, j, v, late[it][tj], late_bias);
           else epi(g, b, z, i, j, v);
         }
       }
@@ -689,6 +1013,9 @@ __global__ void gemm_sp_naive_kernel(const GemmArgs a, const Epi epi, int g_fixe
 struct GemmCfgSel { int wi, wj, ti, tj; };
 
 extern int g_cfd_naive_gemm;  // set from CFD_NAIVE_GEMM env at cfd_create
+extern int g_cfd_gemm_cfg;    // CFD_GEMM_CFG env: force one tile configuration (tuning / A-B runs)
+extern int g_cfd_small3;      // CFD_SMALL3 env (default 1): 3-stage loop for the small-tile classes
+extern int g_cfd_deep;        // CFD_DEEP env: 8-deep prefetch for the small-tile classes when the launch has few workgroups per CU
 
 template <int WI, int WJ, int TI, int TJ, int NSTAGE, int MODE, class Epi>
 static hipError_t launch_cfg(GemmArgs a, const Epi& epi, int nb, int nz, hipStream_t st) {
@@ -702,7 +1029,7 @@ static hipError_t launch_cfg(GemmArgs a, const Epi& epi, int nb, int nz, hipStre
     total += a.tiles_i[g] * a.tiles_j;
   }
   a.tile_start[ng] = total;
-  constexpr int lds = NSTAGE * (BI + BJ) * 128;
+  constexpr int lds = (NSTAGE == 4 ? 3 : NSTAGE) * (BI + BJ) * 128;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sp_kernel<WI, WJ, TI, TJ, NSTAGE, MODE, Epi>),
@@ -714,14 +1041,15 @@ static hipError_t launch_cfg(GemmArgs a, const Epi& epi, int nb, int nz, hipStre
   return hipGetLastError();
 }
 
-// Tile configurations (cfg): 0 = chosen from the shape (below); the five shapes the denoising step launches:
-//   1 = 128 x 128 (2 x 2 waves of 64 x 64, 2-stage)            the large token-side and memory-side products
-//   3 = 128 x 16  (4 waves of 32 x 16, 2-stage)                J <= 16 columns (time tables)
-//   6 = 128 x 112 (4 waves of 32 x 112, 2-stage)               J in (128, 224]: per-row attention products of 196 tokens
-//  19 = 64 x 64   (2 x 2 waves of 32 x 32, 3-stage counted-vmcnt loop)   small problems: few workgroups per CU, latency-bound
-//  20 = 32 x 128  (1 x 4 waves of 32 x 32, 3-stage)            memories of <= 64 keys
-// The variants measured and rejected in round 1 (3-stage / software-pipelined / deep-prefetch / single-buffer loops,
-// 128 x 256, 256 x 128, 128 x 176 and 256 x 176 tiles, the tile-softmax epilogues) live in tools/experiments/gemm_sp_r01_variants.hpp.
+// the one configuration the tile-softmax epilogues (EpiTileSoftmax / EpiResidFold) are written for
+template <class Epi>
+static hipError_t launch_gemm_128(GemmArgs a, const Epi& epi, hipStream_t st) {
+  if (a.nslot < 1) a.nslot = 1;
+  return launch_cfg<2, 2, 4, 4, 2, MODE_PLAIN, Epi>(a, epi, 1, 1, st);
+}
+
+// cfg: 0 = auto, 1 = 128x128 (4 waves, 2-stage), 2 = 64x64, 3 = 128x16, 4 = 128x256 (8 waves, 3-stage), 5 = 128x128 3-stage,
+//      6 = 128x112 (J in (128, 224]: the 196-token attention products), 7 = 32x128 (memories of <= 64 keys)
 template <int MODE, class Epi>
 static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStream_t st, int cfg = 0) {
   if (a.nslot < 1) a.nslot = 1;
@@ -735,6 +1063,7 @@ static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStr
     }
     return hipGetLastError();
   }
+  if (cfg == 0) cfg = g_cfd_gemm_cfg;
   if (cfg == 0) {
     const int ng = (MODE == MODE_GROUPED) ? a.nslot : 1;
     long long big_tiles = 0;
@@ -742,17 +1071,42 @@ static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStr
     big_tiles *= (long long)nb * nz;
     int imax = 0;
     for (int g = 0; g < ng; ++g) imax = a.I[g] > imax ? a.I[g] : imax;
+    // (the small-tile classes run few workgroups per CU and their k-loop is latency-bound: they use the 3-stage
+    //  counted-vmcnt loop -- two k-tiles in flight -- which is worth +3.4 % of a step at the product shape L = 16;
+    //  CFD_SMALL3=0 restores the 2-stage variants)
     if (a.J <= 16) cfg = 3;
-    else if (imax <= 64 && a.J >= 96) cfg = 20;
+    else if (imax <= 64 && a.J >= 96) cfg = g_cfd_small3 ? 20 : 7;
     else if (a.J > 128 && a.J <= 224 && big_tiles * 2 >= 256) cfg = 6;
     else if (big_tiles * 2 >= 384 && a.J >= 96) cfg = 1;
-    else cfg = 19;
+    else cfg = g_cfd_small3 ? 19 : 2;
+    if (g_cfd_deep && (cfg == 19 || cfg == 20) && MODE != MODE_SEGK) {
+      // few workgroups per CU (one fits anyway: 128 KB of LDS) and a k-loop of at least 8 tiles: latency-bound
+      long long wgs = 0;
+      for (int g = 0; g < ng; ++g) wgs += (long long)((a.I[g] + (cfg == 19 ? 63 : 31)) / (cfg == 19 ? 64 : 32)) * ((a.J + (cfg == 19 ? 63 : 127)) / (cfg == 19 ? 64 : 128));
+      wgs *= (long long)nb * nz;
+      if (wgs <= 3 * 256 && a.kt[0] >= 8) cfg = cfg == 19 ? 21 : 22;
+    }
   }
   switch (cfg) {
     case 1: return launch_cfg<2, 2, 4, 4, 2, MODE, Epi>(a, epi, nb, nz, st);
+    case 2: return launch_cfg<2, 2, 2, 2, 2, MODE, Epi>(a, epi, nb, nz, st);
+    case 4: return launch_cfg<2, 4, 4, 4, 3, MODE, Epi>(a, epi, nb, nz, st);
+    case 5: return launch_cfg<2, 2, 4, 4, 3, MODE, Epi>(a, epi, nb, nz, st);
     case 6: return launch_cfg<4, 1, 2, 7, 2, MODE, Epi>(a, epi, nb, nz, st);
-    case 19: return launch_cfg<2, 2, 2, 2, 3, MODE, Epi>(a, epi, nb, nz, st);
-    case 20: return launch_cfg<1, 4, 2, 2, 3, MODE, Epi>(a, epi, nb, nz, st);
+    case 7: return launch_cfg<1, 4, 2, 2, 2, MODE, Epi>(a, epi, nb, nz, st);
+    case 13: return launch_cfg<2, 2, 8, 4, 4, MODE, Epi>(a, epi, nb, nz, st);  // 256 x 128, 4 waves x (128 x 64), software-pipelined
+    case 14: return launch_cfg<2, 2, 4, 8, 4, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 256, 4 waves x (64 x 128), software-pipelined
+    case 15: return launch_cfg<2, 2, 4, 2, 2, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 64 (48 KB LDS: 3 blocks / CU)
+    case 16: return launch_cfg<2, 2, 2, 4, 2, MODE, Epi>(a, epi, nb, nz, st);  // 64 x 128
+    case 19: return launch_cfg<2, 2, 2, 2, 3, MODE, Epi>(a, epi, nb, nz, st);   // 64 x 64, 3-stage counted-vmcnt loop
+    case 20: return launch_cfg<1, 4, 2, 2, 3, MODE, Epi>(a, epi, nb, nz, st);   // 32 x 128, 3-stage
+    case 21: return launch_cfg<2, 2, 2, 2, 8, MODE, Epi>(a, epi, nb, nz, st);   // 64 x 64, 8-deep prefetch (small problems)
+    case 22: return launch_cfg<1, 4, 2, 2, 8, MODE, Epi>(a, epi, nb, nz, st);   // 32 x 128, 8-deep prefetch
+    case 17: return launch_cfg<4, 1, 2, 11, 2, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 176: 43904 rows = 250 x 176 - 96
+    case 18: return launch_cfg<8, 1, 2, 11, 2, MODE, Epi>(a, epi, nb, nz, st);  // 256 x 176, 8 waves
+    case 12: return launch_cfg<2, 2, 4, 4, 1, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 128, single LDS buffer, 3+ blocks / CU
+    case 10: return launch_cfg<2, 4, 4, 4, 4, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 256, 8 waves, software-pipelined
+    case 11: return launch_cfg<2, 2, 4, 4, 4, MODE, Epi>(a, epi, nb, nz, st);  // 128 x 128, 4 waves, software-pipelined
     default: return launch_cfg<4, 1, 2, 1, 2, MODE, Epi>(a, epi, nb, nz, st);
   }
 }

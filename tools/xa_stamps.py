@@ -1,0 +1,32 @@
+"""Developer tool (GPU box): per-section cycle breakdown of xattn_fused_kernel from an XA_STAMP build
+(CFD_LIB=tools/experiments/lib_xastamp.so python tools/xa_stamps.py)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from convofusion_amd import _lib, scheduler  # noqa: E402
+from convofusion_amd.sampler import SamplingRun  # noqa: E402
+
+dev = torch.device("cuda", 0)
+model = bench.make_model(dev)
+mems, masks = bench.make_inputs(32, dev, seed=1234)
+sch = scheduler.DDPMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                              variance_type="fixed_small", clip_sample=True)
+run = SamplingRun(model, sch, mems, masks, 32, bench.L, 1000, guidance_scale=7.5, seed=0)
+run.steps(3)
+prof = run.profile()
+nwg, W, NS = 744, 8, 12
+buf = torch.zeros(nwg * W * NS * 2, dtype=torch.float32, device=dev)
+_lib.check(_lib.load().cfd_debug_read(model._handle, b"xa_stamps", C.c_void_p(buf.data_ptr()), buf.numel()))
+st = buf.cpu().numpy().view(np.int64).reshape(nwg, W, NS).astype(np.float64)
+names = ["prologue+epilogue", "A0a compute", "wait+barrier mid-A0", "A0b+A1 compute", "wait+barrier end-A1", "B0a compute", "wait+barrier mid-B0",
+         "B0b+B1a compute", "wait+barrier mid-B1", "B1b + loop tail", "fill Ka' + softmax", "segment setup"]
+tot = st.sum(-1)
+print("xattn class ms:", prof["xattn"], " per-wave total cycles: mean %.0f  min %.0f  max %.0f" % (tot.mean(), tot.min(), tot.max()))
+for k, n in enumerate(names):
+    print(f"  {n:24s} {st[:, :, k].mean():10.0f} cycles  {100 * st[:, :, k].mean() / tot.mean():5.1f} %   (per step {st[:, :, k].mean() / 51:7.1f})")
