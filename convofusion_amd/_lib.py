@@ -17,7 +17,7 @@ MEM_NAMES = ("spkemb", "alsn", "tlsn", "apb", "lsnemb")
 PROF_CLASSES = ("gemm_token", "gemm_mem", "gemm_attn", "rows", "other", "xattn")
 
 SYMBOLS = [
-    "cfd_create", "cfd_destroy", "cfd_last_error", "cfd_load_tensor", "cfd_finalize_weights",
+    "cfd_create", "cfd_destroy", "cfd_last_error", "cfd_source_hash", "cfd_load_tensor", "cfd_finalize_weights",
     "cfd_set_timestep_table", "cfd_forward", "cfd_sample_begin", "cfd_sample_steps", "cfd_sample_position",
     "cfd_sample_read", "cfd_scheduler_step", "cfd_add_noise", "cfd_philox_normal", "cfd_profile_forward",
     "cfd_test_gemm", "cfd_debug_stop_stage", "cfd_debug_read", "cfd_bench_gemm", "cfd_linear_act",
@@ -74,6 +74,21 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m convofusion_amd.build` "
             "(hipcc --offload-arch=gfx950).  convofusion_amd has no CPU fallback.")
+    if "CFD_LIB" not in os.environ:      # (a developer override is taken as it is)
+        from . import build
+        want = build.source_hash()
+        with open(LIB_PATH, "rb") as f:
+            blob = f.read()
+        k = blob.find(b"cfd-src-hash:")
+        have = blob[k + 13:k + 29].decode(errors="replace") if k >= 0 else "missing"
+        if have != want:
+            # built from other sources (an update changed csrc/ or include/cfdenoise.h): a stale library would mis-read
+            # struct arguments instead of failing.  hipcc needs no GPU, so rebuild before the file is mapped; without hipcc refuse.
+            try:
+                build.build(force=True)
+            except Exception as e:
+                raise ImportError(f"{LIB_PATH} was built from other sources (hash {have}, sources {want}) and could not be rebuilt "
+                                  f"({e}); run `python -m convofusion_amd.build`") from e
     lib = C.CDLL(LIB_PATH)
     lib.cfd_last_error.restype = C.c_char_p
     lib.cfd_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
@@ -122,7 +137,7 @@ def load():
     lib.cfd_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("cfd_last_error", "cfd_destroy"):
+        if name not in ("cfd_last_error", "cfd_destroy", "cfd_source_hash"):
             fn.restype = C.c_int
     _lib = lib
     return lib

@@ -17,6 +17,19 @@ def _hipcc():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+def source_hash():
+    """sha256 over the sources the library is built from (first 16 hex digits): compiled into the library
+    (``cfd_source_hash``) so ``_lib.load`` can tell a library built from other sources -- a stale one after a pull that
+    changed a struct in cfdenoise.h would corrupt arguments instead of failing.  Content-based: immune to copied trees
+    whose modification times are meaningless."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(DEPS):
+        with open(os.path.join(CSRC, d), "rb") as f:
+            h.update(d.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()[:16]
+
+
 def is_stale():
     if not os.path.exists(LIB):
         return True
@@ -29,7 +42,7 @@ def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+           f'-DCFD_SOURCE_HASH="{source_hash()}"', *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)

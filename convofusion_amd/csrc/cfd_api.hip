@@ -200,6 +200,13 @@ static GemmArgs gemm_args() {
 // ---- create / destroy -----------------------------------------------------------------------------
 extern "C" const char* cfd_last_error(void) { return g_err; }
 
+#ifndef CFD_SOURCE_HASH
+#define CFD_SOURCE_HASH "unknown"
+#endif
+// (the marker lets the binding read the hash from the file before it maps it)
+static const char g_source_hash[] = "cfd-src-hash:" CFD_SOURCE_HASH;
+extern "C" const char* cfd_source_hash(void) { return g_source_hash + 13; }
+
 extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   if (!cfg || !out) return fail(CFD_E_ARG, "null argument");
   if (cfg->latent_dim != CFD_LAT || cfg->text_encoded_dim != CFD_D || cfg->ff_size != CFD_FF ||
@@ -1078,6 +1085,9 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
   if (s.scheduler != 0 && s.scheduler != 1) return fail(CFD_E_ARG, "scheduler must be 0 (DDPM) or 1 (DDIM)");
   if (!s.alphas_cumprod || s.num_train_timesteps < 1 || s.num_inference_steps < 1 || s.num_inference_steps > s.num_train_timesteps)
     return fail(CFD_E_ARG, "bad scheduler tables");
+  if (s.scheduler == 0 && s.num_train_timesteps % s.num_inference_steps)
+    return fail(CFD_E_ARG, "DDPM: num_inference_steps = %d must divide num_train_timesteps = %d (the timestep table for other counts "
+                           "differs between diffusers releases and is unpinned)", s.num_inference_steps, s.num_train_timesteps);
   if (s.preseq && (s.preseq_len < 1 || s.preseq_len > s.L)) return fail(CFD_E_ARG, "bad preseq_len");
   hipStream_t st = (hipStream_t)stream;
   c->sargs = s;

@@ -120,6 +120,8 @@ class SamplingRun:
             raise RuntimeError("the fused sampler runs on an MI355X only (no CPU fallback)")
         self.lib = _lib.load()
         self.device = dev
+        if getattr(scheduler, "KIND", None) == 0:      # DDPMScheduler.set_timesteps clamps the count to the training schedule
+            num_inference_steps = min(int(scheduler.config.num_train_timesteps), int(num_inference_steps))
         self.B, self.L, self.N = B, L, num_inference_steps
         G = guidance_chunks
         if row_maps is not None:       # already-distinct memories + maps (build_guidance_batch)
@@ -223,7 +225,17 @@ class SamplingRun:
 
     def close(self):
         if self.open:
-            self.read(close=True)
+            try:
+                self.read(close=True)
+            finally:
+                self.open = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def __del__(self):
         try:
@@ -267,20 +279,23 @@ def sample(denoiser, scheduler, encoder_hidden_states, cond_masks=None, *, B, L=
     run = SamplingRun(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
                       guidance_scale, guidance_chunks, eta, init_latents, step_noise, seed, first_utterance, preseq, dedup,
                       skip_zero_weight_chunks, row_maps)
-    if not return_attention:
-        run.steps(num_inference_steps)
-        return run.read(close=True)
-    scheduler.set_timesteps(num_inference_steps)
-    if return_attention == "all":   # the reference's full dict: one entry per iteration (convofusion.py:523); one extra forward + sync per step
-        atts = {}
-        for t in scheduler.timesteps:
-            atts[int(t)] = last_step_attention(run, denoiser, t, encoder_hidden_states, cond_masks, guidance_chunks, row_maps)
-            run.steps(1)
-        return run.read(close=True), atts
-    run.steps(num_inference_steps - 1)
-    att = last_step_attention(run, denoiser, scheduler.timesteps[-1], encoder_hidden_states, cond_masks, guidance_chunks, row_maps)
-    run.steps(1)
-    return run.read(close=True), att
+    try:
+        if not return_attention:
+            run.steps(num_inference_steps)
+            return run.read(close=True)
+        scheduler.set_timesteps(num_inference_steps)
+        if return_attention == "all":   # the reference's full dict: one entry per iteration (convofusion.py:523); one extra forward + sync per step
+            atts = {}
+            for t in scheduler.timesteps:
+                atts[int(t)] = last_step_attention(run, denoiser, t, encoder_hidden_states, cond_masks, guidance_chunks, row_maps)
+                run.steps(1)
+            return run.read(close=True), atts
+        run.steps(num_inference_steps - 1)
+        att = last_step_attention(run, denoiser, scheduler.timesteps[-1], encoder_hidden_states, cond_masks, guidance_chunks, row_maps)
+        run.steps(1)
+        return run.read(close=True), att
+    finally:
+        run.close()     # an exception must not leave the run open on the denoiser's handle
 
 
 # the WEG constants diffusion_reverse_forecast hard-codes instead of reading cfg.model.weg_parameters (unbounded_synthesis.py:80-84)
@@ -315,51 +330,64 @@ def _loop_from_model(model, encoder_hidden_states, cond_masks, preseq, focus_ind
     kw["return_attention"] = attention
     if len(focus_indices) == 0:
         return sample(model.denoiser, model.scheduler, encoder_hidden_states, cond_masks, **kw)
+    # ``weg_parameters`` given = the rollout (its constants are hard-coded and its scale table is fresh every iteration);
+    # otherwise ``_diffusion_reverse``, which reads model.weg_parameters and carries the table (convofusion.py:395,442-444)
     return sample_with_weg(model.denoiser, model.scheduler, encoder_hidden_states, cond_masks, focus_indices,
-                           weg_parameters if weg_parameters is not None else model.weg_parameters, **kw)
+                           weg_parameters if weg_parameters is not None else model.weg_parameters,
+                           carry_scale_range=weg_parameters is None, **kw)
 
 
 def sample_with_weg(denoiser, scheduler, encoder_hidden_states, cond_masks, focus_indices, weg_parameters, *, B, L=16,
-                    num_inference_steps=1000, guidance_chunks=CFG_CHUNKS, return_attention=False, **kw):
+                    num_inference_steps=1000, guidance_chunks=CFG_CHUNKS, return_attention=False, carry_scale_range=True, **kw):
     """The loop with its word-excitation-guidance branch (convofusion.py:437-496): before iteration i the latents are
     moved down the gradient of the attention-focus objective of the text-only chunk (``convofusion_amd.weg``), then the
     captured guided step runs as usual.  ``weg_parameters``: scale_factor, scale_range, max_iter_to_alter, thresholds,
-    max_refinement_steps (configs/assets.yaml:18-23)."""
+    max_refinement_steps (configs/assets.yaml:18-23).  ``carry_scale_range``: True reproduces ``_diffusion_reverse``, which
+    re-assigns its ``scale_range`` table from the previous iteration's first two entries (convofusion.py:442-444: the step
+    size stays ~scale_factor after iteration 0); False is the rollout, which takes a fresh 1.0 -> 0.5 table every
+    iteration (unbounded_synthesis.py:82-89).  See ``weg.scale_range_schedule``."""
     from . import weg
     G = guidance_chunks
     scheduler.set_timesteps(num_inference_steps)
     run = SamplingRun(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
                       guidance_chunks=G, **kw)
-    rm = kw.get("row_maps")
-    if rm is not None:       # distinct memories + row maps (build_guidance_batch): gather the text-only chunk's rows
-        idx = [m[B:2 * B].long() for m in rm]
-        text_states = [e.index_select(0, i.to(e.device)).contiguous() for e, i in zip(encoder_hidden_states, idx)]
-        text_masks = {k: (v.index_select(0, idx[_lib.MEM_NAMES.index(k)].to(v.device)).to(torch.uint8).contiguous() if v is not None else v)
-                      for k, v in (cond_masks or {}).items()}
-    else:
-        text_states = [enc.chunk(G)[1] for enc in encoder_hidden_states]                           # :447
-        text_masks = {k: (v.chunk(G)[1].to(torch.uint8).contiguous() if v is not None else v) for k, v in (cond_masks or {}).items()}  # :448
-    thresholds = dict(weg_parameters["thresholds"])
-    timesteps = [int(t) for t in scheduler.timesteps]
-    att = None
-    for i, t in enumerate(timesteps):
-        last = i == len(timesteps) - 1
-        # past max_iter_to_alter the reference still evaluates the objective but only acts on it at a threshold step
-        if i >= weg_parameters["max_iter_to_alter"] and i not in thresholds:
-            if not any(k > i for k in thresholds):
-                break
+    try:
+        rm = kw.get("row_maps")
+        if rm is not None:       # distinct memories + row maps (build_guidance_batch): gather the text-only chunk's rows
+            idx = [m[B:2 * B].long() for m in rm]
+            text_states = [e.index_select(0, i.to(e.device)).contiguous() for e, i in zip(encoder_hidden_states, idx)]
+            text_masks = {k: (v.index_select(0, idx[_lib.MEM_NAMES.index(k)].to(v.device)).to(torch.uint8).contiguous() if v is not None else v)
+                          for k, v in (cond_masks or {}).items()}
         else:
-            run.inpaint()   # rollout: the re-noised previous window goes in before the WEG update (unbounded_synthesis.py:70-76)
-            lat, _ = weg.weg_update(denoiser, run.read(), i, t, text_states, text_masks, focus_indices, weg_parameters, len(timesteps))
-            run.write(lat)
-        if last and return_attention:
-            att = last_step_attention(run, denoiser, t, encoder_hidden_states, cond_masks, G, kw.get("row_maps"))
-        run.steps(1)
-    if return_attention and att is None:
-        run.steps(num_inference_steps - 1 - run.position)
-        att = last_step_attention(run, denoiser, timesteps[-1], encoder_hidden_states, cond_masks, G, kw.get("row_maps"))
-    run.steps(num_inference_steps - run.position)
-    lat = run.read(close=True)
+            text_states = [enc.chunk(G)[1] for enc in encoder_hidden_states]                           # :447
+            text_masks = {k: (v.chunk(G)[1].to(torch.uint8).contiguous() if v is not None else v) for k, v in (cond_masks or {}).items()}  # :448
+        thresholds = dict(weg_parameters["thresholds"])
+        timesteps = [int(t) for t in scheduler.timesteps]
+        carry = [weg_parameters["scale_range"][0], weg_parameters["scale_range"][1]] if carry_scale_range else None   # :395
+        att = None
+        for i, t in enumerate(timesteps):
+            last = i == len(timesteps) - 1
+            # past max_iter_to_alter the reference still evaluates the objective but only acts on it at a threshold step
+            if i >= weg_parameters["max_iter_to_alter"] and i not in thresholds:
+                if not any(k > i for k in thresholds):
+                    break
+                if carry is not None:   # the skipped iteration still re-assigns the table (convofusion.py:442-444)
+                    weg.scale_range_schedule(weg_parameters, len(timesteps), i, carry)
+            else:
+                run.inpaint()   # rollout: the re-noised previous window goes in before the WEG update (unbounded_synthesis.py:70-76)
+                lat, _ = weg.weg_update(denoiser, run.read(), i, t, text_states, text_masks, focus_indices, weg_parameters, len(timesteps),
+                                        scale_carry=carry)
+                run.write(lat)
+            if last and return_attention:
+                att = last_step_attention(run, denoiser, t, encoder_hidden_states, cond_masks, G, kw.get("row_maps"))
+            run.steps(1)
+        if return_attention and att is None:
+            run.steps(num_inference_steps - 1 - run.position)
+            att = last_step_attention(run, denoiser, timesteps[-1], encoder_hidden_states, cond_masks, G, kw.get("row_maps"))
+        run.steps(num_inference_steps - run.position)
+        lat = run.read(close=True)
+    finally:
+        run.close()     # an exception (bad focus index, CfdError ...) must not leave the run open on the denoiser's handle
     return (lat, att) if return_attention else lat
 
 

@@ -125,9 +125,17 @@ class DDPMScheduler(_SchedulerBase):
         self._init_tables(num_train_timesteps, beta_start, beta_end, beta_schedule, trained_betas)
 
     def set_timesteps(self, num_inference_steps, device=None):
-        num_inference_steps = min(self.config.num_train_timesteps, num_inference_steps)
+        """``num_inference_steps`` is clamped to the training schedule like diffusers 0.14.0 does.  The step count must divide
+        ``num_train_timesteps`` (the shipped schedule is 1000 of 1000, configs/modules/scheduler.yaml): for other counts the
+        releases of diffusers disagree on the table -- ``arange(0, T, T // N)[::-1]`` (more than N entries) vs
+        ``(arange(N) * (T // N))[::-1]`` -- and the package is not available here to pin either, so they are refused
+        (here, in the oracle and in ``cfd_sample_begin``) instead of silently picking one."""
+        T = self.config.num_train_timesteps
+        num_inference_steps = min(T, num_inference_steps)
+        if num_inference_steps < 1 or T % num_inference_steps:
+            raise ValueError(f"DDPM num_inference_steps = {num_inference_steps} must divide num_train_timesteps = {T}")
         self.num_inference_steps = num_inference_steps
-        step_ratio = self.config.num_train_timesteps // self.num_inference_steps
+        step_ratio = T // self.num_inference_steps
         timesteps = (np.arange(0, num_inference_steps) * step_ratio).round()[::-1].copy().astype(np.int64)
         self.timesteps = torch.from_numpy(timesteps).to(device)
 

@@ -452,10 +452,28 @@ def iterative_refinement_step(denoiser, latents, indices_to_alter, loss, thresho
     return loss, latents, mx, grad
 
 
-def weg_update(denoiser, latents, i, t, text_only_states, text_only_masks, focus_indices, weg_parameters, num_steps):
+def scale_range_schedule(weg_parameters, num_steps, i, carry=None):
+    """The WEG step-size factor table of loop iteration ``i``.
+
+    ``unbounded_synthesis.diffusion_reverse_forecast`` resets ``scale_range = (1., 0.5)`` and takes a fresh
+    ``np.linspace(lo, hi, N)`` every iteration (unbounded_synthesis.py:82-89): entry i runs from 1.0 down to 0.5.
+    ``Convofusion._diffusion_reverse`` instead RE-ASSIGNS the name inside the loop and never resets it
+    (convofusion.py:395,442-444): iteration i takes ``np.linspace(sr[0], sr[1], N)`` of the PREVIOUS iteration's
+    table, so from iteration 1 on the interval collapses and entry i stays ~1.0 (0.9999995 at i = 1, N = 1000).
+    ``carry``: a 2-element list holding (sr[0], sr[1]) of the previous iteration, updated in place -- pass one list
+    through the whole loop to get the `_diffusion_reverse` behaviour; ``None`` gives the rollout's fresh table."""
+    if carry is None:
+        return np.linspace(weg_parameters["scale_range"][0], weg_parameters["scale_range"][1], num_steps)
+    sr = np.linspace(carry[0], carry[1], num_steps)
+    carry[0], carry[1] = sr[0], sr[1] if num_steps > 1 else sr[0]
+    return sr
+
+
+def weg_update(denoiser, latents, i, t, text_only_states, text_only_masks, focus_indices, weg_parameters, num_steps, scale_carry=None):
     """The WEG branch of loop iteration ``i`` at timestep ``t`` (convofusion.py:437-496).  ``text_only_*``: chunk 1 of
-    the 7-way guidance batch (:447-448).  Returns (latents, loss)."""
-    scale_range = np.linspace(weg_parameters["scale_range"][0], weg_parameters["scale_range"][1], num_steps)     # :442-444
+    the 7-way guidance batch (:447-448).  ``scale_carry``: see ``scale_range_schedule`` (a list threaded through the loop
+    for ``_diffusion_reverse``; None for the rollout).  Returns (latents, loss)."""
+    scale_range = scale_range_schedule(weg_parameters, num_steps, i, scale_carry)                                # :442-444
     eot = torch.argmax(text_only_masks["tlsn"].int(), dim=1) - 1                                                  # :460
     step_size = weg_parameters["scale_factor"] * np.sqrt(scale_range[i])
     loss, _, _, grad = loss_and_grad(denoiser, latents, t, text_only_states, text_only_masks, focus_indices, True, eot)

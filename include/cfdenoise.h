@@ -44,6 +44,10 @@ typedef struct {
 int cfd_create(const cfd_config* cfg, cfd_handle* out);
 void cfd_destroy(cfd_handle h);
 const char* cfd_last_error(void);
+/* Hash of the sources this library was built from (convofusion_amd/build.py: source_hash).  The ctypes binding compares
+ * it with the sources on disk before the first call: a library left over from other sources -- e.g. after an update that
+ * changed a struct of this header -- is rebuilt or refused instead of mis-reading its arguments. */
+const char* cfd_source_hash(void);
 
 /* Replaces nn.Module.load_state_dict for the `denoiser.*` entries of the checkpoint
  * (layout: SURVEY.md section 8b; test.py:109-111 -> base.py:106-123).  `name` is the key without the

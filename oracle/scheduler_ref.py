@@ -66,6 +66,10 @@ class DDPMSchedulerRef(_Tables):
         self.clip_sample = clip_sample
 
     def set_timesteps(self, num_inference_steps):
+        num_inference_steps = min(self.num_train_timesteps, num_inference_steps)
+        if num_inference_steps < 1 or self.num_train_timesteps % num_inference_steps:
+            # the diffusers releases disagree on the table when N does not divide T (see convofusion_amd/scheduler.py); unpinned, so refused
+            raise ValueError("DDPM num_inference_steps must divide num_train_timesteps")
         self.num_inference_steps = num_inference_steps
         ratio = self.num_train_timesteps // num_inference_steps
         self.timesteps = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)

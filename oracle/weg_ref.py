@@ -270,10 +270,23 @@ def loss_and_grad(sd, latents, t, encoder_hidden_states, cond_masks, focus_indic
     return loss, losses, max_att, grad
 
 
-def weg_update(sd, latents, i, t, text_only_states, text_only_masks, focus_indices, weg_parameters, num_steps):
+def scale_range_schedule(weg_parameters, num_steps, carry=None):
+    """Step-size factor table of one loop iteration.  ``carry=None``: the rollout's fresh ``np.linspace(lo, hi, N)``
+    (unbounded_synthesis.py:82-89).  ``carry=[lo, hi]`` threaded through the loop: ``Convofusion._diffusion_reverse``'s
+    re-assignment ``scale_range = np.linspace(scale_range[0], scale_range[1], N)`` (convofusion.py:395,442-444), whose
+    interval collapses after iteration 0.  Pinned by tests/golden/weg_scale_schedule.npz (the reference's own statement
+    executed by make_golden_weg_schedule.py)."""
+    if carry is None:
+        return np.linspace(weg_parameters["scale_range"][0], weg_parameters["scale_range"][1], num_steps)
+    sr = np.linspace(carry[0], carry[1], num_steps)
+    carry[0], carry[1] = sr[0], sr[1] if num_steps > 1 else sr[0]
+    return sr
+
+
+def weg_update(sd, latents, i, t, text_only_states, text_only_masks, focus_indices, weg_parameters, num_steps, scale_carry=None):
     """The WEG branch of one loop iteration (convofusion.py:437-496): returns the altered latents.
     ``text_only_states`` / masks are chunk 1 of the 7-way guidance batch (:447-448)."""
-    scale_range = np.linspace(weg_parameters["scale_range"][0], weg_parameters["scale_range"][1], num_steps)  # :442-444
+    scale_range = scale_range_schedule(weg_parameters, num_steps, scale_carry)      # :442-444
     eot = np.argmax(np.asarray(text_only_masks["tlsn"]).astype(np.int64), axis=1) - 1
     step_size = weg_parameters["scale_factor"] * np.sqrt(scale_range[i])
     loss, _, _, grad = loss_and_grad(sd, latents, t, text_only_states, text_only_masks, focus_indices, True, eot)

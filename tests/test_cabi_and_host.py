@@ -94,6 +94,16 @@ def test_scheduler_mirror_tables_and_timesteps():
     assert s.init_noise_sigma == 1.0 and len(s) == 1000
     s.set_timesteps(1000)
     assert int(s.timesteps[0]) == 999 and int(s.timesteps[-1]) == 0
+    s.set_timesteps(5000)            # clamped to the training schedule (diffusers 0.14.0: min(T, N))
+    assert s.num_inference_steps == 1000 and len(s.timesteps) == 1000
+    s.set_timesteps(50)
+    assert s.timesteps.tolist() == list(range(980, -1, -20))
+    from oracle import scheduler_ref
+    for bad in (30, 300):            # T % N != 0: the diffusers releases disagree on the table, nothing here can pin it: refused everywhere
+        with pytest.raises(ValueError):
+            s.set_timesteps(bad)
+        with pytest.raises(ValueError):
+            scheduler_ref.DDPMSchedulerRef().set_timesteps(bad)
     d = scheduler.DDIMScheduler(steps_offset=1, **SCHED_KW)
     d.set_timesteps(50)
     assert int(d.timesteps[0]) == 981
@@ -185,3 +195,53 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--selftest-cpu"], capture_output=True, text=True,
                          timeout=120, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
     assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)
+
+
+def test_stale_library_is_detected_by_content():
+    """The library carries a hash of the sources it was built from; the binding compares it with the sources on disk before
+    mapping the file (a library left over from other sources would mis-read struct arguments instead of failing)."""
+    import ctypes as C
+    from convofusion_amd import _lib, build
+    lib = _lib.load()
+    lib.cfd_source_hash.restype = C.c_char_p
+    assert lib.cfd_source_hash().decode() == build.source_hash()
+    blob = open(build.LIB, "rb").read()
+    k = blob.find(b"cfd-src-hash:")
+    assert k >= 0 and blob[k + 13:k + 29].decode() == build.source_hash()
+    assert len(build.source_hash()) == 16 and set(build.DEPS) >= {"cfd_api.hip", "xattn_fused.hpp", os.path.join("..", "..", "include", "cfdenoise.h")}
+
+
+def test_no_edit_installer_binds_the_reference_entry_points():
+    """convofusion_amd.install(model) / patch_rollout(module): the reference's loop entry points are replaced by binding,
+    not by editing its sources; signatures equal the reference's (convofusion.py:391, unbounded_synthesis.py:28)."""
+    import inspect
+    import types
+    import convofusion_amd
+    from convofusion_amd import installer as inst
+    from convofusion_amd.denoiser import Denoiser
+    from convofusion_amd import scheduler
+    from tests.gpu_helpers import ABL, DENOISER_KW, SCHED_KW
+    assert str(inspect.signature(inst._diffusion_reverse)) == "(self, encoder_hidden_states, lengths=None, cond_masks={}, focus_indices=[])"
+    assert str(inspect.signature(inst.diffusion_reverse_forecast)) == \
+        "(model, encoder_hidden_states, lengths=None, preseq=None, cond_masks={}, focus_indices=[])"
+
+    class RefLike:                      # stands in for the reference Convofusion module: the class method must stay untouched
+        def _diffusion_reverse(self, encoder_hidden_states, lengths=None, cond_masks=dict(), focus_indices=[]):
+            return "reference loop"
+    model = RefLike()
+    with pytest.raises(TypeError):      # yaml still points at the reference denoiser
+        model.denoiser, model.scheduler = object(), object()
+        convofusion_amd.install(model)
+    model.denoiser = Denoiser(ablation=ABL, **DENOISER_KW)
+    model.scheduler = scheduler.DDPMScheduler(variance_type="fixed_small", **SCHED_KW)
+    assert convofusion_amd.install(model) is model
+    assert isinstance(model._diffusion_reverse, types.MethodType) and model._diffusion_reverse.__func__ is inst._diffusion_reverse
+    assert RefLike()._diffusion_reverse(None) == "reference loop"           # other instances and the class are untouched
+    convofusion_amd.uninstall(model)
+    assert model._diffusion_reverse(None) == "reference loop"
+    script = types.ModuleType("unbounded_synthesis")
+    with pytest.raises(AttributeError):
+        convofusion_amd.patch_rollout(script)
+    script.diffusion_reverse_forecast = lambda *a, **k: "reference rollout"
+    orig = convofusion_amd.patch_rollout(script)
+    assert script.diffusion_reverse_forecast is inst.diffusion_reverse_forecast and orig() == "reference rollout"

@@ -353,3 +353,42 @@ def test_headline_shape_loop_row_matches_reference(kind, variant):
     errs["final"] = rel_l2(lat[row], g["latents"][:, 0])
     print(kind, variant, {k: f"{v:.2e}" for k, v in errs.items()})
     assert np.isfinite(lat).all() and all(v < TRAJ_TOL for v in errs.values()), errs
+
+
+def test_no_edit_installer_runs_the_fused_loop():
+    """convofusion_amd.install(model) + patch_rollout(module): the reference call sites (`self._diffusion_reverse(cond_emb, lengths,
+    cond_masks=..., focus_indices=...)`, convofusion.py:1023; `diffusion_reverse_forecast(model, cond_emb, lengths, preseq, cond_masks=...)`,
+    unbounded_synthesis.py:438) reach the fused loop through the bindings, with the reference's keyword usage."""
+    import types
+    from types import SimpleNamespace
+    import torch
+    import convofusion_amd
+    from convofusion_amd.sampler import diffusion_reverse, diffusion_reverse_forecast
+    from tests.gpu_helpers import hip_denoiser, to_dev
+    B, L, S = 2, 16, (6, 20, 6, 8, 1)
+    cb = inputs.make_cfg_batch(seed=3, B=B, L=L, S=S, pad_tail=(2, 0, 1, 0, 0))
+
+    class RefLike:
+        def _diffusion_reverse(self, encoder_hidden_states, lengths=None, cond_masks=dict(), focus_indices=[]):
+            raise AssertionError("the class method must be shadowed by the installed binding")
+    model = RefLike()
+    model.denoiser, model.scheduler, model.guidance_scale, model.clf_guidance_drops = hip_denoiser(1234, 1.0), _sched("ddpm"), 7.5, 6
+    model.latent_dim, model.do_classifier_free_guidance = [1, 128], True
+    model.cfg = SimpleNamespace(model=SimpleNamespace(scheduler=SimpleNamespace(num_inference_timesteps=4, eta=0.0)))
+    convofusion_amd.install(model)
+    enc = [to_dev(x) for x in cb["memories"]]
+    masks = {k: to_dev(v) for k, v in cb["masks"].items()}
+    torch.manual_seed(7)
+    z, att = model._diffusion_reverse(enc, None, cond_masks=masks, focus_indices=[])
+    torch.manual_seed(7)
+    z2, _ = diffusion_reverse(model, enc, None, masks, [])
+    assert tuple(z.shape) == (L, B, 128) and torch.equal(z, z2) and len(att) == 1
+    script = types.ModuleType("unbounded_synthesis")
+    script.diffusion_reverse_forecast = lambda *a, **k: (_ for _ in ()).throw(AssertionError("not replaced"))
+    convofusion_amd.patch_rollout(script)
+    pre = 0.3 * torch.randn((B, 8, 128), device="cuda")
+    torch.manual_seed(9)
+    r, ratt = script.diffusion_reverse_forecast(model, enc, None, pre, cond_masks=masks, focus_indices=[])
+    torch.manual_seed(9)
+    r2, _ = diffusion_reverse_forecast(model, enc, None, pre, masks, [])
+    assert tuple(r.shape) == (L, B, 128) and torch.equal(r, r2) and len(ratt) == 5

@@ -177,9 +177,11 @@ def test_loop_with_weg_matches_oracle(rollout):
     text_states = [np.split(x, 7, axis=0)[1] for x in cb["memories"]]
     text_masks = {k: (np.split(v, 7, axis=0)[1] if v is not None else None) for k, v in cb["masks"].items()}
     log = []
+    # _diffusion_reverse carries its scale_range table from iteration to iteration (convofusion.py:442-444); the rollout does not
+    carry = None if rollout else list(params["scale_range"])
 
     def pre_step(i, t, lat):
-        new, loss = weg_ref.weg_update(sd, lat, i, t, text_states, text_masks, focus, params, n_steps)
+        new, loss = weg_ref.weg_update(sd, lat, i, t, text_states, text_masks, focus, params, n_steps, scale_carry=carry)
         log.append(loss)
         return new
 
@@ -194,7 +196,7 @@ def test_loop_with_weg_matches_oracle(rollout):
     mems = [to_dev(x) for x in cb["memories"]]
     masks = {k: to_dev(v) for k, v in cb["masks"].items()}
     lat = sample_with_weg(m, sch, mems, masks, focus, params, B=B, L=L, num_inference_steps=n_steps, guidance_scale=7.5,
-                          init_latents=to_dev(init), step_noise=to_dev(noise), preseq=to_dev(preseq))
+                          init_latents=to_dev(init), step_noise=to_dev(noise), preseq=to_dev(preseq), carry_scale_range=not rollout)
     lat = lat.permute(1, 0, 2).cpu().numpy()
     err, moved = rel_l2(lat, ref), rel_l2(plain, ref)
     print(f"loop with WEG: vs oracle {err:.2e}; WEG moved the result by {moved:.2e}; oracle objective per step {log}")
@@ -212,7 +214,7 @@ def test_loop_with_weg_matches_oracle(rollout):
                 cm[name] = to_dev(cb["masks"][name])[c * B:(c + 1) * B]
         u_mems, maps, u_masks = build_guidance_batch(cond, unc, cm, um)
         lat2 = sample_with_weg(m, sch, u_mems, u_masks, focus, params, B=B, L=L, num_inference_steps=n_steps, guidance_scale=7.5,
-                               init_latents=to_dev(init), step_noise=to_dev(noise), row_maps=maps)
+                               init_latents=to_dev(init), step_noise=to_dev(noise), row_maps=maps, carry_scale_range=True)
         assert rel_l2(lat2.permute(1, 0, 2).cpu().numpy(), lat) < 1e-5
 
 
