@@ -119,6 +119,18 @@ struct cfd_handle_s {
   bool share0 = true;       // CFD_SHARE0=0: evaluate the pre-cross-attention part of layer 0 for every guidance replica
   DBuf d_step;  // [0] = loop index, [1] = constant 0, [2] = "this iteration's in-painting overwrite is done" (cfd_sample_inpaint)
   DBuf weg_ws, weg_tok;   // cfd_weg_eval: activation arena, focus-token tables
+  // cfd_weg_eval replays its ~400 launches as a hipGraph.  A graph holds its kernels' arguments BY VALUE, so everything the
+  // caller passes per call -- latents in, losses / max_att / grad out, the timestep's sinusoid row -- goes through fixed
+  // staging buffers (weg_io); round 1's attempt captured the caller's own pointers, which are fresh torch tensors on every
+  // call, and so replayed against stale addresses ("wrong gradients when interleaved with the sampling graph").
+  // One graph per variant (full evaluation / memory-side results reused), keyed by everything else the launches depend on;
+  // a key is run eagerly once (function attributes, warm-up) and captured on its second use.  CFD_WEG_GRAPH=0: always eager.
+  DBuf weg_io;
+  bool weg_graph_on = true;
+  struct WegGraph { std::vector<long long> key; int uses = 0; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+  WegGraph weg_graph[2];
+  hipEvent_t weg_ev = nullptr;
+  long long weg_tok_version = 0;
   std::vector<int32_t> weg_tok_host;
   std::vector<long long> weg_sig;   // timestep, shapes, memory pointers and arena of the last evaluation (reuse_memory_side)
   int weg_launches = 0;
@@ -230,6 +242,9 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   g_cfd_naive_gemm = (env && atoi(env) != 0) ? 1 : 0;
   env = getenv("CFD_RUNS");
   c->use_runs = !(env && atoi(env) == 0);
+  env = getenv("CFD_WEG_GRAPH");
+  c->weg_graph_on = !(env && atoi(env) == 0);
+  (void)hipEventCreateWithFlags(&c->weg_ev, hipEventDisableTiming);
   env = getenv("CFD_FUSED_XATTN");
   c->fused_xattn = !(env && atoi(env) == 0);
   env = getenv("CFD_PERMUTE");
@@ -251,6 +266,12 @@ extern "C" void cfd_destroy(cfd_handle c) {
   (void)hipDeviceSynchronize();
   if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
   if (c->graph) (void)hipGraphDestroy(c->graph);
+  for (auto& wg : c->weg_graph) {
+    if (wg.exec) (void)hipGraphExecDestroy(wg.exec);
+    if (wg.graph) (void)hipGraphDestroy(wg.graph);
+  }
+  if (c->weg_ev) (void)hipEventDestroy(c->weg_ev);
+  c->weg_io.release();
   for (auto& kv : c->raw) kv.second.release();
   DBuf* all[] = {&c->we_sp, &c->wp_sp, &c->we_all, &c->be_all, &c->tsin, &c->x, &c->h_sp, &c->qk_sp, &c->vts_sp,
                  &c->ssc, &c->sp_sp, &c->o_sp, &c->u_sp, &c->sc, &c->p_sp, &c->eps, &c->sample_sp, &c->temb_tab,
@@ -1435,7 +1456,12 @@ extern "C" int cfd_weg_eval(cfd_handle c, const cfd_weg_args* a, float* losses, 
   for (int t = 0; t < n_tok; ++t)
     if (a->tok_idx[t] < 1 || a->tok_idx[t] > a->last - 1) return fail(CFD_E_ARG, "focus index %d is outside the text slice [1, %d)", a->tok_idx[t], a->last);
   HIPCHK(hipSetDevice(c->cfg.device));
-  hipStream_t st = (hipStream_t)stream;
+  hipStream_t caller = (hipStream_t)stream;
+  // the evaluation runs on the handle's own stream (capturable, and the one the sampling graph replays on: the two
+  // serialise); it starts behind whatever the caller has queued on `stream`
+  hipStream_t st = c->own_stream;
+  HIPCHK(hipEventRecord(c->weg_ev, caller));
+  HIPCHK(hipStreamWaitEvent(st, c->weg_ev, 0));
   std::vector<int32_t> tok(a->tok_off, a->tok_off + B + 1);
   tok.insert(tok.end(), a->tok_idx, a->tok_idx + n_tok);
   if (tok != c->weg_tok_host) {                       // focus-token tables to the device (the stream may still read the old copy)
@@ -1443,9 +1469,21 @@ extern "C" int cfd_weg_eval(cfd_handle c, const cfd_weg_args* a, float* losses, 
     CHK(c->weg_tok.ensure((size_t)(B + 1 + std::max(1, n_tok)) * 4));
     HIPCHK(hipMemcpy(c->weg_tok.p, tok.data(), tok.size() * 4, hipMemcpyHostToDevice));
     c->weg_tok_host = tok;
+    ++c->weg_tok_version;
   }
-  weg::Args wa{a->latents, c->tsin.as<float>() + (size_t)a->timestep * D, a->mem, c->weg_tok.as<int32_t>(), c->weg_tok.as<int32_t>() + B + 1,
-               a->last, nt_max, {a->kernel3[0], a->kernel3[1], a->kernel3[2]}, losses, max_att, grad};
+  // staging: [latents | timestep row | losses | max_att | grad]
+  const size_t n_lat = (size_t)B * L * CFD_LAT, n_max = (size_t)std::max(1, n_tok);
+  const size_t o_lat = 0, o_trow = o_lat + n_lat, o_loss = o_trow + (size_t)D, o_max = o_loss + (size_t)((B + 63) / 64 * 64),
+               o_grad = o_max + (n_max + 63) / 64 * 64, n_io = o_grad + n_lat;
+  if (n_io * 4 > c->weg_io.bytes) {
+    HIPCHK(hipStreamSynchronize(st));
+    CHK(c->weg_io.ensure(n_io * 4));
+  }
+  float* io = c->weg_io.as<float>();
+  HIPCHK(hipMemcpyAsync(io + o_lat, a->latents, n_lat * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(io + o_trow, c->tsin.as<float>() + (size_t)a->timestep * D, (size_t)D * 4, hipMemcpyDeviceToDevice, st));
+  weg::Args wa{io + o_lat, io + o_trow, a->mem, c->weg_tok.as<int32_t>(), c->weg_tok.as<int32_t>() + B + 1,
+               a->last, nt_max, {a->kernel3[0], a->kernel3[1], a->kernel3[2]}, io + o_loss, io + o_max, io + o_grad};
   // what the memory-side / time-only part of an evaluation depends on: with args->reuse_memory_side the caller states that the
   // memories' CONTENTS are unchanged too (a refinement loop at one timestep), and those launches are skipped
   std::vector<long long> sig = {B, L, a->timestep};
@@ -1466,17 +1504,54 @@ extern "C" int cfd_weg_eval(cfd_handle c, const cfd_weg_args* a, float* losses, 
   x.launches = 0;
   x.reuse = a->reuse_memory_side != 0 && sig == c->weg_sig;
   c->weg_sig.clear();
-  weg::run(x, wa);
+  // everything the launch sequence and its (by-value) kernel arguments depend on, the timestep excepted (its row is staged)
+  std::vector<long long> key = {B, L, a->last, nt_max, c->weg_tok_version, (long long)(size_t)c->weg_tok.p, (long long)(size_t)io, (long long)n_io,
+                                (long long)(size_t)c->weg_ws.p, (long long)x.reuse};
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    key.push_back(a->mem[j].S);
+    key.push_back((long long)(size_t)a->mem[j].data);
+    key.push_back((long long)(size_t)a->mem[j].key_padding_mask);
+  }
+  for (int k = 0; k < 3; ++k) { long long bits = 0; memcpy(&bits, &a->kernel3[k], 4); key.push_back(bits); }
+  auto& wg = c->weg_graph[x.reuse ? 1 : 0];
+  if (wg.key != key) {
+    if (wg.exec) { (void)hipGraphExecDestroy(wg.exec); wg.exec = nullptr; }
+    if (wg.graph) { (void)hipGraphDestroy(wg.graph); wg.graph = nullptr; }
+    wg.key = key;
+    wg.uses = 0;
+  }
+  if (c->weg_graph_on && wg.exec) {
+    HIPCHK(hipGraphLaunch(wg.exec, st));
+    x.launches = c->weg_launches;
+  } else if (c->weg_graph_on && wg.uses >= 1) {       // second use of this key: capture, instantiate, launch
+    HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    weg::run(x, wa);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(st, &g);
+    if (e != hipSuccess) return fail(CFD_E_HIP, "capturing the WEG evaluation failed: %s", hipGetErrorString(e));
+    wg.graph = g;
+    HIPCHK(hipGraphInstantiate(&wg.exec, wg.graph, nullptr, nullptr, 0));
+    HIPCHK(hipGraphLaunch(wg.exec, st));
+  } else {
+    weg::run(x, wa);
+  }
+  ++wg.uses;
   HIPCHK(hipGetLastError());
   c->weg_launches = x.launches;
   c->weg_sig = sig;
+  HIPCHK(hipMemcpyAsync(losses, io + o_loss, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(max_att, io + o_max, n_max * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(grad, io + o_grad, n_lat * 4, hipMemcpyDeviceToDevice, st));
   if (loss_host) {                                   // torch.mean(losses) over the batch (word_excitation_guidance.py:80)
     std::vector<float> l(B);
-    HIPCHK(hipMemcpyAsync(l.data(), losses, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(l.data(), io + o_loss, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     float sum = 0.f;
     for (int b = 0; b < B; ++b) sum += l[b];
     *loss_host = sum / (float)B;
+  } else {                                           // the caller's stream continues behind the evaluation
+    HIPCHK(hipEventRecord(c->weg_ev, st));
+    HIPCHK(hipStreamWaitEvent(caller, c->weg_ev, 0));
   }
   return CFD_OK;
 }

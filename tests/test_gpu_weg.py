@@ -252,3 +252,55 @@ def test_eval_rejects_what_the_reference_cannot_run():
         weg.loss_and_grad(m, lat, 1000, enc, mask, [[2]], True, torch.tensor([8]))
     with pytest.raises(ValueError):          # the conditioning tuple must be the text-only chunk (one row per latent row)
         weg.loss_and_grad(m, lat, 5, [e.expand(7, -1, -1) for e in enc], mask, [[2]], True, torch.tensor([8]))
+
+
+def test_graph_replayed_evaluation_interleaved_with_the_sampling_graph_equals_eager():
+    """cfd_weg_eval replays its launch sequence as a hipGraph from its second use on.  Round 1 found such replays "wrong when
+    interleaved with the sampling graph": the captured kernels held the CALLER's latents / losses / grad pointers by value, and
+    the Python side passes fresh tensors on every call.  With the inputs and outputs staged through fixed buffers the replayed
+    evaluation must equal the eager one (CFD_WEG_GRAPH=0) bit for bit -- here with a new latents tensor (new address) per
+    call, both graph variants (full / memory side reused), and replays of the sampling graph in between."""
+    import os
+    import torch
+    from convofusion_amd import weg
+    from convofusion_amd.denoiser import Denoiser
+    from convofusion_amd.sampler import SamplingRun, sample_with_weg
+    from convofusion_amd import scheduler
+    from tests.gpu_helpers import ABL, DENOISER_KW, SCHED_KW, hip_denoiser, to_dev
+    B, L, S, pad = 1, 16, (6, 20, 12, 8, 1), (2, 0, 3, 0, 0)
+    cb = inputs.make_cfg_batch(seed=23, B=B, L=L, S=S, pad_tail=pad)
+    mems = [to_dev(x) for x in cb["memories"]]
+    masks = {k: to_dev(v) for k, v in cb["masks"].items()}
+    text_states = [e.chunk(7)[1].contiguous() for e in mems]
+    text_masks = {k: (v.chunk(7)[1].to(torch.uint8).contiguous() if v is not None else None) for k, v in masks.items()}
+    eot = torch.argmax(text_masks["tlsn"].int(), dim=1) - 1
+    focus = [[2, 5]]
+    m_graph = hip_denoiser(1234, 1.0)
+    os.environ["CFD_WEG_GRAPH"] = "0"
+    try:
+        m_eager = Denoiser(ablation=ABL, **DENOISER_KW)
+        m_eager.load_state_dict(m_graph.state_dict(), strict=True)
+        m_eager = m_eager.cuda().eval()
+        m_eager.engine(torch.device("cuda"))          # the knob is read when the handle is created
+    finally:
+        del os.environ["CFD_WEG_GRAPH"]
+    sch = scheduler.DDPMScheduler(variance_type="fixed_small", **SCHED_KW)
+    run = SamplingRun(m_graph, sch, mems, masks, B, L, 20, guidance_scale=7.5, seed=3)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    keep = []
+    for it in range(8):
+        lat = torch.randn((B, L, 128), device="cuda", generator=g)     # a fresh tensor (fresh address) every call
+        keep.append(torch.empty(1000 + 37 * it, device="cuda"))        # ... and shift the allocator's next address
+        t, same = (500, it % 4 != 0) if it < 6 else (499, False)       # full, reused x3, full, reused, then another timestep
+        a = weg.loss_and_grad(m_graph, lat, t, text_states, text_masks, focus, True, eot, same_conditioning=same)
+        b = weg.loss_and_grad(m_eager, lat, t, text_states, text_masks, focus, True, eot, same_conditioning=same)
+        assert float(a[0]) == float(b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3]), it
+        assert torch.isfinite(a[3]).all() and float(a[3].abs().max()) > 0
+        run.steps(1)                                                    # a replay of the sampling graph on the same stream
+    run.close()
+    # end to end: the guided loop (threshold step with refinement) through both
+    params = dict(scale_factor=1000, scale_range=[1.0, 0.5], max_iter_to_alter=3, thresholds={1: 0.16}, max_refinement_steps=3)
+    init = to_dev(philox_ref.normal_tensor(23, 0, range(B), 1, L))
+    la = sample_with_weg(m_graph, sch, mems, masks, focus, params, B=B, L=L, num_inference_steps=5, guidance_scale=7.5, init_latents=init, seed=2)
+    lb = sample_with_weg(m_eager, sch, mems, masks, focus, params, B=B, L=L, num_inference_steps=5, guidance_scale=7.5, init_latents=init, seed=2)
+    assert torch.equal(la, lb)
