@@ -868,11 +868,10 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
              (int)(M / Ma));
     }
     // ---- c-e. five cross attentions + fuser, folded                             (:578-652)
-    CHK(ln(w.ln2g, w.ln2b, 0, 0, c->h_sp.as<char>(), M));
-    if (fused_x) {
+    if (fused_x) {   // LayerNorm2 is part of the kernel's prologue
       XAttnArgs a;
       memset(&a, 0, sizeof(a));
-      a.h = c->h_sp.as<char>(); a.x = c->x.as<float>(); a.bias = w.cross_bias.as<float>(); a.L = L;
+      a.x = c->x.as<float>(); a.ln_g = w.ln2g; a.ln_b = w.ln2b; a.bias = w.cross_bias.as<float>(); a.L = L;
       for (int j = 0; j < CFD_NMEM; ++j) {
         const size_t rows = (size_t)p.U[j] * p.Sp[j];
         a.K[j] = c->kall_sp[j].as<char>() + (size_t)l * rows * ROWB;
@@ -889,6 +888,7 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       hipLaunchKernelGGL(xattn_fused_kernel, dim3(p.xa_nwg), dim3(XA_WAVES * 64), XA_LDS, st, a);
       HIPCHK(hipGetLastError());
     } else {
+    CHK(ln(w.ln2g, w.ln2b, 0, 0, c->h_sp.as<char>(), M));
     // Three-launch path (att_mats wanted): scores against the folded keys of every memory.  Long memories and short
     // (<= 64 keys) memories go to different tile shapes; rows in a shared-memory run of the largest memory use one
     // un-batched product per run.

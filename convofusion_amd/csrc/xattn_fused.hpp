@@ -1,6 +1,6 @@
 // Fused cross-attention block of one decoder layer (cross_attention.py:578-652, folded form of DESIGN.md section 3):
 //
-//   x[token][:] += sum_j softmax_s( h[token] . Kf_j[u_j][s] + cb_j[u_j][s] ) Vf_j[u_j][s][:]  + cross_bias
+//   x[token][:] += sum_j softmax_s( LN2(x[token]) . Kf_j[u_j][s] + cb_j[u_j][s] ) Vf_j[u_j][s][:]  + cross_bias
 //
 // for the five memories j (one head of width 512 each), u_j = the memory instance the token's batch row maps to.
 // Scores, probabilities and the per-memory outputs never leave the chip: the kernel replaces the score products,
@@ -23,9 +23,10 @@
 // MFMAs of the previous half (two register sets), so the LDS latency hides under MFMAs instead of in front of them -- with
 // the reads issued only right behind a barrier, two waves per SIMD reach ~45 % of the MFMA rate even with every operand
 // resident.  For the reads of the next sub-phase to be issued early, its sub-buffer is declared ready in the MIDDLE of the
-// current one: barriers sit at mid-A0 (Kb ready), end of A1 (Va ready + the pair's partial scores exchanged), mid-B0 (Vb
-// ready) and mid-B1 (next Ka ready); behind each, the sub-buffer that every wave has finished with is refilled
-// (global_load_lds) with the data of its next use 1.5-2.5 sub-phases ahead.  The fills are waited for with COUNTED
+// current one: three barriers per step -- mid-A0 (Kb ready; Vb is refilled behind it), end of A1 (the whole V^T tile ready +
+// the pair's partial scores exchanged; both K halves are refilled behind it) and mid-B1 (next Ka ready; Va is refilled) --
+// so every fill is issued 1.5-2.5 sub-phases ahead of its use.  (A barrier costs 300-500 cycles of wave skew whatever the
+// slack of the fill it waits for -- measured with s_memtime stamps -- so there are as few as the four sub-buffers allow.)  The fills are waited for with COUNTED
 // s_waitcnt vmcnt(N) + raw s_barrier (a __syncthreads() would drain the queue); for the counts to hold there is no
 // ordinary global load inside the loop: the key bias of a tile arrives through LDS with its Ka fill, and the
 // workgroup's segment list is copied to LDS once.
@@ -78,8 +79,9 @@ struct XaWg {
 };
 
 struct XAttnArgs {
-  const char* h;              // SP [M][512]: LayerNorm2(x)
-  float* x;                   // fp32 [M][512] residual stream (updated in place)
+  float* x;                   // fp32 [M][512] residual stream: read (queries = LayerNorm2(x), norm2 of cross_attention.py:578) and updated in place
+  const float* ln_g;          // norm2.weight [512]
+  const float* ln_b;          // norm2.bias [512]
   const float* bias;          // folded cross-attention bias [512]
   const char* K[CFD_NMEM];    // this layer's folded keys: SP [U_j * Sp_j][512]
   const float* cb[CFD_NMEM];  // this layer's key bias (+ -inf on dead keys): [U_j * Sp_j]
@@ -125,6 +127,25 @@ __device__ __forceinline__ T xa_sel(const T (&arr)[CFD_NMEM], int j) {
 #else
 #define XA_FRAG(p_) (*reinterpret_cast<const spx8*>(p_))
 #endif
+// sum / max over the 4 lanes {l, l^16, l^32, l^48} that share a query, in the vector ALU (v_permlane32_swap /
+// v_permlane16_swap: with both operands the same register, the two results hold the value of the lane's own and of its
+// partner's half / row) -- dependent ds_bpermute round trips otherwise
+__device__ __forceinline__ float xlane_sum(float x) {
+  unsigned xi = __float_as_uint(x);
+  auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+  x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  xi = __float_as_uint(x);
+  auto q = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+__device__ __forceinline__ float xlane_max(float x) {
+  unsigned xi = __float_as_uint(x);
+  auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+  x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  xi = __float_as_uint(x);
+  auto q = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+  return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
 #define XA_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | (0xF << 8) | ((((N) >> 4) & 3) << 14))
 #define XA_WAIT_VM_LGKM0(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | ((((N) >> 4) & 3) << 14))
 
@@ -152,15 +173,47 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   // the segment list of this workgroup -> LDS (read back with ds_read: no vector-memory traffic inside the loop)
   if (threadIdx.x < nseg) reinterpret_cast<int4*>(smem + XA_SEGOFF)[threadIdx.x] = reinterpret_cast<const int4*>(a.segs + seg0)[threadIdx.x];
 
-  // Q fragments (B operand) of this wave's half of the feature axis: lane holds d = 256 half + 32 ks + 8 q4 .. +7 of
-  // query l15 (clamped to a valid one)
+  // Q fragments (B operand) of this wave's half of the feature axis, made here from the residual stream:
+  //   q = LayerNorm2(x[token])  (cross_attention.py:578; two-pass mean / variance like ln_rows_kernel, eps 1e-5).
+  // Lane (q = l15, g = q4) holds d = 32 c + 8 g .. +7 of its query's row for every 32-chunk c = 0..15 (the four lanes of a
+  // query cover the row: statistics need one 4-lane reduction), and keeps chunks 8 half .. 8 half + 7 as its fragments.
   spx8 qh[8], ql[8];
   {
-    const char* qp = a.h + (tok0 + min(l15, max(nq - 1, 0))) * (CFD_D * 4) + half * 1024 + q4 * 16;
+    const float* xr = a.x + (tok0 + min(l15, max(nq - 1, 0))) * CFD_D + q4 * 8;
+    float4 r[32];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      r[2 * c] = *reinterpret_cast<const float4*>(xr + 32 * c);
+      r[2 * c + 1] = *reinterpret_cast<const float4*>(xr + 32 * c + 4);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) sum += (r[i].x + r[i].y) + (r[i].z + r[i].w);
+    const float mean = xlane_sum(sum) * (1.0f / CFD_D);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      r[i].x -= mean; r[i].y -= mean; r[i].z -= mean; r[i].w -= mean;
+      ss += (r[i].x * r[i].x + r[i].y * r[i].y) + (r[i].z * r[i].z + r[i].w * r[i].w);
+    }
+    const float rstd = 1.0f / sqrtf(xlane_sum(ss) * (1.0f / CFD_D) + 1e-5f);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      qh[ks] = *reinterpret_cast<const spx8*>(qp + ks * 128);
-      ql[ks] = *reinterpret_cast<const spx8*>(qp + ks * 128 + 64);
+      const int c = 8 * half + ks;          // (half is wave-uniform: the two candidates are selected, not indexed)
+      const float4 v0 = half ? r[2 * (8 + ks)] : r[2 * ks], v1 = half ? r[2 * (8 + ks) + 1] : r[2 * ks + 1];
+      const float* gp = a.ln_g + 32 * c + q4 * 8;
+      const float* bp = a.ln_b + 32 * c + q4 * 8;
+      const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+      const float y[8] = {v0.x * rstd * g0.x + b0.x, v0.y * rstd * g0.y + b0.y, v0.z * rstd * g0.z + b0.z, v0.w * rstd * g0.w + b0.w,
+                          v1.x * rstd * g1.x + b1.x, v1.y * rstd * g1.y + b1.y, v1.z * rstd * g1.z + b1.z, v1.w * rstd * g1.w + b1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sp_t hi, lo;
+        split_f32(y[e], hi, lo);
+        qh[ks][e] = hi;
+        ql[ks][e] = lo;
+      }
     }
   }
   f32x4 o[16];   // O^T tiles of features 256 half + 16 f .. +15
@@ -244,20 +297,18 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (add_bias) bv = *reinterpret_cast<const float4*>(a.bias + half * 256 + lane * 4);
     float* xp = a.x + tok0 * CFD_D + half * 256 + lane * 4;
+    // all 16 rows are requested before the first is used: one exposed memory round trip per flush instead of four
+    float4 old[16];
 #pragma unroll
-    for (int r0 = 0; r0 < 16; r0 += 4) {
-      float4 old[4];
+    for (int r = 0; r < 16; ++r)
+      if (r < nq) old[r] = *reinterpret_cast<const float4*>(xp + (long long)r * CFD_D);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (r0 + r < nq) old[r] = *reinterpret_cast<const float4*>(xp + (long long)(r0 + r) * CFD_D);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(strip + (r0 + r) * RS + lane * 16);
-        if (r0 + r < nq) {
-          float4 t = old[r];
-          t.x = (t.x + bv.x) + v[0]; t.y = (t.y + bv.y) + v[1]; t.z = (t.z + bv.z) + v[2]; t.w = (t.w + bv.w) + v[3];
-          *reinterpret_cast<float4*>(xp + (long long)(r0 + r) * CFD_D) = t;
-        }
+    for (int r = 0; r < 16; ++r) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(strip + r * RS + lane * 16);
+      if (r < nq) {
+        float4 t = old[r];
+        t.x = (t.x + bv.x) + v[0]; t.y = (t.y + bv.y) + v[1]; t.z = (t.z + bv.z) + v[2]; t.w = (t.w + bv.w) + v[3];
+        *reinterpret_cast<float4*>(xp + (long long)r * CFD_D) = t;
       }
     }
 #pragma unroll
@@ -306,19 +357,6 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     }
   };
   spx8 fa[8], fb[8];   // the two fragment sets
-  // max / sum over the 4 lanes {l, l^16, l^32, l^48} that share a query, in the vector ALU (v_permlane32_swap /
-  // v_permlane16_swap: with both operands the same register, the two results hold the value of the lane's own and of its
-  // partner's half / row) -- four dependent ds_bpermute round trips per step otherwise
-  auto xlane = [&](float x, bool is_max) __attribute__((always_inline)) -> float {
-    unsigned xi = __float_as_uint(x);
-    auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
-    const float a0 = __uint_as_float(r[0]), a1 = __uint_as_float(r[1]);
-    x = is_max ? fmaxf(a0, a1) : a0 + a1;
-    xi = __float_as_uint(x);
-    auto q = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
-    const float b0 = __uint_as_float(q[0]), b1 = __uint_as_float(q[1]);
-    return is_max ? fmaxf(b0, b1) : b0 + b1;
-  };
   bool primed = false;
   int step = 0;
   Tile cur, nseg_t;
@@ -381,10 +419,11 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       *reinterpret_cast<f32x4*>(xch_mine + 1024) = s1;
     }
     XA_T(3);
-    XA_WAIT_VM_LGKM0(4);                 // Va landed (Vb is younger); partial scores written
-    __builtin_amdgcn_s_barrier();        // end of A1: Va ready, partial scores visible, every wave is done with Ka and Kb
+    XA_WAIT_VM_LGKM0(0);                 // Va and Vb landed (nothing younger is in flight); partial scores written
+    __builtin_amdgcn_s_barrier();        // end of A1: the whole V^T tile ready, partial scores visible, every wave is done with Ka and Kb
     XA_T(4);
     fill_k(nxt, 0, slot ^ 1);
+    fill_k(nxt, 1, slot ^ 1);
     read_v(fa, 0);
     float scale = 1.0f;
     if (in_seg && !(XA_ABLATE & 8)) {
@@ -396,36 +435,40 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       float p[8];
       p[0] = (s0[0] + t0[0]) + kb0[0]; p[1] = (s0[1] + t0[1]) + kb0[1]; p[2] = (s0[2] + t0[2]) + kb0[2]; p[3] = (s0[3] + t0[3]) + kb0[3];
       p[4] = (s1[0] + t1[0]) + kb1[0]; p[5] = (s1[1] + t1[1]) + kb1[1]; p[6] = (s1[2] + t1[2]) + kb1[2]; p[7] = (s1[3] + t1[3]) + kb1[3];
-      const float mx = xlane(fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7]))), true);
+      const float mx = xlane_max(fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7]))));
+      // exp(x - m) = exp2(x c - m c), c = log2(e): one fused multiply-add and one v_exp_f32 per key (the rounding of m c is common
+      // to all keys of a row and cancels against the row sum); dead keys carry x = -inf -> 0
+      constexpr float LOG2E = 1.44269504088896340736f;
       if (online) {
         const float m_new = fmaxf(m, mx);
         const bool dead = m_new == -INFINITY;             // nothing but dead keys so far: contribute 0, keep m = -inf
-        scale = dead ? 1.0f : __expf(m - m_new);
+        const float mc = dead ? 0.f : m_new * LOG2E;      // (-inf - (-inf) would be NaN)
+        scale = dead ? 1.0f : __builtin_amdgcn_exp2f(fmaf(m, LOG2E, -mc));
         float ps = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          p[e] = dead ? 0.f : __expf(p[e] - m_new);
+          p[e] = __builtin_amdgcn_exp2f(fmaf(p[e], LOG2E, -mc));
           ps += p[e];
         }
-        lsum = lsum * scale + xlane(ps, false);
+        lsum = lsum * scale + xlane_sum(ps);
         m = m_new;
       } else {
+        const float mc = mx * LOG2E;
         float ps = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          p[e] = __expf(p[e] - mx);                        // all keys dead: (-inf) - (-inf) = NaN, as in the reference
+          p[e] = __builtin_amdgcn_exp2f(fmaf(p[e], LOG2E, -mc));   // all keys dead: (-inf) - (-inf) = NaN, as in the reference
           ps += p[e];
         }
-        const float inv = 1.0f / xlane(ps, false);
+        const float inv = 1.0f / xlane_sum(ps);
 #pragma unroll
         for (int e = 0; e < 8; ++e) p[e] *= inv;
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        sp_t hi, lo;
-        split_f32(p[e], hi, lo);
+      for (int e = 0; e < 8; ++e) {      // probabilities are <= 1: no saturation needed in front of the fp16 split
+        const sp_t hi = (sp_t)p[e];
         ph[e] = hi;
-        pl[e] = lo;
+        pl[e] = (sp_t)(p[e] - (float)hi);
       }
       if (online && !__all(scale == 1.0f)) {
 #pragma unroll
@@ -439,10 +482,6 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     if (in_seg) mfma_v(fa, 0);
     __builtin_amdgcn_sched_barrier(0);
     XA_T(5);
-    XA_WAIT_VM_LGKM0(5);                 // Vb landed (the next Ka + key bias = 5 pieces are younger)
-    __builtin_amdgcn_s_barrier();        // mid-B0: Vb ready
-    XA_T(6);
-    fill_k(nxt, 1, slot ^ 1);            // (Kb has been free since the end of A1)
     read_v(fa, 2);
     __builtin_amdgcn_sched_barrier(0);
     if (in_seg) mfma_v(fb, 1);
@@ -453,7 +492,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     if (in_seg) mfma_v(fa, 2);
     __builtin_amdgcn_sched_barrier(0);
     XA_T(7);
-    XA_WAIT_VM_LGKM0(4);                 // next Ka + key bias landed (the next Kb is younger)
+    XA_WAIT_VM_LGKM0(4);                 // next Ka + key bias landed (the next Kb, 4 pieces, is younger)
     __builtin_amdgcn_s_barrier();        // mid-B1: next Ka ready; every wave is done with Va
     XA_T(8);
     fill_v(nxt, 0);
