@@ -109,6 +109,6 @@ def test_mfma_subnormal_operands(ops):
     X = np.zeros((I, K), np.float32)
     X[np.arange(I), np.arange(I)] = 1.0
     Y = np.full((J, K), 3e-6, np.float32)
-    got = _gemm(ops, X, Y, 2)
+    got = _gemm(ops, X, Y, 19)
     print("subnormal probe: D =", got[0, 0], "(input 3e-6; fp16 subnormal spacing 5.96e-8)")
     assert abs(got[0, 0] - 3e-6) < 1e-7

@@ -129,7 +129,7 @@ pat = {0: (3, 6), 1: (2, 6), 2: (1, 6), 3: (4, 6), 4: (5, 6)}        # chunks th
 enc7 = [torch.cat([(cond1[j] if c in pat[j] else unc1[j]) for c in range(7)], 0).to(dev) for j in range(5)]
 mask7 = {"spkemb": None, "alsn": None, "apb": None, "lsnemb": None, "tlsn": (torch.arange(24) >= 17)[None].expand(7, 24).contiguous().to(dev)}
 sch1 = scheduler.DDPMScheduler(**SCHED)
-sample(model, sch1, enc7, mask7, B=1, L=16, num_inference_steps=3, seed=1)
+sample(model, sch1, enc7, mask7, B=1, L=16, num_inference_steps=4, seed=1)
 sync()
 t0 = time.time()
 sample(model, sch1, enc7, mask7, B=1, L=16, num_inference_steps=1000, seed=1)
