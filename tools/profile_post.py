@@ -1,5 +1,6 @@
 """Condense the raw outputs of tools/profile_round.sh into profiles/ (tracked).
-  --aggregate-only (on the GPU box): per-(kernel, grid) means of FETCH_SIZE / WRITE_SIZE -> gpurun_out/<tag>_hbm_traffic.csv
+  --aggregate-only (on the GPU box): per-(kernel, grid) means of FETCH_SIZE / WRITE_SIZE -> gpurun_out/<tag>_hbm_traffic.csv;
+      per-kernel MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) -> gpurun_out/<tag>_mfma_busy.csv
   default (build container): copy the bench lines, the rocprofv3 kernel-stats summary and the traffic table into
   profiles/<tag>_*, and write profiles/hbm_traffic_gemm.json (the figure bench.py reports as roofline.traffic).
 FETCH_SIZE is doubled: on gfx950 it counts 128-byte requests as 64 bytes (MI355X_MICROARCH.md, HBM)."""
@@ -41,10 +42,36 @@ def aggregate():
             w.writerow([r[0], r[1], r[2], round(r[3]), round(r[4], 1), round(r[5], 1)])
 
 
+def aggregate_mfma():
+    """MFMA-pipe utilisation per kernel: busy cycles summed over the chip's 1024 SIMDs / (kernel cycles x 1024).  GRBM_GUI_ACTIVE is
+    reported as the sum over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)."""
+    acc = defaultdict(lambda: {"SQ_VALU_MFMA_BUSY_CYCLES": 0.0, "GRBM_GUI_ACTIVE": 0.0, "n": 0})
+    for f in glob.glob(os.path.join(OUT, f"{tag}_pmc_mfma", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            a = acc[r["Kernel_Name"]]
+            a[r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                a["n"] += 1
+    rows = []
+    for k, v in acc.items():
+        if v["GRBM_GUI_ACTIVE"] <= 0:
+            continue
+        cyc = v["GRBM_GUI_ACTIVE"] / 8.0
+        rows.append((k, v["n"], cyc / max(v["n"], 1), v["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), cyc))
+    rows.sort(key=lambda r: -r[4])
+    with open(os.path.join(OUT, f"{tag}_mfma_busy.csv"), "w", newline="") as fo:
+        w = csv.writer(fo)
+        w.writerow(["kernel", "launches_in_trace", "mean_kernel_cycles", "mfma_busy_fraction", "share_of_traced_gpu_cycles"])
+        tot = sum(r[4] for r in rows) or 1.0
+        for r in rows:
+            w.writerow([r[0], r[1], round(r[2]), round(r[3], 4), round(r[4] / tot, 4)])
+
+
 def publish():
     os.makedirs(PROF, exist_ok=True)
     for src, dst in ((f"{tag}_bench_c2.json", f"{tag}_bench_c2.json"), (f"{tag}_bench_realshape.json", f"{tag}_bench_realshape.json"),
-                     (f"{tag}_rocprof_stdout.log", f"{tag}_bench_c2_rocprof_stdout.log"), (f"{tag}_hbm_traffic.csv", f"{tag}_bench_c2_hbm_traffic.csv")):
+                     (f"{tag}_rocprof_stdout.log", f"{tag}_bench_c2_rocprof_stdout.log"), (f"{tag}_hbm_traffic.csv", f"{tag}_bench_c2_hbm_traffic.csv"),
+                     (f"{tag}_mfma_busy.csv", f"{tag}_mfma_busy.csv")):
         p = os.path.join(OUT, src)
         if os.path.exists(p):
             shutil.copy(p, os.path.join(PROF, dst))
@@ -68,5 +95,6 @@ def publish():
 
 if "--aggregate-only" in sys.argv:
     aggregate()
+    aggregate_mfma()
 else:
     publish()
