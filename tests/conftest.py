@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# The fused cross-attention kernel is the product path from 48 workgroups up (one utterance at the product shape is 3); the
+# parity tests use small problems the oracle finishes in seconds, so they lift the threshold to exercise that kernel.  The
+# three-launch path those problems take by default is covered by the CFD_FUSED_XATTN=0 legs of
+# test_developer_knobs_keep_parity and by test_small_problems_take_the_three_launch_path_by_default.
+os.environ.setdefault("CFD_FUSED_XATTN_MIN_WGS", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -392,3 +392,38 @@ def test_no_edit_installer_runs_the_fused_loop():
     torch.manual_seed(9)
     r2, _ = diffusion_reverse_forecast(model, enc, None, pre, masks, [])
     assert tuple(r.shape) == (L, B, 128) and torch.equal(r, r2) and len(ratt) == 5
+
+
+def test_small_problems_take_the_three_launch_path_by_default():
+    """Default threshold (48 workgroups): a 2-utterance run goes through the three-launch cross-attention, the same run with the
+    threshold lifted through the fused kernel; both must agree to rounding (different summation orders) and the profile must
+    show which one ran."""
+    import os
+    import torch
+    from convofusion_amd.denoiser import Denoiser
+    from convofusion_amd.sampler import SamplingRun
+    from tests.gpu_helpers import ABL, DENOISER_KW, hip_denoiser, to_dev
+    B, L, S = 2, 16, (24, 161, 24, 8, 1)
+    cb = inputs.make_cfg_batch(seed=5, B=B, L=L, S=S, pad_tail=(4, 0, 6, 0, 0))
+    mems = [to_dev(x) for x in cb["memories"]]
+    masks = {k: to_dev(v) for k, v in cb["masks"].items()}
+    m_fused = hip_denoiser(1234, 1.0)                   # conftest lifts the threshold for the session
+    keep = os.environ.pop("CFD_FUSED_XATTN_MIN_WGS")
+    try:
+        m_default = Denoiser(ablation=ABL, **DENOISER_KW)
+        m_default.load_state_dict(m_fused.state_dict(), strict=True)
+        m_default = m_default.cuda().eval()
+        m_default.engine(torch.device("cuda"))          # the knob is read when the handle is created
+    finally:
+        os.environ["CFD_FUSED_XATTN_MIN_WGS"] = keep
+    outs, launches = [], []
+    for m in (m_fused, m_default):
+        run = SamplingRun(m, _sched("ddpm"), mems, masks, B, L, 4, guidance_scale=7.5, seed=11)
+        run.steps(2)
+        launches.append(run.profile()["xattn"][1])
+        run.steps(2)
+        outs.append(run.read(close=True))
+    assert launches == [9, 0], launches
+    d = float((outs[0] - outs[1]).norm() / outs[1].norm())
+    print("fused vs three-launch cross-attention, 4 guided steps: rel L2", d)
+    assert d < 2e-4
