@@ -54,7 +54,7 @@ class SampleArgs(C.Structure):
                 ("steps_offset", C.c_int), ("alphas_cumprod", C.c_void_p), ("init_latents", C.c_void_p),
                 ("step_noise", C.c_void_p), ("seed", C.c_uint64), ("first_utterance", C.c_uint32),
                 ("preseq", C.c_void_p), ("preseq_len", C.c_int), ("mem", Memory * NUM_MEM),
-                ("skip_zero_weight_chunks", C.c_int)]
+                ("skip_zero_weight_chunks", C.c_int), ("dynamic_memory_mask", C.c_int)]
 
 
 class WegArgs(C.Structure):

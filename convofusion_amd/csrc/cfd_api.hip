@@ -90,6 +90,9 @@ struct Problem {
   int run_row0[8], run_len[8], run_u[8];
   // fused cross-attention (xattn_fused.hpp): workgroups of the work list, 0 = the list was not built
   int xa_nwg = 0;
+  // memories (bit j) whose folded projections were computed once for the run from the centred static part of the memory
+  // (prepare_static_memside); per step they only get their per-key scale and bias (mem_scale_kernel)
+  int static_mask = 0;
 };
 
 struct cfd_handle_s {
@@ -110,6 +113,10 @@ struct cfd_handle_s {
   DBuf x, h_sp, qk_sp, vts_sp, ssc, sp_sp, o_sp, u_sp, sc, p_sp, eps, sample_sp;
   DBuf n_sp[CFD_NMEM], kall_sp[CFD_NMEM], cb[CFD_NMEM], vt_all[CFD_NMEM];
   DBuf temb_tab, h1_tab, ss_tab, trows, iota, long_rows, short_rows, zero_mask;
+  // timestep-independent memory-side projections (rows.hpp mem_center_kernel): per memory the dot products c_l . a_s (ca), |a_s|^2 (asq)
+  // and, per table row t, A_l b_t / c_l . b_t (kbtab) and VV_l b_t (vbtab); b_t = centred timestep embedding.  CFD_HOIST_MEMSIDE=0: off.
+  DBuf ca[CFD_NMEM], asq[CFD_NMEM], kbtab[CFD_NMEM], vbtab[CFD_NMEM], b_tab, b_sp, bsq, zeros512;
+  bool hoist_memside = true;
   bool use_runs = true;   // CFD_RUNS=0 disables the shared-memory run optimisation of the three-launch attention path
   // The cross-attention block is one fused kernel (xattn_fused.hpp) unless the caller wants att_mats, which only the
   // three-launch path (score products -> softmax_rows_kernel -> P.V products) materialises.  CFD_FUSED_XATTN=0 forces
@@ -250,6 +257,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   c->fused_xattn = !(env && atoi(env) == 0);
   env = getenv("CFD_FUSED_XATTN_MIN_WGS");
   if (env) c->fused_xattn_min_wgs = atoi(env);
+  env = getenv("CFD_HOIST_MEMSIDE");
+  c->hoist_memside = !(env && atoi(env) == 0);
   env = getenv("CFD_PERMUTE");
   c->permute = !(env && atoi(env) == 0);
   env = getenv("CFD_SHARE0");
@@ -284,6 +293,7 @@ extern "C" void cfd_destroy(cfd_handle c) {
   for (int j = 0; j < CFD_NMEM; ++j) {
     c->wk_all_sp[j].release(); c->wv_all_sp[j].release(); c->n_sp[j].release(); c->kall_sp[j].release();
     c->cb[j].release(); c->vt_all[j].release(); c->mem_own[j].release(); c->perm_map[j].release();
+    c->ca[j].release(); c->asq[j].release(); c->kbtab[j].release(); c->vbtab[j].release();
   }
   for (auto& l : c->lw) {
     DBuf* lb[] = {&l.wqk_sp, &l.bqk, &l.wv_sp, &l.wo_sp, &l.bo2, &l.wtb1_sp, &l.wtb2_sp, &l.w1_sp, &l.w2_sp, &l.cross_bias};
@@ -702,7 +712,7 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
     const size_t rows = (size_t)p.U[j] * p.Sp[j];
     CHK(c->n_sp[j].ensure(rows * CFD_D * 4));
     CHK(c->kall_sp[j].ensure(rows * nl * CFD_D * 4));
-    CHK(c->cb[j].ensure(rows * nl * 4));
+    CHK(c->cb[j].ensure(rows * (nl + 1) * 4));   // + one plane: the per-key scale of the fused cross-attention kernel
     CHK(c->vt_all[j].ensure(rows * nl * CFD_D * 4));
   }
   CHK(c->temb_tab.ensure((size_t)T * CFD_D * 4));
@@ -739,6 +749,86 @@ static int build_time_tables(Ctx* c, const int32_t* trows_host, int T, hipStream
   return CFD_OK;
 }
 
+__global__ void fill_f32_kernel(float* p, long long n, float v) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// Once per cfd_forward / sampling run, after the time tables: the part of the memory-side work that does not depend on the
+// timestep (see rows.hpp, mem_center_kernel, and xattn_fused.hpp).  Memories in `dynamic_mask` (contents rewritten between the
+// iterations of a run: the dyadic rollout's partner projection) keep their per-step projections, and so does every memory when
+// the fused cross-attention kernel is not the one that runs (att_mats wanted, small problems, per-row timesteps).
+static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool want_att) {
+  Problem& p = c->pb;
+  const int nl = c->nl;
+  const long long ROWB = CFD_D * 4;
+  p.static_mask = 0;
+  for (int j = 0; j < CFD_NMEM; ++j) {   // scale plane = 1 unless mem_scale_kernel writes it
+    const long long rows = (long long)p.U[j] * p.Sp[j];
+    LAUNCH(CFD_PROF_OTHER, fill_f32_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), st, c->cb[j].as<float>() + (size_t)nl * rows, rows, 1.0f);
+  }
+  if (c->zeros512.bytes == 0) {
+    CHK(c->zeros512.ensure(CFD_D * 4));
+    HIPCHK(hipMemsetAsync(c->zeros512.p, 0, CFD_D * 4, st));
+  }
+  const bool fused = c->fused_xattn && p.xa_nwg > 0 && !want_att && !g_cfd_naive_gemm;
+  if (!fused || !c->hoist_memside || p.tmode != 0) return CFD_OK;
+  const int T = p.T;
+  CHK(c->b_tab.ensure((size_t)T * CFD_D * 4));
+  CHK(c->b_sp.ensure((size_t)T * CFD_D * 4));
+  CHK(c->bsq.ensure((size_t)T * 4));
+  LAUNCH(CFD_PROF_OTHER, temb_center_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), st, c->temb_tab.as<float>(), T, c->b_tab.as<float>(),
+         c->b_sp.as<char>(), c->bsq.as<float>());
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    if ((dynamic_mask >> j) & 1) continue;
+    const int rows = p.U[j] * p.Sp[j];
+    const int NK = nl * CFD_D + 32;
+    CHK(c->ca[j].ensure((size_t)rows * nl * 4));
+    CHK(c->asq[j].ensure((size_t)rows * 4));
+    CHK(c->kbtab[j].ensure((size_t)T * NK * 4));
+    CHK(c->vbtab[j].ensure((size_t)T * nl * CFD_D * 4));
+    MemCenterArgs ma{p.mem[j], p.U[j], p.S[j], p.Sp[j], rawp(c, "condition_embedding.weight") + (size_t)j * CFD_D, rawp(c, "mem_pos.pe"),
+                     c->n_sp[j].as<char>(), c->asq[j].as<float>()};
+    LAUNCH(CFD_PROF_ROWS, mem_center_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), st, ma);
+    {  // KA = A a_s for all layers, ca = c_l . a_s (-inf on dead keys)
+      GemmArgs a = gemm_args();
+      a.X[0] = c->wk_all_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = NK; a.Iclamp[0] = NK; a.kt[0] = CFD_D / 32;
+      a.Y = c->n_sp[j].as<char>(); a.ldy = ROWB; a.J = rows; a.Jclamp = rows;
+      a.super_i = 8; a.super_j = 8;
+      EpiMemK e{c->kall_sp[j].as<char>(), (long long)rows, c->ca[j].as<float>(), nl * CFD_D, nl, p.mask[j], p.S[j], p.Sp[j]};
+      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
+    }
+    {  // VA^T
+      GemmArgs a = gemm_args();
+      a.X[0] = c->n_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = rows; a.Iclamp[0] = rows; a.kt[0] = CFD_D / 32;
+      a.Y = c->wv_all_sp[j].as<char>(); a.ldy = ROWB; a.J = nl * CFD_D; a.Jclamp = nl * CFD_D;
+      a.super_i = 8; a.super_j = 8;
+      EpiMemV e{c->vt_all[j].as<char>(), p.Sp[j], p.U[j]};
+      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
+    }
+    {  // kbtab[t][:] = [A_l b_t for all l | c_l . b_t]
+      GemmArgs a = gemm_args();
+      a.X[0] = c->wk_all_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = NK; a.Iclamp[0] = NK; a.kt[0] = CFD_D / 32;
+      a.Y = c->b_sp.as<char>(); a.ldy = ROWB; a.J = T; a.Jclamp = T;
+      EpiF32 e;
+      memset(&e, 0, sizeof(e));
+      e.out = c->kbtab[j].as<float>(); e.ldo = NK;
+      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
+    }
+    {  // vbtab[t][:] = VV_l b_t for all l
+      GemmArgs a = gemm_args();
+      a.X[0] = c->wv_all_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = nl * CFD_D; a.Iclamp[0] = nl * CFD_D; a.kt[0] = CFD_D / 32;
+      a.Y = c->b_sp.as<char>(); a.ldy = ROWB; a.J = T; a.Jclamp = T;
+      EpiF32 e;
+      memset(&e, 0, sizeof(e));
+      e.out = c->vbtab[j].as<float>(); e.ldo = nl * CFD_D;
+      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
+    }
+    p.static_mask |= 1 << j;
+  }
+  return CFD_OK;
+}
+
 // ---- the denoiser forward: Denoiser.forward (denoiser.py:173-386) --------------------------------------
 // Input: c->sample_sp (SP [M][128]); time tables built; output: c->eps (fp32 [M][128]).
 static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int nrows);
@@ -750,8 +840,19 @@ static int enqueue_memside(Ctx* c, hipStream_t st) {
   const int* dstep = p.tmode ? c->d_step.as<int>() + 1 : c->d_step.as<int>();
   const long long ROWB = CFD_D * 4;
   const dim3 blk(256);
+  // memories whose projections were made once for the run: this step's per-key scale and key bias
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    if (!((p.static_mask >> j) & 1)) continue;
+    const long long rows = (long long)p.U[j] * p.Sp[j];
+    const int NK = nl * CFD_D + 32;
+    MemScaleArgs a{c->n_sp[j].as<char>(), c->asq[j].as<float>(), rows, c->b_tab.as<float>(), c->bsq.as<float>(), c->ca[j].as<float>(),
+                   c->kbtab[j].as<float>() + (size_t)nl * CFD_D, (long long)NK, dstep, nl, c->cb[j].as<float>() + (size_t)nl * rows,
+                   c->cb[j].as<float>()};
+    LAUNCH(CFD_PROF_ROWS, mem_scale_kernel, dim3((unsigned)((rows + 3) / 4)), blk, st, a);
+  }
   // 2. memories: + temb + condition id + PE, normalise           (denoiser.py:223-261,332-353)
   for (int j = 0; j < CFD_NMEM; ++j) {
+    if ((p.static_mask >> j) & 1) continue;
     MemPrepArgs a{p.mem[j], p.U[j], p.S[j], p.Sp[j], c->temb_tab.as<float>(), dstep, p.tmode,
                   rawp(c, "condition_embedding.weight") + (size_t)j * CFD_D, rawp(c, "mem_pos.pe"), c->n_sp[j].as<char>()};
     const long long rows = (long long)p.U[j] * p.Sp[j];
@@ -759,6 +860,7 @@ static int enqueue_memside(Ctx* c, hipStream_t st) {
   }
   // 3. memory-side projections for ALL layers at once: folded keys (+ key bias) and folded values^T
   for (int j = 0; j < CFD_NMEM; ++j) {
+    if ((p.static_mask >> j) & 1) continue;
     const int rows = p.U[j] * p.Sp[j];
     {
       GemmArgs a = gemm_args();
@@ -889,7 +991,14 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
         a.cb[j] = c->cb[j].as<float>() + (size_t)l * rows;
         a.VT[j] = c->vt_all[j].as<char>() + (size_t)l * rows * ROWB;
         a.Sp[j] = p.Sp[j];
+        const bool stat = (p.static_mask >> j) & 1;
+        a.rs_off[j] = (unsigned)((size_t)(nl - l) * rows * 4);
+        a.kb[j] = stat ? c->kbtab[j].as<float>() + (size_t)l * CFD_D : c->zeros512.as<float>();
+        a.kb_stride[j] = stat ? nl * CFD_D + 32 : 0;
+        a.vb[j] = stat ? c->vbtab[j].as<float>() + (size_t)l * CFD_D : c->zeros512.as<float>();
+        a.vb_stride[j] = stat ? nl * CFD_D : 0;
       }
+      a.d_step = dstep;
       a.wgs = c->xa_wgs.as<XaWg>(); a.segs = c->xa_segs.as<XaSeg>();
 #if XA_STAMP
       CHK(c->xa_stamps.ensure((size_t)p.xa_nwg * XA_WAVES * XA_NSTAMP * 8));
@@ -1030,6 +1139,11 @@ extern "C" int cfd_forward(cfd_handle c, const float* sample, int Be, int L, con
   // tmode 0 reads table row d_step[0] which must be 0 outside a sampling run
   HIPCHK(hipMemsetAsync(c->d_step.p, 0, 16, st));
   CHK(build_time_tables(c, timesteps, n_t, st));
+  {
+    bool want_att = false;
+    for (int j = 0; j < CFD_NMEM; ++j) want_att = want_att || (att && att[j]);
+    CHK(prepare_static_memside(c, st, 0, want_att));
+  }
   const long long n = c->pb.M * (CFD_LAT / 8);
   LAUNCH(CFD_PROF_OTHER, to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), st, sample, c->sample_sp.as<char>(), c->pb.M,
          CFD_LAT, (long long)CFD_LAT, (long long)CFD_LAT * 4);
@@ -1191,6 +1305,7 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
   HIPCHK(hipMemcpyAsync(c->coef.p, coef.data(), (size_t)N * sizeof(StepCoef), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemsetAsync(c->d_step.p, 0, 16, st));
   CHK(build_time_tables(c, ts.data(), N, st));
+  CHK(prepare_static_memside(c, st, s.dynamic_memory_mask, false));
   HIPCHK(hipStreamSynchronize(st));  // ts / coef host vectors go out of scope
   const size_t lat_bytes = (size_t)s.B * s.L * CFD_LAT * 4;
   CHK(c->latents.ensure(lat_bytes));

@@ -105,6 +105,109 @@ __global__ void __launch_bounds__(256) mem_prep_kernel(const MemPrepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Timestep-independent part of the memory preparation (round 2: the memory-side projections leave the loop).
+// The memory LayerNorm sees v_s = m_s + temb(t) with m_s = raw_s + E_cond + pe_s constant during a sampling run.  With
+// a_s = m_s - mean(m_s) and b = temb(t) - mean(temb(t)):   v_s - mean(v_s) = a_s + b,
+//   var_s = (|a_s|^2 + 2 a_s.b + |b|^2) / 512,   n_s = (a_s + b) * rstd_s,   rstd_s = 1 / sqrt(var_s + eps)
+// so every folded projection W n_s = rstd_s (W a_s + W b): the big products W a_s are computed ONCE per run from a_s (this
+// kernel's output), W b is one vector per timestep, and rstd_s is one scalar per key and step (mem_scale_kernel).
+//   a[u][s][:] = m - mean(m)  as SP,  asq[u][s] = |a|^2   (rows s >= S: zero)
+// ------------------------------------------------------------------------------------------------
+struct MemCenterArgs {
+  const float* raw;   // [U][S][512]
+  int U, S, Sp;
+  const float* cond;  // [512]
+  const float* pe;    // [>=S][512]
+  char* a_sp;         // SP [U*Sp][512]
+  float* asq;         // [U*Sp]
+};
+
+__global__ void __launch_bounds__(256) mem_center_kernel(const MemCenterArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)a.U * a.Sp) return;
+  const int u = (int)(row / a.Sp), s = (int)(row % a.Sp);
+  float v[8];
+  float ss = 0.f;
+  if (s >= a.S) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  } else {
+    const float* r = a.raw + ((long long)u * a.S + s) * CFD_D + lane * 8;
+    const float* ce = a.cond + lane * 8;
+    const float* pe = a.pe + (long long)s * CFD_D + lane * 8;
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] = (r[e] + ce[e]) + pe[e];
+      sum += v[e];
+    }
+    const float mean = wave_sum(sum) * (1.0f / CFD_D);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[e] -= mean; ss += v[e] * v[e]; }
+    ss = wave_sum(ss);
+  }
+  sp_store8(a.a_sp + row * (CFD_D * 4), lane * 8, v);
+  if (lane == 0) a.asq[row] = ss;
+}
+
+// Per step and memory: rstd of every key from its dot product with the centred timestep embedding, and the key bias of every layer
+//   rs[key] = 1 / sqrt((asq + 2 a.b + |b|^2) / 512 + 1e-5)
+//   cbk[l][key] = rs * (ca[l][key] + cbb[l])        ca = c_l . a_s (with -inf on dead keys, written by EpiMemK), cbb = c_l . b
+// One wave per key; a is read back from its split-pair form (hi + lo).
+struct MemScaleArgs {
+  const char* a_sp;    // SP [rows][512]
+  const float* asq;    // [rows]
+  long long rows;
+  const float* btab;   // [T][512] centred timestep embeddings
+  const float* bsq;    // [T]
+  const float* ca;     // [nl][rows]
+  const float* cbb;    // table row t: cbb[t * cbb_tstride + l]
+  long long cbb_tstride;
+  const int* d_step;
+  int nl;
+  float* rs;           // [rows]
+  float* cbk;          // [nl][rows]
+};
+
+__global__ void __launch_bounds__(256) mem_scale_kernel(const MemScaleArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const int t = *a.d_step;
+  const char* ap = a.a_sp + row * (CFD_D * 4) + (size_t)(lane >> 2) * 128 + (lane & 3) * 16;   // 8 consecutive columns: lane * 8
+  const spx8 h = *reinterpret_cast<const spx8*>(ap);
+  const spx8 l = *reinterpret_cast<const spx8*>(ap + 64);
+  const float* bp = a.btab + (long long)t * CFD_D + lane * 8;
+  float dot = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dot += ((float)h[e] + (float)l[e]) * bp[e];
+  dot = wave_sum(dot);
+  const float var = (a.asq[row] + 2.0f * dot + a.bsq[t]) * (1.0f / CFD_D);
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  if (lane == 0) a.rs[row] = rstd;
+  if (lane < a.nl) a.cbk[(long long)lane * a.rows + row] = rstd * (a.ca[(long long)lane * a.rows + row] + a.cbb[(long long)t * a.cbb_tstride + lane]);
+}
+
+// b[t][:] = temb[t][:] - mean(temb[t]) as fp32 and SP, bsq[t] = |b|^2   (one wave per table row)
+__global__ void __launch_bounds__(256) temb_center_kernel(const float* temb, int T, float* b, char* b_sp, float* bsq) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= T) return;
+  float v[8];
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { v[e] = temb[(long long)row * CFD_D + lane * 8 + e]; sum += v[e]; }
+  const float mean = wave_sum(sum) * (1.0f / CFD_D);
+  float ss = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { v[e] -= mean; ss += v[e] * v[e]; b[(long long)row * CFD_D + lane * 8 + e] = v[e]; }
+  ss = wave_sum(ss);
+  sp_store8(b_sp + (long long)row * (CFD_D * 4), lane * 8, v);
+  if (lane == 0) bsq[row] = ss;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Masked softmax over up to 5 key segments of one score row; writes P (SP, zero in the padding) and
 // optionally the probabilities the reference returns as att_mats (cross_attention.py:227-234).
 // One wave per (b, l) row; a segment of Sp <= 2048 keys lives in registers (<= 4 chunks of 8 / lane).

@@ -46,6 +46,16 @@
 // Dead keys (padding, key-padding mask) carry cb = -inf (EpiMemK writes it), so the kernel needs no mask loads.
 // A row whose keys are all dead gives NaN like the reference's softmax.
 //
+// Timestep-independent projections (round 2).  The memories' LayerNorm input is m_s + temb(t): with a_s the centred static part
+// and b the centred timestep embedding,  Kf n_s = rs_s (KA_s + A b),  cb_s = rs_s (ca_s + c.b),  Vf n_s = rs_s (VA_s + VV b)
+// (rows.hpp, mem_center_kernel).  For such a memory the tiles hold KA / VA (computed once per run) and the kernel applies the
+// per-step part itself:
+//   score(q, s) = rs_s (S_raw(q, s) + c_q) + cbk_s        c_q = q . (A b): per query and memory, made in the prologue
+//   O += VA^T P',  P' = p_s rs_s                           and   x += (sum_s P'_s) VV b   in the epilogue (rank one)
+// rs_s and cbk_s (one scalar per key each, mem_scale_kernel) arrive together in the tile's key-bias piece.  A memory whose
+// projections are still made per step (dynamic memories of the dyadic rollout, per-row timesteps) passes rs = 1, A b = VV b = 0:
+// same code, the extra terms vanish exactly.
+//
 // The segment list (which memory instance, which of the four waves take part) is built by the host per problem
 // (build_xattn_worklist, cfd_api.hip): waves of a workgroup share every LDS tile, so a segment whose instance differs
 // between the workgroup's batch rows is split into passes.
@@ -61,7 +71,9 @@
 #define XA_CBOFF (XA_XOFF + XA_WAVES * 2048)
 #define XA_SEGOFF (XA_CBOFF + 512)
 #define XA_MAXSEG 24
-#define XA_LDS (XA_SEGOFF + XA_MAXSEG * 16)
+#define XA_CQOFF (XA_SEGOFF + XA_MAXSEG * 16)   // per wave: c_q partial sums [16 queries][5 memories], then sum_s P' [16][5]
+#define XA_CQW 640
+#define XA_LDS (XA_CQOFF + XA_WAVES * XA_CQW)
 
 struct XaSeg {
   int j;        // memory 0..4
@@ -85,6 +97,11 @@ struct XAttnArgs {
   const float* bias;          // folded cross-attention bias [512]
   const char* K[CFD_NMEM];    // this layer's folded keys: SP [U_j * Sp_j][512]
   const float* cb[CFD_NMEM];  // this layer's key bias (+ -inf on dead keys): [U_j * Sp_j]
+  unsigned rs_off[CFD_NMEM];  // byte offset from cb[j] to the per-key scale rs of memory j (same indexing; a plane of the same buffer)
+  const float* kb[CFD_NMEM];  // A_l b  [512] of table row *d_step: kb[j] + *d_step * kb_stride[j]   (zeros, stride 0: projections made per step)
+  const float* vb[CFD_NMEM];  // VV_l b [512], likewise
+  long long kb_stride[CFD_NMEM], vb_stride[CFD_NMEM];
+  const int* d_step;
   const char* VT[CFD_NMEM];   // this layer's folded values^T: SP [U_j][512][Sp_j]
   int Sp[CFD_NMEM];
   int L;
@@ -178,6 +195,19 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   // Lane (q = l15, g = q4) holds d = 32 c + 8 g .. +7 of its query's row for every 32-chunk c = 0..15 (the four lanes of a
   // query cover the row: statistics need one 4-lane reduction), and keeps chunks 8 half .. 8 half + 7 as its fragments.
   spx8 qh[8], ql[8];
+  float* cq_mine = reinterpret_cast<float*>(smem + XA_CQOFF + wid * XA_CQW);
+  const float* cq_other = reinterpret_cast<const float*>(smem + XA_CQOFF + (wid ^ 4) * XA_CQW);
+  float* wq_mine = cq_mine + 80;
+  const int trow = *a.d_step;
+  // A b of the five memories (2 KB each) -> LDS by the LDS-DMA, issued before anything else so that its round trip runs under the
+  // row loads and the LayerNorm below.  Parked in the part of the V^T tile buffer that is first filled after the first step's mid-A0
+  // barrier (Vb, row groups 16-31); c_q is computed from there behind the first barrier.
+  constexpr int KBOFF = VOFF + 16 * 1024;
+  if (wid < CFD_NMEM) {
+    const char* kp = reinterpret_cast<const char*>(xa_sel(a.kb, wid) + (long long)trow * xa_sel(a.kb_stride, wid)) + lane * 16;
+    __builtin_amdgcn_global_load_lds((gptr_t)kp, (lptr_t)(smem + KBOFF + wid * 2048), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(kp + 1024), (lptr_t)(smem + KBOFF + wid * 2048 + 1024), 16, 0, 0);
+  }
   {
     const float* xr = a.x + (tok0 + min(l15, max(nq - 1, 0))) * CFD_D + q4 * 8;
     float4 r[32];
@@ -216,11 +246,34 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       }
     }
   }
+  XA_WAIT_VM_LGKM0(0);            // row loads consumed, A b landed
+  __builtin_amdgcn_s_barrier();   // A b and the segment list visible
+  // this wave's half of c_q = q . (A b) for every memory, from the fragments (q = hi + lo); the pair's other half sits in cq_other
+  {
+    float qf[8][8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[ks][e] = (float)qh[ks][e] + (float)ql[ks][e];
+#pragma unroll
+    for (int j = 0; j < CFD_NMEM; ++j) {
+      const float* kp = reinterpret_cast<const float*>(smem + KBOFF + j * 2048) + 256 * half + q4 * 8;
+      float acc = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const f32x4 k0 = *reinterpret_cast<const f32x4*>(kp + 32 * ks), k1 = *reinterpret_cast<const f32x4*>(kp + 32 * ks + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += qf[ks][e] * k0[e] + qf[ks][4 + e] * k1[e];
+      }
+      acc = xlane_sum(acc);
+      if (q4 == 0) { cq_mine[l15 * 5 + j] = acc; wq_mine[l15 * 5 + j] = 0.f; }
+    }
+  }
   f32x4 o[16];   // O^T tiles of features 256 half + 16 f .. +15
 #pragma unroll
   for (int f = 0; f < 16; ++f) o[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-  XA_WAIT_VM_LGKM0(0);   // Q fragments have arrived: the counted waits of the loop start from an empty queue
-  __builtin_amdgcn_s_barrier();   // segment list visible
+  XA_WAIT_VM_LGKM0(0);            // the counted waits of the loop start from an empty queue
+  __builtin_amdgcn_s_barrier();   // c_q halves visible to the pair; every wave is done with the parked A b (the tile fills may overwrite it)
 
   // ---- staging: one piece = one global_load_lds_dwordx4 wave-instruction = 8 tile rows x 128 B; a 32 KB sub-buffer is
   //      32 pieces = 4 per wave.  K tile LDS image: [k-step 16][row 32][128 B]; LDS row rho = 16 t + i holds key
@@ -236,12 +289,13 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
 
   // A tile = 32 keys of one memory instance: its K rows, its V^T column block, its key bias; rowb = bytes per V^T feature
   // row of that memory; vlane = this lane's byte offset inside a V^T piece (depends on rowb).  All but vlane are wave-uniform.
-  struct Tile { const char* k; const char* v; const float* cb; long long rowb; unsigned vlane; };
+  struct Tile { const char* k; const char* v; const float* cb; long long rowb; unsigned vlane; unsigned cblane; };
   auto seg_field = [&](int si, int fld) __attribute__((always_inline)) -> int {
     return __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(smem + XA_SEGOFF)[si * 4 + fld]);
   };
-  auto seg_tile = [&](int si, Tile& t, int& T, int& wm, int& fl) __attribute__((always_inline)) {   // first tile of segment si
-    const int j = seg_field(si, 0), u = seg_field(si, 1);
+  auto seg_tile = [&](int si, Tile& t, int& T, int& wm, int& fl, int& j) __attribute__((always_inline)) {   // first tile of segment si
+    j = seg_field(si, 0);
+    const int u = seg_field(si, 1);
     wm = seg_field(si, 2); fl = seg_field(si, 3);
     const int Sp = xa_sel(a.Sp, j);
     T = Sp / XA_KEYS;
@@ -250,12 +304,12 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     t.cb = xa_sel(a.cb, j) + (long long)u * Sp;
     t.rowb = (long long)Sp * 4;
     t.vlane = (unsigned)((wid * 8 + rsub) * Sp * 4 + vsw);    // (512 rows x Sp x 4 B < 4 GiB)
+    t.cblane = (unsigned)((lane & 31) * 4) + (lane >= 32 ? xa_sel(a.rs_off, j) : 0u);   // lanes 0-31: key bias, lanes 32-63: key scale
   };
-  // fills: K half `hb` (0: Ka, 1: Kb) of tile `t`; with Ka travels the key bias of the tile (1 piece: 64 x 4 B, the
-  // upper 32 lanes re-read the lower ones' words) into key-bias slot `slot`.  Every address is a wave-uniform 64-bit base
+  // fills: K half `hb` (0: Ka, 1: Kb) of tile `t`; with Ka travels the key bias and key scale of the tile (1 piece: 64 x 4 B:
+  // 32 biases, 32 scales) into key-bias slot `slot`.  Every address is a wave-uniform 64-bit base
   // (SGPRs) + a loop-invariant 32-bit lane offset: no vector arithmetic per fill.  (The operands are made opaque at every
   // use: otherwise hipcc hoists base + lane offset out of the loop as a 64-bit per-lane pointer and pays vector adds per fill.)
-  const unsigned cb_lane = (lane & 31) * 4;
   auto fill_k = [&](const Tile& t, int hb, int slot) __attribute__((always_inline)) {
     if (XA_ABLATE & 1) return;
 #pragma unroll
@@ -266,7 +320,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       __builtin_amdgcn_global_load_lds((gptr_t)(b + kl), (lptr_t)(smem + kdst_wave + hb * 2048 + n * 16384), 16, 0, 0);
     }
     if (hb == 0) {
-      unsigned cl = cb_lane;
+      unsigned cl = t.cblane;
       asm volatile("" : "+v"(cl));
       __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(t.cb) + cl), (lptr_t)(smem + XA_CBOFF + slot * 256), 4, 0, 0);
     }
@@ -295,7 +349,13 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       *reinterpret_cast<f32x4*>(strip + l15 * RS + (f * 16 + q4 * 4) * 4) = o[f];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private strip: no barrier needed
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (add_bias) bv = *reinterpret_cast<const float4*>(a.bias + half * 256 + lane * 4);
+    float4 vbv[CFD_NMEM];
+    if (add_bias) {
+      bv = *reinterpret_cast<const float4*>(a.bias + half * 256 + lane * 4);
+#pragma unroll
+      for (int j = 0; j < CFD_NMEM; ++j)
+        vbv[j] = *reinterpret_cast<const float4*>(a.vb[j] + (long long)trow * a.vb_stride[j] + half * 256 + lane * 4);
+    }
     float* xp = a.x + tok0 * CFD_D + half * 256 + lane * 4;
     // all 16 rows are requested before the first is used: one exposed memory round trip per flush instead of four
     float4 old[16];
@@ -307,7 +367,15 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       const f32x4 v = *reinterpret_cast<const f32x4*>(strip + r * RS + lane * 16);
       if (r < nq) {
         float4 t = old[r];
-        t.x = (t.x + bv.x) + v[0]; t.y = (t.y + bv.y) + v[1]; t.z = (t.z + bv.z) + v[2]; t.w = (t.w + bv.w) + v[3];
+        float4 c = make_float4(v[0], v[1], v[2], v[3]);
+        if (add_bias) {   // + (sum_s P'_s) VV b of every memory (the final flush only: the sums of all memories are complete)
+#pragma unroll
+          for (int j = 0; j < CFD_NMEM; ++j) {
+            const float wj = wq_mine[r * 5 + j];
+            c.x += wj * vbv[j].x; c.y += wj * vbv[j].y; c.z += wj * vbv[j].z; c.w += wj * vbv[j].w;
+          }
+        }
+        t.x = (t.x + bv.x) + c.x; t.y = (t.y + bv.y) + c.y; t.z = (t.z + bv.z) + c.z; t.w = (t.w + bv.w) + c.w;
         *reinterpret_cast<float4*>(xp + (long long)r * CFD_D) = t;
       }
     }
@@ -316,7 +384,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     XA_WAIT_VM(0);                                       // the counted waits of the loop assume an empty queue
   };
 
-  float m = -INFINITY, lsum = 0.f;
+  float m = -INFINITY, lsum = 0.f, wl = 0.f;
   char* xch_mine = smem + XA_XOFF + wid * 2048 + lane * 16;
   const char* xch_other = smem + XA_XOFF + (wid ^ 4) * 2048 + lane * 16;
   // fragment reads: half `hf` (4 k-steps / 4 feature tiles) of a sub-phase -> 8 fragments (hi, lo alternating)
@@ -360,8 +428,8 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   bool primed = false;
   int step = 0;
   Tile cur, nseg_t;
-  int cT = 1, cmask = 0, cflags = 0, nT = 1, nmask = 0, nflags = 0;
-  if (nseg > 0) seg_tile(0, cur, cT, cmask, cflags);
+  int cT = 1, cmask = 0, cflags = 0, cj = 0, nT = 1, nmask = 0, nflags = 0, nj = 0;
+  if (nseg > 0) seg_tile(0, cur, cT, cmask, cflags, cj);
   XA_T(0);
   for (int si = 0; si < nseg; ++si) {
     const bool in_seg = active && ((cmask >> tile) & 1);   // wave-uniform, the same for both waves of a pair
@@ -369,8 +437,9 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     const bool seg_follows = si + 1 < nseg;
     // the first tile of the next segment (this segment's first tile again when there is none: the trailing fills then land
     // in buffers nobody reads)
-    nseg_t = cur; nT = cT; nmask = cmask; nflags = cflags;
-    if (seg_follows) seg_tile(si + 1, nseg_t, nT, nmask, nflags);
+    nseg_t = cur; nT = cT; nmask = cmask; nflags = cflags; nj = cj;
+    if (seg_follows) seg_tile(si + 1, nseg_t, nT, nmask, nflags, nj);
+    const float cqv = cq_mine[l15 * 5 + cj] + cq_other[l15 * 5 + cj];   // c_q of this segment's memory (a + b = b + a: the same in both waves of the pair)
     XA_T(11);
     for (int kt = 0; kt < cT; ++kt) {
     const bool last_in_seg = kt + 1 == cT;
@@ -380,6 +449,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     nxt.cb = last_in_seg ? nseg_t.cb : cur.cb + XA_KEYS;
     nxt.rowb = last_in_seg ? nseg_t.rowb : cur.rowb;
     nxt.vlane = last_in_seg ? nseg_t.vlane : cur.vlane;
+    nxt.cblane = last_in_seg ? nseg_t.cblane : cur.cblane;
     const int slot = step & 1;
     if (!primed) {   // (re)start of the pipeline: Ka (+ key bias), Kb, Va of this step; Vb follows behind mid-A0
       fill_k(cur, 0, slot);
@@ -432,9 +502,14 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       const f32x4 t1 = *reinterpret_cast<const f32x4*>(xch_other + 1024);
       const f32x4 kb0 = *reinterpret_cast<const f32x4*>(smem + XA_CBOFF + slot * 256 + q4 * 32);
       const f32x4 kb1 = *reinterpret_cast<const f32x4*>(smem + XA_CBOFF + slot * 256 + q4 * 32 + 16);
+      const f32x4 rs0 = *reinterpret_cast<const f32x4*>(smem + XA_CBOFF + slot * 256 + 128 + q4 * 32);
+      const f32x4 rs1 = *reinterpret_cast<const f32x4*>(smem + XA_CBOFF + slot * 256 + 128 + q4 * 32 + 16);
+      const float rs[8] = {rs0[0], rs0[1], rs0[2], rs0[3], rs1[0], rs1[1], rs1[2], rs1[3]};
       float p[8];
-      p[0] = (s0[0] + t0[0]) + kb0[0]; p[1] = (s0[1] + t0[1]) + kb0[1]; p[2] = (s0[2] + t0[2]) + kb0[2]; p[3] = (s0[3] + t0[3]) + kb0[3];
-      p[4] = (s1[0] + t1[0]) + kb1[0]; p[5] = (s1[1] + t1[1]) + kb1[1]; p[6] = (s1[2] + t1[2]) + kb1[2]; p[7] = (s1[3] + t1[3]) + kb1[3];
+      p[0] = fmaf((s0[0] + t0[0]) + cqv, rs[0], kb0[0]); p[1] = fmaf((s0[1] + t0[1]) + cqv, rs[1], kb0[1]);
+      p[2] = fmaf((s0[2] + t0[2]) + cqv, rs[2], kb0[2]); p[3] = fmaf((s0[3] + t0[3]) + cqv, rs[3], kb0[3]);
+      p[4] = fmaf((s1[0] + t1[0]) + cqv, rs[4], kb1[0]); p[5] = fmaf((s1[1] + t1[1]) + cqv, rs[5], kb1[1]);
+      p[6] = fmaf((s1[2] + t1[2]) + cqv, rs[6], kb1[2]); p[7] = fmaf((s1[3] + t1[3]) + cqv, rs[7], kb1[3]);
       const float mx = xlane_max(fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7]))));
       // exp(x - m) = exp2(x c - m c), c = log2(e): one fused multiply-add and one v_exp_f32 per key (the rounding of m c is common
       // to all keys of a row and cancels against the row sum); dead keys carry x = -inf -> 0
@@ -452,6 +527,10 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
         }
         lsum = lsum * scale + xlane_sum(ps);
         m = m_new;
+        float pw = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { p[e] *= rs[e]; pw += p[e]; }     // P' = p rs: the operand of VA^T P'
+        wl = wl * scale + pw;
       } else {
         const float mc = mx * LOG2E;
         float ps = 0.f;
@@ -462,10 +541,10 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
         }
         const float inv = 1.0f / xlane_sum(ps);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) p[e] *= inv;
+        for (int e = 0; e < 8; ++e) { p[e] = (p[e] * inv) * rs[e]; wl += p[e]; }
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {      // probabilities are <= 1: no saturation needed in front of the fp16 split
+      for (int e = 0; e < 8; ++e) {      // p <= 1 and rs <= 1 / sqrt(eps) = 316: no saturation needed in front of the fp16 split
         const sp_t hi = (sp_t)p[e];
         ph[e] = hi;
         pl[e] = (sp_t)(p[e] - (float)hi);
@@ -504,10 +583,15 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     ++step;
     XA_T(9);
     }   // kt
-    if (in_seg && online) {   // normalise the finished online memory in registers (all keys dead: 0 * inf = NaN)
-      const float inv = 1.0f / lsum;
+    if (in_seg) {
+      float wsum = xlane_sum(wl);
+      if (online) {   // normalise the finished online memory in registers (all keys dead: 0 * inf = NaN)
+        const float inv = 1.0f / lsum;
 #pragma unroll
-      for (int f = 0; f < 16; ++f) { o[f][0] *= inv; o[f][1] *= inv; o[f][2] *= inv; o[f][3] *= inv; }
+        for (int f = 0; f < 16; ++f) { o[f][0] *= inv; o[f][1] *= inv; o[f][2] *= inv; o[f][3] *= inv; }
+        wsum *= inv;
+      }
+      if (q4 == 0) wq_mine[l15 * 5 + cj] = wsum;
     }
     if (cflags & XA_FLUSH) {   // one accumulator: hand the finished online memory to x before the next one starts
       XA_WAIT_VM_LGKM0(0);
@@ -519,7 +603,8 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     }
     m = -INFINITY;
     lsum = 0.f;
-    cT = nT; cmask = nmask; cflags = nflags;   // (cur already points at the next segment's first tile)
+    wl = 0.f;
+    cT = nT; cmask = nmask; cflags = nflags; cj = nj;   // (cur already points at the next segment's first tile)
   }
   XA_WAIT_VM_LGKM0(0);
   __builtin_amdgcn_s_barrier();   // last B1 done everywhere and the trailing (unused) fills have landed: the tile buffers become the epilogue strips

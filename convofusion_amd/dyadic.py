@@ -9,7 +9,9 @@ Before every iteration the conditional ``spkemb`` memory of side A is ``TextAudi
 Each side is an ordinary ``SamplingRun`` (one captured hipGraph per handle) over the structured guidance batch
 (``build_guidance_batch``: B + 1 distinct memories, no 7x materialisation).  The graph reads the memories
 through the pointers given at capture time, so the partner projection writes straight into the conditional rows of
-the speaker memory between replays: two small ``cfd_linear_act`` launches per side per step, no re-capture.
+the speaker memory between replays: two small ``cfd_linear_act`` launches per side per step, no re-capture.  The speaker
+memory is declared dynamic (``cfd_sample_args.dynamic_memory_mask``), so its projections stay inside the captured iteration; the
+other four memories are constants of the run and are projected once.
 """
 import torch
 
@@ -40,7 +42,7 @@ class DyadicRun:
             uniq, maps, masks = build_guidance_batch(cond, uncond, cmask, uncond_masks)
             run = SamplingRun(den, scheduler, uniq, masks, B, L, num_inference_steps, guidance_scale=guidance_scale, eta=eta,
                               init_latents=init, step_noise=noise, seed=seed + side, first_utterance=first_utterance,
-                              dedup=False, row_maps=maps)
+                              dedup=False, row_maps=maps, dynamic_memories=(0,))
             self.runs.append(run)
             self.spk.append(uniq[0][1:])     # rows 1..B of the distinct speaker memories = the conditional ones (a view)
         self.position = 0

@@ -112,7 +112,11 @@ class SamplingRun:
 
     def __init__(self, denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
                  guidance_scale=7.5, guidance_chunks=CFG_CHUNKS, eta=0.0, init_latents=None, step_noise=None,
-                 seed=0, first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False, row_maps=None):
+                 seed=0, first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False, row_maps=None,
+                 dynamic_memories=()):
+        """dynamic_memories: indices j of memories whose CONTENTS the caller rewrites between iterations (DyadicRun's partner
+        projection).  All others are constants of the run, as in the reference loop, and the library computes the
+        timestep-independent part of their projections once (cfd_sample_args.dynamic_memory_mask)."""
         if not isinstance(denoiser, Denoiser):
             raise TypeError("denoiser must be a convofusion_amd.denoiser.Denoiser")
         dev = encoder_hidden_states[0].device
@@ -179,6 +183,7 @@ class SamplingRun:
         # optionally do not evaluate it (identical latents, 1/7 less work; the reference needs it only for
         # the per-step attention maps it logs)
         a.skip_zero_weight_chunks = 1 if skip_zero_weight_chunks else 0
+        a.dynamic_memory_mask = sum(1 << int(j) for j in set(dynamic_memories))
         self._args = a
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):

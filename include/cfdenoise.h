@@ -119,6 +119,11 @@ typedef struct {
                                  reference computes the full-conditioning chunk and multiplies it by
                                  guidance_scale * 0 (convofusion.py:538); its forward only feeds the per-step
                                  attention maps, which the fused loop does not keep.  Results are identical. */
+  int dynamic_memory_mask;    /* bit j set: the CONTENTS of memory j may be rewritten by the caller between iterations of the
+                                 run (the dyadic rollout's partner projection); its projections are then made in every
+                                 iteration.  0 (the reference loop: memories are constants of a run, convofusion.py:391-549):
+                                 the timestep-independent part of every memory's projections is computed once at
+                                 cfd_sample_begin and the memories are not read again. */
 } cfd_sample_args;
 
 /* Opens a sampling run: builds the per-step coefficient and timestep-embedding tables, draws / copies
