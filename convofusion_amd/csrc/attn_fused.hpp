@@ -1,12 +1,12 @@
 // Fused (flash-style) self-attention for the 4-head, head-dim-128 block (cross_attention.py:568-572):
 //   o[b, q, h*128:(h+1)*128] = softmax_k( q_h . k_h ) v_h          (q pre-scaled by 1/sqrt(128) in the weights)
-// One workgroup = 8 waves = 128 queries of one (batch row, head); keys are consumed in tiles of 64 with an
-// online softmax, so neither the score matrix nor the probabilities ever leave the chip.
+// One workgroup = 8 waves = 128 queries of one (batch row, head); keys are consumed in tiles of 32 (double-buffered in LDS)
+// with an online softmax, so neither the score matrix nor the probabilities ever leave the chip.
 //
 // MFMA orientation (v_mfma_f32_16x16x32, split-pair operands, 3 MFMAs per product):
 //   S^T[key][q] = sum_d K[key][d] Q[q][d]      K tile from LDS (A operand), Q fragments in registers (B operand)
 //   O^T[f][q]  += sum_key V^T[f][key] P[q][key] V^T tile from LDS (A operand), P straight from the S accumulators
-// A lane (q = lane&15, g = lane>>4) ends the first product holding S[q][16t + 4g + r] (t, r = 0..3).  Feeding those
+// A lane (q = lane&15, g = lane>>4) ends the first product holding S[q][16t + 4g + r] (t = 0..1, r = 0..3).  Feeding those
 // registers as the B operand of the second product means k-slot (8g + e) of 32-key step s is key
 // 32s + 16(e>>2) + 4g + (e&3): the V^T tile must list its keys in that order, which the V^T GEMM's epilogue
 // produces for free (EpiSplit::perm32) -- no transpose, no LDS round trip for P.
@@ -21,9 +21,12 @@ struct SelfAttnArgs {
 };
 
 #define SELF_ATTN_WAVES 8
+#define SA_WAIT_VM_LGKM0(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | ((((N) >> 4) & 3) << 14))
 __global__ void __launch_bounds__(SELF_ATTN_WAVES * 64, 4) self_attn_fused_kernel(const SelfAttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // K tile 32 KB | V^T tile 32 KB
-  constexpr int KOFF = 0, VOFF = 32768;
+  // two stages of (K tile 16 KB | V^T tile 16 KB): keys are consumed in tiles of 32; the LDS-DMA fill of tile kt + 1 runs
+  // under the MFMAs of tile kt (one barrier per tile), and two workgroups per CU cover each other's softmax sections
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = 32768, VOFF = 16384;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l15 = lane & 15, q4 = lane >> 4, sw = l15 >> 1;
@@ -34,6 +37,29 @@ __global__ void __launch_bounds__(SELF_ATTN_WAVES * 64, 4) self_attn_fused_kerne
   const bool wave_active = (int)(blockIdx.x * (SELF_ATTN_WAVES * 16)) + wid * 16 < a.L;   // wave-uniform
   const int qc = qvalid ? q : a.L - 1;
   const long long ROW = 4096;  // bytes per qk row (1024 columns)
+
+  const int cpos = lane & 7, rsub = lane >> 3;
+  const int nkv = (a.L + 31) / 32;
+  // fill of tile kt into stage kt & 1: 32 pieces of 1 KB (8 rows x 128 B), 4 per wave -- K: 4 k-steps x 4 row groups; V^T: 16 row groups
+  auto fill = [&](int kt) __attribute__((always_inline)) {
+    char* st = smem + (kt & 1) * STAGE;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int g = wid + SELF_ATTN_WAVES * n, ks = g >> 2, rg = g & 3;
+      const int r = rg * 8 + rsub;
+      const int key = min(kt * 32 + r, a.L - 1);
+      const char* src = a.qk + ((long long)b * a.L + key) * ROW + (long long)(16 + h * 4 + ks) * 128 + ((cpos ^ ((r >> 1) & 7)) << 4);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + ks * 4096 + rg * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int rg = wid + SELF_ATTN_WAVES * n;
+      const int r = rg * 8 + rsub;
+      const char* src = a.vts + ((long long)b * CFD_D + h * 128 + r) * ((long long)a.Lv * 4) + (long long)kt * 128 + ((cpos ^ ((r >> 1) & 7)) << 4);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + VOFF + rg * 1024), 16, 0, 0);
+    }
+  };
+  fill(0);
 
   // Q fragments (B operand): lane holds d = 32*ks + 8*q4 .. +7 of its query
   spx8 qh[4], ql[4];
@@ -50,40 +76,22 @@ __global__ void __launch_bounds__(SELF_ATTN_WAVES * 64, 4) self_attn_fused_kerne
   for (int f = 0; f < 8; ++f) o[f] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, lsum = 0.f;
 
-  const int cpos = lane & 7, rsub = lane >> 3;
-  const int nkv = (a.L + 63) / 64;
   for (int kt = 0; kt < nkv; ++kt) {
-    __syncthreads();   // previous tile fully consumed
-    // K tile: 4 k-steps x 64 keys x 128 B ; group g = ks*8 + rg covers rows rg*8..rg*8+7 of k-step ks
-#pragma unroll
-    for (int n = 0; n < 32 / SELF_ATTN_WAVES; ++n) {
-      const int g = wid + SELF_ATTN_WAVES * n, ks = g >> 3, rg = g & 7;
-      const int r = rg * 8 + rsub;
-      const int key = min(kt * 64 + r, a.L - 1);
-      const char* src = a.qk + ((long long)b * a.L + key) * ROW + (long long)(16 + h * 4 + ks) * 128 + ((cpos ^ ((r >> 1) & 7)) << 4);
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + KOFF + ks * 8192 + rg * 1024), 16, 0, 0);
-    }
-    // V^T tile: 2 k-steps x 128 features x 128 B
-#pragma unroll
-    for (int n = 0; n < 32 / SELF_ATTN_WAVES; ++n) {
-      const int g = wid + SELF_ATTN_WAVES * n, ks = g >> 4, rg = g & 15;
-      const int r = rg * 8 + rsub;
-      const char* src = a.vts + ((long long)b * CFD_D + h * 128 + r) * ((long long)a.Lv * 4) + (long long)(kt * 2 + ks) * 128 +
-                        ((cpos ^ ((r >> 1) & 7)) << 4);
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + VOFF + ks * 16384 + rg * 1024), 16, 0, 0);
-    }
-    __syncthreads();
+    SA_WAIT_VM_LGKM0(0);               // tile kt (the only fill in flight) has landed; on the first pass also the Q fragments
+    __builtin_amdgcn_s_barrier();      // ... everywhere, and every wave is done with tile kt - 1 (the other stage)
+    if (kt + 1 < nkv) fill(kt + 1);
     if (!wave_active) continue;
+    const char* st = smem + (kt & 1) * STAGE;
 
-    // S^T tile: 64 keys x 16 queries per wave
-    f32x4 s[4];
+    // S^T tile: 32 keys x 16 queries per wave
+    f32x4 s[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 2; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const char* kp = smem + KOFF + ks * 8192 + (t * 16 + l15) * 128;
+      for (int t = 0; t < 2; ++t) {
+        const char* kp = st + ks * 4096 + (t * 16 + l15) * 128;
         const spx8 xh = *reinterpret_cast<const spx8*>(kp + ((q4 ^ sw) << 4));
         const spx8 xl = *reinterpret_cast<const spx8*>(kp + (((4 + q4) ^ sw) << 4));
         s[t] = SP_MFMA(xl, qh[ks], s[t], 0, 0, 0);
@@ -91,55 +99,50 @@ __global__ void __launch_bounds__(SELF_ATTN_WAVES * 64, 4) self_attn_fused_kerne
         s[t] = SP_MFMA(xh, qh[ks], s[t], 0, 0, 0);
       }
     }
-    // mask the padding keys, online softmax over this tile (a query's 64 scores live in 4 lanes x 16 registers)
+    // mask the padding keys, online softmax over this tile (a query's 32 scores live in 4 lanes x 8 registers);
+    // exp(x - m) = exp2(x c - m c), c = log2(e)
+    constexpr float LOG2E = 1.44269504088896340736f;
+    float p[8];
     float mx = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 64 + 16 * t + 4 * q4 + r;
-        if (key >= a.L) s[t][r] = -INFINITY;
-        mx = fmaxf(mx, s[t][r]);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m, mx);
-    const float scale = __expf(m - m_new);
+    for (int e = 0; e < 8; ++e) {
+      const int key = kt * 32 + 16 * (e >> 2) + 4 * q4 + (e & 3);
+      p[e] = key < a.L ? s[e >> 2][e & 3] : -INFINITY;
+      mx = fmaxf(mx, p[e]);
+    }
+    mx = xlane_max(mx);
+    const float m_new = fmaxf(m, mx);            // (finite: every tile has at least one valid key)
+    const float mc = m_new * LOG2E;
+    const float scale = __builtin_amdgcn_exp2f(fmaf(m, LOG2E, -mc));
     float ps = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s[t][r] = __expf(s[t][r] - m_new);
-        ps += s[t][r];
-      }
-    ps += __shfl_xor(ps, 16, 64);
-    ps += __shfl_xor(ps, 32, 64);
-    lsum = lsum * scale + ps;
+    for (int e = 0; e < 8; ++e) {
+      p[e] = __builtin_amdgcn_exp2f(fmaf(p[e], LOG2E, -mc));
+      ps += p[e];
+    }
+    lsum = lsum * scale + xlane_sum(ps);
     m = m_new;
+    if (!__all(scale == 1.0f)) {
 #pragma unroll
-    for (int f = 0; f < 8; ++f) { o[f][0] *= scale; o[f][1] *= scale; o[f][2] *= scale; o[f][3] *= scale; }
-
+      for (int f = 0; f < 8; ++f) { o[f][0] *= scale; o[f][1] *= scale; o[f][2] *= scale; o[f][3] *= scale; }
+    }
     // O^T += V^T P^T : P fragments come straight out of the S registers (k-slot order matches perm32)
+    spx8 ph, pl;
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      spx8 ph, pl;
+    for (int e = 0; e < 8; ++e) {
+      sp_t hi, lo;
+      split_f32(p[e], hi, lo);
+      ph[e] = hi;
+      pl[e] = lo;
+    }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        sp_t hi, lo;
-        split_f32(s[2 * s2 + (e >> 2)][e & 3], hi, lo);
-        ph[e] = hi;
-        pl[e] = lo;
-      }
-#pragma unroll
-      for (int f = 0; f < 8; ++f) {
-        const char* vp = smem + VOFF + s2 * 16384 + (f * 16 + l15) * 128;
-        const spx8 xh = *reinterpret_cast<const spx8*>(vp + ((q4 ^ sw) << 4));
-        const spx8 xl = *reinterpret_cast<const spx8*>(vp + (((4 + q4) ^ sw) << 4));
-        o[f] = SP_MFMA(xl, ph, o[f], 0, 0, 0);
-        o[f] = SP_MFMA(xh, pl, o[f], 0, 0, 0);
-        o[f] = SP_MFMA(xh, ph, o[f], 0, 0, 0);
-      }
+    for (int f = 0; f < 8; ++f) {
+      const char* vp = st + VOFF + (f * 16 + l15) * 128;
+      const spx8 xh = *reinterpret_cast<const spx8*>(vp + ((q4 ^ sw) << 4));
+      const spx8 xl = *reinterpret_cast<const spx8*>(vp + (((4 + q4) ^ sw) << 4));
+      o[f] = SP_MFMA(xl, ph, o[f], 0, 0, 0);
+      o[f] = SP_MFMA(xh, pl, o[f], 0, 0, 0);
+      o[f] = SP_MFMA(xh, ph, o[f], 0, 0, 0);
     }
   }
   // Epilogue.  The MFMA layout gives a lane 4 features of one query: 8-byte stores in 32-byte row segments.  Each

@@ -89,6 +89,25 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // v_exp_f32-based exponential (__expf): ~1e-7 relative near 0, grows with |x| only where the result is negligible
+// sum / max over the 4 lanes {l, l^16, l^32, l^48} that share a query, in the vector ALU (v_permlane32_swap /
+// v_permlane16_swap: with both operands the same register, the two results hold the value of the lane's own and of its
+// partner's half / row) -- dependent ds_bpermute round trips otherwise
+__device__ __forceinline__ float xlane_sum(float x) {
+  unsigned xi = __float_as_uint(x);
+  auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+  x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  xi = __float_as_uint(x);
+  auto q = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+__device__ __forceinline__ float xlane_max(float x) {
+  unsigned xi = __float_as_uint(x);
+  auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+  x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  xi = __float_as_uint(x);
+  auto q = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+  return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
 // GELU for the FFN epilogue (45 M evaluations per launch; erff's two-range code costs 41 of the launch's 188 us).

@@ -144,25 +144,6 @@ __device__ __forceinline__ T xa_sel(const T (&arr)[CFD_NMEM], int j) {
 #else
 #define XA_FRAG(p_) (*reinterpret_cast<const spx8*>(p_))
 #endif
-// sum / max over the 4 lanes {l, l^16, l^32, l^48} that share a query, in the vector ALU (v_permlane32_swap /
-// v_permlane16_swap: with both operands the same register, the two results hold the value of the lane's own and of its
-// partner's half / row) -- dependent ds_bpermute round trips otherwise
-__device__ __forceinline__ float xlane_sum(float x) {
-  unsigned xi = __float_as_uint(x);
-  auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
-  x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  xi = __float_as_uint(x);
-  auto q = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
-  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
-}
-__device__ __forceinline__ float xlane_max(float x) {
-  unsigned xi = __float_as_uint(x);
-  auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
-  x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-  xi = __float_as_uint(x);
-  auto q = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
-  return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
-}
 #define XA_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | (0xF << 8) | ((((N) >> 4) & 3) << 14))
 #define XA_WAIT_VM_LGKM0(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | ((((N) >> 4) & 3) << 14))
 

@@ -295,12 +295,14 @@ def test_ddim_with_eta_matches_oracle():
     assert e < TRAJ_TOL
 
 
-@pytest.mark.parametrize("env", [{"CFD_NAIVE_GEMM": "1"}, {"CFD_RUNS": "0", "CFD_FUSED_XATTN": "0"}, {"CFD_FUSED_XATTN": "0"}])
+@pytest.mark.parametrize("env", [{"CFD_NAIVE_GEMM": "1"}, {"CFD_RUNS": "0", "CFD_FUSED_XATTN": "0"}, {"CFD_FUSED_XATTN": "0"},
+                                 {"CFD_HOIST_MEMSIDE": "0"}])
 def test_developer_knobs_keep_parity(env):
     """The debug switches that select another code path for the same arithmetic (read once at cfd_create) must not change
     results: CFD_NAIVE_GEMM=1 (one-thread-per-output products instead of the MFMA kernels, three-launch attention),
-    CFD_FUSED_XATTN=0 (three-launch cross-attention everywhere, with its shared-memory runs) and the same with
-    CFD_RUNS=0 (per-row attention products only).  Each leg runs the golden forward, the 20-step trajectory, the run-path
+    CFD_FUSED_XATTN=0 (three-launch cross-attention everywhere, with its shared-memory runs), the same with
+    CFD_RUNS=0 (per-row attention products only), and CFD_HOIST_MEMSIDE=0 (fused cross-attention kernel fed by memory-side
+    projections made in every iteration instead of once per run).  Each leg runs the golden forward, the 20-step trajectory, the run-path
     test and the headline-shape loop rows in a child process."""
     import os
     import subprocess
@@ -427,3 +429,43 @@ def test_small_problems_take_the_three_launch_path_by_default():
     d = float((outs[0] - outs[1]).norm() / outs[1].norm())
     print("fused vs three-launch cross-attention, 4 guided steps: rel L2", d)
     assert d < 2e-4
+
+
+def test_static_and_dynamic_memory_declarations_agree_and_mean_what_they_say():
+    """cfd_sample_args.dynamic_memory_mask.  Memories are constants of a reference sampling run (convofusion.py:391-549), so by
+    default the library projects the timestep-independent part of every memory once at cfd_sample_begin and never reads the
+    memory again; a memory declared dynamic (the dyadic rollout's partner projection) is projected in every iteration.
+    (1) With unchanged memories every declaration gives the same latents (the two forms of the same arithmetic; tolerance =
+    rounding of the re-associated LayerNorm), also when mixed per memory.  (2) Overwriting a memory between iterations changes
+    the result exactly when it was declared dynamic."""
+    import torch
+    from convofusion_amd.sampler import SamplingRun
+    from tests.gpu_helpers import hip_denoiser, to_dev
+    B, L, S, n, seed = 2, 16, (24, 161, 24, 8, 1), 4, 9
+    cb = inputs.make_cfg_batch(seed=seed, B=B, L=L, S=S, pad_tail=(2, 3, 0, 0, 0))
+    masks = {k: to_dev(v) for k, v in cb["masks"].items()}
+    m = hip_denoiser(1234, 1.0)
+
+    def go(dynamic, overwrite=None):
+        mems = [to_dev(x).clone() for x in cb["memories"]]
+        run = SamplingRun(m, _sched("ddpm"), mems, masks, B, L, n, guidance_scale=7.5, seed=seed, dedup=False, dynamic_memories=dynamic)
+        try:
+            run.steps(2)
+            if overwrite is not None:
+                run.read()                                   # (syncs the run's stream)
+                mems[overwrite].mul_(-0.5)
+                torch.cuda.synchronize()
+            run.steps(n - 2)
+            return run.read(close=True).cpu().numpy()
+        finally:
+            run.close()
+
+    base = go(())
+    for dyn in [(0, 1, 2, 3, 4), (1,), (0, 2, 4)]:
+        e = rel_l2(go(dyn), base)
+        print("dynamic", dyn, "vs static: rel L2", e)
+        assert e < 2e-5
+    assert np.array_equal(go((), overwrite=1), base)                      # static: the memory is not read again
+    changed = go((1,), overwrite=1)
+    assert rel_l2(changed, base) > 1e-3                                   # dynamic: the new contents are used
+    assert np.array_equal(go((1,), overwrite=1), changed)                 # ... deterministically
