@@ -177,7 +177,6 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   // query cover the row: statistics need one 4-lane reduction), and keeps chunks 8 half .. 8 half + 7 as its fragments.
   spx8 qh[8], ql[8];
   float* cq_mine = reinterpret_cast<float*>(smem + XA_CQOFF + wid * XA_CQW);
-  const float* cq_other = reinterpret_cast<const float*>(smem + XA_CQOFF + (wid ^ 4) * XA_CQW);
   float* wq_mine = cq_mine + 80;
   const int trow = *a.d_step;
   // A b of the five memories (2 KB each) -> LDS by the LDS-DMA, issued before anything else so that its round trip runs under the
@@ -229,7 +228,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   }
   XA_WAIT_VM_LGKM0(0);            // row loads consumed, A b landed
   __builtin_amdgcn_s_barrier();   // A b and the segment list visible
-  // this wave's half of c_q = q . (A b) for every memory, from the fragments (q = hi + lo); the pair's other half sits in cq_other
+  // this wave's half of c_q = q . (A b) for every memory, from the fragments (q = hi + lo); kept in LDS, read back by this wave only
   {
     float qf[8][8];
 #pragma unroll
@@ -253,8 +252,8 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   f32x4 o[16];   // O^T tiles of features 256 half + 16 f .. +15
 #pragma unroll
   for (int f = 0; f < 16; ++f) o[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-  XA_WAIT_VM_LGKM0(0);            // the counted waits of the loop start from an empty queue
-  __builtin_amdgcn_s_barrier();   // c_q halves visible to the pair; every wave is done with the parked A b (the tile fills may overwrite it)
+  XA_WAIT_VM_LGKM0(0);            // the counted waits of the loop start from an empty queue.  (No barrier: the c_q halves are wave-private, and
+                                  // the parked A b is overwritten only behind the first step's mid-A0 barrier, which every wave reaches after this point.)
 
   // ---- staging: one piece = one global_load_lds_dwordx4 wave-instruction = 8 tile rows x 128 B; a 32 KB sub-buffer is
   //      32 pieces = 4 per wave.  K tile LDS image: [k-step 16][row 32][128 B]; LDS row rho = 16 t + i holds key
@@ -420,7 +419,9 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     // in buffers nobody reads)
     nseg_t = cur; nT = cT; nmask = cmask; nflags = cflags; nj = cj;
     if (seg_follows) seg_tile(si + 1, nseg_t, nT, nmask, nflags, nj);
-    const float cqv = cq_mine[l15 * 5 + cj] + cq_other[l15 * 5 + cj];   // c_q of this segment's memory (a + b = b + a: the same in both waves of the pair)
+    // this wave's half of c_q for the segment's memory: the score accumulators START from it, so the pair's partial scores already
+    // add up to S_raw + c_q (a + b = b + a: the same in both waves of the pair)
+    const float cqh = cq_mine[l15 * 5 + cj];
     XA_T(11);
     for (int kt = 0; kt < cT; ++kt) {
     const bool last_in_seg = kt + 1 == cT;
@@ -443,7 +444,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       XA_T(0);
     }
     // ---- A0 (fa holds its first half) --------------------------------------------------------------------------------
-    f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    f32x4 s0 = f32x4{cqh, cqh, cqh, cqh}, s1 = s0;
     read_k(fb, 0, 1);
     __builtin_amdgcn_sched_barrier(0);
     if (in_seg) mfma_k(s0, fa, 0);
@@ -487,10 +488,10 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       const f32x4 rs1 = *reinterpret_cast<const f32x4*>(smem + XA_CBOFF + slot * 256 + 128 + q4 * 32 + 16);
       const float rs[8] = {rs0[0], rs0[1], rs0[2], rs0[3], rs1[0], rs1[1], rs1[2], rs1[3]};
       float p[8];
-      p[0] = fmaf((s0[0] + t0[0]) + cqv, rs[0], kb0[0]); p[1] = fmaf((s0[1] + t0[1]) + cqv, rs[1], kb0[1]);
-      p[2] = fmaf((s0[2] + t0[2]) + cqv, rs[2], kb0[2]); p[3] = fmaf((s0[3] + t0[3]) + cqv, rs[3], kb0[3]);
-      p[4] = fmaf((s1[0] + t1[0]) + cqv, rs[4], kb1[0]); p[5] = fmaf((s1[1] + t1[1]) + cqv, rs[5], kb1[1]);
-      p[6] = fmaf((s1[2] + t1[2]) + cqv, rs[6], kb1[2]); p[7] = fmaf((s1[3] + t1[3]) + cqv, rs[7], kb1[3]);
+      p[0] = fmaf(s0[0] + t0[0], rs[0], kb0[0]); p[1] = fmaf(s0[1] + t0[1], rs[1], kb0[1]);
+      p[2] = fmaf(s0[2] + t0[2], rs[2], kb0[2]); p[3] = fmaf(s0[3] + t0[3], rs[3], kb0[3]);
+      p[4] = fmaf(s1[0] + t1[0], rs[4], kb1[0]); p[5] = fmaf(s1[1] + t1[1], rs[5], kb1[1]);
+      p[6] = fmaf(s1[2] + t1[2], rs[6], kb1[2]); p[7] = fmaf(s1[3] + t1[3], rs[7], kb1[3]);
       const float mx = xlane_max(fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7]))));
       // exp(x - m) = exp2(x c - m c), c = log2(e): one fused multiply-add and one v_exp_f32 per key (the rounding of m c is common
       // to all keys of a row and cancels against the row sum); dead keys carry x = -inf -> 0
