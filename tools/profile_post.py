@@ -82,7 +82,8 @@ def publish():
     if os.path.exists(t):
         tot, n = 0.0, 0
         for r in csv.DictReader(open(t)):
-            if "gemm_sp_kernel" in r["kernel"]:
+            # the products launched inside an iteration (the memory-side projections and the timestep tables run once per run: EpiMemK / EpiMemV / EpiF32)
+            if "gemm_sp_kernel" in r["kernel"] and not any(e in r["kernel"] for e in ("EpiMemK", "EpiMemV", "EpiF32")):
                 k = int(r["launches_in_trace"])
                 tot += (float(r["read_MB_per_launch_(2xFETCH)"]) + float(r["write_MB_per_launch_(WRITE_SIZE)"])) * 1e6 * k
                 n += k
