@@ -122,7 +122,7 @@ struct cfd_handle_s {
   // three-launch path (score products -> softmax_rows_kernel -> P.V products) materialises.  CFD_FUSED_XATTN=0 forces
   // the three-launch path everywhere (parity A/B of the two paths).
   bool fused_xattn = true;
-  int fused_xattn_min_wgs = 48;
+  int fused_xattn_min_wgs = 6;
   DBuf xa_wgs, xa_segs, xa_stamps;
   bool share0 = true;       // CFD_SHARE0=0: evaluate the pre-cross-attention part of layer 0 for every guidance replica
   DBuf d_step;  // [0] = loop index, [1] = constant 0, [2] = "this iteration's in-painting overwrite is done" (cfd_sample_inpaint)
@@ -605,10 +605,11 @@ static int build_xattn_worklist(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
     for (size_t i = 0; i < queue[x].size(); ++i) wgs[i * 8 + x] = queue[x][i];
   if (wgs.empty() || segs.empty()) return CFD_OK;
   // A handful of workgroups cannot hide their serial walk over the key tiles (3 barriers and a fill round trip per 32 keys
-  // with nothing else on the chip): one utterance at the product shape (7 rows of 16 queries = 3 workgroups) ran 1.43 ms per
-  // step fused against 1.35 ms through the three-launch path, 32 utterances (72 workgroups) 2.56 against 2.60.  Small
-  // problems therefore keep the three-launch path (CFD_FUSED_XATTN_MIN_WGS=0 lifts the threshold: the test suite runs its
-  // small cases through the fused kernel that way).
+  // with nothing else on the chip).  Round-2 measurements at the product shape, 1000 steps, since the memory-side projections
+  // left the loop (the three-launch path still makes them per step): one utterance (2 workgroups) 1.342 s fused against
+  // 1.318 s three-launch, four utterances (7 workgroups) 1.370 against 1.404, 16 (28 workgroups, one shard of the product-shape
+  // benchmark) 470 against 465 steps/s.  Below 6 workgroups the three-launch path stays (CFD_FUSED_XATTN_MIN_WGS overrides;
+  // the test suite sets 0 and runs its small cases through the fused kernel).
   size_t n_active = 0;
   for (int x = 0; x < 8; ++x) n_active += queue[x].size();
   if ((int)n_active < c->fused_xattn_min_wgs) return CFD_OK;

@@ -113,8 +113,10 @@ class SamplingRun:
     def __init__(self, denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
                  guidance_scale=7.5, guidance_chunks=CFG_CHUNKS, eta=0.0, init_latents=None, step_noise=None,
                  seed=0, first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False, row_maps=None,
-                 dynamic_memories=()):
-        """dynamic_memories: indices j of memories whose CONTENTS the caller rewrites between iterations (DyadicRun's partner
+                 dynamic_memories=(), side_engine=False):
+        """side_engine: open the run on the denoiser's second library handle (its own weights copy, workspace and stream), so that
+        two runs on one module -- two utterance shards of one batch -- can be open and replay concurrently (``sample_concurrent``).
+        dynamic_memories: indices j of memories whose CONTENTS the caller rewrites between iterations (DyadicRun's partner
         projection).  All others are constants of the run, as in the reference loop, and the library computes the
         timestep-independent part of their projections once (cfd_sample_args.dynamic_memory_mask)."""
         if not isinstance(denoiser, Denoiser):
@@ -138,7 +140,7 @@ class SamplingRun:
             mems, maps, masks = dedup_memories(encoder_hidden_states, cond_masks)
         else:
             mems, maps, masks = list(encoder_hidden_states), None, dict(cond_masks or {})
-        self.handle = denoiser.engine(dev, mem_len=max(int(m.shape[1]) for m in mems))
+        self.handle = denoiser.engine(dev, mem_len=max(int(m.shape[1]) for m in mems), side=bool(side_engine))
         marr, keep = Denoiser.pack_memories(mems, masks, maps)
         self._keep = [keep, denoiser]
         a = _lib.SampleArgs()
@@ -249,6 +251,79 @@ class SamplingRun:
             pass
 
 
+def _utterance_slice(t, a, b, total, chunks):
+    """Utterances [a, b) of a chunk-major guidance batch [chunks * total, ...] (same rule as distributed.shard_cfg_batch)."""
+    if t is None:
+        return None
+    v = t.reshape(chunks, total, *t.shape[1:])
+    return v[:, a:b].reshape(chunks * (b - a), *t.shape[1:]).contiguous()
+
+
+class ConcurrentRuns:
+    """One batch as TWO open sampling runs -- utterance shards [0, B/2) and [B/2, B) -- on the denoiser's two library handles,
+    each with its own captured hipGraph, workspace and stream, replayed side by side.
+
+    Utterances are independent and the Philox streams are keyed by global utterance id, so the latents are bit-identical to
+    the single run's (``test_concurrent_shards_equal_the_single_run``).  What it buys is chip utilisation: every kernel of a
+    step ends in a tail in which a few workgroups finish alone; with two half-size graphs on two streams the other shard's
+    kernels fill those tails (measured on MI355X: 71.6 -> 76.0 steps/s at B = 32, L = 196; 460 -> 479 at the product shape;
+    three shards 73.1, four 66.3 -- DESIGN.md section 6).  Same interface as ``SamplingRun`` for steps / read / close.
+    """
+
+    def __init__(self, denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps, guidance_scale=7.5,
+                 guidance_chunks=CFG_CHUNKS, eta=0.0, init_latents=None, step_noise=None, seed=0, first_utterance=0, preseq=None,
+                 dedup=True, skip_zero_weight_chunks=False):
+        if B < 2:
+            raise ValueError("two concurrent shards need at least two utterances")
+        G = guidance_chunks
+        if encoder_hidden_states[0].shape[0] != G * B:
+            raise ValueError(f"conditioning batch is {encoder_hidden_states[0].shape[0]} rows, expected G*B = {G * B}")
+        self.B, self.L, self.N = B, L, num_inference_steps
+        self.runs = []
+        cuts = (0, (B + 1) // 2, B)
+        try:
+            for k in range(2):
+                a, b = cuts[k], cuts[k + 1]
+                mems = [_utterance_slice(m, a, b, B, G) for m in encoder_hidden_states]
+                masks = {n: _utterance_slice(v, a, b, B, G) for n, v in (cond_masks or {}).items()}
+                self.runs.append(SamplingRun(
+                    denoiser, scheduler, mems, masks, b - a, L, num_inference_steps, guidance_scale, G, eta,
+                    None if init_latents is None else init_latents[a:b], None if step_noise is None else step_noise[:, a:b],
+                    seed, first_utterance + a, None if preseq is None else preseq[a:b], dedup, skip_zero_weight_chunks,
+                    side_engine=bool(k)))
+        except Exception:
+            self.close()
+            raise
+        self.open = True
+
+    def steps(self, n):
+        for _ in range(int(n)):      # one replay per shard and iteration: the two streams advance together
+            for r in self.runs:
+                r.steps(1)
+
+    @property
+    def position(self):
+        return self.runs[0].position
+
+    def read(self, close=False):
+        out = torch.cat([r.read(close) for r in self.runs], dim=0)
+        if close:
+            self.open = False
+        return out
+
+    def close(self):
+        for r in self.runs:
+            r.close()
+        self.open = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
 def last_step_attention(run, denoiser, timestep, encoder_hidden_states, cond_masks, guidance_chunks=CFG_CHUNKS, row_maps=None):
     """The attention maps the reference keeps from an iteration: ``att_mats`` of the LAST guidance chunk (full
     conditioning) of the denoiser call (convofusion.py:517-523, unbounded_synthesis.py:159-161) -- 5 tensors
@@ -277,10 +352,26 @@ def last_step_attention(run, denoiser, timestep, encoder_hidden_states, cond_mas
 
 def sample(denoiser, scheduler, encoder_hidden_states, cond_masks=None, *, B, L=16, num_inference_steps=1000,
            guidance_scale=7.5, guidance_chunks=CFG_CHUNKS, eta=0.0, init_latents=None, step_noise=None, seed=0,
-           first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False, row_maps=None, return_attention=False):
+           first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False, row_maps=None, return_attention=False,
+           concurrent_shards=None):
     """Run the whole loop; returns latents [B, L, 128] (batch-first); with ``return_attention=True`` also the last
     iteration's attention maps (``last_step_attention``), with ``return_attention="all"`` a dict {timestep: maps} over every
-    iteration like the reference's (the loop then leaves the device once per step)."""
+    iteration like the reference's (the loop then leaves the device once per step).
+    ``concurrent_shards``: 2 = run the batch as two utterance shards side by side (``ConcurrentRuns``; identical latents);
+    None = do so for batches of 8 utterances and more when nothing else needs the second library handle."""
+    can_split = row_maps is None and not return_attention and B >= 2 and encoder_hidden_states[0].shape[0] == guidance_chunks * B
+    if concurrent_shards is None:
+        concurrent_shards = 2 if (can_split and B >= 8) else 1
+    if concurrent_shards not in (1, 2):
+        raise ValueError("concurrent_shards must be 1 or 2 (more shards were measured slower)")
+    if concurrent_shards == 2:
+        if not can_split:
+            raise ValueError("concurrent shards need the replicated chunk-major batch (no row_maps), B >= 2 and no attention maps")
+        with ConcurrentRuns(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps, guidance_scale,
+                            guidance_chunks, eta, init_latents, step_noise, seed, first_utterance, preseq, dedup,
+                            skip_zero_weight_chunks) as runs:
+            runs.steps(num_inference_steps)
+            return runs.read(close=True)
     run = SamplingRun(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
                       guidance_scale, guidance_chunks, eta, init_latents, step_noise, seed, first_utterance, preseq, dedup,
                       skip_zero_weight_chunks, row_maps)

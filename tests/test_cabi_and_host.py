@@ -245,3 +245,20 @@ def test_no_edit_installer_binds_the_reference_entry_points():
     script.diffusion_reverse_forecast = lambda *a, **k: "reference rollout"
     orig = convofusion_amd.patch_rollout(script)
     assert script.diffusion_reverse_forecast is inst.diffusion_reverse_forecast and orig() == "reference rollout"
+
+
+def test_utterance_slices_of_a_guidance_batch():
+    """sampler._utterance_slice (the shards of ConcurrentRuns) = distributed.shard_cfg_batch: utterances [a, b) of every chunk of a
+    chunk-major batch, chunk order kept; the two shards together are a permutation-free partition of the rows."""
+    import torch
+    from convofusion_amd.distributed import shard_cfg_batch
+    from convofusion_amd.sampler import _utterance_slice
+    G, B = 7, 5
+    t = torch.arange(G * B * 3).reshape(G * B, 3)
+    a = _utterance_slice(t, 0, 3, B, G)
+    b = _utterance_slice(t, 3, 5, B, G)
+    assert torch.equal(a, shard_cfg_batch(t, 0, 3, B, G)) and torch.equal(b, shard_cfg_batch(t, 3, 5, B, G))
+    assert a.shape[0] == G * 3 and b.shape[0] == G * 2
+    back = torch.cat([a.reshape(G, 3, 3), b.reshape(G, 2, 3)], dim=1).reshape(G * B, 3)
+    assert torch.equal(back, t)
+    assert _utterance_slice(None, 0, 1, B, G) is None

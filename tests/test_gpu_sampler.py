@@ -397,7 +397,7 @@ def test_no_edit_installer_runs_the_fused_loop():
 
 
 def test_small_problems_take_the_three_launch_path_by_default():
-    """Default threshold (48 workgroups): a 2-utterance run goes through the three-launch cross-attention, the same run with the
+    """Default threshold (6 workgroups): a 2-utterance run (4 workgroups) goes through the three-launch cross-attention, the same run with the
     threshold lifted through the fused kernel; both must agree to rounding (different summation orders) and the profile must
     show which one ran."""
     import os
@@ -469,3 +469,39 @@ def test_static_and_dynamic_memory_declarations_agree_and_mean_what_they_say():
     changed = go((1,), overwrite=1)
     assert rel_l2(changed, base) > 1e-3                                   # dynamic: the new contents are used
     assert np.array_equal(go((1,), overwrite=1), changed)                 # ... deterministically
+
+
+@pytest.mark.parametrize("kind", ["ddpm", "ddim"])
+def test_concurrent_shards_equal_the_single_run(kind):
+    """ConcurrentRuns: the batch as two utterance shards on the denoiser's two library handles, replayed side by side, gives the
+    single run's latents bit for bit -- device-drawn noise (Philox keyed by global utterance id), caller-supplied initial latents
+    and per-step noise, an in-painting prefix, an odd split (3 + 2 utterances) -- and ``sample()`` takes that path by itself
+    for batches of 8 and more."""
+    import torch
+    from convofusion_amd.sampler import ConcurrentRuns, SamplingRun, sample
+    from tests.gpu_helpers import hip_denoiser, to_dev
+    B, L, S, n, seed = 5, 16, (24, 161, 24, 8, 1), 4, 11
+    cb = inputs.make_cfg_batch(seed=seed, B=B, L=L, S=S, pad_tail=(2, 3, 0, 0, 0))
+    mems = [to_dev(x) for x in cb["memories"]]
+    masks = {k: to_dev(v) for k, v in cb["masks"].items()}
+    m = hip_denoiser(1234, 1.0)
+    g = torch.Generator().manual_seed(3)
+    cases = [dict(seed=seed, first_utterance=7),
+             dict(seed=seed, init_latents=to_dev(torch.randn(B, L, 128, generator=g).numpy()),
+                  step_noise=to_dev(torch.randn(n, B, L, 128, generator=g).numpy())),
+             dict(seed=seed, preseq=to_dev(torch.randn(B, 6, 128, generator=g).numpy()))]
+    for kw in cases:
+        with SamplingRun(m, _sched(kind), mems, masks, B, L, n, guidance_scale=7.5, **kw) as one:
+            one.steps(n)
+            want = one.read(close=True)
+        with ConcurrentRuns(m, _sched(kind), mems, masks, B, L, n, guidance_scale=7.5, **kw) as two:
+            two.steps(n)
+            got = two.read(close=True)
+        assert torch.equal(got, want), sorted(kw)
+    B8 = 8
+    cb = inputs.make_cfg_batch(seed=seed + 1, B=B8, L=L, S=S, pad_tail=(2, 3, 0, 0, 0))
+    mems = [to_dev(x) for x in cb["memories"]]
+    masks = {k: to_dev(v) for k, v in cb["masks"].items()}
+    auto = sample(m, _sched(kind), mems, masks, B=B8, L=L, num_inference_steps=n, seed=seed)
+    single = sample(m, _sched(kind), mems, masks, B=B8, L=L, num_inference_steps=n, seed=seed, concurrent_shards=1)
+    assert torch.equal(auto, single)
