@@ -321,6 +321,11 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   // through a private LDS strip (the caller has drained every fill and passed a barrier, so the tile buffers are free)
   // and moves whole 1 KB row pieces.
   auto flush = [&](bool add_bias) __attribute__((always_inline)) {
+    // The arguments only the flush needs are re-read from the kernel-argument segment HERE (through a pointer the compiler cannot see
+    // through): kept in SGPRs across the main loop they push the loop's own wave-uniform pointers into VGPRs and from there into
+    // scratch memory (68 bytes per lane before this; tests/test_cabi_and_host.py checks that no kernel of the library has any).
+    const XAttnArgs* ka = reinterpret_cast<const XAttnArgs*>((unsigned long long)__builtin_amdgcn_kernarg_segment_ptr());   // (constant -> flat address: the same bits)
+    asm volatile("" : "+s"(ka));
     constexpr int RS = 256 * 4 + 16;
     static_assert(XA_WAVES * 16 * RS <= XA_XOFF, "the epilogue strips must not reach the exchange / key-bias / segment areas");
     char* strip = smem + wid * (16 * RS);
@@ -331,12 +336,12 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 vbv[CFD_NMEM];
     if (add_bias) {
-      bv = *reinterpret_cast<const float4*>(a.bias + half * 256 + lane * 4);
+      bv = *reinterpret_cast<const float4*>(ka->bias + half * 256 + lane * 4);
 #pragma unroll
       for (int j = 0; j < CFD_NMEM; ++j)
-        vbv[j] = *reinterpret_cast<const float4*>(a.vb[j] + (long long)trow * a.vb_stride[j] + half * 256 + lane * 4);
+        vbv[j] = *reinterpret_cast<const float4*>(ka->vb[j] + (long long)trow * ka->vb_stride[j] + half * 256 + lane * 4);
     }
-    float* xp = a.x + tok0 * CFD_D + half * 256 + lane * 4;
+    float* xp = ka->x + tok0 * CFD_D + half * 256 + lane * 4;
     // all 16 rows are requested before the first is used: one exposed memory round trip per flush instead of four
     float4 old[16];
 #pragma unroll

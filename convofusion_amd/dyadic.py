@@ -46,15 +46,22 @@ class DyadicRun:
             self.runs.append(run)
             self.spk.append(uniq[0][1:])     # rows 1..B of the distinct speaker memories = the conditional ones (a view)
         self.position = 0
+        self._lat = None
 
     def steps(self, n):
         for _ in range(n):
-            la, lb = self.runs[0].read(), self.runs[1].read()        # (syncs each run's stream)
+            la, lb = self._lat if self._lat is not None else (self.runs[0].read(), self.runs[1].read())   # (read syncs the run's stream)
             self.fuser.project_latents(lb, out=self.spk[0])          # A attends to B
             self.fuser.project_latents(la, out=self.spk[1])          # B attends to A
             torch.cuda.current_stream(la.device).synchronize()       # the graphs replay on the runs' own streams
+            # One side after the other: side A's replay is waited for (its latents are needed for the next iteration anyway) before
+            # side B's is launched.  Two captured graphs replaying at the same time are not reliable on this stack (see
+            # sampler.ConcurrentRuns, tools/concurrency_soak.py); the overlap was worth ~5 % of an iteration.
             self.runs[0].steps(1)
+            la = self.runs[0].read()
             self.runs[1].steps(1)
+            lb = self.runs[1].read()
+            self._lat = (la, lb)
             self.position += 1
 
     def read(self, close=False):

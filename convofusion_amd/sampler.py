@@ -260,14 +260,17 @@ def _utterance_slice(t, a, b, total, chunks):
 
 
 class ConcurrentRuns:
-    """One batch as TWO open sampling runs -- utterance shards [0, B/2) and [B/2, B) -- on the denoiser's two library handles,
-    each with its own captured hipGraph, workspace and stream, replayed side by side.
+    """EXPERIMENTAL, not used by default.  One batch as TWO open sampling runs -- utterance shards [0, B/2) and [B/2, B) -- on the
+    denoiser's two library handles, each with its own captured hipGraph, workspace and stream, replayed side by side.
 
-    Utterances are independent and the Philox streams are keyed by global utterance id, so the latents are bit-identical to
-    the single run's (``test_concurrent_shards_equal_the_single_run``).  What it buys is chip utilisation: every kernel of a
-    step ends in a tail in which a few workgroups finish alone; with two half-size graphs on two streams the other shard's
-    kernels fill those tails (measured on MI355X: 71.6 -> 76.0 steps/s at B = 32, L = 196; 460 -> 479 at the product shape;
-    three shards 73.1, four 66.3 -- DESIGN.md section 6).  Same interface as ``SamplingRun`` for steps / read / close.
+    Utterances are independent and the Philox streams are keyed by global utterance id, so the latents should be bit-identical to
+    the single run's, and two half-size graphs fill each other's kernel tails: 71.6 -> 76.0 steps/s at B = 32, L = 196.  BUT on this
+    stack (ROCm 7.2, MI355X) two graphs replaying concurrently are not reliable: ``tools/concurrency_soak.py`` shows single utterances
+    with wrong latents about once per 1 000 - 1 500 step pairs (fused and three-launch attention paths alike, the shard whose graph
+    is launched first in a step more often; a device synchronisation after every step pair does not remove it; buffers of the two
+    handles are disjoint, no kernel uses scratch memory).  The cause was not found in round 2, so nothing
+    in the package selects this class by itself; ``sample(..., concurrent_shards=2)`` and ``bench.py --shards 2`` are opt-in.
+    Same interface as ``SamplingRun`` for steps / read / close.
     """
 
     def __init__(self, denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps, guidance_scale=7.5,
@@ -357,11 +360,11 @@ def sample(denoiser, scheduler, encoder_hidden_states, cond_masks=None, *, B, L=
     """Run the whole loop; returns latents [B, L, 128] (batch-first); with ``return_attention=True`` also the last
     iteration's attention maps (``last_step_attention``), with ``return_attention="all"`` a dict {timestep: maps} over every
     iteration like the reference's (the loop then leaves the device once per step).
-    ``concurrent_shards``: 2 = run the batch as two utterance shards side by side (``ConcurrentRuns``; identical latents);
-    None = do so for batches of 8 utterances and more when nothing else needs the second library handle."""
+    ``concurrent_shards``: 2 = run the batch as two utterance shards side by side (``ConcurrentRuns``: faster, but EXPERIMENTAL --
+    see its docstring; the default is 1)."""
     can_split = row_maps is None and not return_attention and B >= 2 and encoder_hidden_states[0].shape[0] == guidance_chunks * B
     if concurrent_shards is None:
-        concurrent_shards = 2 if (can_split and B >= 8) else 1
+        concurrent_shards = 1
     if concurrent_shards not in (1, 2):
         raise ValueError("concurrent_shards must be 1 or 2 (more shards were measured slower)")
     if concurrent_shards == 2:

@@ -262,3 +262,25 @@ def test_utterance_slices_of_a_guidance_batch():
     back = torch.cat([a.reshape(G, 3, 3), b.reshape(G, 2, 3)], dim=1).reshape(G * B, 3)
     assert torch.equal(back, t)
     assert _utterance_slice(None, 0, 1, B, G) is None
+
+
+def test_no_kernel_of_the_library_uses_scratch_memory():
+    """Every kernel keeps its state in registers / LDS: private (scratch) memory is slow, and it was the first suspect when two
+    captured graphs replaying side by side (sampler.ConcurrentRuns) gave wrong latents in an experiment (the spills
+    turned out not to be the cause, but they are gone -- 68 bytes per lane of wave-uniform pointers in xattn_fused_kernel -- and this
+    keeps it that way).  hipcc's resource-usage remarks are the check (cross-compiles without a GPU)."""
+    import re
+    import subprocess
+    import tempfile
+    from convofusion_amd import build
+    src = os.path.join(build.CSRC, "cfd_api.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-c",
+                            "-Rpass-analysis=kernel-resource-usage", src, "-o", os.path.join(tmp, "cfd_api.o")],
+                           capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", r.stderr)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    assert len(names) == len(scratch) and len(names) > 40
+    bad = {n: s for n, s in zip(names, scratch) if s != 0}
+    assert not bad, bad

@@ -473,10 +473,11 @@ def test_static_and_dynamic_memory_declarations_agree_and_mean_what_they_say():
 
 @pytest.mark.parametrize("kind", ["ddpm", "ddim"])
 def test_concurrent_shards_equal_the_single_run(kind):
-    """ConcurrentRuns: the batch as two utterance shards on the denoiser's two library handles, replayed side by side, gives the
+    """ConcurrentRuns (experimental, opt-in): the batch as two utterance shards on the denoiser's two library handles gives the
     single run's latents bit for bit -- device-drawn noise (Philox keyed by global utterance id), caller-supplied initial latents
-    and per-step noise, an in-painting prefix, an odd split (3 + 2 utterances) -- and ``sample()`` takes that path by itself
-    for batches of 8 and more."""
+    and per-step noise, an in-painting prefix, an odd split (3 + 2 utterances).  This checks the sharding logic on a few steps; the
+    rare wrong utterance of two graphs replaying at the same time (tools/concurrency_soak.py: about one per 1 000 step pairs at the
+    benchmark shape) is why nothing selects this path by default."""
     import torch
     from convofusion_amd.sampler import ConcurrentRuns, SamplingRun, sample
     from tests.gpu_helpers import hip_denoiser, to_dev
@@ -502,6 +503,6 @@ def test_concurrent_shards_equal_the_single_run(kind):
     cb = inputs.make_cfg_batch(seed=seed + 1, B=B8, L=L, S=S, pad_tail=(2, 3, 0, 0, 0))
     mems = [to_dev(x) for x in cb["memories"]]
     masks = {k: to_dev(v) for k, v in cb["masks"].items()}
-    auto = sample(m, _sched(kind), mems, masks, B=B8, L=L, num_inference_steps=n, seed=seed)
-    single = sample(m, _sched(kind), mems, masks, B=B8, L=L, num_inference_steps=n, seed=seed, concurrent_shards=1)
-    assert torch.equal(auto, single)
+    two = sample(m, _sched(kind), mems, masks, B=B8, L=L, num_inference_steps=n, seed=seed, concurrent_shards=2)
+    single = sample(m, _sched(kind), mems, masks, B=B8, L=L, num_inference_steps=n, seed=seed)       # the default: one graph
+    assert torch.equal(two, single)

@@ -19,7 +19,8 @@ sch = scheduler.DDPMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta
                               variance_type="fixed_small", clip_sample=True)
 sample(model, sch, mems, masks, B=B, L=16, num_inference_steps=4, seed=0)
 ts = []
-for _ in range(3):
+REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+for _ in range(REPS):
     torch.cuda.synchronize()
     t0 = time.time()
     sample(model, sch, mems, masks, B=B, L=16, num_inference_steps=1000, seed=0)
