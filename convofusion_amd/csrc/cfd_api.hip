@@ -1367,7 +1367,11 @@ extern "C" int cfd_sample_steps(cfd_handle c, int n) {
   if (n < 0 || c->run_pos + n > c->sargs.num_inference_steps)
     return fail(CFD_E_ARG, "run has %d of %d iterations done; cannot run %d more", c->run_pos, c->sargs.num_inference_steps, n);
   HIPCHK(hipSetDevice(c->cfg.device));
-  for (int i = 0; i < n; ++i) HIPCHK(hipGraphLaunch(c->gexec, c->run_stream));
+  static const bool eager = getenv("CFD_EAGER_STEPS") != nullptr;   // developer experiment: enqueue every iteration's launches instead of replaying the graph
+  for (int i = 0; i < n; ++i) {
+    if (eager) CHK(enqueue_loop_iteration(c, c->run_stream));
+    else HIPCHK(hipGraphLaunch(c->gexec, c->run_stream));
+  }
   c->run_pos += n;
   return CFD_OK;
 }

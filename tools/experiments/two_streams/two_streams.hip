@@ -1,0 +1,93 @@
+// Developer experiment: is a chain of dependent read-modify-write kernels on one stream still exact when a second
+// stream runs its own chain on its own buffer at the same time?  Each kernel applies one LCG step to every element, with a
+// block -> data mapping that changes from kernel to kernel (so every line is touched by a different CU / XCD each time); after K
+// kernels every element must equal the K-fold LCG of its start value.
+//   hipcc --offload-arch=gfx950 -O3 tools/experiments/two_streams/two_streams.hip -o tools/experiments/two_streams/two_streams
+//   ./two_streams [kernels per chain] [MiB per buffer] [repetitions] [lds]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+__global__ void __launch_bounds__(256) lcg_step(unsigned* x, size_t n, unsigned rot) {
+  const size_t blk = ((size_t)blockIdx.x * 7 + rot) % gridDim.x;
+  const size_t i = blk * 1024 + threadIdx.x * 4;
+  if (i + 3 < n) {
+    uint4 v = *reinterpret_cast<uint4*>(x + i);
+    v.x = v.x * 1664525u + 1013904223u; v.y = v.y * 1664525u + 1013904223u;
+    v.z = v.z * 1664525u + 1013904223u; v.w = v.w * 1664525u + 1013904223u;
+    *reinterpret_cast<uint4*>(x + i) = v;
+  }
+}
+// the same step with the element taken through LDS by the LDS-DMA (global_load_lds_dwordx4, as the product's GEMM / attention kernels
+// stage their tiles), 64 KB of LDS per workgroup so that two workgroups -- under two streams: of two different launches -- share a CU
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__global__ void __launch_bounds__(256) lcg_step_lds(unsigned* x, size_t n, unsigned rot) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const size_t blk = ((size_t)blockIdx.x * 7 + rot) % gridDim.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const size_t i = blk * 1024 + threadIdx.x * 4;
+  char* slot = smem + ((rot & 3) * 4 + wid) * 1024;      // a different part of the 64 KB each kernel
+  __builtin_amdgcn_global_load_lds((gptr_t)(x + blk * 1024 + wid * 256 + lane * 4), (lptr_t)slot, 16, 0, 0);
+  __builtin_amdgcn_s_waitcnt(0x0070 | (0xF << 8));        // vmcnt(0)
+  __builtin_amdgcn_s_barrier();
+  uint4 v = *reinterpret_cast<const uint4*>(slot + lane * 16);
+  v.x = v.x * 1664525u + 1013904223u; v.y = v.y * 1664525u + 1013904223u;
+  v.z = v.z * 1664525u + 1013904223u; v.w = v.w * 1664525u + 1013904223u;
+  if (i + 3 < n) *reinterpret_cast<uint4*>(x + i) = v;
+}
+__global__ void check(const unsigned* x, size_t n, unsigned mul, unsigned add, unsigned long long* bad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && x[i] != (unsigned)i * mul + add) atomicAdd(bad, 1ull);
+}
+__global__ void init(unsigned* x, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = (unsigned)i;
+}
+
+int main(int argc, char** argv) {
+  const int K = argc > 1 ? atoi(argv[1]) : 500, mib = argc > 2 ? atoi(argv[2]) : 90, reps = argc > 3 ? atoi(argv[3]) : 20;
+  const bool use_lds = argc > 4;
+  CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lcg_step_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  const size_t n = (size_t)mib * 1024 * 1024 / 4 / 1024 * 1024;
+  unsigned* buf[2];
+  unsigned long long* bad;
+  hipStream_t st[2];
+  for (int s = 0; s < 2; ++s) { CHK(hipMalloc(&buf[s], n * 4)); CHK(hipStreamCreateWithFlags(&st[s], hipStreamNonBlocking)); }
+  CHK(hipMalloc(&bad, 16));
+  unsigned mul = 1, add = 0;   // K-fold LCG: x -> mul * x + add
+  for (int k = 0; k < K; ++k) { mul = mul * 1664525u; add = add * 1664525u + 1013904223u; }
+  const unsigned grid = (unsigned)(n / 1024);
+  for (int mode = 0; mode < 2; ++mode) {   // 0: one chain after the other, 1: both at once
+    unsigned long long total_bad = 0;
+    for (int r = 0; r < reps; ++r) {
+      CHK(hipMemset(bad, 0, 16));
+      for (int s = 0; s < 2; ++s) hipLaunchKernelGGL(init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st[s], buf[s], n);
+      CHK(hipDeviceSynchronize());
+      for (int k = 0; k < K; ++k)
+        for (int s = 0; s < 2; ++s) {
+          if (mode == 0 && s == 1) continue;
+          if (use_lds) hipLaunchKernelGGL(lcg_step_lds, dim3(grid), dim3(256), 65536, st[s], buf[s], n, (unsigned)(k * 13 + s));
+          else hipLaunchKernelGGL(lcg_step, dim3(grid), dim3(256), 0, st[s], buf[s], n, (unsigned)(k * 13 + s));
+        }
+      if (mode == 0) {
+        CHK(hipDeviceSynchronize());
+        for (int k = 0; k < K; ++k) {
+          if (use_lds) hipLaunchKernelGGL(lcg_step_lds, dim3(grid), dim3(256), 65536, st[1], buf[1], n, (unsigned)(k * 13 + 1));
+          else hipLaunchKernelGGL(lcg_step, dim3(grid), dim3(256), 0, st[1], buf[1], n, (unsigned)(k * 13 + 1));
+        }
+      }
+      CHK(hipDeviceSynchronize());
+      for (int s = 0; s < 2; ++s) hipLaunchKernelGGL(check, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st[s], buf[s], n, mul, add, bad);
+      CHK(hipDeviceSynchronize());
+      unsigned long long h = 0;
+      CHK(hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost));
+      total_bad += h;
+    }
+    printf("%s%s: %d repetitions x 2 chains x %d kernels on %d MiB buffers: %llu wrong elements\n", use_lds ? "[LDS-DMA] " : "", mode ? "two streams at once" : "one stream at a time",
+           reps, K, mib, total_bad);
+  }
+  return 0;
+}
