@@ -1218,8 +1218,12 @@ static int enqueue_loop_iteration(Ctx* c, hipStream_t st) {
   ca.kind = s.scheduler; ca.clip = s.clip_sample; ca.coef = c->coef.as<StepCoef>(); ca.d_step = c->d_step.as<int>();
   ca.noise = s.step_noise; ca.seed = s.seed; ca.utt0 = s.first_utterance;
   const long long n4 = (long long)s.B * s.L * CFD_LAT / 4;
+  // the loop index is advanced by the last workgroup of cfg_step_kernel (CFD_TINY_ADVANCE=1: by a one-thread kernel behind it, as in
+  // round 1 -- kept for the A/B of tools/concurrency_soak.py)
+  static const bool tiny_advance = getenv("CFD_TINY_ADVANCE") != nullptr;
+  ca.advance = tiny_advance ? nullptr : c->d_step.as<int>();
   LAUNCH(CFD_PROF_OTHER, cfg_step_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), st, ca);
-  LAUNCH(CFD_PROF_OTHER, advance_step_kernel, dim3(1), dim3(1), st, c->d_step.as<int>());
+  if (tiny_advance) LAUNCH(CFD_PROF_OTHER, advance_step_kernel, dim3(1), dim3(1), st, c->d_step.as<int>());
   return CFD_OK;
 }
 

@@ -559,6 +559,8 @@ struct CfgStepArgs {
   int clip;
   const StepCoef* coef;
   const int* d_step;
+  int* advance;          // non-null: the last workgroup to finish advances the loop (d_step[0] += 1, d_step[2] = 0; d_step[3] is its ticket
+                         // counter), so the iteration needs no one-thread kernel behind this one
   const float* noise;    // injected [n_steps][B][L][128] or null -> Philox
   unsigned long long seed;
   unsigned int utt0;
@@ -568,8 +570,8 @@ __global__ void cfg_step_kernel(const CfgStepArgs a) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one thread = 4 elements
   const int per_utt = a.L * CFD_LAT;
   const long long n4 = (long long)a.B * per_utt / 4;
-  if (idx >= n4) return;
   const int i = *a.d_step;
+  if (idx < n4) {
   const StepCoef c = a.coef[i];
   const long long e0 = idx * 4;
   const long long chunk = (long long)a.B * per_utt;
@@ -614,6 +616,19 @@ __global__ void cfg_step_kernel(const CfgStepArgs a) {
     o[q] = prev;
   }
   *reinterpret_cast<float4*>(a.latents + e0) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  if (a.advance) {   // every thread of every workgroup has read the step index above before the last ticket is taken
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      const unsigned t = atomicAdd(reinterpret_cast<unsigned*>(a.advance + 3), 1u);
+      if (t == gridDim.x - 1) {
+        a.advance[3] = 0;
+        a.advance[2] = 0;
+        a.advance[0] = i + 1;
+      }
+    }
+  }
 }
 
 __global__ void advance_step_kernel(int* d_step) {

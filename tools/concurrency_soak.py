@@ -52,5 +52,36 @@ for rep in range(REPS):
     bad1 = [int(i) for i in torch.nonzero((p1 - full[h:]).abs().amax(dim=(1, 2)) > 0).flatten()]
     if bad0 or bad1:
         bad_reps += 1
-        print("rep", rep, "utterances that differ: shard 0", bad0, " shard 1", bad1)
+        cnt = [int(((p0[i] - full[i]).abs() > 0).sum()) for i in bad0] + [int(((p1[i] - full[h + i]).abs() > 0).sum()) for i in bad1]
+        print("rep", rep, "utterances that differ: shard 0", bad0, " shard 1", bad1, " elements that differ per utterance (of", p0[0].numel(), "):", cnt)
 print(f"concurrency soak: B={B} L={L} steps={N}: {bad_reps} of {REPS} repetitions differed ({REPS * N} step pairs)")
+
+if os.environ.get("ORIGIN"):
+    # where a difference starts: the single run's latents after every step, then concurrent shards compared step by step
+    # (the per-step read synchronises, so the two graphs still start together inside every step)
+    NS = int(os.environ["ORIGIN"])
+    with open_(0, B, False) as r:
+        traj = []
+        for _ in range(NS):
+            r.steps(1)
+            traj.append(r.read())
+    found = 0
+    for rep in range(REPS):
+        r0, r1 = open_(0, h, False), open_(h, B, True)
+        for k in range(NS):
+            r0.steps(1)
+            r1.steps(1)
+            p = torch.cat([r0.read(), r1.read()], 0)
+            d = (p - traj[k]).abs()
+            if float(d.max()) > 0:
+                utt = [int(i) for i in torch.nonzero(d.amax(dim=(1, 2)) > 0).flatten()]
+                u = utt[0]
+                du = d[u]
+                rows = [int(i) for i in torch.nonzero(du.amax(dim=1) > 0).flatten()]
+                print(f"rep {rep} step {k}: utterances {utt}; utterance {u}: {int((du > 0).sum())} of {du.numel()} elements differ, max abs {float(du.max()):.3e}, "
+                      f"median abs of differing {float(du[du > 0].median()):.3e}, latent rows that differ: {len(rows)} of {du.shape[0]} (first {rows[:8]})")
+                found += 1
+                break
+        r0.close()
+        r1.close()
+    print(f"origin search: {found} of {REPS} repetitions diverged within {NS} steps")
