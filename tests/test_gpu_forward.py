@@ -6,7 +6,8 @@ relative L2 (split-bf16x3 products carry ~2^-16 operand error) and attention pro
 import numpy as np
 import pytest
 
-from tests.helpers import forward_case, max_abs, rel_l2
+from oracle import inputs
+from tests.helpers import forward_case, max_abs, rel_l2, state_dict
 
 pytestmark = pytest.mark.gpu
 FWD_TOL = 1e-4
@@ -169,3 +170,31 @@ def test_headline_shape_rows_match_reference():
             del att
     finally:
         m.return_attention = keep
+
+
+def test_fused_cross_attention_with_several_long_memories_and_degenerate_rows():
+    """The fused cross-attention kernel on the shapes the golden cases do not have: THREE memories longer than one 32-key tile (the
+    single output accumulator is flushed to the residual stream between two online memories, and the per-memory sums of the rank-one
+    timestep term must survive those flushes), key lengths that are not multiples of 32, ragged key-padding masks, a memory row whose
+    512 features are all equal (the static part of its LayerNorm variance is 0: the per-step variance comes from the timestep
+    embedding alone) and one that is all zeros, queries in a partial last tile (L = 36).  Against the numpy oracle."""
+    import torch
+    from oracle import denoiser_ref
+    from tests.gpu_helpers import hip_denoiser, to_dev
+    B, L, S = 2, 36, (70, 200, 40, 33, 1)
+    cb = inputs.make_cfg_batch(seed=77, B=B, L=L, S=S, pad_tail=(5, 9, 0, 2, 0))
+    mems = [x.copy() for x in cb["memories"]]
+    mems[1][3, 17, :] = 0.731       # constant row
+    mems[0][5, 2, :] = 0.0          # zero row
+    rng = np.random.Generator(np.random.PCG64(5))
+    sample = rng.standard_normal((7 * B, L, 128)).astype(np.float32)
+    sd = state_dict()
+    m = hip_denoiser(1234, 1.0)
+    for t in (3, 640):
+        want, _ = denoiser_ref.denoiser_forward(sd, sample, t, mems, cb["masks"])
+        with torch.no_grad():
+            out, _ = m(torch.from_numpy(sample).cuda(), torch.tensor([t]).cuda(), [to_dev(x) for x in mems],
+                       mem_mask_dict={k: to_dev(v) for k, v in cb["masks"].items()})
+        e = rel_l2(out.cpu().numpy(), want)
+        print("t =", t, "rel L2 vs oracle", e)
+        assert e < FWD_TOL
