@@ -3,7 +3,7 @@
 // block -> data mapping that changes from kernel to kernel (so every line is touched by a different CU / XCD each time); after K
 // kernels every element must equal the K-fold LCG of its start value.
 //   hipcc --offload-arch=gfx950 -O3 tools/experiments/two_streams/two_streams.hip -o tools/experiments/two_streams/two_streams
-//   ./two_streams [kernels per chain] [MiB per buffer] [repetitions] [lds]
+//   ./two_streams [kernels per chain] [MiB per buffer] [repetitions] [lds|snap]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -38,6 +38,21 @@ __global__ void __launch_bounds__(256) lcg_step_lds(unsigned* x, size_t n, unsig
   v.z = v.z * 1664525u + 1013904223u; v.w = v.w * 1664525u + 1013904223u;
   if (i + 3 < n) *reinterpret_cast<uint4*>(x + i) = v;
 }
+// a SHORT consumer behind every big step: copies a 256 KB window of the buffer (position changes every kernel) into a log; the log must
+// hold the window as it is after exactly k + 1 steps
+__global__ void __launch_bounds__(256) snapshot(const unsigned* x, unsigned* log, size_t win0, int k) {
+  const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;     // 64 workgroups x 1024 elements
+  *reinterpret_cast<uint4*>(log + (size_t)k * 65536 + i) = *reinterpret_cast<const uint4*>(x + win0 + i);
+}
+__global__ void check_log(const unsigned* log, size_t win_stride, size_t n, int K, unsigned long long* bad) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)K * 65536) return;
+  const int k = (int)(idx / 65536);
+  const size_t i = ((size_t)k * win_stride) % (n - 65536) / 1024 * 1024 + idx % 65536;
+  unsigned v = (unsigned)i;
+  for (int q = 0; q <= k; ++q) v = v * 1664525u + 1013904223u;
+  if (log[idx] != v) atomicAdd(bad, 1ull);
+}
 __global__ void check(const unsigned* x, size_t n, unsigned mul, unsigned add, unsigned long long* bad) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && x[i] != (unsigned)i * mul + add) atomicAdd(bad, 1ull);
@@ -49,7 +64,11 @@ __global__ void init(unsigned* x, size_t n) {
 
 int main(int argc, char** argv) {
   const int K = argc > 1 ? atoi(argv[1]) : 500, mib = argc > 2 ? atoi(argv[2]) : 90, reps = argc > 3 ? atoi(argv[3]) : 20;
-  const bool use_lds = argc > 4;
+  const bool use_lds = argc > 4 && argv[4][0] == 'l';
+  const bool snap = argc > 4 && argv[4][0] == 's';
+  unsigned* logb[2] = {nullptr, nullptr};
+  const size_t win_stride = 7777777;
+  if (snap) for (int s2 = 0; s2 < 2; ++s2) CHK(hipMalloc(&logb[s2], (size_t)K * 65536 * 4));
   CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lcg_step_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   const size_t n = (size_t)mib * 1024 * 1024 / 4 / 1024 * 1024;
   unsigned* buf[2];
@@ -71,22 +90,27 @@ int main(int argc, char** argv) {
           if (mode == 0 && s == 1) continue;
           if (use_lds) hipLaunchKernelGGL(lcg_step_lds, dim3(grid), dim3(256), 65536, st[s], buf[s], n, (unsigned)(k * 13 + s));
           else hipLaunchKernelGGL(lcg_step, dim3(grid), dim3(256), 0, st[s], buf[s], n, (unsigned)(k * 13 + s));
+          if (snap) hipLaunchKernelGGL(snapshot, dim3(64), dim3(256), 0, st[s], buf[s], logb[s], ((size_t)k * win_stride) % (n - 65536) / 1024 * 1024, k);
         }
       if (mode == 0) {
         CHK(hipDeviceSynchronize());
         for (int k = 0; k < K; ++k) {
           if (use_lds) hipLaunchKernelGGL(lcg_step_lds, dim3(grid), dim3(256), 65536, st[1], buf[1], n, (unsigned)(k * 13 + 1));
           else hipLaunchKernelGGL(lcg_step, dim3(grid), dim3(256), 0, st[1], buf[1], n, (unsigned)(k * 13 + 1));
+          if (snap) hipLaunchKernelGGL(snapshot, dim3(64), dim3(256), 0, st[1], buf[1], logb[1], ((size_t)k * win_stride) % (n - 65536) / 1024 * 1024, k);
         }
       }
       CHK(hipDeviceSynchronize());
       for (int s = 0; s < 2; ++s) hipLaunchKernelGGL(check, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st[s], buf[s], n, mul, add, bad);
+      if (snap)
+        for (int s = 0; s < 2; ++s)
+          hipLaunchKernelGGL(check_log, dim3((unsigned)(((size_t)K * 65536 + 255) / 256)), dim3(256), 0, st[s], logb[s], win_stride, n, K, bad);
       CHK(hipDeviceSynchronize());
       unsigned long long h = 0;
       CHK(hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost));
       total_bad += h;
     }
-    printf("%s%s: %d repetitions x 2 chains x %d kernels on %d MiB buffers: %llu wrong elements\n", use_lds ? "[LDS-DMA] " : "", mode ? "two streams at once" : "one stream at a time",
+    printf("%s%s: %d repetitions x 2 chains x %d kernels on %d MiB buffers: %llu wrong elements\n", use_lds ? "[LDS-DMA] " : (snap ? "[short consumer behind every step] " : ""), mode ? "two streams at once" : "one stream at a time",
            reps, K, mib, total_bad);
   }
   return 0;
