@@ -215,9 +215,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shape", default="C2", choices=["C2", "R"])
-    ap.add_argument("--shards", type=int, default=1, choices=[1, 2],
-                    help="1 (default): one captured graph for the whole batch; 2: EXPERIMENTAL, each rank's batch as two utterance shards "
-                         "replayed side by side on two streams (sampler.ConcurrentRuns: ~+6 %%, but not reliable on this stack -- DESIGN.md section 6)")
     ap.add_argument("--no-full-loop", action="store_true", help="skip the secondary whole-1000-step-run wall time")
     ap.add_argument("--selftest-cpu", action="store_true", help="exercise only the N-rank launch path on CPU (gloo); no measurement")
     args = ap.parse_args()
@@ -247,7 +244,7 @@ def main():
 
     from convofusion_amd import scheduler
     from convofusion_amd.distributed import gather_latents
-    from convofusion_amd.sampler import ConcurrentRuns, SamplingRun
+    from convofusion_amd.sampler import SamplingRun
 
     model = make_model(device)
     mems, masks = make_inputs(B_PER_GPU, device, seed=1234 + rank)
@@ -256,11 +253,10 @@ def main():
     n_sched = 1000
     assert args.steps + args.warmup <= n_sched
 
-    def open_run(shards, **kw):
-        cls = ConcurrentRuns if shards == 2 else SamplingRun
-        return cls(model, sch, mems, masks, B_PER_GPU, L, n_sched, guidance_scale=7.5, seed=0, first_utterance=rank * B_PER_GPU, **kw)
+    def open_run(**kw):
+        return SamplingRun(model, sch, mems, masks, B_PER_GPU, L, n_sched, guidance_scale=7.5, seed=0, first_utterance=rank * B_PER_GPU, **kw)
 
-    run = open_run(args.shards)
+    run = open_run()
 
     def barrier():
         if world > 1:
@@ -292,27 +288,15 @@ def main():
     assert torch.isfinite(total).all()
     assert total.shape[0] == world * B_PER_GPU
 
+    # per-kernel-class timing with HIP events on the launch stream: ONE EAGER forward of the whole batch, every launch bracketed by
+    # an event pair (cfd_profile_forward).  The brackets cost a few per cent (the classes sum to more than ms_per_step, which is
+    # the replayed graph); the roofline objects below are built from these class times, i.e. slightly pessimistic.
+    prof = run.profile()
     run.close()
-
-    # The single-graph configuration: its rate, and per-kernel-class timing with HIP events on the launch stream (one eager forward of
-    # the whole batch).  The roofline object below describes the dominant kernel in THIS configuration, where nothing overlaps it.
-    run1 = open_run(1)
-    run1.steps(args.warmup)
-    run1.read()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    run1.steps(args.steps)
-    single = run1.read()
-    torch.cuda.synchronize()
-    dt_single = time.perf_counter() - t1
-    if not torch.equal(single, local):
-        print("WARNING: the two-shard run and the single run differ (tools/concurrency_soak.py, DESIGN.md section 6)", file=sys.stderr)
-    prof = run1.profile()
-    run1.close()
 
     # secondary measurement (NOT the headline value): same job without evaluating the full-conditioning chunk,
     # whose guidance weight is 7.5 * 0 in the reference (convofusion.py:538) -- identical latents, 6/7 of the work
-    run2 = open_run(args.shards, skip_zero_weight_chunks=True)
+    run2 = open_run(skip_zero_weight_chunks=True)
     run2.steps(args.warmup)
     run2.read()
     torch.cuda.synchronize()
@@ -330,7 +314,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         t2 = time.perf_counter()
-        run3 = open_run(args.shards)
+        run3 = open_run()
         run3.steps(n_sched)
         fin = run3.read(close=True)
         torch.cuda.synchronize()
@@ -361,6 +345,13 @@ def main():
             classes[k]["algorithmic_tflop"] = round(ex[k] / 1e12, 4)
             classes[k]["tflops"] = round(ex[k] / (prof[k][0] * 1e-3) / 1e12, 1) if prof[k][0] > 0 else None
             classes[k]["frac_of_peak"] = round(classes[k]["tflops"] / PEAK_BF16_TFLOPS, 4) if classes[k]["tflops"] else None
+        xa_ms, xa_n = prof["xattn"]
+        xa_ach = ex["xattn"] / (xa_ms * 1e-3) / 1e12 if xa_ms > 0 else 0.0
+        xattn_roofline = {"bound": "mfma", "kernel": "xattn_fused_kernel (the largest single symbol of the trace: LayerNorm2, scores, softmax, "
+                                                     "P.V and residual update of a layer's five cross-attentions in one launch)",
+                          "achieved": xa_ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": xa_ach / PEAK_BF16_TFLOPS,
+                          "frac_issued": 3.0 * xa_ach / PEAK_BF16_TFLOPS, "frac_of_issued_peak_div3": xa_ach / (PEAK_BF16_TFLOPS / 3.0),
+                          "launches_per_step": xa_n, "avg_launch_ms": xa_ms / max(xa_n, 1), "traffic": None}
         mfma_ms = sum(prof[k][0] for k in ex)
         all_mfma = sum(ex.values()) / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
         out = {
@@ -376,10 +367,7 @@ def main():
             "config": {"workload": f"configs[1]: B={B_PER_GPU}/GPU synthetic, L={L}, S={S}, 7-way guidance (denoiser batch {Be}), "
                                    f"DDPM 1000-step schedule, {args.steps} timed iterations of the hipGraph-captured loop",
                        "shape": args.shape,
-                       "parallelism": f"batch-shard x{world}, one all_gather of latents"
-                                      + ("; per GPU two utterance shards replayed side by side on two streams" if args.shards == 2 else "")},
-            "shards_per_gpu": args.shards,
-            "value_single_graph": args.steps / dt_single,
+                       "parallelism": f"batch-shard x{world}, one all_gather of latents"},
             "utterance_steps_per_s": world * B_PER_GPU * args.steps / dt,
             "value_without_zero_weight_chunk": args.steps / dt_skip,
             "full_loop_s": full_loop_s,
@@ -389,12 +377,18 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_sp_kernel (the matrix products launched inside one iteration: token side; the memory-side "
                                                             "projections run once per run since round 2)", "achieved": achieved,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                         "frac_issued": 3.0 * achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                         "frac_issued": 3.0 * achieved / PEAK_BF16_TFLOPS,
+                         "peak_div3": PEAK_BF16_TFLOPS / 3.0, "frac_of_issued_peak_div3": achieved / (PEAK_BF16_TFLOPS / 3.0),
+                         "traffic": traffic,
                          "launches_per_step": dom_n, "avg_launch_ms": dom_ms / max(dom_n, 1),
                          "all_mfma_kernels_achieved": all_mfma, "all_mfma_kernels_frac": all_mfma / PEAK_BF16_TFLOPS,
-                         "note": "achieved = algorithmic (single-product) FLOPs of the launched GEMMs / their HIP-event time; "
-                                 "each product is issued as 3 f16 MFMAs, so the MFMA pipe sees 3x this; traffic = mean HBM bytes "
+                         "note": "achieved = algorithmic (single-product) FLOPs of the launched GEMMs / their HIP-event time, taken "
+                                 "from ONE EAGER forward with every launch bracketed by an event pair (the class times sum to a few "
+                                 "per cent more than ms_per_step, which is the replayed hipGraph: the brackets cost that); "
+                                 "each product is issued as 3 f16 MFMAs, so the MFMA pipe sees 3x this and the ceiling of the "
+                                 "f16x3 instruction mix is peak / 3 = 833 TFLOP/s (frac_of_issued_peak_div3); traffic = mean HBM bytes "
                                  "per launch from rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE (profiles/)"},
+            "roofline_xattn": xattn_roofline,
             "kernel_classes": classes,
             "tflop_once_per_run_not_per_step": once_per_run,
         }

@@ -54,7 +54,8 @@ class SampleArgs(C.Structure):
                 ("steps_offset", C.c_int), ("alphas_cumprod", C.c_void_p), ("init_latents", C.c_void_p),
                 ("step_noise", C.c_void_p), ("seed", C.c_uint64), ("first_utterance", C.c_uint32),
                 ("preseq", C.c_void_p), ("preseq_len", C.c_int), ("mem", Memory * NUM_MEM),
-                ("skip_zero_weight_chunks", C.c_int), ("dynamic_memory_mask", C.c_int)]
+                ("skip_zero_weight_chunks", C.c_int), ("dynamic_memory_mask", C.c_int),
+                ("timesteps", C.c_void_p), ("num_timesteps", C.c_int)]
 
 
 class WegArgs(C.Structure):
@@ -63,6 +64,17 @@ class WegArgs(C.Structure):
 
 
 _lib = None
+
+
+def _built_hash():
+    """The source hash embedded in the built library file ("missing" if there is none)."""
+    try:
+        with open(LIB_PATH, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return "missing"
+    k = blob.find(b"cfd-src-hash:")
+    return blob[k + 13:k + 29].decode(errors="replace") if k >= 0 else "missing"
 
 
 def load():
@@ -77,18 +89,26 @@ def load():
     if "CFD_LIB" not in os.environ:      # (a developer override is taken as it is)
         from . import build
         want = build.source_hash()
-        with open(LIB_PATH, "rb") as f:
-            blob = f.read()
-        k = blob.find(b"cfd-src-hash:")
-        have = blob[k + 13:k + 29].decode(errors="replace") if k >= 0 else "missing"
-        if have != want:
+        if _built_hash() != want:
             # built from other sources (an update changed csrc/ or include/cfdenoise.h): a stale library would mis-read
             # struct arguments instead of failing.  hipcc needs no GPU, so rebuild before the file is mapped; without hipcc refuse.
-            try:
-                build.build(force=True)
-            except Exception as e:
-                raise ImportError(f"{LIB_PATH} was built from other sources (hash {have}, sources {want}) and could not be rebuilt "
-                                  f"({e}); run `python -m convofusion_amd.build`") from e
+            # One process rebuilds (file lock: the ranks of a multi-GPU launch all get here at once); build.build() writes to a
+            # temporary name and renames it into place, and the hash is read again before the file is mapped.
+            import fcntl
+            with open(LIB_PATH + ".lock", "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                try:
+                    have = _built_hash()
+                    if have != want:
+                        try:
+                            build.build(force=True)
+                        except Exception as e:
+                            raise ImportError(f"{LIB_PATH} was built from other sources (hash {have}, sources {want}) and could not be "
+                                              f"rebuilt ({e}); run `python -m convofusion_amd.build`") from e
+                        if _built_hash() != want:
+                            raise ImportError(f"{LIB_PATH}: rebuilt library still carries hash {_built_hash()}, sources are {want}")
+                finally:
+                    fcntl.flock(lock, fcntl.LOCK_UN)
     lib = C.CDLL(LIB_PATH)
     lib.cfd_last_error.restype = C.c_char_p
     lib.cfd_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]

@@ -41,11 +41,17 @@ def build(force=False, verbose=False):
     """Compile the HIP library for gfx950.  Returns the path of the shared object."""
     if not force and not is_stale():
         return LIB
+    tmp = f"{LIB}.{os.getpid()}.tmp"     # never a half-written file under the final name: another process may be mapping it
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
-           f'-DCFD_SOURCE_HASH="{source_hash()}"', *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+           f'-DCFD_SOURCE_HASH="{source_hash()}"', *[os.path.join(CSRC, s) for s in SOURCES], "-o", tmp]
     if verbose:
         print(" ".join(cmd))
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    try:
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 

@@ -149,6 +149,7 @@ struct cfd_handle_s {
   float prof_ms[CFD_PROF_NCLASS];
   int prof_n[CFD_PROF_NCLASS];
   int stop_stage = 0;  // test hook: leave enqueue_denoise after this tap point (0 = run everything)
+  int run_iters = 0;                 // loop iterations of the open run (= length of the timestep table)
   hipStream_t own_stream = nullptr;  // non-blocking stream the captured loop iteration replays on
   // sampling run
   bool run_open = false;
@@ -935,11 +936,11 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     EpiResid e{c->x.as<float>(), 0, bias};
     return run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st);
   };
-  static bool attr = false;
-  if (!attr) {
+  static unsigned long long attr = 0;   // per device (one bit per ordinal): a process may hold handles on several GPUs
+  if (!((attr >> (c->cfg.device & 63)) & 1ull)) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
-    attr = true;
+    attr |= 1ull << (c->cfg.device & 63);
   }
 
   for (int l = 0; l < nl; ++l) {
@@ -1157,7 +1158,7 @@ extern "C" int cfd_profile_forward(cfd_handle c, float ms[CFD_PROF_NCLASS], int 
   if (!c || !ms || !launches) return fail(CFD_E_ARG, "null argument");
   if (c->pb.Be == 0) return fail(CFD_E_STATE, "no problem configured (call cfd_forward or cfd_sample_begin first)");
   HIPCHK(hipSetDevice(c->cfg.device));
-  if (c->run_open && c->run_pos >= c->sargs.num_inference_steps)
+  if (c->run_open && c->run_pos >= c->run_iters)
     return fail(CFD_E_STATE, "sampling run is complete; profile before the last iteration");
   hipStream_t st = c->run_open ? c->run_stream : nullptr;
   HIPCHK(hipStreamSynchronize(st));
@@ -1236,16 +1237,22 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
   if (s.scheduler != 0 && s.scheduler != 1) return fail(CFD_E_ARG, "scheduler must be 0 (DDPM) or 1 (DDIM)");
   if (!s.alphas_cumprod || s.num_train_timesteps < 1 || s.num_inference_steps < 1 || s.num_inference_steps > s.num_train_timesteps)
     return fail(CFD_E_ARG, "bad scheduler tables");
-  if (s.scheduler == 0 && s.num_train_timesteps % s.num_inference_steps)
-    return fail(CFD_E_ARG, "DDPM: num_inference_steps = %d must divide num_train_timesteps = %d (the timestep table for other counts "
-                           "differs between diffusers releases and is unpinned)", s.num_inference_steps, s.num_train_timesteps);
+  if (s.timesteps && (s.num_timesteps < 1 || s.num_timesteps > s.num_train_timesteps)) return fail(CFD_E_ARG, "bad num_timesteps");
+  if (!s.timesteps && s.scheduler == 0 && s.num_train_timesteps % s.num_inference_steps)
+    return fail(CFD_E_ARG, "DDPM: num_inference_steps = %d does not divide num_train_timesteps = %d: the loop's timestep table for such "
+                           "counts differs between diffusers releases (unpinned); pass the scheduler's table in cfd_sample_args.timesteps",
+                s.num_inference_steps, s.num_train_timesteps);
   if (s.preseq && (s.preseq_len < 1 || s.preseq_len > s.L)) return fail(CFD_E_ARG, "bad preseq_len");
   hipStream_t st = (hipStream_t)stream;
   c->sargs = s;
   c->run_stream = st;
   if (s.skip_zero_weight_chunks)   // chunk-major batch: dropping trailing chunks = using the first G' * B rows
     while (c->sargs.G > 1 && s.guidance_weight[c->sargs.G - 1] == 0.0f) c->sargs.G -= 1;
-  const int Be = c->sargs.G * s.B, N = s.num_inference_steps, T = s.num_train_timesteps;
+  // N = loop iterations (the length of scheduler.timesteps); n_inf = the count given to set_timesteps, which fixes the
+  // stride `prev_t = t - T // n_inf` of the step formulas.  They differ only for a caller-supplied table.
+  const int Be = c->sargs.G * s.B, n_inf = s.num_inference_steps, N = s.timesteps ? s.num_timesteps : n_inf, T = s.num_train_timesteps;
+  c->sargs.timesteps = nullptr;   // (host pointer: not kept beyond this call)
+  c->run_iters = N;
   for (int k = 0; k < 8; ++k) c->chunk_pos[k] = k;
   cfd_memory mem_in[CFD_NMEM];
   for (int j = 0; j < CFD_NMEM; ++j) mem_in[j] = s.mem[j];
@@ -1297,14 +1304,13 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
   // timesteps: (arange(N) * (T // N)).round()[::-1] (+ steps_offset for DDIM)
   std::vector<int32_t> ts(N);
   std::vector<StepCoef> coef(N);
-  const int ratio = T / N;
+  const int ratio = T / n_inf;
   for (int i = 0; i < N; ++i) {
-    int t = (N - 1 - i) * ratio;
-    if (s.scheduler == 1) t += s.steps_offset;
+    int t = s.timesteps ? s.timesteps[i] : (N - 1 - i) * ratio + (s.scheduler == 1 ? s.steps_offset : 0);
     if (t < 0 || t >= T) return fail(CFD_E_ARG, "timestep %d out of range", t);
     ts[i] = t;
-    if (s.scheduler == 0) ddpm_coef(s.alphas_cumprod, T, N, t, &coef[i]);
-    else ddim_coef(s.alphas_cumprod, T, N, t, s.eta, s.set_alpha_to_one, &coef[i]);
+    if (s.scheduler == 0) ddpm_coef(s.alphas_cumprod, T, n_inf, t, &coef[i]);
+    else ddim_coef(s.alphas_cumprod, T, n_inf, t, s.eta, s.set_alpha_to_one, &coef[i]);
   }
   CHK(c->coef.ensure((size_t)N * sizeof(StepCoef)));
   HIPCHK(hipMemcpyAsync(c->coef.p, coef.data(), (size_t)N * sizeof(StepCoef), hipMemcpyHostToDevice, st));
@@ -1368,8 +1374,8 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
 extern "C" int cfd_sample_steps(cfd_handle c, int n) {
   if (!c) return fail(CFD_E_ARG, "null handle");
   if (!c->run_open) return fail(CFD_E_STATE, "no sampling run open");
-  if (n < 0 || c->run_pos + n > c->sargs.num_inference_steps)
-    return fail(CFD_E_ARG, "run has %d of %d iterations done; cannot run %d more", c->run_pos, c->sargs.num_inference_steps, n);
+  if (n < 0 || c->run_pos + n > c->run_iters)
+    return fail(CFD_E_ARG, "run has %d of %d iterations done; cannot run %d more", c->run_pos, c->run_iters, n);
   HIPCHK(hipSetDevice(c->cfg.device));
   static const bool eager = getenv("CFD_EAGER_STEPS") != nullptr;   // developer experiment: enqueue every iteration's launches instead of replaying the graph
   for (int i = 0; i < n; ++i) {

@@ -38,6 +38,9 @@
 #ifndef CFD_READS_FIRST
 #define CFD_READS_FIRST 1
 #endif
+#ifndef CFD_EXP
+#define CFD_EXP 0   // developer builds for the two-queue investigation (tools/concurrency_variants.sh); 0 = product
+#endif
 #define GEMM_SLOTS 5
 enum { MODE_PLAIN = 0, MODE_GROUPED = 1, MODE_SEGK = 2 };
 
@@ -96,7 +99,16 @@ struct EpiF32 {  // out_f32[j][goff+i] = v (+ bias[i] | + key-bias of group g)
   }
   __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v, const Pre& t) const {
     float* p = out + (long long)b * obs + (long long)z * ozs + (long long)j * ldo + sel5(goff, g) + i;
+#if CFD_EXP == 2 || CFD_EXP == 3   // two-queue investigation: write-through stores of the hand-off buffer
+    const f32x4 r = f32x4{v[0] + t.x, v[1] + t.y, v[2] + t.z, v[3] + t.w};
+#if CFD_EXP == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(r) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(r) : "memory");
+#endif
+#else
     *reinterpret_cast<float4*>(p) = make_float4(v[0] + t.x, v[1] + t.y, v[2] + t.z, v[3] + t.w);
+#endif
   }
 };
 
@@ -645,6 +657,13 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
         }
       }
   }
+#if CFD_EXP == 1 || CFD_EXP == 2 || CFD_EXP == 3
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // every store acknowledged before the wave ends
+#elif CFD_EXP == 4
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                  // L2 write-back by every wave
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 }
 
 // Reference kernel with the same operands / epilogues, one thread per (4 i, 1 j): used by the
@@ -703,12 +722,15 @@ static hipError_t launch_cfg(GemmArgs a, const Epi& epi, int nb, int nz, hipStre
   }
   a.tile_start[ng] = total;
   constexpr int lds = NSTAGE * (BI + BJ) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the attribute is per device: one bit per device ordinal (a process may hold handles on several GPUs)
+  static unsigned long long attr_set = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!((attr_set >> (dev & 63)) & 1ull)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sp_kernel<WI, WJ, TI, TJ, NSTAGE, MODE, Epi>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set |= 1ull << (dev & 63);
   }
   hipLaunchKernelGGL((gemm_sp_kernel<WI, WJ, TI, TJ, NSTAGE, MODE, Epi>), dim3(total, nb, nz), dim3(WI * WJ * 64), lds, st, a, epi);
   return hipGetLastError();

@@ -571,6 +571,12 @@ __global__ void cfg_step_kernel(const CfgStepArgs a) {
   const int per_utt = a.L * CFD_LAT;
   const long long n4 = (long long)a.B * per_utt / 4;
   const int i = *a.d_step;
+#if CFD_EXP == 5   // two-queue investigation: agent-scope acquire (L1 invalidate) in front of the first read of eps
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#elif CFD_EXP == 6 // ... or simply a delay of ~10 us in front of it (is a write of the previous kernel still on its way?)
+  for (int w = 0; w < 200; ++w) __builtin_amdgcn_s_sleep(127);
+#endif
   if (idx < n4) {
   const StepCoef c = a.coef[i];
   const long long e0 = idx * 4;

@@ -37,7 +37,8 @@ def _diffusion_reverse(self, encoder_hidden_states, lengths=None, cond_masks=dic
     """Bound replacement of ``Convofusion._diffusion_reverse`` (same signature, same return value: latents [L, B, 128] and
     the attention-matrix dict -- see ``convofusion_amd.sampler.diffusion_reverse`` for which entries it holds)."""
     from .sampler import diffusion_reverse
-    return diffusion_reverse(self, encoder_hidden_states, lengths, cond_masks, focus_indices)
+    return diffusion_reverse(self, encoder_hidden_states, lengths, cond_masks, focus_indices,
+                             attention_steps=getattr(self, "_cfd_attention_steps", "last"))
 
 
 def diffusion_reverse_forecast(model, encoder_hidden_states, lengths=None, preseq=None, cond_masks=dict(), focus_indices=[]):
@@ -46,9 +47,18 @@ def diffusion_reverse_forecast(model, encoder_hidden_states, lengths=None, prese
     return impl(model, encoder_hidden_states, lengths, preseq, cond_masks, focus_indices)
 
 
-def install(model):
-    """Bind the fused loop as ``model._diffusion_reverse``.  Returns the model.  ``uninstall`` removes the binding."""
+def install(model, attention_steps="last"):
+    """Bind the fused loop as ``model._diffusion_reverse``.  Returns the model.  ``uninstall`` removes the binding.
+
+    ``attention_steps``: which entries the returned attention-matrix dict holds.  The reference keeps the full-conditioning
+    chunk's maps of EVERY iteration (convofusion.py:517-523) and its result writer dumps one ``att_<t>.npy`` per entry and
+    memory (convofusion/models/modeltype/base.py:252-259).  "last" (default) returns the final iteration's entry only -- the
+    loop then never leaves the device; "all" reproduces the reference's dict (one extra forward of the B full-conditioning
+    rows and one host round trip per iteration), so an unchanged ``test.py`` writes the same files."""
     _check_model(model)
+    if attention_steps not in ("last", "all"):
+        raise ValueError("attention_steps must be 'last' or 'all'")
+    model._cfd_attention_steps = attention_steps
     model._diffusion_reverse = types.MethodType(_diffusion_reverse, model)
     return model
 
@@ -57,6 +67,7 @@ def uninstall(model):
     """Remove the instance binding: the class's own ``_diffusion_reverse`` is visible again."""
     if "_diffusion_reverse" in vars(model):
         del model._diffusion_reverse
+    vars(model).pop("_cfd_attention_steps", None)
     return model
 
 

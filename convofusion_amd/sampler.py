@@ -115,7 +115,7 @@ class SamplingRun:
                  seed=0, first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False, row_maps=None,
                  dynamic_memories=(), side_engine=False):
         """side_engine: open the run on the denoiser's second library handle (its own weights copy, workspace and stream), so that
-        two runs on one module -- two utterance shards of one batch -- can be open and replay concurrently (``sample_concurrent``).
+        two runs on one module can be open at once (the attention forward of ``last_step_attention`` uses it for a plain forward).
         dynamic_memories: indices j of memories whose CONTENTS the caller rewrites between iterations (DyadicRun's partner
         projection).  All others are constants of the run, as in the reference loop, and the library computes the
         timestep-independent part of their projections once (cfd_sample_args.dynamic_memory_mask)."""
@@ -126,9 +126,13 @@ class SamplingRun:
             raise RuntimeError("the fused sampler runs on an MI355X only (no CPU fallback)")
         self.lib = _lib.load()
         self.device = dev
-        if getattr(scheduler, "KIND", None) == 0:      # DDPMScheduler.set_timesteps clamps the count to the training schedule
-            num_inference_steps = min(int(scheduler.config.num_train_timesteps), int(num_inference_steps))
-        self.B, self.L, self.N = B, L, num_inference_steps
+        if getattr(scheduler, "KIND", None) is None:
+            raise TypeError("scheduler must be a convofusion_amd.scheduler DDPMScheduler / DDIMScheduler")
+        # the loop runs over scheduler.timesteps: DDPM clamps the count to the training schedule, and for a count that does not
+        # divide it the (opt-in, unpinned) 0.14.0 table has more entries than the count (scheduler.timestep_table)
+        num_inference_steps, table = scheduler.timestep_table(num_inference_steps)
+        self.timesteps = [int(t) for t in table]
+        self.B, self.L, self.N = B, L, len(self.timesteps)     # N = loop iterations
         G = guidance_chunks
         if row_maps is not None:       # already-distinct memories + maps (build_guidance_batch)
             if any(int(m.numel()) != G * B for m in row_maps):
@@ -155,10 +159,7 @@ class SamplingRun:
             for k in range(1, G):
                 w[k] = float(guidance_scale)
         a.guidance_weight = (C.c_float * 8)(*w)
-        kind = getattr(scheduler, "KIND", None)
-        if kind is None:
-            raise TypeError("scheduler must be a convofusion_amd.scheduler DDPMScheduler / DDIMScheduler")
-        a.scheduler = kind
+        a.scheduler = scheduler.KIND
         a.num_train_timesteps = scheduler.config.num_train_timesteps
         a.num_inference_steps = num_inference_steps
         a.clip_sample = 1 if scheduler.config.clip_sample else 0
@@ -175,8 +176,8 @@ class SamplingRun:
                 setattr(a, name, t.data_ptr())
         if init_latents is not None and tuple(init_latents.shape) != (B, L, 128):
             raise ValueError("init_latents must be [B, L, 128]")
-        if step_noise is not None and tuple(step_noise.shape) != (num_inference_steps, B, L, 128):
-            raise ValueError("step_noise must be [num_inference_steps, B, L, 128]")
+        if step_noise is not None and tuple(step_noise.shape) != (self.N, B, L, 128):
+            raise ValueError("step_noise must be [len(scheduler.timesteps), B, L, 128]")
         a.preseq_len = int(preseq.shape[1]) if preseq is not None else 0
         a.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         a.first_utterance = int(first_utterance)
@@ -186,6 +187,9 @@ class SamplingRun:
         # the per-step attention maps it logs)
         a.skip_zero_weight_chunks = 1 if skip_zero_weight_chunks else 0
         a.dynamic_memory_mask = sum(1 << int(j) for j in set(dynamic_memories))
+        ts = (C.c_int32 * self.N)(*self.timesteps)
+        self._keep.append(ts)
+        a.timesteps, a.num_timesteps = C.cast(ts, C.c_void_p), self.N
         self._args = a
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
@@ -251,82 +255,6 @@ class SamplingRun:
             pass
 
 
-def _utterance_slice(t, a, b, total, chunks):
-    """Utterances [a, b) of a chunk-major guidance batch [chunks * total, ...] (same rule as distributed.shard_cfg_batch)."""
-    if t is None:
-        return None
-    v = t.reshape(chunks, total, *t.shape[1:])
-    return v[:, a:b].reshape(chunks * (b - a), *t.shape[1:]).contiguous()
-
-
-class ConcurrentRuns:
-    """EXPERIMENTAL, not used by default.  One batch as TWO open sampling runs -- utterance shards [0, B/2) and [B/2, B) -- on the
-    denoiser's two library handles, each with its own captured hipGraph, workspace and stream, replayed side by side.
-
-    Utterances are independent and the Philox streams are keyed by global utterance id, so the latents should be bit-identical to
-    the single run's, and two half-size graphs fill each other's kernel tails: 71.6 -> 76.0 steps/s at B = 32, L = 196.  BUT on this
-    stack (ROCm 7.2, MI355X) two graphs replaying concurrently are not reliable: ``tools/concurrency_soak.py`` shows single utterances
-    with wrong latents about once per 1 000 - 1 500 step pairs (fused and three-launch attention paths alike, the shard whose graph
-    is launched first in a step more often; a device synchronisation after every step pair does not remove it; buffers of the two
-    handles are disjoint, no kernel uses scratch memory).  The cause was not found in round 2, so nothing
-    in the package selects this class by itself; ``sample(..., concurrent_shards=2)`` and ``bench.py --shards 2`` are opt-in.
-    Same interface as ``SamplingRun`` for steps / read / close.
-    """
-
-    def __init__(self, denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps, guidance_scale=7.5,
-                 guidance_chunks=CFG_CHUNKS, eta=0.0, init_latents=None, step_noise=None, seed=0, first_utterance=0, preseq=None,
-                 dedup=True, skip_zero_weight_chunks=False):
-        if B < 2:
-            raise ValueError("two concurrent shards need at least two utterances")
-        G = guidance_chunks
-        if encoder_hidden_states[0].shape[0] != G * B:
-            raise ValueError(f"conditioning batch is {encoder_hidden_states[0].shape[0]} rows, expected G*B = {G * B}")
-        self.B, self.L, self.N = B, L, num_inference_steps
-        self.runs = []
-        cuts = (0, (B + 1) // 2, B)
-        try:
-            for k in range(2):
-                a, b = cuts[k], cuts[k + 1]
-                mems = [_utterance_slice(m, a, b, B, G) for m in encoder_hidden_states]
-                masks = {n: _utterance_slice(v, a, b, B, G) for n, v in (cond_masks or {}).items()}
-                self.runs.append(SamplingRun(
-                    denoiser, scheduler, mems, masks, b - a, L, num_inference_steps, guidance_scale, G, eta,
-                    None if init_latents is None else init_latents[a:b], None if step_noise is None else step_noise[:, a:b],
-                    seed, first_utterance + a, None if preseq is None else preseq[a:b], dedup, skip_zero_weight_chunks,
-                    side_engine=bool(k)))
-        except Exception:
-            self.close()
-            raise
-        self.open = True
-
-    def steps(self, n):
-        for _ in range(int(n)):      # one replay per shard and iteration: the two streams advance together
-            for r in self.runs:
-                r.steps(1)
-
-    @property
-    def position(self):
-        return self.runs[0].position
-
-    def read(self, close=False):
-        out = torch.cat([r.read(close) for r in self.runs], dim=0)
-        if close:
-            self.open = False
-        return out
-
-    def close(self):
-        for r in self.runs:
-            r.close()
-        self.open = False
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        self.close()
-        return False
-
-
 def last_step_attention(run, denoiser, timestep, encoder_hidden_states, cond_masks, guidance_chunks=CFG_CHUNKS, row_maps=None):
     """The attention maps the reference keeps from an iteration: ``att_mats`` of the LAST guidance chunk (full
     conditioning) of the denoiser call (convofusion.py:517-523, unbounded_synthesis.py:159-161) -- 5 tensors
@@ -348,6 +276,9 @@ def last_step_attention(run, denoiser, timestep, encoder_hidden_states, cond_mas
     try:
         with torch.no_grad():
             _, att = denoiser(sample=lat, timestep=int(timestep), encoder_hidden_states=enc, mem_mask_dict=masks, side_engine=True)
+        # the side engine's forward runs on torch's current stream, the captured iteration replays on the run's own stream: wait
+        # here, so that the two never execute side by side (two queues at once are not reliable on this stack)
+        torch.cuda.current_stream(lat.device).synchronize()
     finally:
         denoiser.return_attention = keep
     return att
@@ -355,42 +286,26 @@ def last_step_attention(run, denoiser, timestep, encoder_hidden_states, cond_mas
 
 def sample(denoiser, scheduler, encoder_hidden_states, cond_masks=None, *, B, L=16, num_inference_steps=1000,
            guidance_scale=7.5, guidance_chunks=CFG_CHUNKS, eta=0.0, init_latents=None, step_noise=None, seed=0,
-           first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False, row_maps=None, return_attention=False,
-           concurrent_shards=None):
+           first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False, row_maps=None, return_attention=False):
     """Run the whole loop; returns latents [B, L, 128] (batch-first); with ``return_attention=True`` also the last
     iteration's attention maps (``last_step_attention``), with ``return_attention="all"`` a dict {timestep: maps} over every
-    iteration like the reference's (the loop then leaves the device once per step).
-    ``concurrent_shards``: 2 = run the batch as two utterance shards side by side (``ConcurrentRuns``: faster, but EXPERIMENTAL --
-    see its docstring; the default is 1)."""
-    can_split = row_maps is None and not return_attention and B >= 2 and encoder_hidden_states[0].shape[0] == guidance_chunks * B
-    if concurrent_shards is None:
-        concurrent_shards = 1
-    if concurrent_shards not in (1, 2):
-        raise ValueError("concurrent_shards must be 1 or 2 (more shards were measured slower)")
-    if concurrent_shards == 2:
-        if not can_split:
-            raise ValueError("concurrent shards need the replicated chunk-major batch (no row_maps), B >= 2 and no attention maps")
-        with ConcurrentRuns(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps, guidance_scale,
-                            guidance_chunks, eta, init_latents, step_noise, seed, first_utterance, preseq, dedup,
-                            skip_zero_weight_chunks) as runs:
-            runs.steps(num_inference_steps)
-            return runs.read(close=True)
+    iteration like the reference's (the loop then leaves the device once per step)."""
     run = SamplingRun(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
                       guidance_scale, guidance_chunks, eta, init_latents, step_noise, seed, first_utterance, preseq, dedup,
                       skip_zero_weight_chunks, row_maps)
     try:
         if not return_attention:
-            run.steps(num_inference_steps)
+            run.steps(run.N)
             return run.read(close=True)
         scheduler.set_timesteps(num_inference_steps)
         if return_attention == "all":   # the reference's full dict: one entry per iteration (convofusion.py:523); one extra forward + sync per step
             atts = {}
-            for t in scheduler.timesteps:
+            for t in run.timesteps:
                 atts[int(t)] = last_step_attention(run, denoiser, t, encoder_hidden_states, cond_masks, guidance_chunks, row_maps)
                 run.steps(1)
             return run.read(close=True), atts
-        run.steps(num_inference_steps - 1)
-        att = last_step_attention(run, denoiser, scheduler.timesteps[-1], encoder_hidden_states, cond_masks, guidance_chunks, row_maps)
+        run.steps(run.N - 1)
+        att = last_step_attention(run, denoiser, run.timesteps[-1], encoder_hidden_states, cond_masks, guidance_chunks, row_maps)
         run.steps(1)
         return run.read(close=True), att
     finally:
@@ -461,14 +376,19 @@ def sample_with_weg(denoiser, scheduler, encoder_hidden_states, cond_masks, focu
             text_states = [enc.chunk(G)[1] for enc in encoder_hidden_states]                           # :447
             text_masks = {k: (v.chunk(G)[1].to(torch.uint8).contiguous() if v is not None else v) for k, v in (cond_masks or {}).items()}  # :448
         thresholds = dict(weg_parameters["thresholds"])
-        timesteps = [int(t) for t in scheduler.timesteps]
+        timesteps = run.timesteps
         carry = [weg_parameters["scale_range"][0], weg_parameters["scale_range"][1]] if carry_scale_range else None   # :395
-        att = None
+        every = return_attention == "all"     # the reference's dict: one entry per iteration (convofusion.py:517-523)
+        att = {} if every else None
+
+        def maps(t):
+            return last_step_attention(run, denoiser, t, encoder_hidden_states, cond_masks, G, kw.get("row_maps"))
+
         for i, t in enumerate(timesteps):
             last = i == len(timesteps) - 1
             # past max_iter_to_alter the reference still evaluates the objective but only acts on it at a threshold step
             if i >= weg_parameters["max_iter_to_alter"] and i not in thresholds:
-                if not any(k > i for k in thresholds):
+                if not any(k > i for k in thresholds) and not every:
                     break
                 if carry is not None:   # the skipped iteration still re-assigns the table (convofusion.py:442-444)
                     weg.scale_range_schedule(weg_parameters, len(timesteps), i, carry)
@@ -477,13 +397,15 @@ def sample_with_weg(denoiser, scheduler, encoder_hidden_states, cond_masks, focu
                 lat, _ = weg.weg_update(denoiser, run.read(), i, t, text_states, text_masks, focus_indices, weg_parameters, len(timesteps),
                                         scale_carry=carry)
                 run.write(lat)
-            if last and return_attention:
-                att = last_step_attention(run, denoiser, t, encoder_hidden_states, cond_masks, G, kw.get("row_maps"))
+            if every:
+                att[int(t)] = maps(t)
+            elif last and return_attention:
+                att = maps(t)
             run.steps(1)
         if return_attention and att is None:
-            run.steps(num_inference_steps - 1 - run.position)
-            att = last_step_attention(run, denoiser, timesteps[-1], encoder_hidden_states, cond_masks, G, kw.get("row_maps"))
-        run.steps(num_inference_steps - run.position)
+            run.steps(run.N - 1 - run.position)
+            att = maps(timesteps[-1])
+        run.steps(run.N - run.position)
         lat = run.read(close=True)
     finally:
         run.close()     # an exception (bad focus index, CfdError ...) must not leave the run open on the denoiser's handle
@@ -497,10 +419,13 @@ def diffusion_reverse(model, encoder_hidden_states, lengths=None, cond_masks=dic
     clf_guidance_drops / latent_dim / do_classifier_free_guidance exactly like the reference).
     Returns (latents [L, B, 128], attention_matrices dict).  The reference fills the dict with the full-conditioning
     chunk's ``att_mats`` of EVERY iteration (1000 x 5 tensors kept alive, written out as att_<t>.npy by base.py:252-259);
-    the fused loop keeps the last iteration's entry only: {t_last: att_mats} (``last_step_attention``);
-    ``attention_steps="all"`` (without focus_indices) fills the whole dict at the price of one extra forward and one host
-    round trip per iteration."""
-    if attention_steps == "all" and len(focus_indices) == 0:
+    by default the fused loop keeps the last iteration's entry only: {t_last: att_mats} (``last_step_attention``);
+    ``attention_steps="all"`` fills the whole dict like the reference at the price of one extra forward of the B
+    full-conditioning rows and one host round trip per iteration (``convofusion_amd.install(model, attention_steps="all")``
+    makes the binding do that, so that base.py's per-timestep dump comes out complete)."""
+    if attention_steps not in ("last", "all"):
+        raise ValueError("attention_steps must be 'last' or 'all'")
+    if attention_steps == "all":
         lat, atts = _loop_from_model(model, encoder_hidden_states, cond_masks, None, focus_indices, init_latents, seed, attention="all")
         return lat.permute(1, 0, 2), atts
     lat, att = _loop_from_model(model, encoder_hidden_states, cond_masks, None, focus_indices, init_latents, seed)

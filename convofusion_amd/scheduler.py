@@ -113,30 +113,42 @@ class DDPMScheduler(_SchedulerBase):
     KIND = 0
 
     def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
-                 trained_betas=None, variance_type="fixed_small", clip_sample=True, prediction_type="epsilon", **kwargs):
+                 trained_betas=None, variance_type="fixed_small", clip_sample=True, prediction_type="epsilon",
+                 allow_unpinned_timesteps=False, **kwargs):
         if variance_type != "fixed_small":
             raise NotImplementedError("only variance_type='fixed_small' (configs/modules/scheduler.yaml:10)")
         if prediction_type != "epsilon":
             raise NotImplementedError("only prediction_type='epsilon' (TRAIN.ABLATION.PREDICT_EPSILON)")
         self.config = _Config(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
                               beta_schedule=beta_schedule, variance_type=variance_type, clip_sample=clip_sample,
-                              prediction_type=prediction_type)
+                              prediction_type=prediction_type, allow_unpinned_timesteps=bool(allow_unpinned_timesteps))
         self.variance_type = variance_type
         self._init_tables(num_train_timesteps, beta_start, beta_end, beta_schedule, trained_betas)
 
-    def set_timesteps(self, num_inference_steps, device=None):
-        """``num_inference_steps`` is clamped to the training schedule like diffusers 0.14.0 does.  The step count must divide
-        ``num_train_timesteps`` (the shipped schedule is 1000 of 1000, configs/modules/scheduler.yaml): for other counts the
-        releases of diffusers disagree on the table -- ``arange(0, T, T // N)[::-1]`` (more than N entries) vs
-        ``(arange(N) * (T // N))[::-1]`` -- and the package is not available here to pin either, so they are refused
-        (here, in the oracle and in ``cfd_sample_begin``) instead of silently picking one."""
+    def timestep_table(self, num_inference_steps):
+        """(clamped step count, int64 timestep array) of ``set_timesteps`` without touching the scheduler's state.
+
+        A count that divides ``num_train_timesteps`` (the shipped schedule is 1000 of 1000, configs/modules/scheduler.yaml) gives
+        ``(arange(N) * (T // N))[::-1]``, on which every diffusers release agrees.  For other counts the releases disagree:
+        0.14.0 (the reference's pin, environment.yml:85) builds ``arange(0, T, T // N)[::-1]`` -- which has MORE than N entries,
+        e.g. 334 for N = 300 -- later ones ``(arange(N) * (T // N)).round()[::-1]``.  The package is not available here to pin
+        either, so such counts are refused unless the scheduler was built with ``allow_unpinned_timesteps=True``, which selects
+        the 0.14.0 form (restated from the release's published source, NOT checked against it: parity unpinned)."""
         T = self.config.num_train_timesteps
-        num_inference_steps = min(T, num_inference_steps)
-        if num_inference_steps < 1 or T % num_inference_steps:
-            raise ValueError(f"DDPM num_inference_steps = {num_inference_steps} must divide num_train_timesteps = {T}")
-        self.num_inference_steps = num_inference_steps
-        step_ratio = T // self.num_inference_steps
-        timesteps = (np.arange(0, num_inference_steps) * step_ratio).round()[::-1].copy().astype(np.int64)
+        n = min(T, int(num_inference_steps))
+        if n < 1:
+            raise ValueError(f"num_inference_steps = {num_inference_steps}")
+        if T % n == 0:
+            return n, (np.arange(0, n) * (T // n)).round()[::-1].copy().astype(np.int64)
+        if not self.config.get("allow_unpinned_timesteps", False):
+            raise ValueError(f"DDPM num_inference_steps = {n} does not divide num_train_timesteps = {T}: the timestep table for such "
+                             "counts differs between diffusers releases; build the scheduler with allow_unpinned_timesteps=True to "
+                             "get the 0.14.0 table arange(0, T, T // N)[::-1] (unpinned)")
+        return n, np.arange(0, T, T // n)[::-1].copy().astype(np.int64)
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        """``num_inference_steps`` is clamped to the training schedule like diffusers 0.14.0 does; see ``timestep_table``."""
+        self.num_inference_steps, timesteps = self.timestep_table(num_inference_steps)
         self.timesteps = torch.from_numpy(timesteps).to(device)
 
     def step(self, model_output, timestep, sample, generator=None, return_dict=True, variance_noise=None):
@@ -159,12 +171,15 @@ class DDIMScheduler(_SchedulerBase):
         self._init_tables(num_train_timesteps, beta_start, beta_end, beta_schedule, trained_betas)
         self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
 
+    def timestep_table(self, num_inference_steps):
+        """(step count, int64 timestep array) of ``set_timesteps`` without touching the scheduler's state."""
+        n = int(num_inference_steps)
+        step_ratio = self.config.num_train_timesteps // n
+        return n, (np.arange(0, n) * step_ratio).round()[::-1].copy().astype(np.int64) + self.config.steps_offset
+
     def set_timesteps(self, num_inference_steps, device=None):
-        self.num_inference_steps = num_inference_steps
-        step_ratio = self.config.num_train_timesteps // self.num_inference_steps
-        timesteps = (np.arange(0, num_inference_steps) * step_ratio).round()[::-1].copy().astype(np.int64)
+        self.num_inference_steps, timesteps = self.timestep_table(num_inference_steps)
         self.timesteps = torch.from_numpy(timesteps).to(device)
-        self.timesteps += self.config.steps_offset
 
     def step(self, model_output, timestep, sample, eta=0.0, use_clipped_model_output=False, generator=None,
              variance_noise=None, return_dict=True):

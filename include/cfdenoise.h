@@ -109,7 +109,7 @@ typedef struct {
   const float* alphas_cumprod;/* HOST float32 [num_train_timesteps] (the scheduler's table) */
   const float* init_latents;  /* dev [B][L][128] N(0,1) draws (scaled by init_noise_sigma = 1), or NULL:
                                  drawn on the device, Philox stream 1 */
-  const float* step_noise;    /* dev [num_inference_steps][B][L][128] or NULL: Philox stream 0 */
+  const float* step_noise;    /* dev [iterations][B][L][128] or NULL: Philox stream 0 */
   uint64_t seed;              /* Philox key */
   uint32_t first_utterance;   /* global id of utterance 0 (shards draw independent sub-streams) */
   const float* preseq;        /* dev [B][preseq_len][128] previous-window latents to in-paint, or NULL */
@@ -124,6 +124,12 @@ typedef struct {
                                  iteration.  0 (the reference loop: memories are constants of a run, convofusion.py:391-549):
                                  the timestep-independent part of every memory's projections is computed once at
                                  cfd_sample_begin and the memories are not read again. */
+  const int32_t* timesteps;   /* HOST int32 [num_timesteps]: the loop's timestep sequence `scheduler.timesteps` (convofusion.py:423),
+                                 or NULL: (arange(N) * (T // N))[::-1] (+ steps_offset for DDIM), N = num_inference_steps.  The step
+                                 formulas keep `prev_t = t - T // N` either way.  Needed for DDPM counts that do not divide T, where
+                                 diffusers 0.14.0's table arange(0, T, T // N)[::-1] has MORE than N entries (unpinned, see
+                                 convofusion_amd/scheduler.py); the run then has num_timesteps iterations. */
+  int num_timesteps;
 } cfd_sample_args;
 
 /* Opens a sampling run: builds the per-step coefficient and timestep-embedding tables, draws / copies

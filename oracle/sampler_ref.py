@@ -31,7 +31,7 @@ def cfg_combine(noise_pred, guidance_scale):
 
 def diffusion_reverse(denoise_fn, scheduler, encoder_hidden_states, cond_masks, init_latents,
                       step_noise, guidance_scale=7.5, num_inference_steps=1000, eta=0.0,
-                      preseq=None, keep_steps=(), return_att=False, pre_step=None):
+                      preseq=None, keep_steps=(), return_att=False, pre_step=None, stop_after=None):
     """denoise_fn(sample[7B,L,128], t, enc, masks) -> (eps[7B,L,128], att_mats).
     ``step_noise(i, t)`` returns the [B,L,128] N(0,1) draw for loop index i (used when t > 0
     for DDPM, when eta > 0 for DDIM).  Returns (latents [L,B,128], snapshots, att dict)."""
@@ -41,6 +41,8 @@ def diffusion_reverse(denoise_fn, scheduler, encoder_hidden_states, cond_masks, 
     is_ddim = hasattr(scheduler, "final_alpha_cumprod")
     snaps, atts = {}, {}
     for i, t in enumerate(scheduler.timesteps):
+        if stop_after is not None and i >= stop_after:   # tests that only look at the first snapshots
+            break
         if preseq is not None:  # unbounded_synthesis.py:70-76
             pl = preseq.shape[1]
             latents = latents.copy()

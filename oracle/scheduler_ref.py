@@ -60,19 +60,28 @@ class _Tables:
 
 
 class DDPMSchedulerRef(_Tables):
-    def __init__(self, clip_sample=True, variance_type="fixed_small", **kw):
+    def __init__(self, clip_sample=True, variance_type="fixed_small", allow_unpinned_timesteps=False, **kw):
         super().__init__(**kw)
         assert variance_type == "fixed_small"
         self.clip_sample = clip_sample
+        self.allow_unpinned_timesteps = allow_unpinned_timesteps
 
     def set_timesteps(self, num_inference_steps):
-        num_inference_steps = min(self.num_train_timesteps, num_inference_steps)
-        if num_inference_steps < 1 or self.num_train_timesteps % num_inference_steps:
-            # the diffusers releases disagree on the table when N does not divide T (see convofusion_amd/scheduler.py); unpinned, so refused
-            raise ValueError("DDPM num_inference_steps must divide num_train_timesteps")
+        T = self.num_train_timesteps
+        num_inference_steps = min(T, num_inference_steps)
+        if num_inference_steps < 1:
+            raise ValueError("num_inference_steps")
         self.num_inference_steps = num_inference_steps
-        ratio = self.num_train_timesteps // num_inference_steps
-        self.timesteps = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)
+        ratio = T // num_inference_steps
+        if T % num_inference_steps == 0:
+            self.timesteps = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)
+        elif self.allow_unpinned_timesteps:
+            # diffusers 0.14.0 scheduling_ddpm.set_timesteps as published: arange(0, T, T // N)[::-1] -- MORE than N entries
+            # when N does not divide T; later releases build (arange(N) * (T // N))[::-1].  Restated, not checked against the
+            # package (absent here): parity unpinned for such counts.
+            self.timesteps = np.arange(0, T, ratio)[::-1].copy().astype(np.int64)
+        else:
+            raise ValueError("DDPM num_inference_steps must divide num_train_timesteps (or allow_unpinned_timesteps=True)")
 
     def coefficients(self, t):
         """(sqrt_beta_prod_t, sqrt_alpha_prod_t, x0_coeff, x_coeff, sigma) as float32 scalars."""

@@ -32,7 +32,8 @@ def test_struct_layouts_match_header():
     # natural C layout of the header's structs on x86-64
     assert C.sizeof(_lib.Config) == 24
     assert C.sizeof(_lib.Memory) == 32
-    assert _lib.SampleArgs.mem.offset % 8 == 0 and C.sizeof(_lib.SampleArgs) == _lib.SampleArgs.mem.offset + 5 * 32 + 8
+    assert _lib.SampleArgs.mem.offset % 8 == 0 and C.sizeof(_lib.SampleArgs) == _lib.SampleArgs.mem.offset + 5 * 32 + 8 + 16
+    assert _lib.SampleArgs.timesteps.offset == _lib.SampleArgs.mem.offset + 5 * 32 + 8   # (8-aligned pointer behind the two ints)
 
 
 def test_weg_host_logic():
@@ -99,11 +100,22 @@ def test_scheduler_mirror_tables_and_timesteps():
     s.set_timesteps(50)
     assert s.timesteps.tolist() == list(range(980, -1, -20))
     from oracle import scheduler_ref
-    for bad in (30, 300):            # T % N != 0: the diffusers releases disagree on the table, nothing here can pin it: refused everywhere
+    for bad in (30, 300):            # T % N != 0: the diffusers releases disagree on the table, nothing here can pin it: refused by default
         with pytest.raises(ValueError):
             s.set_timesteps(bad)
         with pytest.raises(ValueError):
             scheduler_ref.DDPMSchedulerRef().set_timesteps(bad)
+    # ... and opt-in: the 0.14.0 table arange(0, T, T // N)[::-1] (MORE than N entries), the same in the mirror and the oracle
+    u = scheduler.DDPMScheduler(variance_type="fixed_small", allow_unpinned_timesteps=True, **SCHED_KW)
+    o = scheduler_ref.DDPMSchedulerRef(allow_unpinned_timesteps=True)
+    for n, count in ((300, 334), (30, 31), (999, 1000), (7, 8)):
+        u.set_timesteps(n)
+        o.set_timesteps(n)
+        assert u.num_inference_steps == n and u.timesteps.tolist() == o.timesteps.tolist() == list(range(0, 1000, 1000 // n))[::-1]
+        assert len(u.timesteps) == count
+    u.set_timesteps(50)              # a dividing count is the pinned table whatever the switch
+    assert u.timesteps.tolist() == list(range(980, -1, -20))
+    assert s.timestep_table(50)[1].tolist() == list(range(980, -1, -20)) and s.num_inference_steps == 50   # (no state change)
     d = scheduler.DDIMScheduler(steps_offset=1, **SCHED_KW)
     d.set_timesteps(50)
     assert int(d.timesteps[0]) == 981
@@ -237,8 +249,13 @@ def test_no_edit_installer_binds_the_reference_entry_points():
     assert convofusion_amd.install(model) is model
     assert isinstance(model._diffusion_reverse, types.MethodType) and model._diffusion_reverse.__func__ is inst._diffusion_reverse
     assert RefLike()._diffusion_reverse(None) == "reference loop"           # other instances and the class are untouched
+    assert model._cfd_attention_steps == "last"
+    convofusion_amd.install(model, attention_steps="all")                  # the reference's per-iteration attention dict (base.py:252-259)
+    assert model._cfd_attention_steps == "all"
+    with pytest.raises(ValueError):
+        convofusion_amd.install(model, attention_steps="some")
     convofusion_amd.uninstall(model)
-    assert model._diffusion_reverse(None) == "reference loop"
+    assert model._diffusion_reverse(None) == "reference loop" and "_cfd_attention_steps" not in vars(model)
     script = types.ModuleType("unbounded_synthesis")
     with pytest.raises(AttributeError):
         convofusion_amd.patch_rollout(script)
@@ -247,26 +264,9 @@ def test_no_edit_installer_binds_the_reference_entry_points():
     assert script.diffusion_reverse_forecast is inst.diffusion_reverse_forecast and orig() == "reference rollout"
 
 
-def test_utterance_slices_of_a_guidance_batch():
-    """sampler._utterance_slice (the shards of ConcurrentRuns) = distributed.shard_cfg_batch: utterances [a, b) of every chunk of a
-    chunk-major batch, chunk order kept; the two shards together are a permutation-free partition of the rows."""
-    import torch
-    from convofusion_amd.distributed import shard_cfg_batch
-    from convofusion_amd.sampler import _utterance_slice
-    G, B = 7, 5
-    t = torch.arange(G * B * 3).reshape(G * B, 3)
-    a = _utterance_slice(t, 0, 3, B, G)
-    b = _utterance_slice(t, 3, 5, B, G)
-    assert torch.equal(a, shard_cfg_batch(t, 0, 3, B, G)) and torch.equal(b, shard_cfg_batch(t, 3, 5, B, G))
-    assert a.shape[0] == G * 3 and b.shape[0] == G * 2
-    back = torch.cat([a.reshape(G, 3, 3), b.reshape(G, 2, 3)], dim=1).reshape(G * B, 3)
-    assert torch.equal(back, t)
-    assert _utterance_slice(None, 0, 1, B, G) is None
-
-
 def test_no_kernel_of_the_library_uses_scratch_memory():
     """Every kernel keeps its state in registers / LDS: private (scratch) memory is slow, and it was the first suspect when two
-    captured graphs replaying side by side (sampler.ConcurrentRuns) gave wrong latents in an experiment (the spills
+    captured graphs replaying side by side (tools/experiments/concurrent_runs.py) gave wrong latents in an experiment (the spills
     turned out not to be the cause, but they are gone -- 68 bytes per lane of wave-uniform pointers in xattn_fused_kernel -- and this
     keeps it that way).  hipcc's resource-usage remarks are the check (cross-compiles without a GPU)."""
     import re

@@ -318,12 +318,14 @@ def test_developer_knobs_keep_parity(env):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
 
 
-@pytest.mark.parametrize("kind", ["ddpm5", "ddim5"])
+@pytest.mark.parametrize("kind", ["ddpm5", "ddim5", "ddim50", "ddpm1000"])
 @pytest.mark.parametrize("variant", ["b32", "b32_skip_zero_weight_chunk", "b1_shard"])
 def test_headline_shape_loop_row_matches_reference(kind, variant):
-    """The captured loop at BASELINE configs[1]'s full size (B = 32, L = 196, 1500 audio tokens), 5 guided steps: utterance
+    """The captured loop at BASELINE configs[1]'s full size (B = 32, L = 196, 1500 audio tokens): utterance
     17's latents against the trajectory the restated loop produced driving the REFERENCE denoiser for that utterance alone
-    (tests/golden/traj_c2_*.npz).  Utterances are independent and the Philox streams are keyed by global utterance id, so
+    (tests/golden/traj_c2_*.npz) -- 5 guided steps of either scheduler, and the FULL LENGTH runs north_star's acceptance sentence
+    names: 1000 DDPM steps (snapshots after 1 / 10 / 100 / 500 steps and the final latents) and 50 DDIM steps
+    (tests/golden/make_golden_c2full.py; ~14 s per 1000-step B = 32 run on the GPU).  Utterances are independent and the Philox streams are keyed by global utterance id, so
     the B = 32 run's row 17 (default path: shared-memory runs, chunk permutation, shared layer-0 head), the same with the
     zero-weight chunk skipped, and a one-utterance shard with first_utterance = 17 must all reproduce it."""
     from convofusion_amd.distributed import shard_cfg_batch
@@ -357,6 +359,55 @@ def test_headline_shape_loop_row_matches_reference(kind, variant):
     assert np.isfinite(lat).all() and all(v < TRAJ_TOL for v in errs.values()), errs
 
 
+def test_small_goldens_on_the_default_attention_path():
+    """tests/conftest.py lifts CFD_FUSED_XATTN_MIN_WGS to 0 so that the small goldens exercise the fused cross-attention kernel; in
+    production a problem of fewer than 6 workgroups (one utterance at L = 16 is 3) takes the three-launch path.  The long small-shape
+    trajectories -- 1000 DDPM steps, 50 DDIM steps, the 25-step in-painting rollout -- once more with the library's own default."""
+    import os
+    import subprocess
+    import sys
+    e = dict(os.environ, CFD_FUSED_XATTN_MIN_WGS="6")   # = the library default (cfd_api.hip: fused_xattn_min_wgs)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tests = [f"tests/test_gpu_sampler.py::test_sampler_matches_reference_trajectory[{n}]" for n in ("ddpm1000", "ddim50", "inpaint25")]
+    tests.append("tests/test_gpu_conditioning.py::test_dyadic_loop_matches_oracle")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", *tests], cwd=root, env=e, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+
+
+def test_ddpm_step_count_that_does_not_divide_the_schedule():
+    """DDPM with N = 300 of 1000 (opt-in, unpinned: scheduler.DDPMScheduler(allow_unpinned_timesteps=True)): the loop runs over the
+    334 entries of diffusers 0.14.0's table arange(0, 1000, 3)[::-1] with prev_t = t - 3, like the oracle's restated loop; the
+    default scheduler refuses the count."""
+    import torch
+    from convofusion_amd import scheduler
+    from convofusion_amd.sampler import SamplingRun
+    from tests.gpu_helpers import SCHED_KW, hip_denoiser, to_dev
+    B, L, S, n, seed = 2, 16, (6, 20, 6, 8, 1), 300, 21
+    cb = inputs.make_cfg_batch(seed=seed, B=B, L=L, S=S, pad_tail=(2, 0, 1, 0, 0))
+    mems = [to_dev(x) for x in cb["memories"]]
+    masks = {k: to_dev(v) for k, v in cb["masks"].items()}
+    m = hip_denoiser(1234, 1.0)
+    with pytest.raises(ValueError):
+        SamplingRun(m, _sched("ddpm"), mems, masks, B, L, n, seed=seed)
+    sch = scheduler.DDPMScheduler(variance_type="fixed_small", allow_unpinned_timesteps=True, **SCHED_KW)
+    run = SamplingRun(m, sch, mems, masks, B, L, n, guidance_scale=7.5, seed=seed)
+    assert run.N == 334 and run.timesteps[:3] == [999, 996, 993] and run.timesteps[-1] == 0
+    sd = state_dict(1234, 1.0)
+    ref = scheduler_ref.DDPMSchedulerRef(allow_unpinned_timesteps=True)
+    keep = (1, 8)
+    want, snaps, _ = sampler_ref.diffusion_reverse(
+        lambda x, t, enc, mk: denoiser_ref.denoiser_forward(sd, x, t, enc, mk), ref, cb["memories"], cb["masks"],
+        philox_ref.normal_tensor(seed, 0, range(B), 1, L), lambda i, t: philox_ref.normal_tensor(seed, i, range(B), 0, L),
+        guidance_scale=7.5, num_inference_steps=n, keep_steps=keep, stop_after=max(keep))
+    for k in keep:
+        run.steps(k - run.position)
+        assert rel_l2(run.read().cpu().numpy(), snaps[k]) < TRAJ_TOL
+    with pytest.raises(Exception):
+        run.steps(run.N)          # more than the table holds
+    run.steps(run.N - run.position)
+    assert run.position == 334 and torch.isfinite(run.read(close=True)).all()
+
+
 def test_no_edit_installer_runs_the_fused_loop():
     """convofusion_amd.install(model) + patch_rollout(module): the reference call sites (`self._diffusion_reverse(cond_emb, lengths,
     cond_masks=..., focus_indices=...)`, convofusion.py:1023; `diffusion_reverse_forecast(model, cond_emb, lengths, preseq, cond_masks=...)`,
@@ -385,6 +436,17 @@ def test_no_edit_installer_runs_the_fused_loop():
     torch.manual_seed(7)
     z2, _ = diffusion_reverse(model, enc, None, masks, [])
     assert tuple(z.shape) == (L, B, 128) and torch.equal(z, z2) and len(att) == 1
+    # the reference's dict holds the full-conditioning chunk's maps of EVERY iteration (convofusion.py:517-523; base.py:252-259 dumps
+    # one file per entry): install(model, attention_steps="all") reproduces it -- same latents, one entry per timestep, and the last
+    # entry equals the default binding's only entry
+    convofusion_amd.install(model, attention_steps="all")
+    torch.manual_seed(7)
+    z3, att_all = model._diffusion_reverse(enc, None, cond_masks=masks, focus_indices=[])
+    assert torch.equal(z3, z) and sorted(att_all) == [0, 250, 500, 750]
+    (t_last, last), = att.items()
+    assert t_last == 0 and all(torch.equal(a, b) for a, b in zip(att_all[0], last))
+    assert all(tuple(a.shape) == (B, 9, L, s) for a, s in zip(att_all[750], S))
+    convofusion_amd.install(model)
     script = types.ModuleType("unbounded_synthesis")
     script.diffusion_reverse_forecast = lambda *a, **k: (_ for _ in ()).throw(AssertionError("not replaced"))
     convofusion_amd.patch_rollout(script)
@@ -472,14 +534,14 @@ def test_static_and_dynamic_memory_declarations_agree_and_mean_what_they_say():
 
 
 @pytest.mark.parametrize("kind", ["ddpm", "ddim"])
-def test_concurrent_shards_equal_the_single_run(kind):
-    """ConcurrentRuns (experimental, opt-in): the batch as two utterance shards on the denoiser's two library handles gives the
-    single run's latents bit for bit -- device-drawn noise (Philox keyed by global utterance id), caller-supplied initial latents
-    and per-step noise, an in-painting prefix, an odd split (3 + 2 utterances).  This checks the sharding logic on a few steps; the
-    rare wrong utterance of two graphs replaying at the same time (tools/concurrency_soak.py: about one per 1 000 step pairs at the
-    benchmark shape) is why nothing selects this path by default."""
+def test_utterance_shards_equal_the_single_run(kind):
+    """The batch as two utterance shards (distributed.shard_cfg_batch, an odd 3 + 2 split), run ONE AFTER THE OTHER on the denoiser's
+    two library handles, gives the single run's latents bit for bit -- device-drawn noise (Philox keyed by global utterance id),
+    caller-supplied initial latents and per-step noise, an in-painting prefix.  (Replaying the two shards' graphs at the same time
+    is not a product path: tools/experiments/concurrent_runs.py)"""
     import torch
-    from convofusion_amd.sampler import ConcurrentRuns, SamplingRun, sample
+    from convofusion_amd.distributed import shard_cfg_batch
+    from convofusion_amd.sampler import SamplingRun
     from tests.gpu_helpers import hip_denoiser, to_dev
     B, L, S, n, seed = 5, 16, (24, 161, 24, 8, 1), 4, 11
     cb = inputs.make_cfg_batch(seed=seed, B=B, L=L, S=S, pad_tail=(2, 3, 0, 0, 0))
@@ -495,14 +557,17 @@ def test_concurrent_shards_equal_the_single_run(kind):
         with SamplingRun(m, _sched(kind), mems, masks, B, L, n, guidance_scale=7.5, **kw) as one:
             one.steps(n)
             want = one.read(close=True)
-        with ConcurrentRuns(m, _sched(kind), mems, masks, B, L, n, guidance_scale=7.5, **kw) as two:
-            two.steps(n)
-            got = two.read(close=True)
-        assert torch.equal(got, want), sorted(kw)
-    B8 = 8
-    cb = inputs.make_cfg_batch(seed=seed + 1, B=B8, L=L, S=S, pad_tail=(2, 3, 0, 0, 0))
-    mems = [to_dev(x) for x in cb["memories"]]
-    masks = {k: to_dev(v) for k, v in cb["masks"].items()}
-    two = sample(m, _sched(kind), mems, masks, B=B8, L=L, num_inference_steps=n, seed=seed, concurrent_shards=2)
-    single = sample(m, _sched(kind), mems, masks, B=B8, L=L, num_inference_steps=n, seed=seed)       # the default: one graph
-    assert torch.equal(two, single)
+        got = []
+        for k, (a, b) in enumerate(((0, 3), (3, 5))):
+            skw = dict(kw, first_utterance=kw.get("first_utterance", 0) + a)
+            for name in ("init_latents", "preseq"):
+                if name in skw:
+                    skw[name] = skw[name][a:b]
+            if "step_noise" in skw:
+                skw["step_noise"] = skw["step_noise"][:, a:b]
+            sm = [shard_cfg_batch(x, a, b, B) for x in mems]
+            sk = {name: shard_cfg_batch(v, a, b, B) for name, v in masks.items()}
+            with SamplingRun(m, _sched(kind), sm, sk, b - a, L, n, guidance_scale=7.5, side_engine=bool(k), **skw) as part:
+                part.steps(n)
+                got.append(part.read(close=True))
+        assert torch.equal(torch.cat(got), want), sorted(kw)
