@@ -14,6 +14,7 @@
 
 #include "../../include/cfdenoise.h"
 #include "gemm_sp.hpp"
+#include "gemm_rowln.hpp"
 #include "rows.hpp"
 #include "attn_fused.hpp"
 #include "xattn_fused.hpp"
@@ -123,6 +124,8 @@ struct cfd_handle_s {
   // the three-launch path everywhere (parity A/B of the two paths).
   bool fused_xattn = true;
   int fused_xattn_min_wgs = 6;
+  long long rowln_min_rows = 16384;   // residual products of at least this many rows use the row-complete kernel with the following
+                                      // LayerNorm in its epilogue (gemm_rowln.hpp); CFD_ROWLN=0 turns it off, CFD_ROWLN_MIN_ROWS overrides
   DBuf xa_wgs, xa_segs, xa_stamps;
   bool share0 = true;       // CFD_SHARE0=0: evaluate the pre-cross-attention part of layer 0 for every guidance replica
   DBuf d_step;  // [0] = loop index, [1] = constant 0, [2] = "this iteration's in-painting overwrite is done" (cfd_sample_inpaint)
@@ -258,6 +261,10 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   c->fused_xattn = !(env && atoi(env) == 0);
   env = getenv("CFD_FUSED_XATTN_MIN_WGS");
   if (env) c->fused_xattn_min_wgs = atoi(env);
+  env = getenv("CFD_ROWLN_MIN_ROWS");
+  if (env) c->rowln_min_rows = atoll(env);
+  env = getenv("CFD_ROWLN");
+  if (env && atoi(env) == 0) c->rowln_min_rows = -1;
   env = getenv("CFD_HOIST_MEMSIDE");
   c->hoist_memside = !(env && atoi(env) == 0);
   env = getenv("CFD_PERMUTE");
@@ -708,7 +715,10 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
   CHK(c->u_sp.ensure((size_t)M * CFD_FF * 4));
   CHK(c->sc.ensure((size_t)M * p.Sp_tot * 4));
   CHK(c->p_sp.ensure((size_t)M * p.Sp_tot * 4));
-  CHK(c->eps.ensure((size_t)M * CFD_LAT * 4));
+  CHK(c->eps.ensure((size_t)M * CFD_LAT * 4 + 256));   // (+ 256: the CFD_EXP == 7 developer build keeps three counters behind the matrix)
+#if CFD_EXP == 7
+  HIPCHK(hipMemset(c->eps.as<char>() + (size_t)M * CFD_LAT * 4, 0, 256));
+#endif
   CHK(c->sample_sp.ensure((size_t)M * CFD_LAT * 4));
   for (int j = 0; j < CFD_NMEM; ++j) {
     const size_t rows = (size_t)p.U[j] * p.Sp[j];
@@ -936,6 +946,20 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     EpiResid e{c->x.as<float>(), 0, bias};
     return run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st);
   };
+  // residual product + the LayerNorm that follows it: one row-complete launch for large problems, otherwise the two launches
+  auto token_gemm_resid_ln = [&](const DBuf& w, int K, const char* y, const float* bias, long long rows, const float* g, const float* b,
+                                 int adaln, int tbidx) -> int {
+    if (c->rowln_min_rows < 0 || rows < c->rowln_min_rows || g_cfd_naive_gemm) {
+      CHK(token_gemm_resid(w, K, y, bias, rows));
+      return ln(g, b, adaln, tbidx, c->h_sp.as<char>(), rows);
+    }
+    RowLnArgs a{w.as<char>(), y, K, rows, c->x.as<float>(), bias, c->h_sp.as<char>(), g, b, adaln,
+                c->ss_tab.as<float>() + (size_t)tbidx * 2 * CFD_D, (long long)nl * 2 * 2 * CFD_D, dstep, p.tmode, L, row0};
+    Bracket br(c, CFD_PROF_GEMM_TOKEN, st);
+    hipError_t err = launch_rowln(a, st);
+    if (err != hipSuccess) return fail(CFD_E_HIP, "row-complete gemm launch failed: %s", hipGetErrorString(err));
+    return CFD_OK;
+  };
   static unsigned long long attr = 0;   // per device (one bit per ordinal): a process may hold handles on several GPUs
   if (!((attr >> (c->cfg.device & 63)) & 1ull)) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
@@ -943,13 +967,16 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     attr |= 1ull << (c->cfg.device & 63);
   }
 
+  bool h_ready = false;   // h_sp already holds norm1(x) of the layer that starts
   for (int l = 0; l < nl; ++l) {
     const LayerW& w = c->lw[l];
     // rows of sub-layers a and b: layer 0 runs them once per utterance when the batch is G replicas of it
     const int Ba = (l == 0) ? Bs : Be;
     const long long Ma = (long long)Ba * L;
     // ---- a. self attention: x += Wo softmax(q k^T) v                         (cross_attention.py:568-572)
-    CHK(ln(w.ln1g, w.ln1b, 0, 0, c->h_sp.as<char>(), Ma));
+    // (norm1 of layers 1.. is made by the previous layer's last residual product when that ran row-complete: `h_ready`)
+    if (!h_ready) CHK(ln(w.ln1g, w.ln1b, 0, 0, c->h_sp.as<char>(), Ma));
+    h_ready = false;
     {  // q (pre-scaled) and k, token-major
       GemmArgs a = gemm_args();
       a.X[0] = w.wqk_sp.as<char>(); a.ldx[0] = ROWB; a.I[0] = 2 * CFD_D; a.Iclamp[0] = 2 * CFD_D; a.kt[0] = CFD_D / 32;
@@ -971,10 +998,10 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       hipLaunchKernelGGL(self_attn_fused_kernel, dim3((L + SELF_ATTN_WAVES * 16 - 1) / (SELF_ATTN_WAVES * 16), CFD_NHEAD, Ba), dim3(SELF_ATTN_WAVES * 64), 65536, st, a);
       HIPCHK(hipGetLastError());
     }
-    CHK(token_gemm_resid(w.wo_sp, CFD_D, c->o_sp.as<char>(), w.bo2.as<float>(), Ma));
+    // out-projection + residual, then time block 1's AdaLN + SiLU                 (:572, :575, :426-439)
+    CHK(token_gemm_resid_ln(w.wo_sp, CFD_D, c->o_sp.as<char>(), w.bo2.as<float>(), Ma, w.tb1g, w.tb1b, 1, 2 * l));
     if (c->stop_stage == 2 + 4 * l) return CFD_OK;
-    // ---- b. time block 1                                                        (:575, :426-439)
-    CHK(ln(w.tb1g, w.tb1b, 1, 2 * l, c->h_sp.as<char>(), Ma));
+    // ---- b. time block 1
     CHK(token_gemm_resid(w.wtb1_sp, CFD_D, c->h_sp.as<char>(), w.btb1, Ma));
     if (c->stop_stage == 3 + 4 * l) return CFD_OK;
     if (Ma != M) {   // every guidance chunk starts its first cross-attention from the same state
@@ -1101,9 +1128,9 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     if (c->stop_stage == 4 + 4 * l) return CFD_OK;
     // ---- f. time block 2                                                        (:655)
     CHK(ln(w.tb2g, w.tb2b, 1, 2 * l + 1, c->h_sp.as<char>(), M));
-    CHK(token_gemm_resid(w.wtb2_sp, CFD_D, c->h_sp.as<char>(), w.btb2, M));
+    // time block 2's projection + residual, then norm3                           (:655, :659)
+    CHK(token_gemm_resid_ln(w.wtb2_sp, CFD_D, c->h_sp.as<char>(), w.btb2, M, w.ln3g, w.ln3b, 0, 0));
     // ---- g. FFN                                                                 (:659-661)
-    CHK(ln(w.ln3g, w.ln3b, 0, 0, c->h_sp.as<char>(), M));
     {
       GemmArgs a = gemm_args();
       a.X[0] = w.w1_sp.as<char>(); a.ldx[0] = ROWB; a.I[0] = CFD_FF; a.Iclamp[0] = CFD_FF; a.kt[0] = CFD_D / 32;
@@ -1111,11 +1138,16 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       EpiSplit e{c->u_sp.as<char>(), (long long)CFD_FF * 4, 0, 0, w.b1, 1, 0};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
     }
-    CHK(token_gemm_resid(w.w2_sp, CFD_FF, c->u_sp.as<char>(), w.b2, M));
-    if (c->stop_stage == 5 + 4 * l) return CFD_OK;
+    // second FFN product + residual, then the next layer's norm1 (or the decoder's final norm)   (:661, :568; :238-239)
+    {
+      const float* ng = l + 1 < nl ? c->lw[l + 1].ln1g : rawp(c, "decoder.norm.weight");
+      const float* nb = l + 1 < nl ? c->lw[l + 1].ln1b : rawp(c, "decoder.norm.bias");
+      if (c->stop_stage == 5 + 4 * l) return token_gemm_resid(w.w2_sp, CFD_FF, c->u_sp.as<char>(), w.b2, M);
+      CHK(token_gemm_resid_ln(w.w2_sp, CFD_FF, c->u_sp.as<char>(), w.b2, M, ng, nb, 0, 0));
+      h_ready = true;
+    }
   }
-  // 7. final norm + latent projection                                             (cross_attention.py:238-239, denoiser.py:382)
-  CHK(ln(rawp(c, "decoder.norm.weight"), rawp(c, "decoder.norm.bias"), 0, 0, c->h_sp.as<char>(), M));
+  // 7. final norm (made above) + latent projection                                (cross_attention.py:238-239, denoiser.py:382)
   {
     GemmArgs a = gemm_args();
     a.X[0] = c->wp_sp.as<char>(); a.ldx[0] = ROWB; a.I[0] = CFD_LAT; a.Iclamp[0] = CFD_LAT; a.kt[0] = CFD_D / 32;

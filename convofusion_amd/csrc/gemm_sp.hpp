@@ -300,8 +300,17 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
   constexpr int XG = BI / 8, YG = BJ / 8;                // 8-row load groups per operand tile
   constexpr int XPW = (XG + NW - 1) / NW, YPW = (YG + NW - 1) / NW;
   constexpr int GPW = XPW + YPW;
-  static_assert(NSTAGE == 2 || NSTAGE == 3, "2-stage (one barrier per k-step) or 3-stage (counted vmcnt) loop");
-  static_assert(NSTAGE == 2 || (XG % NW == 0 && YG % NW == 0), "3-stage pipeline needs uniform load counts per wave");
+  // NSTAGE == 4: the ASYMMETRIC ring (round 3).  The column operand Y is the activation stream -- distinct HBM bytes for every
+  // row panel -- while the row operand X (a weight matrix) stays L2-resident; what bounds the big token-side products is the number
+  // of distinct HBM bytes in flight.  So X keeps 2 stages and Y gets 3: (2 BI + 3 BJ) * 128 B = 80 KB for the
+  // 128 x 128 tile, still two workgroups per CU.  vmcnt retires in order, so a wave that requests both operands cannot leave a Y
+  // tile in flight across the wait for the next X tile: the waves split the roles instead -- the first half of the workgroup's
+  // waves requests X tiles only (one ahead, vmcnt(0)), the second half Y tiles only (two ahead, counted vmcnt).
+  constexpr bool ASYM = NSTAGE == 4;
+  constexpr int XPW2 = XG / (NW / 2 > 0 ? NW / 2 : 1), YPW2 = YG / (NW / 2 > 0 ? NW / 2 : 1);   // pieces per loading wave (ASYM)
+  static_assert(NSTAGE == 2 || NSTAGE == 3 || NSTAGE == 4, "2-stage (one barrier per k-step), 3-stage (counted vmcnt) or asymmetric loop");
+  static_assert(NSTAGE != 3 || (XG % NW == 0 && YG % NW == 0), "3-stage pipeline needs uniform load counts per wave");
+  static_assert(!ASYM || (NW % 2 == 0 && XG % (NW / 2) == 0 && YG % (NW / 2) == 0 && MODE == MODE_PLAIN), "asymmetric ring: even wave count, uniform loads, plain mode");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
@@ -451,6 +460,29 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
     }
   };
 
+  // ASYM: this wave's pieces of an X tile (waves [0, NW/2)) or of a Y tile (waves [NW/2, NW)); group gi = hw + (NW/2) n
+  const int hw = wid % (NW / 2 > 0 ? NW / 2 : 1);
+  long long aoff[ASYM ? (XPW2 > YPW2 ? XPW2 : YPW2) : 1];
+  if constexpr (ASYM) {
+    const bool xrole = wid < NW / 2;
+#pragma unroll
+    for (int n = 0; n < (XPW2 > YPW2 ? XPW2 : YPW2); ++n) {
+      const int r = (hw + (NW / 2) * n) * 8 + rsub;
+      const int sw8 = (cpos ^ ((r >> 1) & 7)) << 4;
+      aoff[n] = xrole ? (long long)min(i0 + r, Iclamp_g - 1) * ldx_g + sw8 : (long long)min(j0 + r, a.Jclamp - 1) * a.ldy + sw8;
+    }
+  }
+  auto stage_x = [&](int kt, int buf) __attribute__((always_inline)) {   // ASYM, X-loading waves
+#pragma unroll
+    for (int n = 0; n < XPW2; ++n)
+      __builtin_amdgcn_global_load_lds((gptr_t)(xbase_g + aoff[n] + (long long)kt * 128), (lptr_t)(smem + buf * (BI * 128) + (hw + (NW / 2) * n) * 1024), 16, 0, 0);
+  };
+  auto stage_y = [&](int kt, int buf) __attribute__((always_inline)) {   // ASYM, Y-loading waves
+#pragma unroll
+    for (int n = 0; n < YPW2; ++n)
+      __builtin_amdgcn_global_load_lds((gptr_t)(yb + aoff[n] + (long long)kt * 128), (lptr_t)(smem + 2 * (BI * 128) + buf * (BJ * 128) + (hw + (NW / 2) * n) * 1024), 16, 0, 0);
+  };
+
   // fragment read offsets
   const int l15 = lane & 15, q4 = lane >> 4;
   const int sw = l15 >> 1;
@@ -495,18 +527,17 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
       }
   }
 
-  auto compute = [&](int buf) __attribute__((always_inline)) {
-    const char* sb = smem + buf * STAGE;
+  auto compute2 = [&](const char* sbx, const char* sby) __attribute__((always_inline)) {   // sby: the Y tile's base MINUS BI * 128
     spx8 xh[TI], xl[TI], yh[TJ], yl[TJ];
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti) {
-      xh[ti] = *reinterpret_cast<const spx8*>(sb + xoff_h + ti * 2048);
-      xl[ti] = *reinterpret_cast<const spx8*>(sb + xoff_l + ti * 2048);
+      xh[ti] = *reinterpret_cast<const spx8*>(sbx + xoff_h + ti * 2048);
+      xl[ti] = *reinterpret_cast<const spx8*>(sbx + xoff_l + ti * 2048);
     }
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
-      yh[tj] = *reinterpret_cast<const spx8*>(sb + yoff_h + tj * 2048);
-      yl[tj] = *reinterpret_cast<const spx8*>(sb + yoff_l + tj * 2048);
+      yh[tj] = *reinterpret_cast<const spx8*>(sby + yoff_h + tj * 2048);
+      yl[tj] = *reinterpret_cast<const spx8*>(sby + yoff_l + tj * 2048);
     }
 #if CFD_READS_FIRST
     __builtin_amdgcn_sched_barrier(0);   // all fragment reads of the k-step are issued before its first MFMA
@@ -520,8 +551,36 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
         acc[ti][tj] = SP_MFMA(xh[ti], yh[tj], acc[ti][tj], 0, 0, 0);
       }
   };
+  auto compute = [&](int buf) __attribute__((always_inline)) { compute2(smem + buf * STAGE, smem + buf * STAGE); };
 
-  if constexpr (NSTAGE == 2) {
+  if constexpr (ASYM) {
+    const bool xrole = wid < NW / 2;   // wave-uniform
+    if (xrole) {
+      stage_x(0, 0);
+      __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(0));
+    } else {
+      stage_y(0, 0);
+      if (nkt > 1) { stage_y(1, 1); __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(YPW2)); }
+      else __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(0));
+    }
+    __builtin_amdgcn_s_barrier();
+    int ybuf = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+      int yb2 = ybuf + 2;
+      if (yb2 >= 3) yb2 -= 3;
+      if (xrole) { if (kt + 1 < nkt) stage_x(kt + 1, (kt + 1) & 1); }       // X buffer (kt+1)&1 was last read in iteration kt-1
+      else { if (kt + 2 < nkt) stage_y(kt + 2, yb2); }                      // Y buffer (kt+2)%3 likewise
+      compute2(smem + (kt & 1) * (BI * 128), smem + 2 * (BI * 128) + ybuf * (BJ * 128) - BI * 128);
+#if CFD_MFMA_FENCE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      // the next k-step's tiles have landed; this wave's fragment reads are done before anybody overwrites the buffers
+      if (xrole || kt + 2 >= nkt) __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(0));
+      else __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(YPW2));
+      __builtin_amdgcn_s_barrier();
+      ybuf = (ybuf == 2) ? 0 : ybuf + 1;
+    }
+  } else if constexpr (NSTAGE == 2) {
     stage(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
@@ -663,6 +722,20 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                  // L2 write-back by every wave
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#elif CFD_EXP == 7
+  // does the NEXT kernel of the stream start before this one has finished?  Every workgroup of the final projection (EpiF32 into
+  // a [J][128] matrix) counts itself done in a word behind the matrix; cfg_step_kernel compares the count with what it must be.
+  if constexpr (std::is_same<Epi, EpiF32>::value) {
+    if (epi.ldo == 128 && MODE == MODE_PLAIN && gridDim.y == 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned* cnt = reinterpret_cast<unsigned*>(epi.out + (long long)a.J * epi.ldo);
+        if (blockIdx.x == 0) atomicExch(cnt + 3, gridDim.x);   // workgroups per launch
+        atomicAdd(cnt, 1u);
+      }
+    }
+  }
 #endif
 }
 
@@ -721,7 +794,7 @@ static hipError_t launch_cfg(GemmArgs a, const Epi& epi, int nb, int nz, hipStre
     total += a.tiles_i[g] * a.tiles_j;
   }
   a.tile_start[ng] = total;
-  constexpr int lds = NSTAGE * (BI + BJ) * 128;
+  constexpr int lds = NSTAGE == 4 ? (2 * BI + 3 * BJ) * 128 : NSTAGE * (BI + BJ) * 128;
   // the attribute is per device: one bit per device ordinal (a process may hold handles on several GPUs)
   static unsigned long long attr_set = 0;
   int dev = 0;
@@ -744,6 +817,11 @@ static hipError_t launch_cfg(GemmArgs a, const Epi& epi, int nb, int nz, hipStre
 //  20 = 32 x 128  (1 x 4 waves of 32 x 32, 3-stage)            memories of <= 64 keys
 // The variants measured and rejected in round 1 (3-stage / software-pipelined / deep-prefetch / single-buffer loops,
 // 128 x 256, 256 x 128, 128 x 176 and 256 x 176 tiles, the tile-softmax epilogues) live in tools/experiments/gemm_sp_r01_variants.hpp.
+static inline int big_cfg() {   // the tile configuration of the large products (developer A/B: CFD_BIG_CFG=1 selects the symmetric 2-stage loop)
+  static const int v = getenv("CFD_BIG_CFG") ? atoi(getenv("CFD_BIG_CFG")) : 1;
+  return v;
+}
+
 template <int MODE, class Epi>
 static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStream_t st, int cfg = 0) {
   if (a.nslot < 1) a.nslot = 1;
@@ -767,13 +845,16 @@ static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStr
     if (a.J <= 16) cfg = 3;
     else if (imax <= 64 && a.J >= 96) cfg = 20;
     else if (a.J > 128 && a.J <= 224 && big_tiles * 2 >= 256) cfg = 6;
-    else if (big_tiles * 2 >= 384 && a.J >= 96) cfg = 1;
+    else if (big_tiles * 2 >= 384 && a.J >= 96) cfg = big_cfg();
     else cfg = 19;
   }
   switch (cfg) {
     case 1: return launch_cfg<2, 2, 4, 4, 2, MODE, Epi>(a, epi, nb, nz, st);
     case 6: return launch_cfg<4, 1, 2, 7, 2, MODE, Epi>(a, epi, nb, nz, st);
     case 19: return launch_cfg<2, 2, 2, 2, 3, MODE, Epi>(a, epi, nb, nz, st);
+    case 30:   // 128 x 128 with the asymmetric ring (X 2 stages, Y 3 stages, role-split loading); plain problems only
+      if constexpr (MODE == MODE_PLAIN) return launch_cfg<2, 2, 4, 4, 4, MODE, Epi>(a, epi, nb, nz, st);
+      else return launch_cfg<2, 2, 4, 4, 2, MODE, Epi>(a, epi, nb, nz, st);
     case 20: return launch_cfg<1, 4, 2, 2, 3, MODE, Epi>(a, epi, nb, nz, st);
     default: return launch_cfg<4, 1, 2, 1, 2, MODE, Epi>(a, epi, nb, nz, st);
   }

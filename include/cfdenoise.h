@@ -57,7 +57,7 @@ const char* cfd_source_hash(void);
 int cfd_load_tensor(cfd_handle h, const char* name, const float* data, size_t numel, int is_device);
 
 /* After the last cfd_load_tensor: checks that every tensor is present, folds and re-lays-out the
- * weights on the device (float64 folding, then split-bf16 GEMM operands). */
+ * weights on the device (float64 folding, then split-pair GEMM operands: two fp16 halves hi + lo per value). */
 int cfd_finalize_weights(cfd_handle h);
 
 /* Sinusoid rows of the timestep embedding for integer timesteps 0..n_rows-1
@@ -252,9 +252,11 @@ int cfd_philox_normal(cfd_handle h, float* out, int B, int per_utt, uint64_t see
 #define CFD_PROF_NCLASS 6
 int cfd_profile_forward(cfd_handle h, float ms[CFD_PROF_NCLASS], int launches[CFD_PROF_NCLASS]);
 
-/* Test hook: D[j][i] = sum_k X[i][k] Y[j][k] through the split-bf16 MFMA kernel.
+/* Test hook: D[j][i] = sum_k X[i][k] Y[j][k] through the split-pair (fp16 hi/lo, 3 MFMAs per product) kernel.
  * X dev float32 [I][K], Y dev float32 [J][K], out dev float32 [J][I]; K % 32 == 0, I % 4 == 0.
- * tile_cfg: 0 auto, 1 = 128x128, 2 = 64x64, 3 = 128x16. */
+ * tile_cfg: 0 = chosen from the shape; 1 = 128x128 (2-stage), 30 = 128x128 with the asymmetric ring (weights 2 stages,
+ * activations 3 stages), 6 = 128x112, 19 = 64x64 (3-stage), 20 = 32x128 (3-stage), any other value = 128x16
+ * (csrc/gemm_sp.hpp: launch_gemm). */
 int cfd_test_gemm(cfd_handle h, const float* X, const float* Y, float* out, int I, int J, int K, int tile_cfg,
                   void* stream);
 

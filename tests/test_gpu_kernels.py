@@ -27,7 +27,7 @@ def _gemm(ops, X, Y, cfg):
     return out.cpu().numpy()
 
 
-@pytest.mark.parametrize("cfg", [1, 3, 6, 19, 20])
+@pytest.mark.parametrize("cfg", [1, 3, 6, 19, 20, 30])
 def test_mfma_layout_identity(ops, cfg):
     """A = I against an ASYMMETRIC B: catches swapped row/col maps, k-permutations and swizzle bugs."""
     I, J = 128, 256
@@ -40,7 +40,7 @@ def test_mfma_layout_identity(ops, cfg):
     np.testing.assert_array_equal(got, want.astype(np.float32))
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 3, 6, 19, 20])
+@pytest.mark.parametrize("cfg", [0, 1, 3, 6, 19, 20, 30])
 @pytest.mark.parametrize("shape", [(512, 300, 512), (1536, 77, 128), (36, 16, 1504), (128, 1000, 32), (4640, 130, 512)])
 def test_gemm_split_bf16_accuracy(ops, cfg, shape):
     """D = Y X^T through the 3-MFMA split path; ragged I/J edges; fp32-class accuracy."""

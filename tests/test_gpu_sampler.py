@@ -296,13 +296,16 @@ def test_ddim_with_eta_matches_oracle():
 
 
 @pytest.mark.parametrize("env", [{"CFD_NAIVE_GEMM": "1"}, {"CFD_RUNS": "0", "CFD_FUSED_XATTN": "0"}, {"CFD_FUSED_XATTN": "0"},
-                                 {"CFD_HOIST_MEMSIDE": "0"}])
+                                 {"CFD_HOIST_MEMSIDE": "0"}, {"CFD_ROWLN": "0"}, {"CFD_ROWLN_MIN_ROWS": "1"}, {"CFD_BIG_CFG": "30"}])
 def test_developer_knobs_keep_parity(env):
     """The debug switches that select another code path for the same arithmetic (read once at cfd_create) must not change
     results: CFD_NAIVE_GEMM=1 (one-thread-per-output products instead of the MFMA kernels, three-launch attention),
     CFD_FUSED_XATTN=0 (three-launch cross-attention everywhere, with its shared-memory runs), the same with
-    CFD_RUNS=0 (per-row attention products only), and CFD_HOIST_MEMSIDE=0 (fused cross-attention kernel fed by memory-side
-    projections made in every iteration instead of once per run).  Each leg runs the golden forward, the 20-step trajectory, the run-path
+    CFD_RUNS=0 (per-row attention products only), CFD_HOIST_MEMSIDE=0 (fused cross-attention kernel fed by memory-side
+    projections made in every iteration instead of once per run), CFD_ROWLN=0 (every residual product followed by its own
+    LayerNorm launch, also at the headline size), CFD_ROWLN_MIN_ROWS=1 (the row-complete product with the LayerNorm in its
+    epilogue, gemm_rowln.hpp, also on the small goldens: ragged last tiles, per-row timesteps) and CFD_BIG_CFG=30 (the large
+    products on the asymmetric LDS ring).  Each leg runs the golden forward, the 20-step trajectory, the run-path
     test and the headline-shape loop rows in a child process."""
     import os
     import subprocess
