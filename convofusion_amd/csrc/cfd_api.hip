@@ -18,6 +18,7 @@
 #include "rows.hpp"
 #include "attn_fused.hpp"
 #include "xattn_fused.hpp"
+#include "xattn_role.hpp"
 #include "grad.hpp"
 
 int g_cfd_naive_gemm = 0;
@@ -124,8 +125,9 @@ struct cfd_handle_s {
   // the three-launch path everywhere (parity A/B of the two paths).
   bool fused_xattn = true;
   int fused_xattn_min_wgs = 6;
-  long long rowln_min_rows = 16384;   // residual products of at least this many rows use the row-complete kernel with the following
-                                      // LayerNorm in its epilogue (gemm_rowln.hpp); CFD_ROWLN=0 turns it off, CFD_ROWLN_MIN_ROWS overrides
+  bool xa_role = false;     // CFD_XA_ROLE=1: the role-split variant of the fused cross-attention kernel (xattn_role.hpp)
+  long long rowln_min_rows = -1;      // CFD_ROWLN_MIN_ROWS=<n>: residual products of at least n rows use the row-complete kernel with the
+                                      // following LayerNorm in its epilogue (gemm_rowln.hpp).  Off by default: measured slower
   DBuf xa_wgs, xa_segs, xa_stamps;
   bool share0 = true;       // CFD_SHARE0=0: evaluate the pre-cross-attention part of layer 0 for every guidance replica
   DBuf d_step;  // [0] = loop index, [1] = constant 0, [2] = "this iteration's in-painting overwrite is done" (cfd_sample_inpaint)
@@ -261,10 +263,10 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   c->fused_xattn = !(env && atoi(env) == 0);
   env = getenv("CFD_FUSED_XATTN_MIN_WGS");
   if (env) c->fused_xattn_min_wgs = atoi(env);
+  env = getenv("CFD_XA_ROLE");
+  c->xa_role = env && atoi(env) != 0;
   env = getenv("CFD_ROWLN_MIN_ROWS");
   if (env) c->rowln_min_rows = atoll(env);
-  env = getenv("CFD_ROWLN");
-  if (env && atoi(env) == 0) c->rowln_min_rows = -1;
   env = getenv("CFD_HOIST_MEMSIDE");
   c->hoist_memside = !(env && atoi(env) == 0);
   env = getenv("CFD_PERMUTE");
@@ -590,6 +592,7 @@ static int build_xattn_worklist(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
         if (online && online_seen < n_online && segs.size() > first_seg) segs.back().flags |= XA_FLUSH;
       }
       w.nseg = (int)segs.size() - w.seg0;
+      w.pf_slot = (int)g;   // (the group, until the queues are built)
       group_wgs[g].push_back(w);
     }
   }
@@ -602,6 +605,18 @@ static int build_xattn_worklist(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
   for (size_t g : gorder) {
     if (group_wgs[g].size() > 32) { for (const XaWg& w : group_wgs[g]) queue[shortest()].push_back(w); }
     else { const int q = shortest(); for (const XaWg& w : group_wgs[g]) queue[q].push_back(w); }
+  }
+  // L2 prefetch shares: consecutive workgroups of one group in one XCD's queue run at about the same time (one per CU, 32 CUs) and
+  // walk the same key stream; each of them warms 1 / n of the tile two steps ahead
+  for (int x = 0; x < 8; ++x) {
+    size_t i = 0;
+    while (i < queue[x].size()) {
+      size_t e = i;
+      while (e < queue[x].size() && queue[x][e].pf_slot == queue[x][i].pf_slot) ++e;
+      const int n = (int)std::min<size_t>(e - i, 32);
+      for (size_t k = i; k < e; ++k) { queue[x][k].pf_slot = (int)((k - i) % n); queue[x][k].pf_n = n; }
+      i = e;
+    }
   }
   size_t qlen = 0;
   for (int x = 0; x < 8; ++x) qlen = std::max(qlen, queue[x].size());
@@ -964,6 +979,7 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
   if (!((attr >> (c->cfg.device & 63)) & 1ull)) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_role_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
     attr |= 1ull << (c->cfg.device & 63);
   }
 
@@ -1034,7 +1050,8 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       a.stamps = c->xa_stamps.as<long long>();
 #endif
       Bracket br(c, CFD_PROF_XATTN, st);
-      hipLaunchKernelGGL(xattn_fused_kernel, dim3(p.xa_nwg), dim3(XA_WAVES * 64), XA_LDS, st, a);
+      if (c->xa_role) hipLaunchKernelGGL(xattn_role_kernel, dim3(p.xa_nwg), dim3(XA_WAVES * 64), XA_LDS, st, a);
+      else hipLaunchKernelGGL(xattn_fused_kernel, dim3(p.xa_nwg), dim3(XA_WAVES * 64), XA_LDS, st, a);
       HIPCHK(hipGetLastError());
     } else {
     CHK(ln(w.ln2g, w.ln2b, 0, 0, c->h_sp.as<char>(), M));

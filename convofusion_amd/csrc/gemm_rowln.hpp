@@ -9,8 +9,12 @@
 // output features of 64 rows -- 8 waves, wave w = features [64 w, 64 w + 64) x 64 rows, the same 64 x 64 wave tile (4 x 4 MFMA
 // tiles, 48 MFMAs per k-step) as the 128 x 128 kernel -- so the row statistics are workgroup-local: the epilogue adds the
 // residual, writes x, reduces mean and centred variance through LDS (two passes, like ln_rows_kernel) and stores the
-// normalised (+ modulated + SiLU) split-pair operand of the next product.  One workgroup per CU (2 x 72 KB of LDS).
-// Used for the large token-side problems only (cfd_api.hip: rowln_min_rows); small ones keep gemm_sp_kernel + ln_rows_kernel.
+// normalised (+ modulated + SiLU) split-pair operand of the next product.  One workgroup per CU (152 KB of LDS: weight ring of 2
+// x 64 KB, activation ring of 3 x 8 KB).
+// MEASURED SLOWER than gemm_sp_kernel + ln_rows_kernel at the benchmark shape (one lock-step workgroup per
+// CU exposes every memory wait that two independent 4-wave workgroups cover for each other), so it is OFF by default:
+// CFD_ROWLN_MIN_ROWS=<n> selects it for residual products of at least n rows (cfd_api.hip: rowln_min_rows); parity-tested
+// (tests/test_gpu_sampler.py::test_developer_knobs_keep_parity).
 #pragma once
 #include "gemm_sp.hpp"
 
@@ -36,10 +40,12 @@ struct RowLnArgs {
 
 #define RL_BI 512
 #define RL_BJ 64
-#define RL_STAGE ((RL_BI + RL_BJ) * 128)
-#define RL_LDS (2 * RL_STAGE)
+#define RL_XS (RL_BI * 128)                 // one stage of the weight tile (64 KB)
+#define RL_YS (RL_BJ * 128)                 // one stage of the activation tile (8 KB)
+#define RL_YOFF (2 * RL_XS)
+#define RL_LDS (2 * RL_XS + 3 * RL_YS)      // X ring of 2, Y ring of 3: 152 KB
 #define RL_RS (4 * 64 + 16)                 // epilogue strip row stride in bytes (+16: conflict-free 16-byte writes)
-#define RL_STAT_OFF (8 * 16 * RL_RS)        // behind the 8 strips: partial sums [8 waves][64 rows], then mean / rstd [64]
+#define RL_STAT_OFF (8 * 16 * RL_RS)        // behind the 8 strips: per pass, partial sums [8 waves][64 rows] + the row statistic [64]
 
 __global__ void __launch_bounds__(512, 2) gemm_rowln_kernel(const RowLnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -64,19 +70,20 @@ __global__ void __launch_bounds__(512, 2) gemm_rowln_kernel(const RowLnArgs a) {
     const long long row = (j0 + r < a.M) ? j0 + r : a.M - 1;
     yoff = row * ld + ((cpos ^ ((r >> 1) & 7)) << 4);
   }
-  auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
-    char* sb = smem + buf * RL_STAGE;
+  auto stage_x = [&](int kt, int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int n = 0; n < 8; ++n)
-      __builtin_amdgcn_global_load_lds((gptr_t)(a.W + xoff[n] + (long long)kt * 128), (lptr_t)(sb + (wid + 8 * n) * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(a.Y + yoff + (long long)kt * 128), (lptr_t)(sb + RL_BI * 128 + wid * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(a.W + xoff[n] + (long long)kt * 128), (lptr_t)(smem + buf * RL_XS + (wid + 8 * n) * 1024), 16, 0, 0);
+  };
+  auto stage_y = [&](int kt, int buf) __attribute__((always_inline)) {
+    __builtin_amdgcn_global_load_lds((gptr_t)(a.Y + yoff + (long long)kt * 128), (lptr_t)(smem + RL_YOFF + buf * RL_YS + wid * 1024), 16, 0, 0);
   };
 
   const int l15 = lane & 15, q4 = lane >> 4, sw = l15 >> 1;
   const int xoff_h = (wid * 64 + l15) * 128 + ((q4 ^ sw) << 4);
   const int xoff_l = (wid * 64 + l15) * 128 + (((4 + q4) ^ sw) << 4);
-  const int yoff_h = RL_BI * 128 + l15 * 128 + ((q4 ^ sw) << 4);
-  const int yoff_l = RL_BI * 128 + l15 * 128 + (((4 + q4) ^ sw) << 4);
+  const int yoff_h = RL_YOFF + l15 * 128 + ((q4 ^ sw) << 4);
+  const int yoff_l = RL_YOFF + l15 * 128 + (((4 + q4) ^ sw) << 4);
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -84,12 +91,23 @@ __global__ void __launch_bounds__(512, 2) gemm_rowln_kernel(const RowLnArgs a) {
 #pragma unroll
     for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  stage(0, 0);
-  __syncthreads();
+  // One workgroup per CU: nobody else covers a wait, so the activation tile -- the operand that comes from HBM -- is requested
+  // TWO k-steps ahead.  vmcnt retires in order: every wave requests its 8 weight pieces of k-step kt+1 first and its activation
+  // piece of k-step kt+2 last, and waits with vmcnt(1): the weights of kt+1 and the (older) activation piece of kt+1 have landed,
+  // the youngest request stays in flight across the barrier.
+  stage_x(0, 0);
+  stage_y(0, 0);
+  if (nkt > 1) { stage_y(1, 1); __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(1)); }
+  else __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(0));
+  __builtin_amdgcn_s_barrier();
+  int ybuf = 0;
   for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);
-    const char* sb = smem + buf * RL_STAGE;
+    int yb2 = ybuf + 2;
+    if (yb2 >= 3) yb2 -= 3;
+    if (kt + 1 < nkt) stage_x(kt + 1, (kt + 1) & 1);     // X buffer (kt+1)&1 and Y buffer (kt+2)%3 were last read in iteration kt-1
+    if (kt + 2 < nkt) stage_y(kt + 2, yb2);
+    const char* sb = smem + (kt & 1) * RL_XS;
+    const char* sy = smem + ybuf * RL_YS;
     spx8 xh[4], xl[4], yh[4], yl[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -98,8 +116,8 @@ __global__ void __launch_bounds__(512, 2) gemm_rowln_kernel(const RowLnArgs a) {
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      yh[t] = *reinterpret_cast<const spx8*>(sb + yoff_h + t * 2048);
-      yl[t] = *reinterpret_cast<const spx8*>(sb + yoff_l + t * 2048);
+      yh[t] = *reinterpret_cast<const spx8*>(sy + yoff_h + t * 2048);
+      yl[t] = *reinterpret_cast<const spx8*>(sy + yoff_l + t * 2048);
     }
     __builtin_amdgcn_sched_barrier(0);   // all fragment reads of the k-step are issued before its first MFMA
 #pragma unroll
@@ -111,7 +129,10 @@ __global__ void __launch_bounds__(512, 2) gemm_rowln_kernel(const RowLnArgs a) {
         acc[ti][tj] = SP_MFMA(xh[ti], yh[tj], acc[ti][tj], 0, 0, 0);
       }
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
+    if (kt + 2 < nkt) __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(1));
+    else __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(0));
+    __builtin_amdgcn_s_barrier();
+    ybuf = (ybuf == 2) ? 0 : ybuf + 1;
   }
 
   // ---- epilogue.  Row-major lane mapping (the WIDE mapping of gemm_sp.hpp): 16 lanes per row x 4 consecutive features, 4 rows per
@@ -155,13 +176,14 @@ __global__ void __launch_bounds__(512, 2) gemm_rowln_kernel(const RowLnArgs a) {
 
   // row statistics, two passes (mean, then the centred sum of squares) like ln_rows_kernel: 16-lane partial sums of this wave's 64
   // features -> LDS [wave][row] -> one thread per row adds the 8 partials -> LDS -> every lane reads back its 16 rows
-  float* part = reinterpret_cast<float*>(smem + RL_STAT_OFF);          // [8][64]
-  float* stat = part + 8 * 64;                                         // [64]
+  float* stat_base = reinterpret_cast<float*>(smem + RL_STAT_OFF);     // per pass: partial sums [8][64], then the statistic [64]
   auto sum16 = [](float v) __attribute__((always_inline)) -> float {
     v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
     return v;
   };
   auto reduce_rows = [&](float (&val)[4][4], bool finish_rstd) __attribute__((always_inline)) {
+    float* part = stat_base + (finish_rstd ? 9 * 64 : 0);   // (the two passes use disjoint areas: no barrier between them)
+    float* stat = part + 8 * 64;
 #pragma unroll
     for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
@@ -182,7 +204,6 @@ __global__ void __launch_bounds__(512, 2) gemm_rowln_kernel(const RowLnArgs a) {
     for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
       for (int it = 0; it < 4; ++it) val[tj][it] = stat[tj * 16 + it * 4 + lr];
-    __syncthreads();   // everybody has read `stat` before the next pass overwrites `part` / `stat`
   };
   float st[4][4];
 #pragma unroll

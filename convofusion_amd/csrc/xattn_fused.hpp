@@ -87,7 +87,8 @@ struct XaWg {
   int row[XA_TILES];   // effective-batch row of query tile t, or -1 (idle)
   int q0[XA_TILES];    // first query (token index inside the row) of tile t
   int seg0, nseg;
-  int pad0, pad1;
+  int pf_slot, pf_n;   // L2 prefetch share (xattn_role.hpp): this workgroup is number pf_slot of pf_n that stream the same instance of the
+                       // longest memory on one XCD at about the same time (0, 0: no prefetch)
 };
 
 struct XAttnArgs {
