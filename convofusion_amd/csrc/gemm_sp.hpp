@@ -553,6 +553,13 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
   };
   auto compute = [&](int buf) __attribute__((always_inline)) { compute2(smem + buf * STAGE, smem + buf * STAGE); };
 
+#ifndef CFD_GEMM_PRIO
+#define CFD_GEMM_PRIO 0   // developer A/B: workgroups with an odd linear id run at priority 1 (the two co-resident workgroups of a CU drift
+                          // into lock-step otherwise; MI355X_MICROARCH.md, two waves per SIMD)
+#endif
+#if CFD_GEMM_PRIO
+  if (blockIdx.x & 8) __builtin_amdgcn_s_setprio(1);
+#endif
   if constexpr (ASYM) {
     const bool xrole = wid < NW / 2;   // wave-uniform
     if (xrole) {
@@ -856,6 +863,8 @@ static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStr
       if constexpr (MODE == MODE_PLAIN) return launch_cfg<2, 2, 4, 4, 4, MODE, Epi>(a, epi, nb, nz, st);
       else return launch_cfg<2, 2, 4, 4, 2, MODE, Epi>(a, epi, nb, nz, st);
     case 20: return launch_cfg<1, 4, 2, 2, 3, MODE, Epi>(a, epi, nb, nz, st);
+    case 23: return launch_cfg<2, 2, 2, 4, 3, MODE, Epi>(a, epi, nb, nz, st);   // 64 x 128, 3-stage (product-shape experiment)
+    case 24: return launch_cfg<2, 2, 4, 2, 3, MODE, Epi>(a, epi, nb, nz, st);   // 128 x 64, 3-stage
     default: return launch_cfg<4, 1, 2, 1, 2, MODE, Epi>(a, epi, nb, nz, st);
   }
 }

@@ -56,7 +56,7 @@ class DyadicRun:
             torch.cuda.current_stream(la.device).synchronize()       # the graphs replay on the runs' own streams
             # One side after the other: side A's replay is waited for (its latents are needed for the next iteration anyway) before
             # side B's is launched.  Two captured graphs replaying at the same time are not reliable on this stack (see
-            # sampler.ConcurrentRuns, tools/concurrency_soak.py); the overlap was worth ~5 % of an iteration.
+            # DESIGN.md sections 6 and 7.2, tools/concurrency_soak.py); the overlap was worth ~5 % of an iteration.
             self.runs[0].steps(1)
             la = self.runs[0].read()
             self.runs[1].steps(1)

@@ -1,4 +1,4 @@
-"""Developer tool (GPU box): soak test of sampler.ConcurrentRuns' premise.  One batch as a single run, then REPS times as two utterance
+"""Developer tool (GPU box): soak test of the premise of tools/experiments/concurrent_runs.py (two sampling runs replaying at once).  One batch as a single run, then REPS times as two utterance
 shards replayed side by side on the denoiser's two library handles; every shard result must equal the single run bit for bit.
   python tools/concurrency_soak.py <B> <steps> [R]      (REPS=<n> in the environment, default 50; R = product shape L=16)
 Prints the repetitions in which an utterance differed and a summary line.  (History: with the layer-0 de-duplication experiment of
