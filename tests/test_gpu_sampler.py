@@ -380,6 +380,37 @@ def test_small_goldens_on_the_default_attention_path():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
 
 
+def test_attention_of_every_iteration_leaves_the_latents_alone():
+    """sample(return_attention="all"): one extra forward of the full-conditioning rows on the denoiser's second engine before every
+    replay, the host waiting in between (the two engines must not run side by side: DESIGN.md sections 6 and 7.2).  The latents must
+    equal the attention-free run's bit for bit over a longer run and every entry must equal a plain forward of the iteration's input."""
+    import torch
+    from convofusion_amd.sampler import SamplingRun, sample
+    from tests.gpu_helpers import hip_denoiser, to_dev
+    B, L, S, n, seed = 3, 16, (24, 161, 24, 8, 1), 40, 17
+    cb = inputs.make_cfg_batch(seed=seed, B=B, L=L, S=S, pad_tail=(4, 0, 6, 0, 0))
+    mems = [to_dev(x) for x in cb["memories"]]
+    masks = {k: to_dev(v) for k, v in cb["masks"].items()}
+    m = hip_denoiser(1234, 1.0)
+    plain = sample(m, _sched("ddpm"), mems, masks, B=B, L=L, num_inference_steps=n, seed=seed)
+    lat, atts = sample(m, _sched("ddpm"), mems, masks, B=B, L=L, num_inference_steps=n, seed=seed, return_attention="all")
+    assert torch.equal(lat, plain)
+    assert sorted(atts) == sorted(range(0, 1000, 1000 // n)) and all(len(v) == 5 for v in atts.values())
+    # entry t = att_mats of Denoiser.forward on the full-conditioning chunk with the latents that enter iteration t
+    with SamplingRun(m, _sched("ddpm"), mems, masks, B, L, n, guidance_scale=7.5, seed=seed) as run:
+        run.steps(7)
+        x7, t7 = run.read(), run.timesteps[7]
+    keep = m.return_attention
+    m.return_attention = True
+    try:
+        with torch.no_grad():
+            _, want = m(sample=x7, timestep=t7, encoder_hidden_states=[e.chunk(7)[-1] for e in mems],
+                        mem_mask_dict={k: (v.chunk(7)[-1] if v is not None else None) for k, v in masks.items()})
+    finally:
+        m.return_attention = keep
+    assert all(torch.equal(a, b) for a, b in zip(atts[t7], want))
+
+
 def test_ddpm_step_count_that_does_not_divide_the_schedule():
     """DDPM with N = 300 of 1000 (opt-in, unpinned: scheduler.DDPMScheduler(allow_unpinned_timesteps=True)): the loop runs over the
     334 entries of diffusers 0.14.0's table arange(0, 1000, 3)[::-1] with prev_t = t - 3, like the oracle's restated loop; the

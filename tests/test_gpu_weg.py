@@ -216,6 +216,17 @@ def test_loop_with_weg_matches_oracle(rollout):
         lat2 = sample_with_weg(m, sch, u_mems, u_masks, focus, params, B=B, L=L, num_inference_steps=n_steps, guidance_scale=7.5,
                                init_latents=to_dev(init), step_noise=to_dev(noise), row_maps=maps, carry_scale_range=True)
         assert rel_l2(lat2.permute(1, 0, 2).cpu().numpy(), lat) < 1e-5
+        # the reference's attention dict has one entry per iteration, WEG or not (convofusion.py:517-523): return_attention="all"
+        # leaves the latents untouched bit for bit and its last entry is what return_attention=True returns
+        kw = dict(B=B, L=L, num_inference_steps=n_steps, guidance_scale=7.5, init_latents=to_dev(init), step_noise=to_dev(noise),
+                  carry_scale_range=True)
+        lat_all, att_all = sample_with_weg(m, sch, mems, masks, focus, params, return_attention="all", **kw)
+        lat_last, att_last = sample_with_weg(m, sch, mems, masks, focus, params, return_attention=True, **kw)
+        lat_none = sample_with_weg(m, sch, mems, masks, focus, params, **kw)
+        assert torch.equal(lat_all, lat_none) and torch.equal(lat_last, lat_none)
+        assert sorted(att_all) == [0, 200, 400, 600, 800] and all(len(v) == 5 for v in att_all.values())
+        assert all(torch.equal(a, b) for a, b in zip(att_all[0], att_last))
+        assert all(tuple(a.shape) == (B, 9, L, s) for a, s in zip(att_all[800], S))
 
 
 def test_gradient_at_the_synthetic_shape_matches_oracle():
