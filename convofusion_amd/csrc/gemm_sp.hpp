@@ -183,12 +183,24 @@ struct EpiResid {  // x[(b*rows_per_b + j)][i] += v + bias[i]   (row length CFD_
   __device__ __forceinline__ float4 tile_bias(int i) const {
     return bias ? *reinterpret_cast<const float4*>(bias + i) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+#ifndef CFD_RESID_NT
+#define CFD_RESID_NT 0   // developer A/B: non-temporal loads / stores of the residual stream in the epilogue (read once, written once)
+#endif
   __device__ __forceinline__ float4 band_load(int g, int b, int z, int i, int j) const {
+#if CFD_RESID_NT
+    const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + (long long)b * obs + (long long)j * CFD_D + i));
+    return make_float4(q[0], q[1], q[2], q[3]);
+#else
     return *reinterpret_cast<const float4*>(x + (long long)b * obs + (long long)j * CFD_D + i);
+#endif
   }
   __device__ __forceinline__ void band_store(int g, int b, int z, int i, int j, f32x4 v, float4 r, float4 t) const {
     r.x = (r.x + t.x) + v[0]; r.y = (r.y + t.y) + v[1]; r.z = (r.z + t.z) + v[2]; r.w = (r.w + t.w) + v[3];   // same association as above
+#if CFD_RESID_NT
+    __builtin_nontemporal_store(f32x4{r.x, r.y, r.z, r.w}, reinterpret_cast<f32x4*>(x + (long long)b * obs + (long long)j * CFD_D + i));
+#else
     *reinterpret_cast<float4*>(x + (long long)b * obs + (long long)j * CFD_D + i) = r;
+#endif
   }
 };
 
