@@ -337,10 +337,11 @@ def main():
         dom_ms = sum(prof[k][0] for k in gk)
         dom_n = sum(prof[k][1] for k in gk)
         achieved = sum(ex[k] for k in gk) / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        traffic = None
+        traffic = xa_traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic_gemm.json")
         if os.path.exists(tpath) and args.shape == "C2":
-            traffic = json.load(open(tpath)).get("bytes_per_launch_mean")
+            tj = json.load(open(tpath))
+            traffic, xa_traffic = tj.get("bytes_per_launch_mean"), tj.get("xattn_bytes_per_launch")
         for k in ex:
             classes[k]["algorithmic_tflop"] = round(ex[k] / 1e12, 4)
             classes[k]["tflops"] = round(ex[k] / (prof[k][0] * 1e-3) / 1e12, 1) if prof[k][0] > 0 else None
@@ -351,7 +352,7 @@ def main():
                                                      "P.V and residual update of a layer's five cross-attentions in one launch)",
                           "achieved": xa_ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": xa_ach / PEAK_BF16_TFLOPS,
                           "frac_issued": 3.0 * xa_ach / PEAK_BF16_TFLOPS, "frac_of_issued_peak_div3": xa_ach / (PEAK_BF16_TFLOPS / 3.0),
-                          "launches_per_step": xa_n, "avg_launch_ms": xa_ms / max(xa_n, 1), "traffic": None}
+                          "launches_per_step": xa_n, "avg_launch_ms": xa_ms / max(xa_n, 1), "traffic": xa_traffic}
         mfma_ms = sum(prof[k][0] for k in ex)
         all_mfma = sum(ex.values()) / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
         out = {

@@ -87,7 +87,12 @@ def publish():
                 k = int(r["launches_in_trace"])
                 tot += (float(r["read_MB_per_launch_(2xFETCH)"]) + float(r["write_MB_per_launch_(WRITE_SIZE)"])) * 1e6 * k
                 n += k
+        xt, xn = 0.0, 0
+        for r in csv.DictReader(open(t)):    # the full-batch launches of the fused cross-attention kernel (the largest grid in the trace)
+            if r["kernel"].startswith("xattn_fused_kernel") or r["kernel"].startswith("xattn_role_kernel"):
+                xt, xn = max((xt, xn), ((float(r["read_MB_per_launch_(2xFETCH)"]) + float(r["write_MB_per_launch_(WRITE_SIZE)"])) * 1e6, int(r["launches_in_trace"])))
         json.dump({"bytes_per_launch_mean": tot / max(n, 1), "launches_in_trace": n,
+                   "xattn_bytes_per_launch": xt or None, "xattn_launches_in_trace": xn,
                    "source": f"profiles/{tag}_bench_c2_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
                              "`bench.py --steps 3 --warmup 1`; FETCH doubled per MI355X_MICROARCH.md HBM note for gfx950)"},
                   open(os.path.join(PROF, "hbm_traffic_gemm.json"), "w"), indent=1)
