@@ -125,6 +125,8 @@ struct cfd_handle_s {
   // the three-launch path everywhere (parity A/B of the two paths).
   bool fused_xattn = true;
   int fused_xattn_min_wgs = 6;
+  bool dual_qkv = false;            // CFD_DUAL_QKV=1: the q|k and v^T projections of a layer as one launch (gemm_sp_dual_kernel) ...
+  long long dual_min_rows = 16384;  // ... for problems of at least this many token rows (the 128 x 128 tile class)
   bool xa_role = false;     // CFD_XA_ROLE=1: the role-split variant of the fused cross-attention kernel (xattn_role.hpp)
   long long rowln_min_rows = -1;      // CFD_ROWLN_MIN_ROWS=<n>: residual products of at least n rows use the row-complete kernel with the
                                       // following LayerNorm in its epilogue (gemm_rowln.hpp).  Off by default: measured slower
@@ -263,6 +265,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   c->fused_xattn = !(env && atoi(env) == 0);
   env = getenv("CFD_FUSED_XATTN_MIN_WGS");
   if (env) c->fused_xattn_min_wgs = atoi(env);
+  env = getenv("CFD_DUAL_QKV");
+  c->dual_qkv = env && atoi(env) != 0;
   env = getenv("CFD_XA_ROLE");
   c->xa_role = env && atoi(env) != 0;
   env = getenv("CFD_ROWLN_MIN_ROWS");
@@ -993,20 +997,27 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     // (norm1 of layers 1.. is made by the previous layer's last residual product when that ran row-complete: `h_ready`)
     if (!h_ready) CHK(ln(w.ln1g, w.ln1b, 0, 0, c->h_sp.as<char>(), Ma));
     h_ready = false;
-    {  // q (pre-scaled) and k, token-major
+    const int Lv = (L + 63) / 64 * 64;
+    {
+      // q (pre-scaled) and k, token-major ...
       GemmArgs a = gemm_args();
       a.X[0] = w.wqk_sp.as<char>(); a.ldx[0] = ROWB; a.I[0] = 2 * CFD_D; a.Iclamp[0] = 2 * CFD_D; a.kt[0] = CFD_D / 32;
       a.Y = c->h_sp.as<char>(); a.ldy = ROWB; a.J = (int)Ma; a.Jclamp = (int)Ma;
       EpiSplit e{c->qk_sp.as<char>(), 2 * ROWB, 0, 0, w.bqk.as<float>(), 0, 0};
-      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
-    }
-    const int Lv = (L + 63) / 64 * 64;
-    {  // v^T per batch row: vts[b][f][l] (keys in P-fragment order for the fused kernel)
-      GemmArgs a = gemm_args();
-      a.X[0] = c->h_sp.as<char>(); a.ldx[0] = ROWB; a.xbs[0] = (long long)L * ROWB; a.I[0] = Lv; a.Iclamp[0] = L; a.kt[0] = CFD_D / 32;
-      a.Y = w.wv_sp.as<char>(); a.ldy = ROWB; a.J = CFD_D; a.Jclamp = CFD_D;
-      EpiSplit e{c->vts_sp.as<char>(), (long long)Lv * 4, (long long)CFD_D * Lv * 4, 0, nullptr, 0, 1};
-      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, Ba, 1, st)));
+      // ... and v^T per batch row: vts[b][f][l] (keys in P-fragment order for the fused kernel)
+      GemmArgs av = gemm_args();
+      av.X[0] = c->h_sp.as<char>(); av.ldx[0] = ROWB; av.xbs[0] = (long long)L * ROWB; av.I[0] = Lv; av.Iclamp[0] = L; av.kt[0] = CFD_D / 32;
+      av.Y = w.wv_sp.as<char>(); av.ldy = ROWB; av.J = CFD_D; av.Jclamp = CFD_D;
+      EpiSplit ev{c->vts_sp.as<char>(), (long long)Lv * 4, (long long)CFD_D * Lv * 4, 0, nullptr, 0, 1};
+      if (c->dual_qkv && !g_cfd_naive_gemm && Ma >= c->dual_min_rows) {
+        // both read h and neither fills the chip for a whole number of rounds: one launch (gemm_sp_dual_kernel)
+        Bracket br(c, CFD_PROF_GEMM_TOKEN, st);
+        hipError_t err = launch_gemm_dual(a, e, 1, av, ev, Ba, st);
+        if (err != hipSuccess) return fail(CFD_E_HIP, "dual gemm launch failed: %s", hipGetErrorString(err));
+      } else {
+        CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
+        CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, av, ev, Ba, 1, st)));
+      }
     }
     {
       SelfAttnArgs a{c->qk_sp.as<char>(), c->vts_sp.as<char>(), c->o_sp.as<char>(), L, Lv};

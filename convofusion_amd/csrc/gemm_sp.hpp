@@ -303,9 +303,10 @@ template <class E> struct EpiPre<E, true> { typedef typename E::Pre type; };
 // NSTAGE == 3: two k-tiles of prefetch kept in flight ACROSS the per-k-step barrier: counted
 //              s_waitcnt vmcnt(GPW) + raw s_barrier (a __syncthreads() would drain the LDS-DMA queue).
 //              Requires every wave to issue exactly GPW loads per stage.
+// The body takes its position in the launch as arguments (linear block id `lin_in` of an nx x ny x nz grid): gemm_sp_kernel passes
+// blockIdx / gridDim, gemm_sp_dual_kernel (below) runs two problems in one launch.
 template <int WI, int WJ, int TI, int TJ, int NSTAGE, int MODE, class Epi>
-__global__ void __launch_bounds__(WI * WJ * 64, (WI * WJ * 64) / 256 * ((WI * TI + WJ * TJ) * 16 * 128 * NSTAGE <= 52 * 1024 ? 3 : 2))
-gemm_sp_kernel(const GemmArgs a, const Epi epi) {
+__device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, const long long lin_in, const int nx_in, const int ny_in, const int nz_in) {
   constexpr int NW = WI * WJ;
   constexpr int BI = WI * TI * 16, BJ = WJ * TJ * 16;
   constexpr int STAGE = (BI + BJ) * 128;
@@ -334,9 +335,9 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
   // and, for batched launches, all tiles of one batch row -- share an L2 instead of each fetching from HBM.
   int t, b, z;
   {
-    const int nx = gridDim.x, ny = gridDim.y;
-    const long long total = (long long)nx * ny * gridDim.z;
-    const long long lin = blockIdx.x + (long long)nx * (blockIdx.y + (long long)ny * blockIdx.z);
+    const int nx = nx_in, ny = ny_in;
+    const long long total = (long long)nx * ny * nz_in;
+    const long long lin = lin_in;
     const long long q = total >> 3, k = lin >> 3;
     const int r = (int)(total & 7), xcd = (int)(lin & 7);
     const long long v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
@@ -570,7 +571,7 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
                           // into lock-step otherwise; MI355X_MICROARCH.md, two waves per SIMD)
 #endif
 #if CFD_GEMM_PRIO
-  if (blockIdx.x & 8) __builtin_amdgcn_s_setprio(1);
+  if (lin_in & 8) __builtin_amdgcn_s_setprio(1);
 #endif
   if constexpr (ASYM) {
     const bool xrole = wid < NW / 2;   // wave-uniform
@@ -745,17 +746,36 @@ gemm_sp_kernel(const GemmArgs a, const Epi epi) {
   // does the NEXT kernel of the stream start before this one has finished?  Every workgroup of the final projection (EpiF32 into
   // a [J][128] matrix) counts itself done in a word behind the matrix; cfg_step_kernel compares the count with what it must be.
   if constexpr (std::is_same<Epi, EpiF32>::value) {
-    if (epi.ldo == 128 && MODE == MODE_PLAIN && gridDim.y == 1) {
+    if (epi.ldo == 128 && MODE == MODE_PLAIN && ny_in == 1) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (threadIdx.x == 0) {
         unsigned* cnt = reinterpret_cast<unsigned*>(epi.out + (long long)a.J * epi.ldo);
-        if (blockIdx.x == 0) atomicExch(cnt + 3, gridDim.x);   // workgroups per launch
+        if (lin_in == 0) atomicExch(cnt + 3, (unsigned)nx_in);   // workgroups per launch
         atomicAdd(cnt, 1u);
       }
     }
   }
 #endif
+}
+
+template <int WI, int WJ, int TI, int TJ, int NSTAGE, int MODE, class Epi>
+__global__ void __launch_bounds__(WI * WJ * 64, (WI * WJ * 64) / 256 * ((WI * TI + WJ * TJ) * 16 * 128 * NSTAGE <= 52 * 1024 ? 3 : 2))
+gemm_sp_kernel(const GemmArgs a, const Epi epi) {
+  gemm_sp_body<WI, WJ, TI, TJ, NSTAGE, MODE, Epi>(a, epi, blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z),
+                                                  (int)gridDim.x, (int)gridDim.y, (int)gridDim.z);
+}
+
+// Two independent plain problems of one tile configuration in ONE launch (round 3): the q|k projection and the v^T projection of
+// a layer read the same activation and neither fills the chip for a whole number of rounds (2 744 + 1 792 tiles of 128 x 128 on 512
+// workgroup slots: 6 + 4 rounds apart, 9 together).  Blocks [0, n0) run problem 0, the rest problem 1; each keeps its own
+// XCD-aware order.
+template <int WI, int WJ, int TI, int TJ, int NSTAGE, class Epi0, class Epi1>
+__global__ void __launch_bounds__(WI * WJ * 64, (WI * WJ * 64) / 256 * ((WI * TI + WJ * TJ) * 16 * 128 * NSTAGE <= 52 * 1024 ? 3 : 2))
+gemm_sp_dual_kernel(const GemmArgs a0, const Epi0 e0, const int nx0, const int ny0, const GemmArgs a1, const Epi1 e1, const int nx1, const int ny1) {
+  const int n0 = nx0 * ny0;
+  if ((int)blockIdx.x < n0) gemm_sp_body<WI, WJ, TI, TJ, NSTAGE, MODE_PLAIN, Epi0>(a0, e0, blockIdx.x, nx0, ny0, 1);
+  else gemm_sp_body<WI, WJ, TI, TJ, NSTAGE, MODE_PLAIN, Epi1>(a1, e1, (int)blockIdx.x - n0, nx1, ny1, 1);
 }
 
 // Reference kernel with the same operands / epilogues, one thread per (4 i, 1 j): used by the
@@ -836,6 +856,36 @@ static hipError_t launch_cfg(GemmArgs a, const Epi& epi, int nb, int nz, hipStre
 //  20 = 32 x 128  (1 x 4 waves of 32 x 32, 3-stage)            memories of <= 64 keys
 // The variants measured and rejected in round 1 (3-stage / software-pipelined / deep-prefetch / single-buffer loops,
 // 128 x 256, 256 x 128, 128 x 176 and 256 x 176 tiles, the tile-softmax epilogues) live in tools/experiments/gemm_sp_r01_variants.hpp.
+// Launch two plain problems (nb batches each) as one grid of 128 x 128 tiles (the 2-stage configuration 1).
+template <class Epi0, class Epi1>
+static hipError_t launch_gemm_dual(GemmArgs a0, const Epi0& e0, int nb0, GemmArgs a1, const Epi1& e1, int nb1, hipStream_t st) {
+  constexpr int WI = 2, WJ = 2, TI = 4, TJ = 4, NSTAGE = 2;
+  constexpr int BI = WI * TI * 16, BJ = WJ * TJ * 16;
+  GemmArgs* as[2] = {&a0, &a1};
+  int nx[2];
+  for (int q = 0; q < 2; ++q) {
+    GemmArgs& a = *as[q];
+    if (a.nslot < 1) a.nslot = 1;
+    a.tiles_j = (a.J + BJ - 1) / BJ;
+    a.tiles_i[0] = (a.I[0] + BI - 1) / BI;
+    a.tile_start[0] = 0;
+    a.tile_start[1] = nx[q] = a.tiles_i[0] * a.tiles_j;
+  }
+  constexpr int lds = NSTAGE * (BI + BJ) * 128;
+  static unsigned long long attr_set = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!((attr_set >> (dev & 63)) & 1ull)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sp_dual_kernel<WI, WJ, TI, TJ, NSTAGE, Epi0, Epi1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set |= 1ull << (dev & 63);
+  }
+  hipLaunchKernelGGL((gemm_sp_dual_kernel<WI, WJ, TI, TJ, NSTAGE, Epi0, Epi1>), dim3((unsigned)(nx[0] * nb0 + nx[1] * nb1)), dim3(WI * WJ * 64), lds, st,
+                     a0, e0, nx[0], nb0, a1, e1, nx[1], nb1);
+  return hipGetLastError();
+}
+
 static inline int big_cfg() {   // the tile configuration of the large products (developer A/B: CFD_BIG_CFG=1 selects the symmetric 2-stage loop)
   static const int v = getenv("CFD_BIG_CFG") ? atoi(getenv("CFD_BIG_CFG")) : 1;
   return v;

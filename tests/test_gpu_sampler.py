@@ -296,7 +296,7 @@ def test_ddim_with_eta_matches_oracle():
 
 
 @pytest.mark.parametrize("env", [{"CFD_NAIVE_GEMM": "1"}, {"CFD_RUNS": "0", "CFD_FUSED_XATTN": "0"}, {"CFD_FUSED_XATTN": "0"},
-                                 {"CFD_HOIST_MEMSIDE": "0"}, {"CFD_ROWLN_MIN_ROWS": "1"}, {"CFD_BIG_CFG": "30"}, {"CFD_XA_ROLE": "1"}])
+                                 {"CFD_HOIST_MEMSIDE": "0"}, {"CFD_ROWLN_MIN_ROWS": "1"}, {"CFD_BIG_CFG": "30"}, {"CFD_XA_ROLE": "1"}, {"CFD_DUAL_QKV": "1"}])
 def test_developer_knobs_keep_parity(env):
     """The debug switches that select another code path for the same arithmetic (read once at cfd_create) must not change
     results: CFD_NAIVE_GEMM=1 (one-thread-per-output products instead of the MFMA kernels, three-launch attention),
@@ -304,7 +304,8 @@ def test_developer_knobs_keep_parity(env):
     CFD_RUNS=0 (per-row attention products only), CFD_HOIST_MEMSIDE=0 (fused cross-attention kernel fed by memory-side
     projections made in every iteration instead of once per run), CFD_ROWLN_MIN_ROWS=1 (the row-complete residual product with
     the following LayerNorm in its epilogue, gemm_rowln.hpp, everywhere: ragged last tiles, per-row timesteps, the headline size),
-    CFD_XA_ROLE=1 (the role-split cross-attention kernel, xattn_role.hpp: one wave of a pair scores + softmax, its partner P.V) and CFD_BIG_CFG=30 (the large
+    CFD_XA_ROLE=1 (the role-split cross-attention kernel, xattn_role.hpp: one wave of a pair scores + softmax, its partner P.V),
+    CFD_DUAL_QKV=1 (the q|k and v^T projections of a layer as one launch, gemm_sp_dual_kernel; headline size only) and CFD_BIG_CFG=30 (the large
     products on the asymmetric LDS ring).  Each leg runs the golden forward, the 20-step trajectory, the run-path
     test and the headline-shape loop rows in a child process."""
     import os
