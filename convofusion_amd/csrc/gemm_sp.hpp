@@ -603,8 +603,49 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
   } else if constexpr (NSTAGE == 2) {
     stage(0, 0);
     __syncthreads();
+#ifndef CFD_INTERLEAVE_FILL
+#define CFD_INTERLEAVE_FILL 0   // developer A/B (round 3): the next k-tile's LDS-DMA requests one at a time between groups of MFMAs instead of
+                                // as a burst in front of the k-step (a burst holds the wave at the vector-memory issue for ~100 cycles a piece)
+#endif
+    constexpr bool INTER = CFD_INTERLEAVE_FILL && MODE == MODE_PLAIN && XG % NW == 0 && YG % NW == 0 && (TI * TJ) % GPW == 0;
     for (int kt = 0; kt < nkt; ++kt) {
       const int buf = kt & 1;
+      if constexpr (INTER) {
+        const char* sb = smem + buf * STAGE;
+        char* sn = smem + (buf ^ 1) * STAGE;
+        const bool more = kt + 1 < nkt;
+        spx8 xh[TI], xl[TI], yh[TJ], yl[TJ];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+          xh[ti] = *reinterpret_cast<const spx8*>(sb + xoff_h + ti * 2048);
+          xl[ti] = *reinterpret_cast<const spx8*>(sb + xoff_l + ti * 2048);
+        }
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) {
+          yh[tj] = *reinterpret_cast<const spx8*>(sb + yoff_h + tj * 2048);
+          yl[tj] = *reinterpret_cast<const spx8*>(sb + yoff_l + tj * 2048);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int PER = (TI * TJ) / GPW;   // (ti, tj) pairs of MFMAs per request
+#pragma unroll
+        for (int g = 0; g < GPW; ++g) {
+          if (more) {
+            if (g < XPW) __builtin_amdgcn_global_load_lds((gptr_t)(xbase_g + xoff[g] + (long long)(kt + 1) * 128), (lptr_t)(sn + (wid + NW * g) * 1024), 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds((gptr_t)(yb + yoff[g - XPW] + (long long)(kt + 1) * 128), (lptr_t)(sn + BI * 128 + (wid + NW * (g - XPW)) * 1024), 16, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < PER; ++q) {
+            const int ti = (g * PER + q) / TJ, tj = (g * PER + q) % TJ;
+            acc[ti][tj] = SP_MFMA(xl[ti], yh[tj], acc[ti][tj], 0, 0, 0);
+            acc[ti][tj] = SP_MFMA(xh[ti], yl[tj], acc[ti][tj], 0, 0, 0);
+            acc[ti][tj] = SP_MFMA(xh[ti], yh[tj], acc[ti][tj], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        continue;
+      }
       if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);
       compute(buf);
 #if CFD_MFMA_FENCE
