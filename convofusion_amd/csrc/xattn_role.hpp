@@ -290,6 +290,13 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_role_kernel(const XAtt
 #undef XR_MFMA_K
     };
     char* hand = smem + XR_HOFF(tile);
+#ifndef XR_A_PRIO
+#define XR_A_PRIO 1   // the A wave of a SIMD gets the matrix pipe first: it still has the softmax to do when its MFMAs are through,
+                      // while its partner has nothing but MFMAs (MI355X_MICROARCH.md, two waves per SIMD, item 2: priority, then age)
+#endif
+#if XR_A_PRIO
+    __builtin_amdgcn_s_setprio(XR_A_PRIO);
+#endif
 
     while (s_begin < nseg) {
       int s_end = s_begin;
