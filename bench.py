@@ -251,7 +251,7 @@ def main():
     sch = scheduler.DDPMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012,
                                   beta_schedule="scaled_linear", variance_type="fixed_small", clip_sample=True)
     n_sched = 1000
-    assert args.steps + args.warmup <= n_sched
+    assert args.steps + args.warmup < n_sched, "steps + warmup must leave one iteration of the 1000-step run for the profiled forward"
 
     def open_run(**kw):
         return SamplingRun(model, sch, mems, masks, B_PER_GPU, L, n_sched, guidance_scale=7.5, seed=0, first_utterance=rank * B_PER_GPU, **kw)

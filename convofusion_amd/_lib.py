@@ -95,7 +95,12 @@ def load():
             # One process rebuilds (file lock: the ranks of a multi-GPU launch all get here at once); build.build() writes to a
             # temporary name and renames it into place, and the hash is read again before the file is mapped.
             import fcntl
-            with open(LIB_PATH + ".lock", "w") as lock:
+            try:
+                lock = open(LIB_PATH + ".lock", "w")
+            except OSError as e:    # read-only install: the package directory cannot hold the lock (nor a rebuilt library)
+                raise ImportError(f"{LIB_PATH} was built from other sources (hash {_built_hash()}, sources {want}) and the package "
+                                  f"directory is not writable ({e}); run `python -m convofusion_amd.build` where it is") from e
+            with lock:
                 fcntl.flock(lock, fcntl.LOCK_EX)
                 try:
                     have = _built_hash()

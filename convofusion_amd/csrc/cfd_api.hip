@@ -14,11 +14,9 @@
 
 #include "../../include/cfdenoise.h"
 #include "gemm_sp.hpp"
-#include "gemm_rowln.hpp"
 #include "rows.hpp"
 #include "attn_fused.hpp"
 #include "xattn_fused.hpp"
-#include "xattn_role.hpp"
 #include "grad.hpp"
 
 int g_cfd_naive_gemm = 0;
@@ -125,11 +123,6 @@ struct cfd_handle_s {
   // the three-launch path everywhere (parity A/B of the two paths).
   bool fused_xattn = true;
   int fused_xattn_min_wgs = 6;
-  bool dual_qkv = false;            // CFD_DUAL_QKV=1: the q|k and v^T projections of a layer as one launch (gemm_sp_dual_kernel) ...
-  long long dual_min_rows = 16384;  // ... for problems of at least this many token rows (the 128 x 128 tile class)
-  bool xa_role = false;     // CFD_XA_ROLE=1: the role-split variant of the fused cross-attention kernel (xattn_role.hpp)
-  long long rowln_min_rows = -1;      // CFD_ROWLN_MIN_ROWS=<n>: residual products of at least n rows use the row-complete kernel with the
-                                      // following LayerNorm in its epilogue (gemm_rowln.hpp).  Off by default: measured slower
   DBuf xa_wgs, xa_segs, xa_stamps;
   bool share0 = true;       // CFD_SHARE0=0: evaluate the pre-cross-attention part of layer 0 for every guidance replica
   DBuf d_step;  // [0] = loop index, [1] = constant 0, [2] = "this iteration's in-painting overwrite is done" (cfd_sample_inpaint)
@@ -265,12 +258,6 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   c->fused_xattn = !(env && atoi(env) == 0);
   env = getenv("CFD_FUSED_XATTN_MIN_WGS");
   if (env) c->fused_xattn_min_wgs = atoi(env);
-  env = getenv("CFD_DUAL_QKV");
-  c->dual_qkv = env && atoi(env) != 0;
-  env = getenv("CFD_XA_ROLE");
-  c->xa_role = env && atoi(env) != 0;
-  env = getenv("CFD_ROWLN_MIN_ROWS");
-  if (env) c->rowln_min_rows = atoll(env);
   env = getenv("CFD_HOIST_MEMSIDE");
   c->hoist_memside = !(env && atoi(env) == 0);
   env = getenv("CFD_PERMUTE");
@@ -734,10 +721,7 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
   CHK(c->u_sp.ensure((size_t)M * CFD_FF * 4));
   CHK(c->sc.ensure((size_t)M * p.Sp_tot * 4));
   CHK(c->p_sp.ensure((size_t)M * p.Sp_tot * 4));
-  CHK(c->eps.ensure((size_t)M * CFD_LAT * 4 + 256));   // (+ 256: the CFD_EXP == 7 developer build keeps three counters behind the matrix)
-#if CFD_EXP == 7
-  HIPCHK(hipMemset(c->eps.as<char>() + (size_t)M * CFD_LAT * 4, 0, 256));
-#endif
+  CHK(c->eps.ensure((size_t)M * CFD_LAT * 4));
   CHK(c->sample_sp.ensure((size_t)M * CFD_LAT * 4));
   for (int j = 0; j < CFD_NMEM; ++j) {
     const size_t rows = (size_t)p.U[j] * p.Sp[j];
@@ -965,25 +949,16 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     EpiResid e{c->x.as<float>(), 0, bias};
     return run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st);
   };
-  // residual product + the LayerNorm that follows it: one row-complete launch for large problems, otherwise the two launches
+  // residual product + the LayerNorm that follows it
   auto token_gemm_resid_ln = [&](const DBuf& w, int K, const char* y, const float* bias, long long rows, const float* g, const float* b,
                                  int adaln, int tbidx) -> int {
-    if (c->rowln_min_rows < 0 || rows < c->rowln_min_rows || g_cfd_naive_gemm) {
-      CHK(token_gemm_resid(w, K, y, bias, rows));
-      return ln(g, b, adaln, tbidx, c->h_sp.as<char>(), rows);
-    }
-    RowLnArgs a{w.as<char>(), y, K, rows, c->x.as<float>(), bias, c->h_sp.as<char>(), g, b, adaln,
-                c->ss_tab.as<float>() + (size_t)tbidx * 2 * CFD_D, (long long)nl * 2 * 2 * CFD_D, dstep, p.tmode, L, row0};
-    Bracket br(c, CFD_PROF_GEMM_TOKEN, st);
-    hipError_t err = launch_rowln(a, st);
-    if (err != hipSuccess) return fail(CFD_E_HIP, "row-complete gemm launch failed: %s", hipGetErrorString(err));
-    return CFD_OK;
+    CHK(token_gemm_resid(w, K, y, bias, rows));
+    return ln(g, b, adaln, tbidx, c->h_sp.as<char>(), rows);
   };
   static unsigned long long attr = 0;   // per device (one bit per ordinal): a process may hold handles on several GPUs
   if (!((attr >> (c->cfg.device & 63)) & 1ull)) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_role_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
     attr |= 1ull << (c->cfg.device & 63);
   }
 
@@ -1009,15 +984,8 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       av.X[0] = c->h_sp.as<char>(); av.ldx[0] = ROWB; av.xbs[0] = (long long)L * ROWB; av.I[0] = Lv; av.Iclamp[0] = L; av.kt[0] = CFD_D / 32;
       av.Y = w.wv_sp.as<char>(); av.ldy = ROWB; av.J = CFD_D; av.Jclamp = CFD_D;
       EpiSplit ev{c->vts_sp.as<char>(), (long long)Lv * 4, (long long)CFD_D * Lv * 4, 0, nullptr, 0, 1};
-      if (c->dual_qkv && !g_cfd_naive_gemm && Ma >= c->dual_min_rows) {
-        // both read h and neither fills the chip for a whole number of rounds: one launch (gemm_sp_dual_kernel)
-        Bracket br(c, CFD_PROF_GEMM_TOKEN, st);
-        hipError_t err = launch_gemm_dual(a, e, 1, av, ev, Ba, st);
-        if (err != hipSuccess) return fail(CFD_E_HIP, "dual gemm launch failed: %s", hipGetErrorString(err));
-      } else {
-        CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
-        CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, av, ev, Ba, 1, st)));
-      }
+      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
+      CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, av, ev, Ba, 1, st)));
     }
     {
       SelfAttnArgs a{c->qk_sp.as<char>(), c->vts_sp.as<char>(), c->o_sp.as<char>(), L, Lv};
@@ -1061,8 +1029,7 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       a.stamps = c->xa_stamps.as<long long>();
 #endif
       Bracket br(c, CFD_PROF_XATTN, st);
-      if (c->xa_role) hipLaunchKernelGGL(xattn_role_kernel, dim3(p.xa_nwg), dim3(XA_WAVES * 64), XA_LDS, st, a);
-      else hipLaunchKernelGGL(xattn_fused_kernel, dim3(p.xa_nwg), dim3(XA_WAVES * 64), XA_LDS, st, a);
+      hipLaunchKernelGGL(xattn_fused_kernel, dim3(p.xa_nwg), dim3(XA_WAVES * 64), XA_LDS, st, a);
       HIPCHK(hipGetLastError());
     } else {
     CHK(ln(w.ln2g, w.ln2b, 0, 0, c->h_sp.as<char>(), M));
@@ -1279,12 +1246,8 @@ static int enqueue_loop_iteration(Ctx* c, hipStream_t st) {
   ca.kind = s.scheduler; ca.clip = s.clip_sample; ca.coef = c->coef.as<StepCoef>(); ca.d_step = c->d_step.as<int>();
   ca.noise = s.step_noise; ca.seed = s.seed; ca.utt0 = s.first_utterance;
   const long long n4 = (long long)s.B * s.L * CFD_LAT / 4;
-  // the loop index is advanced by the last workgroup of cfg_step_kernel (CFD_TINY_ADVANCE=1: by a one-thread kernel behind it, as in
-  // round 1 -- kept for the A/B of tools/concurrency_soak.py)
-  static const bool tiny_advance = getenv("CFD_TINY_ADVANCE") != nullptr;
-  ca.advance = tiny_advance ? nullptr : c->d_step.as<int>();
+  ca.advance = c->d_step.as<int>();   // the last workgroup of cfg_step_kernel advances the loop index
   LAUNCH(CFD_PROF_OTHER, cfg_step_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), st, ca);
-  if (tiny_advance) LAUNCH(CFD_PROF_OTHER, advance_step_kernel, dim3(1), dim3(1), st, c->d_step.as<int>());
   return CFD_OK;
 }
 
@@ -1437,11 +1400,7 @@ extern "C" int cfd_sample_steps(cfd_handle c, int n) {
   if (n < 0 || c->run_pos + n > c->run_iters)
     return fail(CFD_E_ARG, "run has %d of %d iterations done; cannot run %d more", c->run_pos, c->run_iters, n);
   HIPCHK(hipSetDevice(c->cfg.device));
-  static const bool eager = getenv("CFD_EAGER_STEPS") != nullptr;   // developer experiment: enqueue every iteration's launches instead of replaying the graph
-  for (int i = 0; i < n; ++i) {
-    if (eager) CHK(enqueue_loop_iteration(c, c->run_stream));
-    else HIPCHK(hipGraphLaunch(c->gexec, c->run_stream));
-  }
+  for (int i = 0; i < n; ++i) HIPCHK(hipGraphLaunch(c->gexec, c->run_stream));
   c->run_pos += n;
   return CFD_OK;
 }

@@ -38,9 +38,6 @@
 #ifndef CFD_READS_FIRST
 #define CFD_READS_FIRST 1
 #endif
-#ifndef CFD_EXP
-#define CFD_EXP 0   // developer builds for the two-queue investigation (tools/concurrency_variants.sh); 0 = product
-#endif
 #define GEMM_SLOTS 5
 enum { MODE_PLAIN = 0, MODE_GROUPED = 1, MODE_SEGK = 2 };
 
@@ -99,16 +96,7 @@ struct EpiF32 {  // out_f32[j][goff+i] = v (+ bias[i] | + key-bias of group g)
   }
   __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v, const Pre& t) const {
     float* p = out + (long long)b * obs + (long long)z * ozs + (long long)j * ldo + sel5(goff, g) + i;
-#if CFD_EXP == 2 || CFD_EXP == 3   // two-queue investigation: write-through stores of the hand-off buffer
-    const f32x4 r = f32x4{v[0] + t.x, v[1] + t.y, v[2] + t.z, v[3] + t.w};
-#if CFD_EXP == 2
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(r) : "memory");
-#else
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(r) : "memory");
-#endif
-#else
     *reinterpret_cast<float4*>(p) = make_float4(v[0] + t.x, v[1] + t.y, v[2] + t.z, v[3] + t.w);
-#endif
   }
 };
 
@@ -183,24 +171,12 @@ struct EpiResid {  // x[(b*rows_per_b + j)][i] += v + bias[i]   (row length CFD_
   __device__ __forceinline__ float4 tile_bias(int i) const {
     return bias ? *reinterpret_cast<const float4*>(bias + i) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-#ifndef CFD_RESID_NT
-#define CFD_RESID_NT 0   // developer A/B: non-temporal loads / stores of the residual stream in the epilogue (read once, written once)
-#endif
   __device__ __forceinline__ float4 band_load(int g, int b, int z, int i, int j) const {
-#if CFD_RESID_NT
-    const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + (long long)b * obs + (long long)j * CFD_D + i));
-    return make_float4(q[0], q[1], q[2], q[3]);
-#else
     return *reinterpret_cast<const float4*>(x + (long long)b * obs + (long long)j * CFD_D + i);
-#endif
   }
   __device__ __forceinline__ void band_store(int g, int b, int z, int i, int j, f32x4 v, float4 r, float4 t) const {
     r.x = (r.x + t.x) + v[0]; r.y = (r.y + t.y) + v[1]; r.z = (r.z + t.z) + v[2]; r.w = (r.w + t.w) + v[3];   // same association as above
-#if CFD_RESID_NT
-    __builtin_nontemporal_store(f32x4{r.x, r.y, r.z, r.w}, reinterpret_cast<f32x4*>(x + (long long)b * obs + (long long)j * CFD_D + i));
-#else
     *reinterpret_cast<float4*>(x + (long long)b * obs + (long long)j * CFD_D + i) = r;
-#endif
   }
 };
 
@@ -304,7 +280,7 @@ template <class E> struct EpiPre<E, true> { typedef typename E::Pre type; };
 //              s_waitcnt vmcnt(GPW) + raw s_barrier (a __syncthreads() would drain the LDS-DMA queue).
 //              Requires every wave to issue exactly GPW loads per stage.
 // The body takes its position in the launch as arguments (linear block id `lin_in` of an nx x ny x nz grid): gemm_sp_kernel passes
-// blockIdx / gridDim, gemm_sp_dual_kernel (below) runs two problems in one launch.
+// blockIdx / gridDim.
 template <int WI, int WJ, int TI, int TJ, int NSTAGE, int MODE, class Epi>
 __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, const long long lin_in, const int nx_in, const int ny_in, const int nz_in) {
   constexpr int NW = WI * WJ;
@@ -313,17 +289,8 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
   constexpr int XG = BI / 8, YG = BJ / 8;                // 8-row load groups per operand tile
   constexpr int XPW = (XG + NW - 1) / NW, YPW = (YG + NW - 1) / NW;
   constexpr int GPW = XPW + YPW;
-  // NSTAGE == 4: the ASYMMETRIC ring (round 3).  The column operand Y is the activation stream -- distinct HBM bytes for every
-  // row panel -- while the row operand X (a weight matrix) stays L2-resident; what bounds the big token-side products is the number
-  // of distinct HBM bytes in flight.  So X keeps 2 stages and Y gets 3: (2 BI + 3 BJ) * 128 B = 80 KB for the
-  // 128 x 128 tile, still two workgroups per CU.  vmcnt retires in order, so a wave that requests both operands cannot leave a Y
-  // tile in flight across the wait for the next X tile: the waves split the roles instead -- the first half of the workgroup's
-  // waves requests X tiles only (one ahead, vmcnt(0)), the second half Y tiles only (two ahead, counted vmcnt).
-  constexpr bool ASYM = NSTAGE == 4;
-  constexpr int XPW2 = XG / (NW / 2 > 0 ? NW / 2 : 1), YPW2 = YG / (NW / 2 > 0 ? NW / 2 : 1);   // pieces per loading wave (ASYM)
-  static_assert(NSTAGE == 2 || NSTAGE == 3 || NSTAGE == 4, "2-stage (one barrier per k-step), 3-stage (counted vmcnt) or asymmetric loop");
+  static_assert(NSTAGE == 2 || NSTAGE == 3, "2-stage (one barrier per k-step) or 3-stage (counted vmcnt) loop");
   static_assert(NSTAGE != 3 || (XG % NW == 0 && YG % NW == 0), "3-stage pipeline needs uniform load counts per wave");
-  static_assert(!ASYM || (NW % 2 == 0 && XG % (NW / 2) == 0 && YG % (NW / 2) == 0 && MODE == MODE_PLAIN), "asymmetric ring: even wave count, uniform loads, plain mode");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
@@ -473,29 +440,6 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
     }
   };
 
-  // ASYM: this wave's pieces of an X tile (waves [0, NW/2)) or of a Y tile (waves [NW/2, NW)); group gi = hw + (NW/2) n
-  const int hw = wid % (NW / 2 > 0 ? NW / 2 : 1);
-  long long aoff[ASYM ? (XPW2 > YPW2 ? XPW2 : YPW2) : 1];
-  if constexpr (ASYM) {
-    const bool xrole = wid < NW / 2;
-#pragma unroll
-    for (int n = 0; n < (XPW2 > YPW2 ? XPW2 : YPW2); ++n) {
-      const int r = (hw + (NW / 2) * n) * 8 + rsub;
-      const int sw8 = (cpos ^ ((r >> 1) & 7)) << 4;
-      aoff[n] = xrole ? (long long)min(i0 + r, Iclamp_g - 1) * ldx_g + sw8 : (long long)min(j0 + r, a.Jclamp - 1) * a.ldy + sw8;
-    }
-  }
-  auto stage_x = [&](int kt, int buf) __attribute__((always_inline)) {   // ASYM, X-loading waves
-#pragma unroll
-    for (int n = 0; n < XPW2; ++n)
-      __builtin_amdgcn_global_load_lds((gptr_t)(xbase_g + aoff[n] + (long long)kt * 128), (lptr_t)(smem + buf * (BI * 128) + (hw + (NW / 2) * n) * 1024), 16, 0, 0);
-  };
-  auto stage_y = [&](int kt, int buf) __attribute__((always_inline)) {   // ASYM, Y-loading waves
-#pragma unroll
-    for (int n = 0; n < YPW2; ++n)
-      __builtin_amdgcn_global_load_lds((gptr_t)(yb + aoff[n] + (long long)kt * 128), (lptr_t)(smem + 2 * (BI * 128) + buf * (BJ * 128) + (hw + (NW / 2) * n) * 1024), 16, 0, 0);
-  };
-
   // fragment read offsets
   const int l15 = lane & 15, q4 = lane >> 4;
   const int sw = l15 >> 1;
@@ -566,86 +510,11 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
   };
   auto compute = [&](int buf) __attribute__((always_inline)) { compute2(smem + buf * STAGE, smem + buf * STAGE); };
 
-#ifndef CFD_GEMM_PRIO
-#define CFD_GEMM_PRIO 0   // developer A/B: workgroups with an odd linear id run at priority 1 (the two co-resident workgroups of a CU drift
-                          // into lock-step otherwise; MI355X_MICROARCH.md, two waves per SIMD)
-#endif
-#if CFD_GEMM_PRIO
-  if (lin_in & 8) __builtin_amdgcn_s_setprio(1);
-#endif
-  if constexpr (ASYM) {
-    const bool xrole = wid < NW / 2;   // wave-uniform
-    if (xrole) {
-      stage_x(0, 0);
-      __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(0));
-    } else {
-      stage_y(0, 0);
-      if (nkt > 1) { stage_y(1, 1); __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(YPW2)); }
-      else __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(0));
-    }
-    __builtin_amdgcn_s_barrier();
-    int ybuf = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-      int yb2 = ybuf + 2;
-      if (yb2 >= 3) yb2 -= 3;
-      if (xrole) { if (kt + 1 < nkt) stage_x(kt + 1, (kt + 1) & 1); }       // X buffer (kt+1)&1 was last read in iteration kt-1
-      else { if (kt + 2 < nkt) stage_y(kt + 2, yb2); }                      // Y buffer (kt+2)%3 likewise
-      compute2(smem + (kt & 1) * (BI * 128), smem + 2 * (BI * 128) + ybuf * (BJ * 128) - BI * 128);
-#if CFD_MFMA_FENCE
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-      // the next k-step's tiles have landed; this wave's fragment reads are done before anybody overwrites the buffers
-      if (xrole || kt + 2 >= nkt) __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(0));
-      else __builtin_amdgcn_s_waitcnt(WAIT_VM_LGKM0(YPW2));
-      __builtin_amdgcn_s_barrier();
-      ybuf = (ybuf == 2) ? 0 : ybuf + 1;
-    }
-  } else if constexpr (NSTAGE == 2) {
+  if constexpr (NSTAGE == 2) {
     stage(0, 0);
     __syncthreads();
-#ifndef CFD_INTERLEAVE_FILL
-#define CFD_INTERLEAVE_FILL 0   // developer A/B (round 3): the next k-tile's LDS-DMA requests one at a time between groups of MFMAs instead of
-                                // as a burst in front of the k-step (a burst holds the wave at the vector-memory issue for ~100 cycles a piece)
-#endif
-    constexpr bool INTER = CFD_INTERLEAVE_FILL && MODE == MODE_PLAIN && XG % NW == 0 && YG % NW == 0 && (TI * TJ) % GPW == 0;
     for (int kt = 0; kt < nkt; ++kt) {
       const int buf = kt & 1;
-      if constexpr (INTER) {
-        const char* sb = smem + buf * STAGE;
-        char* sn = smem + (buf ^ 1) * STAGE;
-        const bool more = kt + 1 < nkt;
-        spx8 xh[TI], xl[TI], yh[TJ], yl[TJ];
-#pragma unroll
-        for (int ti = 0; ti < TI; ++ti) {
-          xh[ti] = *reinterpret_cast<const spx8*>(sb + xoff_h + ti * 2048);
-          xl[ti] = *reinterpret_cast<const spx8*>(sb + xoff_l + ti * 2048);
-        }
-#pragma unroll
-        for (int tj = 0; tj < TJ; ++tj) {
-          yh[tj] = *reinterpret_cast<const spx8*>(sb + yoff_h + tj * 2048);
-          yl[tj] = *reinterpret_cast<const spx8*>(sb + yoff_l + tj * 2048);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        constexpr int PER = (TI * TJ) / GPW;   // (ti, tj) pairs of MFMAs per request
-#pragma unroll
-        for (int g = 0; g < GPW; ++g) {
-          if (more) {
-            if (g < XPW) __builtin_amdgcn_global_load_lds((gptr_t)(xbase_g + xoff[g] + (long long)(kt + 1) * 128), (lptr_t)(sn + (wid + NW * g) * 1024), 16, 0, 0);
-            else __builtin_amdgcn_global_load_lds((gptr_t)(yb + yoff[g - XPW] + (long long)(kt + 1) * 128), (lptr_t)(sn + BI * 128 + (wid + NW * (g - XPW)) * 1024), 16, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int q = 0; q < PER; ++q) {
-            const int ti = (g * PER + q) / TJ, tj = (g * PER + q) % TJ;
-            acc[ti][tj] = SP_MFMA(xl[ti], yh[tj], acc[ti][tj], 0, 0, 0);
-            acc[ti][tj] = SP_MFMA(xh[ti], yl[tj], acc[ti][tj], 0, 0, 0);
-            acc[ti][tj] = SP_MFMA(xh[ti], yh[tj], acc[ti][tj], 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-        continue;
-      }
       if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);
       compute(buf);
 #if CFD_MFMA_FENCE
@@ -777,27 +646,6 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
         }
       }
   }
-#if CFD_EXP == 1 || CFD_EXP == 2 || CFD_EXP == 3
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // every store acknowledged before the wave ends
-#elif CFD_EXP == 4
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                  // L2 write-back by every wave
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#elif CFD_EXP == 7
-  // does the NEXT kernel of the stream start before this one has finished?  Every workgroup of the final projection (EpiF32 into
-  // a [J][128] matrix) counts itself done in a word behind the matrix; cfg_step_kernel compares the count with what it must be.
-  if constexpr (std::is_same<Epi, EpiF32>::value) {
-    if (epi.ldo == 128 && MODE == MODE_PLAIN && ny_in == 1) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        unsigned* cnt = reinterpret_cast<unsigned*>(epi.out + (long long)a.J * epi.ldo);
-        if (lin_in == 0) atomicExch(cnt + 3, (unsigned)nx_in);   // workgroups per launch
-        atomicAdd(cnt, 1u);
-      }
-    }
-  }
-#endif
 }
 
 template <int WI, int WJ, int TI, int TJ, int NSTAGE, int MODE, class Epi>
@@ -805,18 +653,6 @@ __global__ void __launch_bounds__(WI * WJ * 64, (WI * WJ * 64) / 256 * ((WI * TI
 gemm_sp_kernel(const GemmArgs a, const Epi epi) {
   gemm_sp_body<WI, WJ, TI, TJ, NSTAGE, MODE, Epi>(a, epi, blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z),
                                                   (int)gridDim.x, (int)gridDim.y, (int)gridDim.z);
-}
-
-// Two independent plain problems of one tile configuration in ONE launch (round 3): the q|k projection and the v^T projection of
-// a layer read the same activation and neither fills the chip for a whole number of rounds (2 744 + 1 792 tiles of 128 x 128 on 512
-// workgroup slots: 6 + 4 rounds apart, 9 together).  Blocks [0, n0) run problem 0, the rest problem 1; each keeps its own
-// XCD-aware order.
-template <int WI, int WJ, int TI, int TJ, int NSTAGE, class Epi0, class Epi1>
-__global__ void __launch_bounds__(WI * WJ * 64, (WI * WJ * 64) / 256 * ((WI * TI + WJ * TJ) * 16 * 128 * NSTAGE <= 52 * 1024 ? 3 : 2))
-gemm_sp_dual_kernel(const GemmArgs a0, const Epi0 e0, const int nx0, const int ny0, const GemmArgs a1, const Epi1 e1, const int nx1, const int ny1) {
-  const int n0 = nx0 * ny0;
-  if ((int)blockIdx.x < n0) gemm_sp_body<WI, WJ, TI, TJ, NSTAGE, MODE_PLAIN, Epi0>(a0, e0, blockIdx.x, nx0, ny0, 1);
-  else gemm_sp_body<WI, WJ, TI, TJ, NSTAGE, MODE_PLAIN, Epi1>(a1, e1, (int)blockIdx.x - n0, nx1, ny1, 1);
 }
 
 // Reference kernel with the same operands / epilogues, one thread per (4 i, 1 j): used by the
@@ -874,7 +710,7 @@ static hipError_t launch_cfg(GemmArgs a, const Epi& epi, int nb, int nz, hipStre
     total += a.tiles_i[g] * a.tiles_j;
   }
   a.tile_start[ng] = total;
-  constexpr int lds = NSTAGE == 4 ? (2 * BI + 3 * BJ) * 128 : NSTAGE * (BI + BJ) * 128;
+  constexpr int lds = NSTAGE * (BI + BJ) * 128;
   // the attribute is per device: one bit per device ordinal (a process may hold handles on several GPUs)
   static unsigned long long attr_set = 0;
   int dev = 0;
@@ -897,41 +733,6 @@ static hipError_t launch_cfg(GemmArgs a, const Epi& epi, int nb, int nz, hipStre
 //  20 = 32 x 128  (1 x 4 waves of 32 x 32, 3-stage)            memories of <= 64 keys
 // The variants measured and rejected in round 1 (3-stage / software-pipelined / deep-prefetch / single-buffer loops,
 // 128 x 256, 256 x 128, 128 x 176 and 256 x 176 tiles, the tile-softmax epilogues) live in tools/experiments/gemm_sp_r01_variants.hpp.
-// Launch two plain problems (nb batches each) as one grid of 128 x 128 tiles (the 2-stage configuration 1).
-template <class Epi0, class Epi1>
-static hipError_t launch_gemm_dual(GemmArgs a0, const Epi0& e0, int nb0, GemmArgs a1, const Epi1& e1, int nb1, hipStream_t st) {
-  constexpr int WI = 2, WJ = 2, TI = 4, TJ = 4, NSTAGE = 2;
-  constexpr int BI = WI * TI * 16, BJ = WJ * TJ * 16;
-  GemmArgs* as[2] = {&a0, &a1};
-  int nx[2];
-  for (int q = 0; q < 2; ++q) {
-    GemmArgs& a = *as[q];
-    if (a.nslot < 1) a.nslot = 1;
-    a.tiles_j = (a.J + BJ - 1) / BJ;
-    a.tiles_i[0] = (a.I[0] + BI - 1) / BI;
-    a.tile_start[0] = 0;
-    a.tile_start[1] = nx[q] = a.tiles_i[0] * a.tiles_j;
-  }
-  constexpr int lds = NSTAGE * (BI + BJ) * 128;
-  static unsigned long long attr_set = 0;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (!((attr_set >> (dev & 63)) & 1ull)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sp_dual_kernel<WI, WJ, TI, TJ, NSTAGE, Epi0, Epi1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_set |= 1ull << (dev & 63);
-  }
-  hipLaunchKernelGGL((gemm_sp_dual_kernel<WI, WJ, TI, TJ, NSTAGE, Epi0, Epi1>), dim3((unsigned)(nx[0] * nb0 + nx[1] * nb1)), dim3(WI * WJ * 64), lds, st,
-                     a0, e0, nx[0], nb0, a1, e1, nx[1], nb1);
-  return hipGetLastError();
-}
-
-static inline int big_cfg() {   // the tile configuration of the large products (developer A/B: CFD_BIG_CFG=1 selects the symmetric 2-stage loop)
-  static const int v = getenv("CFD_BIG_CFG") ? atoi(getenv("CFD_BIG_CFG")) : 1;
-  return v;
-}
-
 template <int MODE, class Epi>
 static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStream_t st, int cfg = 0) {
   if (a.nslot < 1) a.nslot = 1;
@@ -955,19 +756,14 @@ static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStr
     if (a.J <= 16) cfg = 3;
     else if (imax <= 64 && a.J >= 96) cfg = 20;
     else if (a.J > 128 && a.J <= 224 && big_tiles * 2 >= 256) cfg = 6;
-    else if (big_tiles * 2 >= 384 && a.J >= 96) cfg = big_cfg();
+    else if (big_tiles * 2 >= 384 && a.J >= 96) cfg = 1;
     else cfg = 19;
   }
   switch (cfg) {
     case 1: return launch_cfg<2, 2, 4, 4, 2, MODE, Epi>(a, epi, nb, nz, st);
     case 6: return launch_cfg<4, 1, 2, 7, 2, MODE, Epi>(a, epi, nb, nz, st);
     case 19: return launch_cfg<2, 2, 2, 2, 3, MODE, Epi>(a, epi, nb, nz, st);
-    case 30:   // 128 x 128 with the asymmetric ring (X 2 stages, Y 3 stages, role-split loading); plain problems only
-      if constexpr (MODE == MODE_PLAIN) return launch_cfg<2, 2, 4, 4, 4, MODE, Epi>(a, epi, nb, nz, st);
-      else return launch_cfg<2, 2, 4, 4, 2, MODE, Epi>(a, epi, nb, nz, st);
     case 20: return launch_cfg<1, 4, 2, 2, 3, MODE, Epi>(a, epi, nb, nz, st);
-    case 23: return launch_cfg<2, 2, 2, 4, 3, MODE, Epi>(a, epi, nb, nz, st);   // 64 x 128, 3-stage (product-shape experiment)
-    case 24: return launch_cfg<2, 2, 4, 2, 3, MODE, Epi>(a, epi, nb, nz, st);   // 128 x 64, 3-stage
     default: return launch_cfg<4, 1, 2, 1, 2, MODE, Epi>(a, epi, nb, nz, st);
   }
 }

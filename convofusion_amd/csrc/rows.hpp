@@ -571,25 +571,6 @@ __global__ void cfg_step_kernel(const CfgStepArgs a) {
   const int per_utt = a.L * CFD_LAT;
   const long long n4 = (long long)a.B * per_utt / 4;
   const int i = *a.d_step;
-#if CFD_EXP == 5   // two-queue investigation: agent-scope acquire (L1 invalidate) in front of the first read of eps
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#elif CFD_EXP == 6 // ... or simply a delay of ~10 us in front of it (is a write of the previous kernel still on its way?)
-  for (int w = 0; w < 200; ++w) __builtin_amdgcn_s_sleep(127);
-#elif CFD_EXP == 7 // ... or is the previous kernel (the final projection) still RUNNING?  (counter: gemm_sp.hpp)
-  {
-    unsigned* cnt = reinterpret_cast<unsigned*>(const_cast<float*>(a.eps) + (long long)a.G * a.B * a.L * CFD_LAT);
-    if (threadIdx.x == 0) {
-      const unsigned done = atomicAdd(cnt, 0u);          // projection workgroups finished so far (all launches on this buffer)
-      const unsigned steps = atomicAdd(cnt + 2, 0u);     // cfg_step kernels finished so far
-      const unsigned tiles = atomicAdd(cnt + 3, 0u);     // projection workgroups per launch (0: not even its block 0 is done)
-      if (tiles == 0 || done < (steps + 1) * tiles) {
-        const unsigned n = atomicAdd(cnt + 1, 1u);
-        if (n < 4) printf("ORDER VIOLATION: cfg_step_kernel block %d started with %u of %u projection workgroups done\n", (int)blockIdx.x, done, (steps + 1) * tiles);
-      }
-    }
-  }
-#endif
   if (idx < n4) {
   const StepCoef c = a.coef[i];
   const long long e0 = idx * 4;
@@ -645,17 +626,9 @@ __global__ void cfg_step_kernel(const CfgStepArgs a) {
         a.advance[3] = 0;
         a.advance[2] = 0;
         a.advance[0] = i + 1;
-#if CFD_EXP == 7
-        atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(a.eps) + (long long)a.G * a.B * a.L * CFD_LAT) + 2, 1u);
-#endif
       }
     }
   }
-}
-
-__global__ void advance_step_kernel(int* d_step) {
-  *d_step += 1;
-  d_step[2] = 0;
 }
 
 // The in-painting overwrite of begin_step_kernel alone, ahead of the captured iteration (cfd_sample_inpaint): the WEG

@@ -87,7 +87,7 @@ struct XaWg {
   int row[XA_TILES];   // effective-batch row of query tile t, or -1 (idle)
   int q0[XA_TILES];    // first query (token index inside the row) of tile t
   int seg0, nseg;
-  int pf_slot, pf_n;   // L2 prefetch share (xattn_role.hpp): this workgroup is number pf_slot of pf_n that stream the same instance of the
+  int pf_slot, pf_n;   // L2 prefetch share (used by the archived role-split kernel, tools/experiments/r03_variants/xattn_role.hpp): this workgroup is number pf_slot of pf_n that stream the same instance of the
                        // longest memory on one XCD at about the same time (0, 0: no prefetch)
 };
 
@@ -416,12 +416,6 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   Tile cur, nseg_t;
   int cT = 1, cmask = 0, cflags = 0, cj = 0, nT = 1, nmask = 0, nflags = 0, nj = 0;
   if (nseg > 0) seg_tile(0, cur, cT, cmask, cflags, cj);
-#ifndef XA_PRIO
-#define XA_PRIO 0   // developer A/B: static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-#endif
-#if XA_PRIO
-  if (wid >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
   XA_T(0);
   for (int si = 0; si < nseg; ++si) {
     const bool in_seg = active && ((cmask >> tile) & 1);   // wave-uniform, the same for both waves of a pair

@@ -45,6 +45,7 @@ class DyadicRun:
                               dedup=False, row_maps=maps, dynamic_memories=(0,))
             self.runs.append(run)
             self.spk.append(uniq[0][1:])     # rows 1..B of the distinct speaker memories = the conditional ones (a view)
+        self.N = self.runs[0].N      # loop iterations = len(scheduler.timesteps): differs from num_inference_steps for a count that does not divide the schedule
         self.position = 0
         self._lat = None
 
@@ -71,5 +72,6 @@ class DyadicRun:
 def sample_dyadic(denoiser_a, denoiser_b, scheduler, fuser, cond_a, cond_b, uncond, *, B, L, num_inference_steps, **kw):
     """Run both loops to the end; returns (latents_a, latents_b), each [B, L, 128]."""
     run = DyadicRun(denoiser_a, denoiser_b, scheduler, fuser, cond_a, cond_b, uncond, B, L, num_inference_steps, **kw)
-    run.steps(num_inference_steps)
+    run.steps(run.N)
+    assert run.position == run.N
     return run.read(close=True)

@@ -1,5 +1,9 @@
-cd $GRAFT_REPO_ROOT
+#!/bin/bash
+# GPU box: rocprofv3 kernel stats of one utterance at the product shape (C1), 1000-step DDPM.
+set -eu
+cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+mkdir -p gpurun_out
 rm -rf gpurun_out/c1prof
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/c1prof -o run -- python tools/c1_time.py 1 1 > gpurun_out/c1prof.log 2>&1
 tail -3 gpurun_out/c1prof.log

@@ -32,7 +32,8 @@ class ConcurrentRuns:
     with wrong latents about once per 1 000 - 1 500 step pairs (fused and three-launch attention paths alike, the shard whose graph
     is launched first in a step more often; a device synchronisation after every step pair does not remove it; buffers of the two
     handles are disjoint, no kernel uses scratch memory).  The cause was not found in round 2, so nothing
-    in the package selects this class by itself; ``sample(..., concurrent_shards=2)`` and ``bench.py --shards 2`` are opt-in.
+    in the package selects this class; it is reachable only through ``tools/concurrency_soak.py`` and ``tools/shard2_experiment.py``
+    (``sample(..., concurrent_shards=2)`` and ``bench.py --shards 2`` were removed in round 3).
     Same interface as ``SamplingRun`` for steps / read / close.
     """
 
