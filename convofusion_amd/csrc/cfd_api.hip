@@ -17,6 +17,7 @@
 #include "rows.hpp"
 #include "attn_fused.hpp"
 #include "xattn_fused.hpp"
+#include "rowtile.hpp"
 #include "grad.hpp"
 
 int g_cfd_naive_gemm = 0;
@@ -93,6 +94,8 @@ struct Problem {
   // memories (bit j) whose folded projections were computed once for the run from the centred static part of the memory
   // (prepare_static_memside); per step they only get their per-key scale and bias (mem_scale_kernel)
   int static_mask = 0;
+  // small problems (rowtile.hpp): every launch of the forward is a grid of 16-token x 16-feature workgroups; needs every memory static
+  bool rt = false;
 };
 
 struct cfd_handle_s {
@@ -124,6 +127,12 @@ struct cfd_handle_s {
   bool fused_xattn = true;
   int fused_xattn_min_wgs = 6;
   DBuf xa_wgs, xa_segs, xa_stamps;
+  // Row-tile path for small problems (rowtile.hpp): chosen by SHAPE -- at most rt_max_rows token rows of at most RT_MAX_L tokens per batch
+  // row, one timestep for all rows, no dynamic memories.  CFD_ROWTILE=0 turns it off (parity A/B against the tile kernels),
+  // CFD_ROWTILE_MAX_ROWS moves the threshold.
+  bool rt_on = true;
+  long long rt_max_rows = 1024;
+  DBuf rt_vt, rt_cbt[CFD_NMEM];
   bool share0 = true;       // CFD_SHARE0=0: evaluate the pre-cross-attention part of layer 0 for every guidance replica
   DBuf d_step;  // [0] = loop index, [1] = constant 0, [2] = "this iteration's in-painting overwrite is done" (cfd_sample_inpaint)
   DBuf weg_ws, weg_tok;   // cfd_weg_eval: activation arena, focus-token tables
@@ -258,6 +267,10 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   c->fused_xattn = !(env && atoi(env) == 0);
   env = getenv("CFD_FUSED_XATTN_MIN_WGS");
   if (env) c->fused_xattn_min_wgs = atoi(env);
+  env = getenv("CFD_ROWTILE");
+  c->rt_on = !(env && atoi(env) == 0);
+  env = getenv("CFD_ROWTILE_MAX_ROWS");
+  if (env) c->rt_max_rows = atoll(env);
   env = getenv("CFD_HOIST_MEMSIDE");
   c->hoist_memside = !(env && atoi(env) == 0);
   env = getenv("CFD_PERMUTE");
@@ -289,12 +302,12 @@ extern "C" void cfd_destroy(cfd_handle c) {
   DBuf* all[] = {&c->we_sp, &c->wp_sp, &c->we_all, &c->be_all, &c->tsin, &c->x, &c->h_sp, &c->qk_sp, &c->vts_sp,
                  &c->ssc, &c->sp_sp, &c->o_sp, &c->u_sp, &c->sc, &c->p_sp, &c->eps, &c->sample_sp, &c->temb_tab,
                  &c->h1_tab, &c->ss_tab, &c->trows, &c->d_step, &c->weg_ws, &c->weg_tok, &c->latents, &c->coef, &c->inoise, &c->xa_wgs, &c->xa_segs, &c->xa_stamps,
-                 &c->long_rows, &c->short_rows, &c->zero_mask, &c->iota};
+                 &c->long_rows, &c->short_rows, &c->zero_mask, &c->iota, &c->rt_vt};
   for (DBuf* b : all) b->release();
   for (int j = 0; j < CFD_NMEM; ++j) {
     c->wk_all_sp[j].release(); c->wv_all_sp[j].release(); c->n_sp[j].release(); c->kall_sp[j].release();
     c->cb[j].release(); c->vt_all[j].release(); c->mem_own[j].release(); c->perm_map[j].release();
-    c->ca[j].release(); c->asq[j].release(); c->kbtab[j].release(); c->vbtab[j].release();
+    c->ca[j].release(); c->asq[j].release(); c->kbtab[j].release(); c->vbtab[j].release(); c->rt_cbt[j].release();
   }
   for (auto& l : c->lw) {
     DBuf* lb[] = {&l.wqk_sp, &l.bqk, &l.wv_sp, &l.wo_sp, &l.bo2, &l.wtb1_sp, &l.wtb2_sp, &l.w1_sp, &l.w2_sp, &l.cross_bias};
@@ -708,6 +721,11 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
       }
     }
   }
+  p.rt = c->rt_on && tmode == 0 && !g_cfd_naive_gemm && L <= RT_MAX_L && p.M <= c->rt_max_rows && p.Sp_tot <= RT_MAX_KEYS && c->hoist_memside;
+  if (p.rt) {
+    CHK(c->rt_vt.ensure((size_t)Be * CFD_D * RT_MAX_L * 4));
+    HIPCHK(hipMemset(c->rt_vt.p, 0, (size_t)Be * CFD_D * RT_MAX_L * 4));   // keys beyond L stay zero
+  }
   CHK(build_xattn_worklist(c, mem));
   const long long M = p.M;
   const int nl = c->nl;
@@ -786,7 +804,8 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
     CHK(c->zeros512.ensure(CFD_D * 4));
     HIPCHK(hipMemsetAsync(c->zeros512.p, 0, CFD_D * 4, st));
   }
-  const bool fused = c->fused_xattn && p.xa_nwg > 0 && !want_att && !g_cfd_naive_gemm;
+  if (dynamic_mask) p.rt = false;   // (a memory rewritten between iterations keeps its per-step projections: tile-kernel path)
+  const bool fused = p.rt || (c->fused_xattn && p.xa_nwg > 0 && !want_att && !g_cfd_naive_gemm);
   if (!fused || !c->hoist_memside || p.tmode != 0) return CFD_OK;
   const int T = p.T;
   CHK(c->b_tab.ensure((size_t)T * CFD_D * 4));
@@ -841,6 +860,15 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
     }
     p.static_mask |= 1 << j;
   }
+  if (p.rt) {   // per-key scale and key bias of every step of the run (the tile-kernel path makes one step's per iteration: mem_scale_kernel)
+    for (int j = 0; j < CFD_NMEM; ++j) {
+      const long long rows = (long long)p.U[j] * p.Sp[j];
+      CHK(c->rt_cbt[j].ensure((size_t)T * (nl + 1) * rows * 4));
+      MemScaleTabArgs a{c->n_sp[j].as<char>(), c->asq[j].as<float>(), rows, c->b_tab.as<float>(), c->bsq.as<float>(), c->ca[j].as<float>(),
+                        c->kbtab[j].as<float>() + (size_t)nl * CFD_D, (long long)(nl * CFD_D + 32), nl, c->rt_cbt[j].as<float>()};
+      LAUNCH(CFD_PROF_ROWS, mem_scale_table_kernel, dim3((unsigned)((rows + 3) / 4), (unsigned)T), dim3(256), st, a);
+    }
+  }
   return CFD_OK;
 }
 
@@ -851,6 +879,7 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int nrows);
 // memory-side work of one forward: shared by every row chunk
 static int enqueue_memside(Ctx* c, hipStream_t st) {
   const Problem& p = c->pb;
+  if (p.rt) return CFD_OK;   // every memory is static and its per-step scalars are tabulated (prepare_static_memside)
   const int nl = c->nl;
   const int* dstep = p.tmode ? c->d_step.as<int>() + 1 : c->d_step.as<int>();
   const long long ROWB = CFD_D * 4;
@@ -898,9 +927,132 @@ static int enqueue_memside(Ctx* c, hipStream_t st) {
   return CFD_OK;
 }
 
+static int enqueue_rows_rt(Ctx* c, hipStream_t st);
+
 static int enqueue_denoise(Ctx* c, hipStream_t st) {
   CHK(enqueue_memside(c, st));
+  if (c->pb.rt) return enqueue_rows_rt(c, st);
   return enqueue_rows(c, st, 0, c->pb.Be);
+}
+
+// The forward for small problems: launches of 16-token x 16-feature workgroups (rowtile.hpp); same buffers, same tap points.
+static int enqueue_rows_rt(Ctx* c, hipStream_t st) {
+  const Problem& p = c->pb;
+  const int nl = c->nl, L = p.L, tpr = (L + 15) / 16, ntile = p.Be * tpr;
+  const int* dstep = c->d_step.as<int>();
+  constexpr int LDS_LN = 16 * 2048 + 8 * 1024, LDS_SP4 = 4 * 1024, LDS_SP8 = 8 * 1024;
+  const int lds_xs = 16 * 2048 + 8 * 1024 + 64, lds_xpv = (p.Sp_tot / 32) * 2048 + 8 * 1024 + 512;
+  static unsigned long long attr = 0;
+  if (!((attr >> (c->cfg.device & 63)) & 1ull)) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_xpv_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (RT_MAX_KEYS / 32) * 2048 + 8 * 1024 + 512));
+    attr |= 1ull << (c->cfg.device & 63);
+  }
+  RtGemmArgs base;
+  memset(&base, 0, sizeof(base));
+  base.L = L; base.tpr = tpr; base.x = c->x.as<float>(); base.xo = c->x.as<float>(); base.d_step = dstep;
+  base.ss_tstride = (long long)nl * 2 * 2 * CFD_D;
+#define RT_LAUNCH(cls, PRO, EPI, NT, nfb, lds, args)                                                        \
+  do {                                                                                                      \
+    Bracket _br(c, cls, st);                                                                                \
+    hipLaunchKernelGGL((rt_gemm_kernel<PRO, EPI, NT>), dim3(nfb, ntile), dim3(NT), lds, st, args);          \
+    hipError_t _e = hipGetLastError();                                                                      \
+    if (_e != hipSuccess) return fail(CFD_E_HIP, "row-tile launch failed: %s", hipGetErrorString(_e));      \
+  } while (0)
+  // 1. latent embedding + body/hand embedding + query PE          (denoiser.py:187,316-326)
+  {
+    RtGemmArgs a = base;
+    a.KT = CFD_LAT / 32; a.a_sp = c->sample_sp.as<char>(); a.w = c->we_sp.as<char>(); a.bias = rawp(c, "latent_embd.bias");
+    a.bh = rawp(c, "bh_embedding.weight"); a.qpe = rawp(c, "query_pos.pe");
+    RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_EMBED, 256, CFD_D / 16, LDS_SP4, a);
+  }
+  if (c->stop_stage == 1) return CFD_OK;
+  auto time_block = [&](const DBuf& w, const float* g, const float* b, const float* bias, int tbidx) -> int {
+    RtGemmArgs a = base;
+    a.KT = CFD_D / 32; a.g = g; a.b = b; a.ss = c->ss_tab.as<float>() + (size_t)tbidx * 2 * CFD_D; a.w = w.as<char>(); a.bias = bias;
+    RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_ADALN, RT_EPI_RESID, 512, CFD_D / 16, LDS_LN, a);
+    return CFD_OK;
+  };
+  RtXArgs xa;
+  memset(&xa, 0, sizeof(xa));
+  xa.x = c->x.as<float>(); xa.L = L; xa.tpr = tpr; xa.nl = nl; xa.d_step = dstep; xa.Sp_tot = p.Sp_tot; xa.sc = c->sc.as<float>();
+  int nkb = 0;
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    xa.map[j] = p.map[j]; xa.rows[j] = p.U[j] * p.Sp[j]; xa.S[j] = p.S[j]; xa.Sp[j] = p.Sp[j]; xa.off[j] = p.off[j];
+    xa.cbt[j] = c->rt_cbt[j].as<float>(); xa.att[j] = p.att[j];
+    xa.kb_stride[j] = nl * CFD_D + 32; xa.vb_stride[j] = nl * CFD_D;
+    xa.blk0[j] = nkb; nkb += p.Sp[j] / 16;
+  }
+  xa.blk0[CFD_NMEM] = nkb;
+  for (int l = 0; l < nl; ++l) {
+    const LayerW& w = c->lw[l];
+    // ---- a. self attention: x += Wo softmax(q k^T) v                         (cross_attention.py:568-572)
+    {
+      RtGemmArgs a = base;   // norm1 + q | k | v^T projections
+      a.KT = CFD_D / 32; a.g = w.ln1g; a.b = w.ln1b; a.w = w.wqk_sp.as<char>(); a.w2 = w.wv_sp.as<char>(); a.nfb_qk = 2 * CFD_D / 16;
+      a.bias = w.bqk.as<float>(); a.o_sp = c->qk_sp.as<char>(); a.ld_o = 2 * CFD_D * 4; a.vt = c->rt_vt.as<char>();
+      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_LN, RT_EPI_QKV, 512, 3 * CFD_D / 16, LDS_LN, a);
+    }
+    {
+      RtSelfArgs a{c->qk_sp.as<char>(), c->rt_vt.as<char>(), c->o_sp.as<char>(), L, tpr};
+      LAUNCH(CFD_PROF_GEMM_ATTN, rt_selfattn_kernel, dim3(CFD_NHEAD, ntile), dim3(256), st, a);
+    }
+    {
+      RtGemmArgs a = base;   // out-projection + residual
+      a.KT = CFD_D / 32; a.a_sp = c->o_sp.as<char>(); a.w = w.wo_sp.as<char>(); a.bias = w.bo2.as<float>();
+      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_RESID, 256, CFD_D / 16, LDS_SP4, a);
+    }
+    if (c->stop_stage == 2 + 4 * l) return CFD_OK;
+    // ---- b. time block 1                                                        (:575, :426-439)
+    CHK(time_block(w.wtb1_sp, w.tb1g, w.tb1b, w.btb1, 2 * l));
+    if (c->stop_stage == 3 + 4 * l) return CFD_OK;
+    // ---- c-e. five cross attentions + fuser, folded                             (:578-652)
+    {
+      RtXArgs a = xa;
+      a.ln_g = w.ln2g; a.ln_b = w.ln2b; a.bias = w.cross_bias.as<float>(); a.layer = l;
+      for (int j = 0; j < CFD_NMEM; ++j) {
+        const size_t rows = (size_t)p.U[j] * p.Sp[j];
+        a.K[j] = c->kall_sp[j].as<char>() + (size_t)l * rows * CFD_D * 4;
+        a.VT[j] = c->vt_all[j].as<char>() + (size_t)l * rows * CFD_D * 4;
+        a.kb[j] = c->kbtab[j].as<float>() + (size_t)l * CFD_D;
+        a.vb[j] = c->vbtab[j].as<float>() + (size_t)l * CFD_D;
+      }
+      {
+        Bracket br(c, CFD_PROF_XATTN, st);
+        hipLaunchKernelGGL(rt_xscore_kernel<512>, dim3(nkb, ntile), dim3(512), lds_xs, st, a);
+        HIPCHK(hipGetLastError());
+      }
+      {
+        Bracket br(c, CFD_PROF_XATTN, st);
+        hipLaunchKernelGGL(rt_xpv_kernel<512>, dim3(CFD_D / 16, ntile), dim3(512), lds_xpv, st, a);
+        HIPCHK(hipGetLastError());
+      }
+    }
+    if (c->stop_stage == 4 + 4 * l) return CFD_OK;
+    // ---- f. time block 2                                                        (:655)
+    CHK(time_block(w.wtb2_sp, w.tb2g, w.tb2b, w.btb2, 2 * l + 1));
+    // ---- g. FFN                                                                 (:659-661)
+    {
+      RtGemmArgs a = base;   // norm3 + linear1 + GELU
+      a.KT = CFD_D / 32; a.g = w.ln3g; a.b = w.ln3b; a.w = w.w1_sp.as<char>(); a.bias = w.b1; a.o_sp = c->u_sp.as<char>(); a.ld_o = CFD_FF * 4; a.gelu = 1;
+      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_LN, RT_EPI_SPLIT, 512, CFD_FF / 16, LDS_LN, a);
+    }
+    {
+      RtGemmArgs a = base;   // linear2 + residual
+      a.KT = CFD_FF / 32; a.a_sp = c->u_sp.as<char>(); a.w = w.w2_sp.as<char>(); a.bias = w.b2;
+      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_RESID, 512, CFD_D / 16, LDS_SP8, a);
+    }
+    if (c->stop_stage == 5 + 4 * l) return CFD_OK;
+  }
+  // 7. final norm + latent projection                                (cross_attention.py:238-239, denoiser.py:382)
+  {
+    RtGemmArgs a = base;
+    a.KT = CFD_D / 32; a.g = rawp(c, "decoder.norm.weight"); a.b = rawp(c, "decoder.norm.bias"); a.w = c->wp_sp.as<char>();
+    a.bias = rawp(c, "latent_proj.bias"); a.o_f32 = c->eps.as<float>(); a.ldo_f = CFD_LAT;
+    RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_LN, RT_EPI_F32, 512, CFD_LAT / 16, LDS_LN, a);
+  }
+#undef RT_LAUNCH
+  return CFD_OK;
 }
 
 static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
