@@ -940,7 +940,7 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st) {
   const Problem& p = c->pb;
   const int nl = c->nl, L = p.L, tpr = (L + 15) / 16, ntile = p.Be * tpr;
   const int* dstep = c->d_step.as<int>();
-  constexpr int LDS_LN = 16 * 2048 + 8 * 1024, LDS_SP4 = 4 * 1024, LDS_SP8 = 8 * 1024;
+  constexpr int LDS_LN = 16 * 2048 + 8 * 1024, LDS_LN2 = 16 * 2048 + 16 * 1024, LDS_SP4 = 4 * 1024, LDS_SP8 = 8 * 1024;
   const int lds_xs = 16 * 2048 + 8 * 1024 + 64, lds_xpv = (p.Sp_tot / 32) * 2048 + 8 * 1024 + 512;
   static unsigned long long attr = 0;
   if (!((attr >> (c->cfg.device & 63)) & 1ull)) {
@@ -950,32 +950,32 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st) {
   }
   RtGemmArgs base;
   memset(&base, 0, sizeof(base));
-  base.L = L; base.tpr = tpr; base.x = c->x.as<float>(); base.xo = c->x.as<float>(); base.d_step = dstep;
+  base.L = L; base.tpr = tpr; base.x = c->x.as<float>(); base.xr = c->x.as<float>(); base.xo = c->x.as<float>(); base.d_step = dstep;
   base.ss_tstride = (long long)nl * 2 * 2 * CFD_D;
-#define RT_LAUNCH(cls, PRO, EPI, NT, nfb, lds, args)                                                        \
-  do {                                                                                                      \
-    Bracket _br(c, cls, st);                                                                                \
-    hipLaunchKernelGGL((rt_gemm_kernel<PRO, EPI, NT>), dim3(nfb, ntile), dim3(NT), lds, st, args);          \
-    hipError_t _e = hipGetLastError();                                                                      \
-    if (_e != hipSuccess) return fail(CFD_E_HIP, "row-tile launch failed: %s", hipGetErrorString(_e));      \
+#define RT_LAUNCH(cls, PRO, EPI, NT, KT, NFB, nfeat, lds, args)                                                   \
+  do {                                                                                                          \
+    Bracket _br(c, cls, st);                                                                                    \
+    hipLaunchKernelGGL((rt_gemm_kernel<PRO, EPI, NT, KT, NFB>), dim3((nfeat) / (16 * NFB), ntile), dim3(NT), lds, st, args); \
+    hipError_t _e = hipGetLastError();                                                                          \
+    if (_e != hipSuccess) return fail(CFD_E_HIP, "row-tile launch failed: %s", hipGetErrorString(_e));          \
   } while (0)
   // 1. latent embedding + body/hand embedding + query PE          (denoiser.py:187,316-326)
   {
     RtGemmArgs a = base;
-    a.KT = CFD_LAT / 32; a.a_sp = c->sample_sp.as<char>(); a.w = c->we_sp.as<char>(); a.bias = rawp(c, "latent_embd.bias");
+    a.a_sp = c->sample_sp.as<char>(); a.w = c->we_sp.as<char>(); a.bias = rawp(c, "latent_embd.bias");
     a.bh = rawp(c, "bh_embedding.weight"); a.qpe = rawp(c, "query_pos.pe");
-    RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_EMBED, 256, CFD_D / 16, LDS_SP4, a);
+    RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_EMBED, 256, CFD_LAT / 32, 1, CFD_D, LDS_SP4, a);
   }
   if (c->stop_stage == 1) return CFD_OK;
   auto time_block = [&](const DBuf& w, const float* g, const float* b, const float* bias, int tbidx) -> int {
     RtGemmArgs a = base;
-    a.KT = CFD_D / 32; a.g = g; a.b = b; a.ss = c->ss_tab.as<float>() + (size_t)tbidx * 2 * CFD_D; a.w = w.as<char>(); a.bias = bias;
-    RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_ADALN, RT_EPI_RESID, 512, CFD_D / 16, LDS_LN, a);
+    a.g = g; a.b = b; a.ss = c->ss_tab.as<float>() + (size_t)tbidx * 2 * CFD_D; a.w = w.as<char>(); a.bias = bias;
+    RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_ADALN, RT_EPI_RESID, 512, CFD_D / 32, 1, CFD_D, LDS_LN, a);
     return CFD_OK;
   };
   RtXArgs xa;
   memset(&xa, 0, sizeof(xa));
-  xa.x = c->x.as<float>(); xa.L = L; xa.tpr = tpr; xa.nl = nl; xa.d_step = dstep; xa.Sp_tot = p.Sp_tot; xa.sc = c->sc.as<float>();
+  xa.x = c->x.as<float>(); xa.L = L; xa.tpr = tpr; xa.nl = nl; xa.d_step = dstep; xa.Sp_tot = p.Sp_tot; xa.sc = c->sc.as<float>(); xa.rsp = c->p_sp.as<float>();
   int nkb = 0;
   for (int j = 0; j < CFD_NMEM; ++j) {
     xa.map[j] = p.map[j]; xa.rows[j] = p.U[j] * p.Sp[j]; xa.S[j] = p.S[j]; xa.Sp[j] = p.Sp[j]; xa.off[j] = p.off[j];
@@ -989,9 +989,9 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st) {
     // ---- a. self attention: x += Wo softmax(q k^T) v                         (cross_attention.py:568-572)
     {
       RtGemmArgs a = base;   // norm1 + q | k | v^T projections
-      a.KT = CFD_D / 32; a.g = w.ln1g; a.b = w.ln1b; a.w = w.wqk_sp.as<char>(); a.w2 = w.wv_sp.as<char>(); a.nfb_qk = 2 * CFD_D / 16;
+      a.g = w.ln1g; a.b = w.ln1b; a.w = w.wqk_sp.as<char>(); a.w2 = w.wv_sp.as<char>(); a.nfb_qk = 2 * CFD_D / 16;
       a.bias = w.bqk.as<float>(); a.o_sp = c->qk_sp.as<char>(); a.ld_o = 2 * CFD_D * 4; a.vt = c->rt_vt.as<char>();
-      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_LN, RT_EPI_QKV, 512, 3 * CFD_D / 16, LDS_LN, a);
+      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_LN, RT_EPI_QKV, 512, CFD_D / 32, 2, 3 * CFD_D, LDS_LN2, a);
     }
     {
       RtSelfArgs a{c->qk_sp.as<char>(), c->rt_vt.as<char>(), c->o_sp.as<char>(), L, tpr};
@@ -999,8 +999,8 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st) {
     }
     {
       RtGemmArgs a = base;   // out-projection + residual
-      a.KT = CFD_D / 32; a.a_sp = c->o_sp.as<char>(); a.w = w.wo_sp.as<char>(); a.bias = w.bo2.as<float>();
-      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_RESID, 256, CFD_D / 16, LDS_SP4, a);
+      a.a_sp = c->o_sp.as<char>(); a.w = w.wo_sp.as<char>(); a.bias = w.bo2.as<float>();
+      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_RESID, 256, CFD_D / 32, 1, CFD_D, LDS_SP4, a);
     }
     if (c->stop_stage == 2 + 4 * l) return CFD_OK;
     // ---- b. time block 1                                                        (:575, :426-439)
@@ -1034,22 +1034,22 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st) {
     // ---- g. FFN                                                                 (:659-661)
     {
       RtGemmArgs a = base;   // norm3 + linear1 + GELU
-      a.KT = CFD_D / 32; a.g = w.ln3g; a.b = w.ln3b; a.w = w.w1_sp.as<char>(); a.bias = w.b1; a.o_sp = c->u_sp.as<char>(); a.ld_o = CFD_FF * 4; a.gelu = 1;
-      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_LN, RT_EPI_SPLIT, 512, CFD_FF / 16, LDS_LN, a);
+      a.g = w.ln3g; a.b = w.ln3b; a.w = w.w1_sp.as<char>(); a.bias = w.b1; a.o_sp = c->u_sp.as<char>(); a.ld_o = CFD_FF * 4; a.gelu = 1;
+      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_LN, RT_EPI_SPLIT, 512, CFD_D / 32, 2, CFD_FF, LDS_LN2, a);
     }
     {
       RtGemmArgs a = base;   // linear2 + residual
-      a.KT = CFD_FF / 32; a.a_sp = c->u_sp.as<char>(); a.w = w.w2_sp.as<char>(); a.bias = w.b2;
-      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_RESID, 512, CFD_D / 16, LDS_SP8, a);
+      a.a_sp = c->u_sp.as<char>(); a.w = w.w2_sp.as<char>(); a.bias = w.b2;
+      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_RESID, 512, CFD_FF / 32, 1, CFD_D, LDS_SP8, a);
     }
     if (c->stop_stage == 5 + 4 * l) return CFD_OK;
   }
   // 7. final norm + latent projection                                (cross_attention.py:238-239, denoiser.py:382)
   {
     RtGemmArgs a = base;
-    a.KT = CFD_D / 32; a.g = rawp(c, "decoder.norm.weight"); a.b = rawp(c, "decoder.norm.bias"); a.w = c->wp_sp.as<char>();
+    a.g = rawp(c, "decoder.norm.weight"); a.b = rawp(c, "decoder.norm.bias"); a.w = c->wp_sp.as<char>();
     a.bias = rawp(c, "latent_proj.bias"); a.o_f32 = c->eps.as<float>(); a.ldo_f = CFD_LAT;
-    RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_LN, RT_EPI_F32, 512, CFD_LAT / 16, LDS_LN, a);
+    RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_LN, RT_EPI_F32, 512, CFD_D / 32, 1, CFD_LAT, LDS_LN, a);
   }
 #undef RT_LAUNCH
   return CFD_OK;

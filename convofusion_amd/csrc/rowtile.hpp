@@ -79,47 +79,93 @@ __device__ __forceinline__ void rt_lstore8(char* img, int r, int c0, const float
   *reinterpret_cast<spx8*>(p + (((4 + ch) ^ sw) << 4)) = l;
 }
 
-// sum over the LPR lanes that share a row (LPR = 16 or 32 consecutive lanes)
+// Reductions over the LPR lanes that share a prologue row (LPR = 16: one DPP row; 32: two adjacent DPP rows), in the vector ALU:
+// quad permutes, row_half_mirror and row_mirror (each lane ends with the value of its whole 16-lane row), then
+// v_permlane16_swap for the neighbouring row -- five dependent ds_bpermute round trips per reduction otherwise (__shfl_xor).
+template <int CTRL>
+__device__ __forceinline__ float rt_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 template <int LPR>
 __device__ __forceinline__ float rt_row_sum(float v) {
-#pragma unroll
-  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  static_assert(LPR == 16 || LPR == 32, "16 or 32 lanes per row");
+  v += rt_dpp<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += rt_dpp<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += rt_dpp<0x141>(v);    // row_half_mirror
+  v += rt_dpp<0x140>(v);    // row_mirror
+  if constexpr (LPR == 32) {
+    const unsigned xi = __float_as_uint(v);
+    auto q = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+    v = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+  }
   return v;
 }
 template <int LPR>
 __device__ __forceinline__ float rt_row_max(float v) {
-#pragma unroll
-  for (int o = LPR / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  static_assert(LPR == 16 || LPR == 32, "16 or 32 lanes per row");
+  v = fmaxf(v, rt_dpp<0xB1>(v));
+  v = fmaxf(v, rt_dpp<0x4E>(v));
+  v = fmaxf(v, rt_dpp<0x141>(v));
+  v = fmaxf(v, rt_dpp<0x140>(v));
+  if constexpr (LPR == 32) {
+    const unsigned xi = __float_as_uint(v);
+    auto q = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+    v = fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+  }
   return v;
 }
+// 1 / x to float32 rounding noise: v_rcp_f32 (1 ulp) + one Newton step, instead of the ~10-instruction IEEE division sequence
+__device__ __forceinline__ float rt_rcp(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float rt_silu(float x) { return x * rt_rcp(1.0f + __expf(-x)); }
 
-// sum of the waves' partial accumulators (fixed order: bit-reproducible), result valid in wave 0
-template <int NW>
-__device__ __forceinline__ f32x4 rt_reduce(char* red, int wid, int lane, f32x4 acc) {
-  reinterpret_cast<f32x4*>(red)[wid * 64 + lane] = acc;
+// sum of the waves' partial accumulators of NFB feature blocks (fixed order: bit-reproducible); block i's sum is returned in wave i
+template <int NW, int NFB>
+__device__ __forceinline__ f32x4 rt_reduce(char* red, int wid, int lane, const f32x4 (&acc)[NFB]) {
+#pragma unroll
+  for (int i = 0; i < NFB; ++i) reinterpret_cast<f32x4*>(red)[(i * NW + wid) * 64 + lane] = acc[i];
   __syncthreads();
-  f32x4 s = reinterpret_cast<const f32x4*>(red)[lane];
-  if (wid == 0) {
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (wid < NFB) {
+    s = reinterpret_cast<const f32x4*>(red)[(wid * NW) * 64 + lane];
 #pragma unroll
     for (int w = 1; w < NW; ++w) {
-      const f32x4 t = reinterpret_cast<const f32x4*>(red)[w * 64 + lane];
+      const f32x4 t = reinterpret_cast<const f32x4*>(red)[(wid * NW + w) * 64 + lane];
       s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
     }
   }
   return s;
 }
 
+// LayerNorm statistics of a prologue row: v (this lane's columns) is centred in place, returns 1 / sqrt(var + eps)
+template <int LPR, int CH>
+__device__ __forceinline__ float rt_ln_stats(float (&v)[CH][8]) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[c][e];
+  const float mean = rt_row_sum<LPR>(s) * (1.0f / CFD_D);
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[c][e] -= mean; ss += v[c][e] * v[c][e]; }
+  return 1.0f / sqrtf(rt_row_sum<LPR>(ss) * (1.0f / CFD_D) + 1e-5f);
+}
+
 // ------------------------------------------------------------------------------------------------
-// Generic token-tile product:  out[16 tokens][16 features] = A[16][K] . W[f0 .. f0+15][K]^T
+// Generic token-tile product:  out[16 tokens][NFB x 16 features] = A[16][K] . W[f0 ..][K]^T
 // ------------------------------------------------------------------------------------------------
 enum { RT_PRO_SP = 0, RT_PRO_LN = 1, RT_PRO_ADALN = 2 };
 enum { RT_EPI_RESID = 0, RT_EPI_SPLIT = 1, RT_EPI_F32 = 2, RT_EPI_EMBED = 3, RT_EPI_QKV = 4 };
 
 struct RtGemmArgs {
   int L, tpr;              // tokens per batch row, token tiles per batch row
-  int KT;                  // k-groups of 32 (K / 32): 4, 16 or 32
   // A operand
-  const float* x;          // fp32 [M][512] residual stream (LN / AdaLN prologues)
+  const float* x;          // fp32 [M][512] residual stream: source of the LN / AdaLN prologues
   const char* a_sp;        // SP [M][K] (RT_PRO_SP)
   const float* g;          // LayerNorm weight / bias [512]
   const float* b;
@@ -132,10 +178,12 @@ struct RtGemmArgs {
   int nfb_qk;
   const float* bias;       // [N] or null
   // outputs
-  float* xo;               // RESID / EMBED: fp32 [M][512]
+  const float* xr;         // RESID: the residual rows (fp32 [M][512]) ...
+  float* xo;               // ... and where the sum goes (RESID / EMBED); xo == xr: in place
   char* o_sp;              // SPLIT / QKV: SP matrix, ld_o bytes per token row
   long long ld_o;
   int gelu;
+  float* pre;              // SPLIT: optional copy of the pre-activation values, fp32 [M][ld_o / 4] (kept for the WEG backward)
   float* o_f32;            // F32: [M][ldo_f]
   int ldo_f;
   char* vt;                // QKV: V^T, SP [Be][512][32 keys]
@@ -143,27 +191,31 @@ struct RtGemmArgs {
   const float* qpe;
 };
 
-template <int PRO, int EPI, int NT>
-__global__ void __launch_bounds__(NT) rt_gemm_kernel(const RtGemmArgs a) {
+template <int PRO, int EPI, int NT, int KT, int NFB>
+__global__ void __launch_bounds__(NT, NT / 128) rt_gemm_kernel(const RtGemmArgs a) {
   constexpr int NW = NT / 64;
+  constexpr int NK = KT / NW;                // k-groups per wave: kt = wid + NW * n
   constexpr int LPR = NT / 16;               // lanes per token row in the prologue
   constexpr int CH = CFD_D / (LPR * 8);      // 8-column chunks per lane
+  static_assert(KT % NW == 0 && NK >= 1, "the k-groups divide evenly over the waves");
+  static_assert(PRO == RT_PRO_SP || KT == CFD_D / 32, "LayerNorm prologues are 512 wide");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* img = smem;                                              // A image (LN prologues): 16 k-groups x 2 KB
-  char* red = smem + (PRO == RT_PRO_SP ? 0 : 16 * 2048);         // reduction scratch: NW KB
+  char* red = smem + (PRO == RT_PRO_SP ? 0 : 16 * 2048);         // reduction scratch: NFB x NW KB
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l15 = lane & 15, q4 = lane >> 4;
-  const int fb = blockIdx.x, tile = blockIdx.y;
+  const int tile = blockIdx.y;
   const int b = tile / a.tpr, q0 = (tile - b * a.tpr) * 16, nq = min(16, a.L - q0);
   const long long tok0 = (long long)b * a.L + q0;
-  const int KT = a.KT;
-  const bool swapped = EPI == RT_EPI_QKV && fb >= a.nfb_qk;      // workgroup-uniform
-  const int f0 = (swapped ? fb - a.nfb_qk : fb) * 16;
+  const int fb0 = blockIdx.x * NFB;                              // first 16-feature block of this workgroup
+  const bool swapped = EPI == RT_EPI_QKV && fb0 >= a.nfb_qk;     // workgroup-uniform (nfb_qk is a multiple of NFB)
+  const int f0 = (swapped ? fb0 - a.nfb_qk : fb0) * 16;
 
   // ---- 1. every global load of the kernel is issued here ------------------------------------------------
   // prologue rows first (vmcnt retires in order: the LayerNorm can start while the weight fragments are still in flight)
   float v[CH][8];
+  float4 lg[CH][2], lb[CH][2], ls[CH][2], lh[CH][2];             // LayerNorm weight / bias, AdaLN (1 + scale) / shift of this lane's columns
   const int pr = threadIdx.x / LPR, plr = threadIdx.x % LPR;     // prologue: row, lane in row
   if constexpr (PRO != RT_PRO_SP) {
     const float* xr = a.x + (tok0 + min(pr, nq - 1)) * CFD_D + plr * 8;
@@ -173,9 +225,6 @@ __global__ void __launch_bounds__(NT) rt_gemm_kernel(const RtGemmArgs a) {
       const float4 p1 = *reinterpret_cast<const float4*>(xr + c * (LPR * 8) + 4);
       v[c][0] = p0.x; v[c][1] = p0.y; v[c][2] = p0.z; v[c][3] = p0.w; v[c][4] = p1.x; v[c][5] = p1.y; v[c][6] = p1.z; v[c][7] = p1.w;
     }
-  }
-  float4 lg[CH][2], lb[CH][2], ls[CH][2], lh[CH][2];             // LayerNorm weight / bias, AdaLN (1 + scale) / shift of this lane's columns
-  if constexpr (PRO != RT_PRO_SP) {
     const float* sc = nullptr;
     if constexpr (PRO == RT_PRO_ADALN) sc = a.ss + (long long)(*a.d_step) * a.ss_tstride;
 #pragma unroll
@@ -189,27 +238,23 @@ __global__ void __launch_bounds__(NT) rt_gemm_kernel(const RtGemmArgs a) {
       }
     }
   }
-  // this wave's k-groups: kt = wid + NW * n
-  constexpr int MAXN = 4;
-  const int nk = (KT - wid + NW - 1) / NW;                       // wave-uniform, <= MAXN
-  spx8 wh[MAXN], wl[MAXN], ah[MAXN], al[MAXN];
-  {
-    const char* wrow = (swapped ? a.w2 : a.w) + (size_t)(f0 + l15) * KT * 128;
+  spx8 wh[NFB][NK], wl[NFB][NK], ah[NK], al[NK];
 #pragma unroll
-    for (int n = 0; n < MAXN; ++n)
-      if (n < nk) rt_gfrag(wrow, wid + NW * n, q4, wh[n], wl[n]);
+  for (int i = 0; i < NFB; ++i) {
+    const char* wrow = (swapped ? a.w2 : a.w) + (size_t)(f0 + 16 * i + l15) * (KT * 128);
+#pragma unroll
+    for (int n = 0; n < NK; ++n) rt_gfrag(wrow, wid + NW * n, q4, wh[i][n], wl[i][n]);
   }
   if constexpr (PRO == RT_PRO_SP) {
-    const char* arow = a.a_sp + (size_t)(tok0 + min(l15, nq - 1)) * KT * 128;
+    const char* arow = a.a_sp + (size_t)(tok0 + min(l15, nq - 1)) * (KT * 128);
 #pragma unroll
-    for (int n = 0; n < MAXN; ++n)
-      if (n < nk) rt_gfrag(arow, wid + NW * n, q4, ah[n], al[n]);
+    for (int n = 0; n < NK; ++n) rt_gfrag(arow, wid + NW * n, q4, ah[n], al[n]);
   }
-  // epilogue operands of wave 0
+  // epilogue operands: wave i finishes feature block i
   float4 ep_r = make_float4(0.f, 0.f, 0.f, 0.f), ep_t = ep_r, ep_t1 = ep_r, ep_t2 = ep_r;
-  const int fcol = f0 + 4 * q4;                                  // standard roles: this lane's 4 features, token l15
-  if (wid == 0) {
-    if constexpr (EPI == RT_EPI_RESID) ep_r = *reinterpret_cast<const float4*>(a.xo + (tok0 + min(l15, nq - 1)) * CFD_D + fcol);
+  const int fcol = f0 + 16 * wid + 4 * q4;                       // standard roles: this lane's 4 features, token l15
+  if (wid < NFB) {
+    if constexpr (EPI == RT_EPI_RESID) ep_r = *reinterpret_cast<const float4*>(a.xr + (tok0 + min(l15, nq - 1)) * CFD_D + fcol);
     if (a.bias && !swapped) ep_t = *reinterpret_cast<const float4*>(a.bias + fcol);
     if constexpr (EPI == RT_EPI_EMBED) {
       const int l = q0 + min(l15, nq - 1);
@@ -220,18 +265,7 @@ __global__ void __launch_bounds__(NT) rt_gemm_kernel(const RtGemmArgs a) {
 
   // ---- 2. prologue: LayerNorm (+ AdaLN, SiLU) of the tile's rows -> split-pair image in LDS ---------------
   if constexpr (PRO != RT_PRO_SP) {
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s += v[c][e];
-    const float mean = rt_row_sum<LPR>(s) * (1.0f / CFD_D);
-    float ss = 0.f;
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { v[c][e] -= mean; ss += v[c][e] * v[c][e]; }
-    const float rstd = 1.0f / sqrtf(rt_row_sum<LPR>(ss) * (1.0f / CFD_D) + 1e-5f);
+    const float rstd = rt_ln_stats<LPR, CH>(v);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int c0 = c * (LPR * 8) + plr * 8;
@@ -243,31 +277,33 @@ __global__ void __launch_bounds__(NT) rt_gemm_kernel(const RtGemmArgs a) {
         const float sv[8] = {ls[c][0].x, ls[c][0].y, ls[c][0].z, ls[c][0].w, ls[c][1].x, ls[c][1].y, ls[c][1].z, ls[c][1].w};
         const float hv[8] = {lh[c][0].x, lh[c][0].y, lh[c][0].z, lh[c][0].w, lh[c][1].x, lh[c][1].y, lh[c][1].z, lh[c][1].w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[c][e] = silu_f(v[c][e] * sv[e] + hv[e]);
+        for (int e = 0; e < 8; ++e) v[c][e] = rt_silu(v[c][e] * sv[e] + hv[e]);
       }
       rt_lstore8(img, pr, c0, v[c]);
     }
     __syncthreads();
 #pragma unroll
-    for (int n = 0; n < MAXN; ++n)
-      if (n < nk) rt_lfrag(img, wid + NW * n, l15, q4, ah[n], al[n]);
+    for (int n = 0; n < NK; ++n) rt_lfrag(img, wid + NW * n, l15, q4, ah[n], al[n]);
   }
 
   // ---- 3. product over this wave's k-groups, then the sum over the waves -----------------------------------
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 part[NFB];
 #pragma unroll
-  for (int n = 0; n < MAXN; ++n)
-    if (n < nk) acc = swapped ? rt_mma(ah[n], al[n], wh[n], wl[n], acc) : rt_mma(wh[n], wl[n], ah[n], al[n], acc);
-  acc = rt_reduce<NW>(red, wid, lane, acc);
-  if (wid != 0) return;
+  for (int i = 0; i < NFB; ++i) {
+    part[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < NK; ++n) part[i] = swapped ? rt_mma(ah[n], al[n], wh[i][n], wl[i][n], part[i]) : rt_mma(wh[i][n], wl[i][n], ah[n], al[n], part[i]);
+  }
+  const f32x4 acc = rt_reduce<NW, NFB>(red, wid, lane, part);
+  if (wid >= NFB) return;
 
-  // ---- 4. epilogue (wave 0).  Standard roles: lane (token l15) holds features fcol .. fcol + 3 ---------------
+  // ---- 4. epilogue (wave i: feature block i).  Standard roles: lane (token l15) holds features fcol .. fcol + 3 ---------------
   if constexpr (EPI == RT_EPI_QKV) {
-    if (swapped) {   // lane (feature f0 + l15) holds tokens q0 + 4 q4 .. + 3 of V^T; tokens beyond L are stored as zero
+    if (swapped) {   // lane (feature f0 + 16 wid + l15) holds tokens q0 + 4 q4 .. + 3 of V^T; tokens beyond L are stored as zero
       float o[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = (4 * q4 + r < nq) ? acc[r] : 0.f;
-      sp_store4(a.vt + ((size_t)b * CFD_D + f0 + l15) * (RT_MAX_L * 4), q0 + 4 * q4, o[0], o[1], o[2], o[3]);
+      sp_store4(a.vt + ((size_t)b * CFD_D + f0 + 16 * wid + l15) * (RT_MAX_L * 4), q0 + 4 * q4, o[0], o[1], o[2], o[3]);
       return;
     }
   }
@@ -279,6 +315,9 @@ __global__ void __launch_bounds__(NT) rt_gemm_kernel(const RtGemmArgs a) {
     *reinterpret_cast<float4*>(a.xo + tok * CFD_D + fcol) = r;
   } else if constexpr (EPI == RT_EPI_SPLIT || EPI == RT_EPI_QKV) {
     float o[4] = {acc[0] + ep_t.x, acc[1] + ep_t.y, acc[2] + ep_t.z, acc[3] + ep_t.w};
+    if constexpr (EPI == RT_EPI_SPLIT) {
+      if (a.pre) *reinterpret_cast<float4*>(a.pre + tok * (a.ld_o / 4) + fcol) = make_float4(o[0], o[1], o[2], o[3]);
+    }
     if (a.gelu) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = gelu_fast_f(o[r]);
@@ -389,7 +428,8 @@ struct RtXArgs {
   int S[CFD_NMEM], Sp[CFD_NMEM], off[CFD_NMEM];
   int blk0[CFD_NMEM + 1];       // first 16-key block of memory j in the score launch's grid
   int Sp_tot;
-  float* sc;                    // fp32 [M][Sp_tot]
+  float* sc;                    // fp32 [M][Sp_tot] scores
+  float* rsp;                   // fp32 [M][Sp_tot]: rs of every key, repeated per token by the score launch
   float* att[CFD_NMEM];         // optional att_mats [Be][nl][L][S_j]
 };
 
@@ -455,18 +495,7 @@ __global__ void __launch_bounds__(NT) rt_xscore_kernel(const RtXArgs a) {
   }
   // LayerNorm2 -> image; c_q = q . (A b_t)
   {
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s += v[c][e];
-    const float mean = rt_row_sum<LPR>(s) * (1.0f / CFD_D);
-    float ss = 0.f;
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { v[c][e] -= mean; ss += v[c][e] * v[c][e]; }
-    const float rstd = 1.0f / sqrtf(rt_row_sum<LPR>(ss) * (1.0f / CFD_D) + 1e-5f);
+    const float rstd = rt_ln_stats<LPR, CH>(v);
     float dot = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -488,15 +517,17 @@ __global__ void __launch_bounds__(NT) rt_xscore_kernel(const RtXArgs a) {
   __syncthreads();
 #pragma unroll
   for (int n = 0; n < NK; ++n) rt_lfrag(img, wid + NW * n, l15, q4, ah[n], al[n]);
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 part[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-  for (int n = 0; n < NK; ++n) acc = rt_mma(kh[n], kl[n], ah[n], al[n], acc);   // S^T[key][token]
-  acc = rt_reduce<NW>(red, wid, lane, acc);
+  for (int n = 0; n < NK; ++n) part[0] = rt_mma(kh[n], kl[n], ah[n], al[n], part[0]);   // S^T[key][token]
+  const f32x4 acc = rt_reduce<NW, 1>(red, wid, lane, part);
   if (wid != 0 || l15 >= nq) return;
   const float c_q = cq[l15];
   const float4 o = make_float4(e_rs.x * (acc[0] + c_q) + e_cb.x, e_rs.y * (acc[1] + c_q) + e_cb.y, e_rs.z * (acc[2] + c_q) + e_cb.z,
                                e_rs.w * (acc[3] + c_q) + e_cb.w);
-  *reinterpret_cast<float4*>(a.sc + (tok0 + l15) * a.Sp_tot + rt_sel(a.off, j) + s0 + 4 * q4) = o;
+  const long long so = (tok0 + l15) * a.Sp_tot + rt_sel(a.off, j) + s0 + 4 * q4;
+  *reinterpret_cast<float4*>(a.sc + so) = o;
+  *reinterpret_cast<float4*>(a.rsp + so) = e_rs;   // the keys' scales next to the scores: the second half then has no load that waits for another
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -540,8 +571,7 @@ __global__ void __launch_bounds__(NT) rt_xpv_kernel(const RtXArgs a) {
       cj[n] = j;
       const float4 p0 = *reinterpret_cast<const float4*>(srow + c0), p1 = *reinterpret_cast<const float4*>(srow + c0 + 4);
       s[n][0] = p0.x; s[n][1] = p0.y; s[n][2] = p0.z; s[n][3] = p0.w; s[n][4] = p1.x; s[n][5] = p1.y; s[n][6] = p1.z; s[n][7] = p1.w;
-      const int rows = rt_sel(a.rows, j);
-      const float* rp = rt_sel(a.cbt, j) + ((long long)t * (a.nl + 1) + a.nl) * rows + (long long)inst(j) * rt_sel(a.Sp, j) + (c0 - rt_sel(a.off, j));
+      const float* rp = a.rsp + (tok0 + min(pr, nq - 1)) * a.Sp_tot + c0;
       const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
       rsv[n][0] = r0.x; rsv[n][1] = r0.y; rsv[n][2] = r0.z; rsv[n][3] = r0.w; rsv[n][4] = r1.x; rsv[n][5] = r1.y; rsv[n][6] = r1.z; rsv[n][7] = r1.w;
     }
@@ -590,6 +620,7 @@ __global__ void __launch_bounds__(NT) rt_xpv_kernel(const RtXArgs a) {
         for (int e = 0; e < 8; ++e) { s[n][e] = __expf(s[n][e] - mx); sum += s[n][e]; }   // all keys dead: NaN, as the reference
       }
     sum = rt_row_sum<LPR>(sum);
+    const float inv = rt_rcp(sum);
     float wsum = 0.f;
     float* att = a.att[j];
     const int S = a.S[j];
@@ -598,7 +629,7 @@ __global__ void __launch_bounds__(NT) rt_xpv_kernel(const RtXArgs a) {
       if (cj[n] == j) {
         const int c0 = (plr + LPR * n) * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[n][e] = s[n][e] / sum;
+        for (int e = 0; e < 8; ++e) s[n][e] = s[n][e] * inv;
         if (att && fb == 0 && pr < nq) {
           float* ap = att + (((long long)b * a.nl + a.layer) * a.L + q0 + pr) * S;
           const int k0 = c0 - a.off[j];
@@ -621,7 +652,8 @@ __global__ void __launch_bounds__(NT) rt_xpv_kernel(const RtXArgs a) {
       rt_lfrag(img, wid + NW * n, l15, q4, ph[n], pl[n]);
       acc = rt_mma(vh[n], vl[n], ph[n], pl[n], acc);   // O^T[feature][token]
     }
-  acc = rt_reduce<NW>(red, wid, lane, acc);
+  const f32x4 part[1] = {acc};
+  acc = rt_reduce<NW, 1>(red, wid, lane, part);
   if (wid != 0 || l15 >= nq) return;
   float o[4] = {acc[0], acc[1], acc[2], acc[3]};
 #pragma unroll
