@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcfdenoise.so")
 SOURCES = ["cfd_api.hip"]
-DEPS = ["cfd_api.hip", "gemm_sp.hpp", "rowtile.hpp", "rows.hpp", "attn_fused.hpp", "xattn_fused.hpp", "grad.hpp", "weg_eval.hpp", "cfd_common.hpp", os.path.join("..", "..", "include", "cfdenoise.h")]
+DEPS = ["cfd_api.hip", "gemm_sp.hpp", "rowtile.hpp", "rowtile_bwd.hpp", "weg_rt.hpp", "rows.hpp", "attn_fused.hpp", "xattn_fused.hpp", "grad.hpp", "weg_eval.hpp", "cfd_common.hpp", os.path.join("..", "..", "include", "cfdenoise.h")]
 
 
 def _hipcc():

@@ -98,6 +98,46 @@ struct Problem {
   bool rt = false;
 };
 
+struct RtSave {
+  float* x[CFD_MAX_LAYERS + 1][5];   // [l][0] layer input, [1] after self-attention, [2] after time block 1, [3] after cross-attention, [4] after time block 2
+  char* qk[CFD_MAX_LAYERS];
+  char* vt[CFD_MAX_LAYERS];
+  float* sc[CFD_MAX_LAYERS];
+  float* pre[CFD_MAX_LAYERS];
+};
+
+// cfd_weg_eval on the row-tile kernels (weg_rt.hpp): the arena of saved activations and gradient buffers
+struct WegRtState {
+  std::vector<long long> sig;   // shapes and pointers the arena and the problem of wk[1] were prepared for
+  RtSave sv;
+  float *att = nullptr, *d_att = nullptr, *fws = nullptr, *dP = nullptr, *G[3] = {nullptr, nullptr, nullptr}, *dz = nullptr, *dy = nullptr,
+        *dh = nullptr, *dO = nullptr, *dqkv = nullptr;
+  int launches = 0;
+};
+
+// One problem's device workspace: everything setup_problem / prepare_static_memside allocate and the launches of a forward touch.
+struct Work {
+  Problem pb;
+  DBuf x, h_sp, qk_sp, vts_sp, ssc, sp_sp, o_sp, u_sp, sc, p_sp, eps, sample_sp;
+  DBuf n_sp[CFD_NMEM], kall_sp[CFD_NMEM], cb[CFD_NMEM], vt_all[CFD_NMEM];
+  DBuf temb_tab, h1_tab, ss_tab, trows, iota, long_rows, short_rows, zero_mask;
+  // timestep-independent memory-side projections (rows.hpp mem_center_kernel): per memory the dot products c_l . a_s (ca), |a_s|^2 (asq)
+  // and, per table row t, A_l b_t / c_l . b_t (kbtab) and VV_l b_t (vbtab); b_t = centred timestep embedding.  CFD_HOIST_MEMSIDE=0: off.
+  DBuf ca[CFD_NMEM], asq[CFD_NMEM], kbtab[CFD_NMEM], vbtab[CFD_NMEM], b_tab, b_sp, bsq, zeros512;
+  DBuf xa_wgs, xa_segs, xa_stamps;
+  DBuf d_step;  // [0] = loop index, [1] = constant 0, [2] = "this iteration's in-painting overwrite is done" (cfd_sample_inpaint)
+  DBuf rt_vt, rt_cbt[CFD_NMEM];   // row-tile path: V^T of the self-attention, per-step key tables
+  void release() {
+    DBuf* all[] = {&x, &h_sp, &qk_sp, &vts_sp, &ssc, &sp_sp, &o_sp, &u_sp, &sc, &p_sp, &eps, &sample_sp, &temb_tab, &h1_tab, &ss_tab, &trows, &iota,
+                   &long_rows, &short_rows, &zero_mask, &b_tab, &b_sp, &bsq, &zeros512, &xa_wgs, &xa_segs, &xa_stamps, &d_step, &rt_vt};
+    for (DBuf* b : all) b->release();
+    for (int j = 0; j < CFD_NMEM; ++j) {
+      n_sp[j].release(); kall_sp[j].release(); cb[j].release(); vt_all[j].release(); ca[j].release(); asq[j].release(); kbtab[j].release();
+      vbtab[j].release(); rt_cbt[j].release();
+    }
+  }
+};
+
 struct cfd_handle_s {
   cfd_config cfg;
   int nl = 0;
@@ -112,13 +152,10 @@ struct cfd_handle_s {
   // timestep sinusoid table
   DBuf tsin;
   int tsin_rows = 0;
-  // workspace
-  DBuf x, h_sp, qk_sp, vts_sp, ssc, sp_sp, o_sp, u_sp, sc, p_sp, eps, sample_sp;
-  DBuf n_sp[CFD_NMEM], kall_sp[CFD_NMEM], cb[CFD_NMEM], vt_all[CFD_NMEM];
-  DBuf temb_tab, h1_tab, ss_tab, trows, iota, long_rows, short_rows, zero_mask;
-  // timestep-independent memory-side projections (rows.hpp mem_center_kernel): per memory the dot products c_l . a_s (ca), |a_s|^2 (asq)
-  // and, per table row t, A_l b_t / c_l . b_t (kbtab) and VV_l b_t (vbtab); b_t = centred timestep embedding.  CFD_HOIST_MEMSIDE=0: off.
-  DBuf ca[CFD_NMEM], asq[CFD_NMEM], kbtab[CFD_NMEM], vbtab[CFD_NMEM], b_tab, b_sp, bsq, zeros512;
+  // workspaces (struct Work): wk[0] belongs to cfd_forward / the sampling run (its captured graph holds these pointers), wk[1] to the
+  // row-tile WEG evaluation, which runs between two replays of an open run and must not disturb it; `w` is the one in use
+  Work wk[2];
+  Work* w = &wk[0];
   bool hoist_memside = true;
   bool use_runs = true;   // CFD_RUNS=0 disables the shared-memory run optimisation of the three-launch attention path
   // The cross-attention block is one fused kernel (xattn_fused.hpp) unless the caller wants att_mats, which only the
@@ -126,15 +163,12 @@ struct cfd_handle_s {
   // the three-launch path everywhere (parity A/B of the two paths).
   bool fused_xattn = true;
   int fused_xattn_min_wgs = 6;
-  DBuf xa_wgs, xa_segs, xa_stamps;
   // Row-tile path for small problems (rowtile.hpp): chosen by SHAPE -- at most rt_max_rows token rows of at most RT_MAX_L tokens per batch
   // row, one timestep for all rows, no dynamic memories.  CFD_ROWTILE=0 turns it off (parity A/B against the tile kernels),
   // CFD_ROWTILE_MAX_ROWS moves the threshold.
   bool rt_on = true;
-  long long rt_max_rows = 1024;
-  DBuf rt_vt, rt_cbt[CFD_NMEM];
+  long long rt_max_rows = 576;    // measured crossover at the product shape (L = 16): 4 utterances 1.11 s vs 1.36 s per 1000 steps, 6 utterances 1.50 vs 1.42
   bool share0 = true;       // CFD_SHARE0=0: evaluate the pre-cross-attention part of layer 0 for every guidance replica
-  DBuf d_step;  // [0] = loop index, [1] = constant 0, [2] = "this iteration's in-painting overwrite is done" (cfd_sample_inpaint)
   DBuf weg_ws, weg_tok;   // cfd_weg_eval: activation arena, focus-token tables
   // cfd_weg_eval replays its ~400 launches as a hipGraph.  A graph holds its kernels' arguments BY VALUE, so everything the
   // caller passes per call -- latents in, losses / max_att / grad out, the timestep's sinusoid row -- goes through fixed
@@ -143,6 +177,11 @@ struct cfd_handle_s {
   // One graph per variant (full evaluation / memory-side results reused), keyed by everything else the launches depend on;
   // a key is run eagerly once (function attributes, warm-up) and captured on its second use.  CFD_WEG_GRAPH=0: always eager.
   DBuf weg_io;
+  // Row-tile evaluation (weg_rt.hpp): the product path for small problems; CFD_WEG_ROWTILE=0 keeps the float32 launch sequence of weg_eval.hpp
+  bool weg_rt_on = true;
+  DBuf weg_rt_ws;
+  WegRtState wrt;
+  int weg_t_host = 0;   // the evaluation's timestep, copied to wk[1].trows in front of every launch sequence
   bool weg_graph_on = true;
   struct WegGraph { std::vector<long long> key; int uses = 0; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
   WegGraph weg_graph[2];
@@ -151,7 +190,6 @@ struct cfd_handle_s {
   std::vector<int32_t> weg_tok_host;
   std::vector<long long> weg_sig;   // timestep, shapes, memory pointers and arena of the last evaluation (reuse_memory_side)
   int weg_launches = 0;
-  Problem pb;
   // profiling
   bool prof = false;
   hipEvent_t pev[2] = {nullptr, nullptr};
@@ -269,6 +307,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   if (env) c->fused_xattn_min_wgs = atoi(env);
   env = getenv("CFD_ROWTILE");
   c->rt_on = !(env && atoi(env) == 0);
+  env = getenv("CFD_WEG_ROWTILE");
+  c->weg_rt_on = !(env && atoi(env) == 0);
   env = getenv("CFD_ROWTILE_MAX_ROWS");
   if (env) c->rt_max_rows = atoll(env);
   env = getenv("CFD_HOIST_MEMSIDE");
@@ -277,8 +317,10 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   c->permute = !(env && atoi(env) == 0);
   env = getenv("CFD_SHARE0");
   c->share0 = !(env && atoi(env) == 0);
-  if (c->d_step.ensure(16) != CFD_OK) { delete c; return CFD_E_HIP; }
-  if (hipMemset(c->d_step.p, 0, 16) != hipSuccess) { delete c; return fail(CFD_E_HIP, "memset"); }
+  for (Work& wk : c->wk) {
+    if (wk.d_step.ensure(16) != CFD_OK) { delete c; return CFD_E_HIP; }
+    if (hipMemset(wk.d_step.p, 0, 16) != hipSuccess) { delete c; return fail(CFD_E_HIP, "memset"); }
+  }
   (void)hipEventCreate(&c->pev[0]);
   (void)hipEventCreate(&c->pev[1]);
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(CFD_E_HIP, "stream create"); }
@@ -298,16 +340,14 @@ extern "C" void cfd_destroy(cfd_handle c) {
   }
   if (c->weg_ev) (void)hipEventDestroy(c->weg_ev);
   c->weg_io.release();
+  c->weg_rt_ws.release();
   for (auto& kv : c->raw) kv.second.release();
-  DBuf* all[] = {&c->we_sp, &c->wp_sp, &c->we_all, &c->be_all, &c->tsin, &c->x, &c->h_sp, &c->qk_sp, &c->vts_sp,
-                 &c->ssc, &c->sp_sp, &c->o_sp, &c->u_sp, &c->sc, &c->p_sp, &c->eps, &c->sample_sp, &c->temb_tab,
-                 &c->h1_tab, &c->ss_tab, &c->trows, &c->d_step, &c->weg_ws, &c->weg_tok, &c->latents, &c->coef, &c->inoise, &c->xa_wgs, &c->xa_segs, &c->xa_stamps,
-                 &c->long_rows, &c->short_rows, &c->zero_mask, &c->iota, &c->rt_vt};
+  DBuf* all[] = {&c->we_sp, &c->wp_sp, &c->we_all, &c->be_all, &c->tsin, &c->weg_ws, &c->weg_tok, &c->latents, &c->coef, &c->inoise};
   for (DBuf* b : all) b->release();
+  c->wk[0].release();
+  c->wk[1].release();
   for (int j = 0; j < CFD_NMEM; ++j) {
-    c->wk_all_sp[j].release(); c->wv_all_sp[j].release(); c->n_sp[j].release(); c->kall_sp[j].release();
-    c->cb[j].release(); c->vt_all[j].release(); c->mem_own[j].release(); c->perm_map[j].release();
-    c->ca[j].release(); c->asq[j].release(); c->kbtab[j].release(); c->vbtab[j].release(); c->rt_cbt[j].release();
+    c->wk_all_sp[j].release(); c->wv_all_sp[j].release(); c->mem_own[j].release(); c->perm_map[j].release();
   }
   for (auto& l : c->lw) {
     DBuf* lb[] = {&l.wqk_sp, &l.bqk, &l.wv_sp, &l.wo_sp, &l.bo2, &l.wtb1_sp, &l.wtb2_sp, &l.w1_sp, &l.w2_sp, &l.cross_bias};
@@ -536,7 +576,7 @@ extern "C" int cfd_set_timestep_table(cfd_handle c, const float* rows, int n_row
 //  * workgroups that read the same instance are placed on one XCD (block id % 8) next to each other so the stream is
 //    fetched into that XCD's L2 once; big groups are dealt over all XCDs.
 static int build_xattn_worklist(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
-  Problem& p = c->pb;
+  Problem& p = c->w->pb;
   p.xa_nwg = 0;
   if (!c->fused_xattn) return CFD_OK;
   const int Be = p.Be, L = p.L, nqt = (L + 15) / 16;
@@ -640,10 +680,10 @@ static int build_xattn_worklist(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
   size_t n_active = 0;
   for (int x = 0; x < 8; ++x) n_active += queue[x].size();
   if ((int)n_active < c->fused_xattn_min_wgs) return CFD_OK;
-  CHK(c->xa_wgs.ensure(wgs.size() * sizeof(XaWg)));
-  CHK(c->xa_segs.ensure(segs.size() * sizeof(XaSeg)));
-  HIPCHK(hipMemcpy(c->xa_wgs.p, wgs.data(), wgs.size() * sizeof(XaWg), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->xa_segs.p, segs.data(), segs.size() * sizeof(XaSeg), hipMemcpyHostToDevice));
+  CHK(c->w->xa_wgs.ensure(wgs.size() * sizeof(XaWg)));
+  CHK(c->w->xa_segs.ensure(segs.size() * sizeof(XaSeg)));
+  HIPCHK(hipMemcpy(c->w->xa_wgs.p, wgs.data(), wgs.size() * sizeof(XaWg), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->w->xa_segs.p, segs.data(), segs.size() * sizeof(XaSeg), hipMemcpyHostToDevice));
   p.xa_nwg = (int)wgs.size();
   return CFD_OK;
 }
@@ -654,13 +694,13 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
   if (Be < 1 || L < 2) return fail(CFD_E_ARG, "bad batch / length");
   if (L % 2) return fail(CFD_E_SHAPE, "latent length %d is odd (reference: broadcasting error at position_encoding.py:160-161)", L);
   if (L / 2 > c->qpe_rows) return fail(CFD_E_SHAPE, "L/2 = %d exceeds the query PE buffer (%d rows)", L / 2, c->qpe_rows);
-  if ((size_t)Be * 4 > c->iota.bytes) {   // identity row map (memories passed without de-duplication)
-    CHK(c->iota.ensure((size_t)Be * 4));
+  if ((size_t)Be * 4 > c->w->iota.bytes) {   // identity row map (memories passed without de-duplication)
+    CHK(c->w->iota.ensure((size_t)Be * 4));
     std::vector<int> id(Be);
     for (int i = 0; i < Be; ++i) id[i] = i;
-    HIPCHK(hipMemcpy(c->iota.p, id.data(), (size_t)Be * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->w->iota.p, id.data(), (size_t)Be * 4, hipMemcpyHostToDevice));
   }
-  Problem& p = c->pb;
+  Problem& p = c->w->pb;
   p.Be = Be; p.L = L; p.Lp = (L + 31) / 32 * 32; p.M = (long long)Be * L; p.tmode = tmode; p.T = T;
   p.share_B = 0;
   if (p.Lp > SM_MAX_CHUNKS * 512) return fail(CFD_E_SHAPE, "L = %d exceeds the in-register softmax limit (%d)", L, SM_MAX_CHUNKS * 512);
@@ -675,20 +715,20 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
                   MEM_NAMES[j], m.S, c->mpe_rows);
     p.U[j] = m.U; p.S[j] = m.S; p.Sp[j] = (m.S + 31) / 32 * 32; p.off[j] = off; off += p.Sp[j];
     if (p.Sp[j] > SM_MAX_CHUNKS * 512) return fail(CFD_E_SHAPE, "memory %s: %d keys exceed the in-register softmax limit", MEM_NAMES[j], m.S);
-    p.mem[j] = m.data; p.map[j] = m.row_map ? m.row_map : c->iota.as<int>(); p.mask[j] = m.key_padding_mask;
+    p.mem[j] = m.data; p.map[j] = m.row_map ? m.row_map : c->w->iota.as<int>(); p.mask[j] = m.key_padding_mask;
     p.att[j] = att ? att[j] : nullptr;
   }
   p.Sp_tot = off;
   {  // memories without a key-padding mask get an all-zero one, so the softmax kernel needs no null test
     size_t need = (size_t)Be * L;   // (the un-fused self-attention softmax indexes it per batch row)
     for (int j = 0; j < CFD_NMEM; ++j) need = std::max(need, (size_t)p.U[j] * p.S[j]);
-    if (need > c->zero_mask.bytes) {
-      CHK(c->zero_mask.ensure(need));
-      HIPCHK(hipMemset(c->zero_mask.p, 0, need));
+    if (need > c->w->zero_mask.bytes) {
+      CHK(c->w->zero_mask.ensure(need));
+      HIPCHK(hipMemset(c->w->zero_mask.p, 0, need));
     }
     for (int j = 0; j < CFD_NMEM; ++j) {
       p.has_mask[j] = p.mask[j] != nullptr;
-      if (!p.mask[j]) p.mask[j] = c->zero_mask.as<uint8_t>();
+      if (!p.mask[j]) p.mask[j] = c->w->zero_mask.as<uint8_t>();
     }
   }
   p.jbig = -1; p.nruns = 0; p.nlong = 0; p.nshort = Be;
@@ -714,70 +754,76 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
       }
       if (p.nruns > 0) {
         p.jbig = jb; p.nlong = (int)lrows.size(); p.nshort = (int)srows.size();
-        CHK(c->long_rows.ensure(lrows.size() * 4 + 16));
-        CHK(c->short_rows.ensure(srows.size() * 4 + 16));
-        HIPCHK(hipMemcpy(c->long_rows.p, lrows.data(), lrows.size() * 4, hipMemcpyHostToDevice));
-        if (!srows.empty()) HIPCHK(hipMemcpy(c->short_rows.p, srows.data(), srows.size() * 4, hipMemcpyHostToDevice));
+        CHK(c->w->long_rows.ensure(lrows.size() * 4 + 16));
+        CHK(c->w->short_rows.ensure(srows.size() * 4 + 16));
+        HIPCHK(hipMemcpy(c->w->long_rows.p, lrows.data(), lrows.size() * 4, hipMemcpyHostToDevice));
+        if (!srows.empty()) HIPCHK(hipMemcpy(c->w->short_rows.p, srows.data(), srows.size() * 4, hipMemcpyHostToDevice));
       }
     }
   }
   p.rt = c->rt_on && tmode == 0 && !g_cfd_naive_gemm && L <= RT_MAX_L && p.M <= c->rt_max_rows && p.Sp_tot <= RT_MAX_KEYS && c->hoist_memside;
   if (p.rt) {
-    CHK(c->rt_vt.ensure((size_t)Be * CFD_D * RT_MAX_L * 4));
-    HIPCHK(hipMemset(c->rt_vt.p, 0, (size_t)Be * CFD_D * RT_MAX_L * 4));   // keys beyond L stay zero
+    CHK(c->w->rt_vt.ensure((size_t)Be * CFD_D * RT_MAX_L * 4));
+    HIPCHK(hipMemset(c->w->rt_vt.p, 0, (size_t)Be * CFD_D * RT_MAX_L * 4));   // keys beyond L stay zero
   }
   CHK(build_xattn_worklist(c, mem));
   const long long M = p.M;
   const int nl = c->nl;
-  CHK(c->x.ensure((size_t)M * CFD_D * 4));
-  CHK(c->h_sp.ensure((size_t)M * CFD_D * 4));
-  CHK(c->qk_sp.ensure((size_t)M * 2 * CFD_D * 4));
-  CHK(c->vts_sp.ensure((size_t)Be * CFD_D * ((L + 63) / 64 * 64) * 4));
-  CHK(c->ssc.ensure((size_t)Be * CFD_NHEAD * L * p.Lp * 4));
-  CHK(c->sp_sp.ensure((size_t)Be * CFD_NHEAD * L * p.Lp * 4));
-  CHK(c->o_sp.ensure((size_t)M * CFD_D * 4));
-  CHK(c->u_sp.ensure((size_t)M * CFD_FF * 4));
-  CHK(c->sc.ensure((size_t)M * p.Sp_tot * 4));
-  CHK(c->p_sp.ensure((size_t)M * p.Sp_tot * 4));
-  CHK(c->eps.ensure((size_t)M * CFD_LAT * 4));
-  CHK(c->sample_sp.ensure((size_t)M * CFD_LAT * 4));
+  CHK(c->w->x.ensure((size_t)M * CFD_D * 4));
+  CHK(c->w->h_sp.ensure((size_t)M * CFD_D * 4));
+  CHK(c->w->qk_sp.ensure((size_t)M * 2 * CFD_D * 4));
+  CHK(c->w->vts_sp.ensure((size_t)Be * CFD_D * ((L + 63) / 64 * 64) * 4));
+  CHK(c->w->ssc.ensure((size_t)Be * CFD_NHEAD * L * p.Lp * 4));
+  CHK(c->w->sp_sp.ensure((size_t)Be * CFD_NHEAD * L * p.Lp * 4));
+  CHK(c->w->o_sp.ensure((size_t)M * CFD_D * 4));
+  CHK(c->w->u_sp.ensure((size_t)M * CFD_FF * 4));
+  CHK(c->w->sc.ensure((size_t)M * p.Sp_tot * 4));
+  CHK(c->w->p_sp.ensure((size_t)M * p.Sp_tot * 4));
+  CHK(c->w->eps.ensure((size_t)M * CFD_LAT * 4));
+  CHK(c->w->sample_sp.ensure((size_t)M * CFD_LAT * 4));
   for (int j = 0; j < CFD_NMEM; ++j) {
     const size_t rows = (size_t)p.U[j] * p.Sp[j];
-    CHK(c->n_sp[j].ensure(rows * CFD_D * 4));
-    CHK(c->kall_sp[j].ensure(rows * nl * CFD_D * 4));
-    CHK(c->cb[j].ensure(rows * (nl + 1) * 4));   // + one plane: the per-key scale of the fused cross-attention kernel
-    CHK(c->vt_all[j].ensure(rows * nl * CFD_D * 4));
+    CHK(c->w->n_sp[j].ensure(rows * CFD_D * 4));
+    CHK(c->w->kall_sp[j].ensure(rows * nl * CFD_D * 4));
+    CHK(c->w->cb[j].ensure(rows * (nl + 1) * 4));   // + one plane: the per-key scale of the fused cross-attention kernel
+    CHK(c->w->vt_all[j].ensure(rows * nl * CFD_D * 4));
   }
-  CHK(c->temb_tab.ensure((size_t)T * CFD_D * 4));
-  CHK(c->h1_tab.ensure((size_t)T * CFD_D * 4));
-  CHK(c->ss_tab.ensure((size_t)T * nl * 2 * 2 * CFD_D * 4));
-  CHK(c->trows.ensure((size_t)T * 4));
+  CHK(c->w->temb_tab.ensure((size_t)T * CFD_D * 4));
+  CHK(c->w->h1_tab.ensure((size_t)T * CFD_D * 4));
+  CHK(c->w->ss_tab.ensure((size_t)T * nl * 2 * 2 * CFD_D * 4));
+  CHK(c->w->trows.ensure((size_t)T * 4));
   return CFD_OK;
 }
 
 // temb / TimeBlock modulation tables for the T timesteps in `trows_host` (embeddings.py:298-305,
 // cross_attention.py:432-434).  temb depends only on t, so a sampling run computes all of its steps once.
+static int enqueue_time_tables(Ctx* c, int T, hipStream_t st);
 static int build_time_tables(Ctx* c, const int32_t* trows_host, int T, hipStream_t st) {
   for (int i = 0; i < T; ++i)
     if (trows_host[i] < 0 || trows_host[i] >= c->tsin_rows)
       return fail(CFD_E_ARG, "timestep %d outside the sinusoid table (0..%d)", trows_host[i], c->tsin_rows - 1);
-  HIPCHK(hipMemcpyAsync(c->trows.p, trows_host, (size_t)T * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(c->w->trows.p, trows_host, (size_t)T * 4, hipMemcpyHostToDevice, st));
+  return enqueue_time_tables(c, T, st);
+}
+
+// the launches of build_time_tables: table rows from the timestep indices already in w->trows
+static int enqueue_time_tables(Ctx* c, int T, hipStream_t st) {
   const int ry = T < 64 ? T : 64;
   const float* W1 = rawp(c, "time_embedding.linear_1.weight");
   const float* b1 = rawp(c, "time_embedding.linear_1.bias");
   const float* W2 = rawp(c, "time_embedding.linear_2.weight");
   const float* b2 = rawp(c, "time_embedding.linear_2.bias");
   const int NE = c->nl * 2 * 2 * CFD_D;
-  LAUNCH(CFD_PROF_OTHER, small_linear_kernel, dim3(CFD_D / 4, ry), dim3(256), st, c->tsin.as<float>(), c->trows.as<int>(),
-         (long long)CFD_D, W1, b1, c->h1_tab.as<float>(), (long long)CFD_D, T, CFD_D, 0, 1);
-  LAUNCH(CFD_PROF_OTHER, small_linear_kernel, dim3(CFD_D / 4, ry), dim3(256), st, c->h1_tab.as<float>(), (const int*)nullptr,
-         (long long)CFD_D, W2, b2, c->temb_tab.as<float>(), (long long)CFD_D, T, CFD_D, 0, 0);
+  LAUNCH(CFD_PROF_OTHER, small_linear_kernel, dim3(CFD_D / 4, ry), dim3(256), st, c->tsin.as<float>(), c->w->trows.as<int>(),
+         (long long)CFD_D, W1, b1, c->w->h1_tab.as<float>(), (long long)CFD_D, T, CFD_D, 0, 1);
+  LAUNCH(CFD_PROF_OTHER, small_linear_kernel, dim3(CFD_D / 4, ry), dim3(256), st, c->w->h1_tab.as<float>(), (const int*)nullptr,
+         (long long)CFD_D, W2, b2, c->w->temb_tab.as<float>(), (long long)CFD_D, T, CFD_D, 0, 0);
   // 18 emb_layers at once: rows (2l+tb)*1024 + n ; "post 2" adds 1 to the scale half
   // (post=2 tests n < 512 within each 1024 block -> handled by launching per time block)
   for (int tb = 0; tb < c->nl * 2; ++tb) {
-    LAUNCH(CFD_PROF_OTHER, small_linear_kernel, dim3(2 * CFD_D / 4, ry), dim3(256), st, c->temb_tab.as<float>(), (const int*)nullptr,
+    LAUNCH(CFD_PROF_OTHER, small_linear_kernel, dim3(2 * CFD_D / 4, ry), dim3(256), st, c->w->temb_tab.as<float>(), (const int*)nullptr,
            (long long)CFD_D, c->we_all.as<float>() + (size_t)tb * 2 * CFD_D * CFD_D, c->be_all.as<float>() + (size_t)tb * 2 * CFD_D,
-           c->ss_tab.as<float>() + (size_t)tb * 2 * CFD_D, (long long)NE, T, 2 * CFD_D, 1, 2);
+           c->w->ss_tab.as<float>() + (size_t)tb * 2 * CFD_D, (long long)NE, T, 2 * CFD_D, 1, 2);
   }
   return CFD_OK;
 }
@@ -792,70 +838,70 @@ __global__ void fill_f32_kernel(float* p, long long n, float v) {
 // iterations of a run: the dyadic rollout's partner projection) keep their per-step projections, and so does every memory when
 // the fused cross-attention kernel is not the one that runs (att_mats wanted, small problems, per-row timesteps).
 static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool want_att) {
-  Problem& p = c->pb;
+  Problem& p = c->w->pb;
   const int nl = c->nl;
   const long long ROWB = CFD_D * 4;
   p.static_mask = 0;
   for (int j = 0; j < CFD_NMEM; ++j) {   // scale plane = 1 unless mem_scale_kernel writes it
     const long long rows = (long long)p.U[j] * p.Sp[j];
-    LAUNCH(CFD_PROF_OTHER, fill_f32_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), st, c->cb[j].as<float>() + (size_t)nl * rows, rows, 1.0f);
+    LAUNCH(CFD_PROF_OTHER, fill_f32_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), st, c->w->cb[j].as<float>() + (size_t)nl * rows, rows, 1.0f);
   }
-  if (c->zeros512.bytes == 0) {
-    CHK(c->zeros512.ensure(CFD_D * 4));
-    HIPCHK(hipMemsetAsync(c->zeros512.p, 0, CFD_D * 4, st));
+  if (c->w->zeros512.bytes == 0) {
+    CHK(c->w->zeros512.ensure(CFD_D * 4));
+    HIPCHK(hipMemsetAsync(c->w->zeros512.p, 0, CFD_D * 4, st));
   }
   if (dynamic_mask) p.rt = false;   // (a memory rewritten between iterations keeps its per-step projections: tile-kernel path)
   const bool fused = p.rt || (c->fused_xattn && p.xa_nwg > 0 && !want_att && !g_cfd_naive_gemm);
   if (!fused || !c->hoist_memside || p.tmode != 0) return CFD_OK;
   const int T = p.T;
-  CHK(c->b_tab.ensure((size_t)T * CFD_D * 4));
-  CHK(c->b_sp.ensure((size_t)T * CFD_D * 4));
-  CHK(c->bsq.ensure((size_t)T * 4));
-  LAUNCH(CFD_PROF_OTHER, temb_center_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), st, c->temb_tab.as<float>(), T, c->b_tab.as<float>(),
-         c->b_sp.as<char>(), c->bsq.as<float>());
+  CHK(c->w->b_tab.ensure((size_t)T * CFD_D * 4));
+  CHK(c->w->b_sp.ensure((size_t)T * CFD_D * 4));
+  CHK(c->w->bsq.ensure((size_t)T * 4));
+  LAUNCH(CFD_PROF_OTHER, temb_center_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), st, c->w->temb_tab.as<float>(), T, c->w->b_tab.as<float>(),
+         c->w->b_sp.as<char>(), c->w->bsq.as<float>());
   for (int j = 0; j < CFD_NMEM; ++j) {
     if ((dynamic_mask >> j) & 1) continue;
     const int rows = p.U[j] * p.Sp[j];
     const int NK = nl * CFD_D + 32;
-    CHK(c->ca[j].ensure((size_t)rows * nl * 4));
-    CHK(c->asq[j].ensure((size_t)rows * 4));
-    CHK(c->kbtab[j].ensure((size_t)T * NK * 4));
-    CHK(c->vbtab[j].ensure((size_t)T * nl * CFD_D * 4));
+    CHK(c->w->ca[j].ensure((size_t)rows * nl * 4));
+    CHK(c->w->asq[j].ensure((size_t)rows * 4));
+    CHK(c->w->kbtab[j].ensure((size_t)T * NK * 4));
+    CHK(c->w->vbtab[j].ensure((size_t)T * nl * CFD_D * 4));
     MemCenterArgs ma{p.mem[j], p.U[j], p.S[j], p.Sp[j], rawp(c, "condition_embedding.weight") + (size_t)j * CFD_D, rawp(c, "mem_pos.pe"),
-                     c->n_sp[j].as<char>(), c->asq[j].as<float>()};
+                     c->w->n_sp[j].as<char>(), c->w->asq[j].as<float>()};
     LAUNCH(CFD_PROF_ROWS, mem_center_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), st, ma);
     {  // KA = A a_s for all layers, ca = c_l . a_s (-inf on dead keys)
       GemmArgs a = gemm_args();
       a.X[0] = c->wk_all_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = NK; a.Iclamp[0] = NK; a.kt[0] = CFD_D / 32;
-      a.Y = c->n_sp[j].as<char>(); a.ldy = ROWB; a.J = rows; a.Jclamp = rows;
+      a.Y = c->w->n_sp[j].as<char>(); a.ldy = ROWB; a.J = rows; a.Jclamp = rows;
       a.super_i = 8; a.super_j = 8;
-      EpiMemK e{c->kall_sp[j].as<char>(), (long long)rows, c->ca[j].as<float>(), nl * CFD_D, nl, p.mask[j], p.S[j], p.Sp[j]};
+      EpiMemK e{c->w->kall_sp[j].as<char>(), (long long)rows, c->w->ca[j].as<float>(), nl * CFD_D, nl, p.mask[j], p.S[j], p.Sp[j]};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }
     {  // VA^T
       GemmArgs a = gemm_args();
-      a.X[0] = c->n_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = rows; a.Iclamp[0] = rows; a.kt[0] = CFD_D / 32;
+      a.X[0] = c->w->n_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = rows; a.Iclamp[0] = rows; a.kt[0] = CFD_D / 32;
       a.Y = c->wv_all_sp[j].as<char>(); a.ldy = ROWB; a.J = nl * CFD_D; a.Jclamp = nl * CFD_D;
       a.super_i = 8; a.super_j = 8;
-      EpiMemV e{c->vt_all[j].as<char>(), p.Sp[j], p.U[j]};
+      EpiMemV e{c->w->vt_all[j].as<char>(), p.Sp[j], p.U[j]};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }
     {  // kbtab[t][:] = [A_l b_t for all l | c_l . b_t]
       GemmArgs a = gemm_args();
       a.X[0] = c->wk_all_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = NK; a.Iclamp[0] = NK; a.kt[0] = CFD_D / 32;
-      a.Y = c->b_sp.as<char>(); a.ldy = ROWB; a.J = T; a.Jclamp = T;
+      a.Y = c->w->b_sp.as<char>(); a.ldy = ROWB; a.J = T; a.Jclamp = T;
       EpiF32 e;
       memset(&e, 0, sizeof(e));
-      e.out = c->kbtab[j].as<float>(); e.ldo = NK;
+      e.out = c->w->kbtab[j].as<float>(); e.ldo = NK;
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }
     {  // vbtab[t][:] = VV_l b_t for all l
       GemmArgs a = gemm_args();
       a.X[0] = c->wv_all_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = nl * CFD_D; a.Iclamp[0] = nl * CFD_D; a.kt[0] = CFD_D / 32;
-      a.Y = c->b_sp.as<char>(); a.ldy = ROWB; a.J = T; a.Jclamp = T;
+      a.Y = c->w->b_sp.as<char>(); a.ldy = ROWB; a.J = T; a.Jclamp = T;
       EpiF32 e;
       memset(&e, 0, sizeof(e));
-      e.out = c->vbtab[j].as<float>(); e.ldo = nl * CFD_D;
+      e.out = c->w->vbtab[j].as<float>(); e.ldo = nl * CFD_D;
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }
     p.static_mask |= 1 << j;
@@ -863,9 +909,9 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
   if (p.rt) {   // per-key scale and key bias of every step of the run (the tile-kernel path makes one step's per iteration: mem_scale_kernel)
     for (int j = 0; j < CFD_NMEM; ++j) {
       const long long rows = (long long)p.U[j] * p.Sp[j];
-      CHK(c->rt_cbt[j].ensure((size_t)T * (nl + 1) * rows * 4));
-      MemScaleTabArgs a{c->n_sp[j].as<char>(), c->asq[j].as<float>(), rows, c->b_tab.as<float>(), c->bsq.as<float>(), c->ca[j].as<float>(),
-                        c->kbtab[j].as<float>() + (size_t)nl * CFD_D, (long long)(nl * CFD_D + 32), nl, c->rt_cbt[j].as<float>()};
+      CHK(c->w->rt_cbt[j].ensure((size_t)T * (nl + 1) * rows * 4));
+      MemScaleTabArgs a{c->w->n_sp[j].as<char>(), c->w->asq[j].as<float>(), rows, c->w->b_tab.as<float>(), c->w->bsq.as<float>(), c->w->ca[j].as<float>(),
+                        c->w->kbtab[j].as<float>() + (size_t)nl * CFD_D, (long long)(nl * CFD_D + 32), nl, c->w->rt_cbt[j].as<float>()};
       LAUNCH(CFD_PROF_ROWS, mem_scale_table_kernel, dim3((unsigned)((rows + 3) / 4), (unsigned)T), dim3(256), st, a);
     }
   }
@@ -873,15 +919,15 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
 }
 
 // ---- the denoiser forward: Denoiser.forward (denoiser.py:173-386) --------------------------------------
-// Input: c->sample_sp (SP [M][128]); time tables built; output: c->eps (fp32 [M][128]).
+// Input: c->w->sample_sp (SP [M][128]); time tables built; output: c->w->eps (fp32 [M][128]).
 static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int nrows);
 
 // memory-side work of one forward: shared by every row chunk
 static int enqueue_memside(Ctx* c, hipStream_t st) {
-  const Problem& p = c->pb;
+  const Problem& p = c->w->pb;
   if (p.rt) return CFD_OK;   // every memory is static and its per-step scalars are tabulated (prepare_static_memside)
   const int nl = c->nl;
-  const int* dstep = p.tmode ? c->d_step.as<int>() + 1 : c->d_step.as<int>();
+  const int* dstep = p.tmode ? c->w->d_step.as<int>() + 1 : c->w->d_step.as<int>();
   const long long ROWB = CFD_D * 4;
   const dim3 blk(256);
   // memories whose projections were made once for the run: this step's per-key scale and key bias
@@ -889,16 +935,16 @@ static int enqueue_memside(Ctx* c, hipStream_t st) {
     if (!((p.static_mask >> j) & 1)) continue;
     const long long rows = (long long)p.U[j] * p.Sp[j];
     const int NK = nl * CFD_D + 32;
-    MemScaleArgs a{c->n_sp[j].as<char>(), c->asq[j].as<float>(), rows, c->b_tab.as<float>(), c->bsq.as<float>(), c->ca[j].as<float>(),
-                   c->kbtab[j].as<float>() + (size_t)nl * CFD_D, (long long)NK, dstep, nl, c->cb[j].as<float>() + (size_t)nl * rows,
-                   c->cb[j].as<float>()};
+    MemScaleArgs a{c->w->n_sp[j].as<char>(), c->w->asq[j].as<float>(), rows, c->w->b_tab.as<float>(), c->w->bsq.as<float>(), c->w->ca[j].as<float>(),
+                   c->w->kbtab[j].as<float>() + (size_t)nl * CFD_D, (long long)NK, dstep, nl, c->w->cb[j].as<float>() + (size_t)nl * rows,
+                   c->w->cb[j].as<float>()};
     LAUNCH(CFD_PROF_ROWS, mem_scale_kernel, dim3((unsigned)((rows + 3) / 4)), blk, st, a);
   }
   // 2. memories: + temb + condition id + PE, normalise           (denoiser.py:223-261,332-353)
   for (int j = 0; j < CFD_NMEM; ++j) {
     if ((p.static_mask >> j) & 1) continue;
-    MemPrepArgs a{p.mem[j], p.U[j], p.S[j], p.Sp[j], c->temb_tab.as<float>(), dstep, p.tmode,
-                  rawp(c, "condition_embedding.weight") + (size_t)j * CFD_D, rawp(c, "mem_pos.pe"), c->n_sp[j].as<char>()};
+    MemPrepArgs a{p.mem[j], p.U[j], p.S[j], p.Sp[j], c->w->temb_tab.as<float>(), dstep, p.tmode,
+                  rawp(c, "condition_embedding.weight") + (size_t)j * CFD_D, rawp(c, "mem_pos.pe"), c->w->n_sp[j].as<char>()};
     const long long rows = (long long)p.U[j] * p.Sp[j];
     LAUNCH(CFD_PROF_ROWS, mem_prep_kernel, dim3((unsigned)((rows + 3) / 4)), blk, st, a);
   }
@@ -909,17 +955,17 @@ static int enqueue_memside(Ctx* c, hipStream_t st) {
     {
       GemmArgs a = gemm_args();
       a.X[0] = c->wk_all_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = nl * CFD_D + 32; a.Iclamp[0] = nl * CFD_D + 32; a.kt[0] = CFD_D / 32;
-      a.Y = c->n_sp[j].as<char>(); a.ldy = ROWB; a.J = rows; a.Jclamp = rows;
+      a.Y = c->w->n_sp[j].as<char>(); a.ldy = ROWB; a.J = rows; a.Jclamp = rows;
       a.super_i = 8; a.super_j = 8;
-      EpiMemK e{c->kall_sp[j].as<char>(), (long long)rows, c->cb[j].as<float>(), nl * CFD_D, nl, p.mask[j], p.S[j], p.Sp[j]};
+      EpiMemK e{c->w->kall_sp[j].as<char>(), (long long)rows, c->w->cb[j].as<float>(), nl * CFD_D, nl, p.mask[j], p.S[j], p.Sp[j]};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }
     {
       GemmArgs a = gemm_args();
-      a.X[0] = c->n_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = rows; a.Iclamp[0] = rows; a.kt[0] = CFD_D / 32;
+      a.X[0] = c->w->n_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = rows; a.Iclamp[0] = rows; a.kt[0] = CFD_D / 32;
       a.Y = c->wv_all_sp[j].as<char>(); a.ldy = ROWB; a.J = nl * CFD_D; a.Jclamp = nl * CFD_D;
       a.super_i = 8; a.super_j = 8;
-      EpiMemV e{c->vt_all[j].as<char>(), p.Sp[j], p.U[j]};
+      EpiMemV e{c->w->vt_all[j].as<char>(), p.Sp[j], p.U[j]};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }
   }
@@ -927,19 +973,23 @@ static int enqueue_memside(Ctx* c, hipStream_t st) {
   return CFD_OK;
 }
 
-static int enqueue_rows_rt(Ctx* c, hipStream_t st);
+static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv = nullptr);
 
 static int enqueue_denoise(Ctx* c, hipStream_t st) {
   CHK(enqueue_memside(c, st));
-  if (c->pb.rt) return enqueue_rows_rt(c, st);
-  return enqueue_rows(c, st, 0, c->pb.Be);
+  if (c->w->pb.rt) return enqueue_rows_rt(c, st);
+  return enqueue_rows(c, st, 0, c->w->pb.Be);
 }
 
 // The forward for small problems: launches of 16-token x 16-feature workgroups (rowtile.hpp); same buffers, same tap points.
-static int enqueue_rows_rt(Ctx* c, hipStream_t st) {
-  const Problem& p = c->pb;
+// With `sv` (the WEG evaluation, weg_rt.hpp) every residual update goes to a buffer of its own, the self-attention operands, the
+// cross-attention scores and the FFN pre-activations of every layer are kept, and the pass ends behind the last layer's
+// cross-attention (nothing above it reaches the objective).
+
+static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
+  const Problem& p = c->w->pb;
   const int nl = c->nl, L = p.L, tpr = (L + 15) / 16, ntile = p.Be * tpr;
-  const int* dstep = c->d_step.as<int>();
+  const int* dstep = c->w->d_step.as<int>();
   constexpr int LDS_LN = 16 * 2048 + 8 * 1024, LDS_LN2 = 16 * 2048 + 16 * 1024, LDS_SP4 = 4 * 1024, LDS_SP8 = 8 * 1024;
   const int lds_xs = 16 * 2048 + 8 * 1024 + 64, lds_xpv = (p.Sp_tot / 32) * 2048 + 8 * 1024 + 512;
   static unsigned long long attr = 0;
@@ -948,9 +998,11 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st) {
                                (RT_MAX_KEYS / 32) * 2048 + 8 * 1024 + 512));
     attr |= 1ull << (c->cfg.device & 63);
   }
+  float* const xw = c->w->x.as<float>();
+  auto X = [&](int l, int k) -> float* { return sv ? sv->x[l][k] : xw; };
   RtGemmArgs base;
   memset(&base, 0, sizeof(base));
-  base.L = L; base.tpr = tpr; base.x = c->x.as<float>(); base.xr = c->x.as<float>(); base.xo = c->x.as<float>(); base.d_step = dstep;
+  base.L = L; base.tpr = tpr; base.d_step = dstep;
   base.ss_tstride = (long long)nl * 2 * 2 * CFD_D;
 #define RT_LAUNCH(cls, PRO, EPI, NT, KT, NFB, nfeat, lds, args)                                                   \
   do {                                                                                                          \
@@ -962,60 +1014,67 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st) {
   // 1. latent embedding + body/hand embedding + query PE          (denoiser.py:187,316-326)
   {
     RtGemmArgs a = base;
-    a.a_sp = c->sample_sp.as<char>(); a.w = c->we_sp.as<char>(); a.bias = rawp(c, "latent_embd.bias");
-    a.bh = rawp(c, "bh_embedding.weight"); a.qpe = rawp(c, "query_pos.pe");
+    a.a_sp = c->w->sample_sp.as<char>(); a.w = c->we_sp.as<char>(); a.bias = rawp(c, "latent_embd.bias");
+    a.bh = rawp(c, "bh_embedding.weight"); a.qpe = rawp(c, "query_pos.pe"); a.xo = X(0, 0);
     RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_EMBED, 256, CFD_LAT / 32, 1, CFD_D, LDS_SP4, a);
   }
   if (c->stop_stage == 1) return CFD_OK;
-  auto time_block = [&](const DBuf& w, const float* g, const float* b, const float* bias, int tbidx) -> int {
+  auto time_block = [&](const DBuf& w, const float* g, const float* b, const float* bias, int tbidx, const float* xin, float* xout) -> int {
     RtGemmArgs a = base;
-    a.g = g; a.b = b; a.ss = c->ss_tab.as<float>() + (size_t)tbidx * 2 * CFD_D; a.w = w.as<char>(); a.bias = bias;
+    a.x = xin; a.xr = xin; a.xo = xout;
+    a.g = g; a.b = b; a.ss = c->w->ss_tab.as<float>() + (size_t)tbidx * 2 * CFD_D; a.w = w.as<char>(); a.bias = bias;
     RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_ADALN, RT_EPI_RESID, 512, CFD_D / 32, 1, CFD_D, LDS_LN, a);
     return CFD_OK;
   };
   RtXArgs xa;
   memset(&xa, 0, sizeof(xa));
-  xa.x = c->x.as<float>(); xa.L = L; xa.tpr = tpr; xa.nl = nl; xa.d_step = dstep; xa.Sp_tot = p.Sp_tot; xa.sc = c->sc.as<float>(); xa.rsp = c->p_sp.as<float>();
+  xa.L = L; xa.tpr = tpr; xa.nl = nl; xa.d_step = dstep; xa.Sp_tot = p.Sp_tot; xa.rsp = c->w->p_sp.as<float>();
   int nkb = 0;
   for (int j = 0; j < CFD_NMEM; ++j) {
     xa.map[j] = p.map[j]; xa.rows[j] = p.U[j] * p.Sp[j]; xa.S[j] = p.S[j]; xa.Sp[j] = p.Sp[j]; xa.off[j] = p.off[j];
-    xa.cbt[j] = c->rt_cbt[j].as<float>(); xa.att[j] = p.att[j];
+    xa.cbt[j] = c->w->rt_cbt[j].as<float>(); xa.att[j] = p.att[j];
     xa.kb_stride[j] = nl * CFD_D + 32; xa.vb_stride[j] = nl * CFD_D;
     xa.blk0[j] = nkb; nkb += p.Sp[j] / 16;
   }
   xa.blk0[CFD_NMEM] = nkb;
   for (int l = 0; l < nl; ++l) {
     const LayerW& w = c->lw[l];
+    char* qk = sv ? sv->qk[l] : c->w->qk_sp.as<char>();
+    char* vt = sv ? sv->vt[l] : c->w->rt_vt.as<char>();
     // ---- a. self attention: x += Wo softmax(q k^T) v                         (cross_attention.py:568-572)
     {
       RtGemmArgs a = base;   // norm1 + q | k | v^T projections
+      a.x = X(l, 0);
       a.g = w.ln1g; a.b = w.ln1b; a.w = w.wqk_sp.as<char>(); a.w2 = w.wv_sp.as<char>(); a.nfb_qk = 2 * CFD_D / 16;
-      a.bias = w.bqk.as<float>(); a.o_sp = c->qk_sp.as<char>(); a.ld_o = 2 * CFD_D * 4; a.vt = c->rt_vt.as<char>();
+      a.bias = w.bqk.as<float>(); a.o_sp = qk; a.ld_o = 2 * CFD_D * 4; a.vt = vt;
       RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_LN, RT_EPI_QKV, 512, CFD_D / 32, 2, 3 * CFD_D, LDS_LN2, a);
     }
     {
-      RtSelfArgs a{c->qk_sp.as<char>(), c->rt_vt.as<char>(), c->o_sp.as<char>(), L, tpr};
+      RtSelfArgs a{qk, vt, c->w->o_sp.as<char>(), L, tpr};
       LAUNCH(CFD_PROF_GEMM_ATTN, rt_selfattn_kernel, dim3(CFD_NHEAD, ntile), dim3(256), st, a);
     }
     {
       RtGemmArgs a = base;   // out-projection + residual
-      a.a_sp = c->o_sp.as<char>(); a.w = w.wo_sp.as<char>(); a.bias = w.bo2.as<float>();
+      a.xr = X(l, 0); a.xo = X(l, 1);
+      a.a_sp = c->w->o_sp.as<char>(); a.w = w.wo_sp.as<char>(); a.bias = w.bo2.as<float>();
       RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_RESID, 256, CFD_D / 32, 1, CFD_D, LDS_SP4, a);
     }
     if (c->stop_stage == 2 + 4 * l) return CFD_OK;
     // ---- b. time block 1                                                        (:575, :426-439)
-    CHK(time_block(w.wtb1_sp, w.tb1g, w.tb1b, w.btb1, 2 * l));
+    CHK(time_block(w.wtb1_sp, w.tb1g, w.tb1b, w.btb1, 2 * l, X(l, 1), X(l, 2)));
     if (c->stop_stage == 3 + 4 * l) return CFD_OK;
     // ---- c-e. five cross attentions + fuser, folded                             (:578-652)
     {
       RtXArgs a = xa;
+      a.x = X(l, 2); a.xo = X(l, 3);
+      a.sc = sv ? sv->sc[l] : c->w->sc.as<float>();
       a.ln_g = w.ln2g; a.ln_b = w.ln2b; a.bias = w.cross_bias.as<float>(); a.layer = l;
       for (int j = 0; j < CFD_NMEM; ++j) {
         const size_t rows = (size_t)p.U[j] * p.Sp[j];
-        a.K[j] = c->kall_sp[j].as<char>() + (size_t)l * rows * CFD_D * 4;
-        a.VT[j] = c->vt_all[j].as<char>() + (size_t)l * rows * CFD_D * 4;
-        a.kb[j] = c->kbtab[j].as<float>() + (size_t)l * CFD_D;
-        a.vb[j] = c->vbtab[j].as<float>() + (size_t)l * CFD_D;
+        a.K[j] = c->w->kall_sp[j].as<char>() + (size_t)l * rows * CFD_D * 4;
+        a.VT[j] = c->w->vt_all[j].as<char>() + (size_t)l * rows * CFD_D * 4;
+        a.kb[j] = c->w->kbtab[j].as<float>() + (size_t)l * CFD_D;
+        a.vb[j] = c->w->vbtab[j].as<float>() + (size_t)l * CFD_D;
       }
       {
         Bracket br(c, CFD_PROF_XATTN, st);
@@ -1029,17 +1088,21 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st) {
       }
     }
     if (c->stop_stage == 4 + 4 * l) return CFD_OK;
+    if (sv && l == nl - 1) return CFD_OK;
     // ---- f. time block 2                                                        (:655)
-    CHK(time_block(w.wtb2_sp, w.tb2g, w.tb2b, w.btb2, 2 * l + 1));
+    CHK(time_block(w.wtb2_sp, w.tb2g, w.tb2b, w.btb2, 2 * l + 1, X(l, 3), X(l, 4)));
     // ---- g. FFN                                                                 (:659-661)
     {
       RtGemmArgs a = base;   // norm3 + linear1 + GELU
-      a.g = w.ln3g; a.b = w.ln3b; a.w = w.w1_sp.as<char>(); a.bias = w.b1; a.o_sp = c->u_sp.as<char>(); a.ld_o = CFD_FF * 4; a.gelu = 1;
+      a.x = X(l, 4);
+      a.g = w.ln3g; a.b = w.ln3b; a.w = w.w1_sp.as<char>(); a.bias = w.b1; a.o_sp = c->w->u_sp.as<char>(); a.ld_o = CFD_FF * 4; a.gelu = 1;
+      a.pre = sv ? sv->pre[l] : nullptr;
       RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_LN, RT_EPI_SPLIT, 512, CFD_D / 32, 2, CFD_FF, LDS_LN2, a);
     }
     {
       RtGemmArgs a = base;   // linear2 + residual
-      a.a_sp = c->u_sp.as<char>(); a.w = w.w2_sp.as<char>(); a.bias = w.b2;
+      a.xr = X(l, 4); a.xo = X(l + 1, 0);
+      a.a_sp = c->w->u_sp.as<char>(); a.w = w.w2_sp.as<char>(); a.bias = w.b2;
       RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_RESID, 512, CFD_FF / 32, 1, CFD_D, LDS_SP8, a);
     }
     if (c->stop_stage == 5 + 4 * l) return CFD_OK;
@@ -1047,8 +1110,9 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st) {
   // 7. final norm + latent projection                                (cross_attention.py:238-239, denoiser.py:382)
   {
     RtGemmArgs a = base;
+    a.x = X(nl, 0);
     a.g = rawp(c, "decoder.norm.weight"); a.b = rawp(c, "decoder.norm.bias"); a.w = c->wp_sp.as<char>();
-    a.bias = rawp(c, "latent_proj.bias"); a.o_f32 = c->eps.as<float>(); a.ldo_f = CFD_LAT;
+    a.bias = rawp(c, "latent_proj.bias"); a.o_f32 = c->w->eps.as<float>(); a.ldo_f = CFD_LAT;
     RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_LN, RT_EPI_F32, 512, CFD_D / 32, 1, CFD_LAT, LDS_LN, a);
   }
 #undef RT_LAUNCH
@@ -1056,14 +1120,14 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st) {
 }
 
 static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
-  const Problem& p = c->pb;
+  const Problem& p = c->w->pb;
   const int nl = c->nl, L = p.L;
   const long long M = (long long)Be * L;
-  const int* dstep = p.tmode ? c->d_step.as<int>() + 1 : c->d_step.as<int>();
+  const int* dstep = p.tmode ? c->w->d_step.as<int>() + 1 : c->w->d_step.as<int>();
   const long long ROWB = CFD_D * 4;  // bytes per SP row of 512
   const dim3 blk(256);
-  const char* sample_sp = c->sample_sp.as<char>() + (size_t)row0 * L * CFD_LAT * 4;
-  float* eps_out = c->eps.as<float>() + (size_t)row0 * L * CFD_LAT;
+  const char* sample_sp = c->w->sample_sp.as<char>() + (size_t)row0 * L * CFD_LAT * 4;
+  float* eps_out = c->w->eps.as<float>() + (size_t)row0 * L * CFD_LAT;
   const int* mapj[CFD_NMEM];
   float* attj[CFD_NMEM];
   bool want_att = false;
@@ -1084,12 +1148,12 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     GemmArgs a = gemm_args();
     a.X[0] = c->we_sp.as<char>(); a.ldx[0] = CFD_LAT * 4; a.I[0] = CFD_D; a.Iclamp[0] = CFD_D; a.kt[0] = CFD_LAT / 32;
     a.Y = sample_sp; a.ldy = CFD_LAT * 4; a.J = (int)Ms; a.Jclamp = (int)Ms;
-    EpiEmbed e{c->x.as<float>(), rawp(c, "latent_embd.bias"), rawp(c, "bh_embedding.weight"), rawp(c, "query_pos.pe"), L};
+    EpiEmbed e{c->w->x.as<float>(), rawp(c, "latent_embd.bias"), rawp(c, "bh_embedding.weight"), rawp(c, "query_pos.pe"), L};
     CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
   }
   if (c->stop_stage == 1) return CFD_OK;
   auto ln = [&](const float* g, const float* b, int adaln, int tbidx, char* out, long long rows) -> int {
-    LnArgs a{c->x.as<float>(), out, rows, g, b, adaln, c->ss_tab.as<float>() + (size_t)tbidx * 2 * CFD_D,
+    LnArgs a{c->w->x.as<float>(), out, rows, g, b, adaln, c->w->ss_tab.as<float>() + (size_t)tbidx * 2 * CFD_D,
              (long long)nl * 2 * 2 * CFD_D, dstep, p.tmode, L, row0};
     LAUNCH(CFD_PROF_ROWS, ln_rows_kernel, dim3((unsigned)((rows + 3) / 4)), blk, st, a);
     return CFD_OK;
@@ -1098,14 +1162,14 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     GemmArgs a = gemm_args();
     a.X[0] = w.as<char>(); a.ldx[0] = (long long)K * 4; a.I[0] = CFD_D; a.Iclamp[0] = CFD_D; a.kt[0] = K / 32;
     a.Y = y; a.ldy = (long long)K * 4; a.J = (int)rows; a.Jclamp = (int)rows;
-    EpiResid e{c->x.as<float>(), 0, bias};
+    EpiResid e{c->w->x.as<float>(), 0, bias};
     return run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st);
   };
   // residual product + the LayerNorm that follows it
   auto token_gemm_resid_ln = [&](const DBuf& w, int K, const char* y, const float* bias, long long rows, const float* g, const float* b,
                                  int adaln, int tbidx) -> int {
     CHK(token_gemm_resid(w, K, y, bias, rows));
-    return ln(g, b, adaln, tbidx, c->h_sp.as<char>(), rows);
+    return ln(g, b, adaln, tbidx, c->w->h_sp.as<char>(), rows);
   };
   static unsigned long long attr = 0;   // per device (one bit per ordinal): a process may hold handles on several GPUs
   if (!((attr >> (c->cfg.device & 63)) & 1ull)) {
@@ -1122,69 +1186,69 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     const long long Ma = (long long)Ba * L;
     // ---- a. self attention: x += Wo softmax(q k^T) v                         (cross_attention.py:568-572)
     // (norm1 of layers 1.. is made by the previous layer's last residual product when that ran row-complete: `h_ready`)
-    if (!h_ready) CHK(ln(w.ln1g, w.ln1b, 0, 0, c->h_sp.as<char>(), Ma));
+    if (!h_ready) CHK(ln(w.ln1g, w.ln1b, 0, 0, c->w->h_sp.as<char>(), Ma));
     h_ready = false;
     const int Lv = (L + 63) / 64 * 64;
     {
       // q (pre-scaled) and k, token-major ...
       GemmArgs a = gemm_args();
       a.X[0] = w.wqk_sp.as<char>(); a.ldx[0] = ROWB; a.I[0] = 2 * CFD_D; a.Iclamp[0] = 2 * CFD_D; a.kt[0] = CFD_D / 32;
-      a.Y = c->h_sp.as<char>(); a.ldy = ROWB; a.J = (int)Ma; a.Jclamp = (int)Ma;
-      EpiSplit e{c->qk_sp.as<char>(), 2 * ROWB, 0, 0, w.bqk.as<float>(), 0, 0};
+      a.Y = c->w->h_sp.as<char>(); a.ldy = ROWB; a.J = (int)Ma; a.Jclamp = (int)Ma;
+      EpiSplit e{c->w->qk_sp.as<char>(), 2 * ROWB, 0, 0, w.bqk.as<float>(), 0, 0};
       // ... and v^T per batch row: vts[b][f][l] (keys in P-fragment order for the fused kernel)
       GemmArgs av = gemm_args();
-      av.X[0] = c->h_sp.as<char>(); av.ldx[0] = ROWB; av.xbs[0] = (long long)L * ROWB; av.I[0] = Lv; av.Iclamp[0] = L; av.kt[0] = CFD_D / 32;
+      av.X[0] = c->w->h_sp.as<char>(); av.ldx[0] = ROWB; av.xbs[0] = (long long)L * ROWB; av.I[0] = Lv; av.Iclamp[0] = L; av.kt[0] = CFD_D / 32;
       av.Y = w.wv_sp.as<char>(); av.ldy = ROWB; av.J = CFD_D; av.Jclamp = CFD_D;
-      EpiSplit ev{c->vts_sp.as<char>(), (long long)Lv * 4, (long long)CFD_D * Lv * 4, 0, nullptr, 0, 1};
+      EpiSplit ev{c->w->vts_sp.as<char>(), (long long)Lv * 4, (long long)CFD_D * Lv * 4, 0, nullptr, 0, 1};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, av, ev, Ba, 1, st)));
     }
     {
-      SelfAttnArgs a{c->qk_sp.as<char>(), c->vts_sp.as<char>(), c->o_sp.as<char>(), L, Lv};
+      SelfAttnArgs a{c->w->qk_sp.as<char>(), c->w->vts_sp.as<char>(), c->w->o_sp.as<char>(), L, Lv};
       Bracket br(c, CFD_PROF_GEMM_ATTN, st);
       hipLaunchKernelGGL(self_attn_fused_kernel, dim3((L + SELF_ATTN_WAVES * 16 - 1) / (SELF_ATTN_WAVES * 16), CFD_NHEAD, Ba), dim3(SELF_ATTN_WAVES * 64), 65536, st, a);
       HIPCHK(hipGetLastError());
     }
     // out-projection + residual, then time block 1's AdaLN + SiLU                 (:572, :575, :426-439)
-    CHK(token_gemm_resid_ln(w.wo_sp, CFD_D, c->o_sp.as<char>(), w.bo2.as<float>(), Ma, w.tb1g, w.tb1b, 1, 2 * l));
+    CHK(token_gemm_resid_ln(w.wo_sp, CFD_D, c->w->o_sp.as<char>(), w.bo2.as<float>(), Ma, w.tb1g, w.tb1b, 1, 2 * l));
     if (c->stop_stage == 2 + 4 * l) return CFD_OK;
     // ---- b. time block 1
-    CHK(token_gemm_resid(w.wtb1_sp, CFD_D, c->h_sp.as<char>(), w.btb1, Ma));
+    CHK(token_gemm_resid(w.wtb1_sp, CFD_D, c->w->h_sp.as<char>(), w.btb1, Ma));
     if (c->stop_stage == 3 + 4 * l) return CFD_OK;
     if (Ma != M) {   // every guidance chunk starts its first cross-attention from the same state
       const long long n4 = Ma * (CFD_D / 4);
-      LAUNCH(CFD_PROF_ROWS, replicate_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), blk, st, reinterpret_cast<float4*>(c->x.as<float>()), n4,
+      LAUNCH(CFD_PROF_ROWS, replicate_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), blk, st, reinterpret_cast<float4*>(c->w->x.as<float>()), n4,
              (int)(M / Ma));
     }
     // ---- c-e. five cross attentions + fuser, folded                             (:578-652)
     if (fused_x) {   // LayerNorm2 is part of the kernel's prologue
       XAttnArgs a;
       memset(&a, 0, sizeof(a));
-      a.x = c->x.as<float>(); a.ln_g = w.ln2g; a.ln_b = w.ln2b; a.bias = w.cross_bias.as<float>(); a.L = L;
+      a.x = c->w->x.as<float>(); a.ln_g = w.ln2g; a.ln_b = w.ln2b; a.bias = w.cross_bias.as<float>(); a.L = L;
       for (int j = 0; j < CFD_NMEM; ++j) {
         const size_t rows = (size_t)p.U[j] * p.Sp[j];
-        a.K[j] = c->kall_sp[j].as<char>() + (size_t)l * rows * ROWB;
-        a.cb[j] = c->cb[j].as<float>() + (size_t)l * rows;
-        a.VT[j] = c->vt_all[j].as<char>() + (size_t)l * rows * ROWB;
+        a.K[j] = c->w->kall_sp[j].as<char>() + (size_t)l * rows * ROWB;
+        a.cb[j] = c->w->cb[j].as<float>() + (size_t)l * rows;
+        a.VT[j] = c->w->vt_all[j].as<char>() + (size_t)l * rows * ROWB;
         a.Sp[j] = p.Sp[j];
         const bool stat = (p.static_mask >> j) & 1;
         a.rs_off[j] = (unsigned)((size_t)(nl - l) * rows * 4);
-        a.kb[j] = stat ? c->kbtab[j].as<float>() + (size_t)l * CFD_D : c->zeros512.as<float>();
+        a.kb[j] = stat ? c->w->kbtab[j].as<float>() + (size_t)l * CFD_D : c->w->zeros512.as<float>();
         a.kb_stride[j] = stat ? nl * CFD_D + 32 : 0;
-        a.vb[j] = stat ? c->vbtab[j].as<float>() + (size_t)l * CFD_D : c->zeros512.as<float>();
+        a.vb[j] = stat ? c->w->vbtab[j].as<float>() + (size_t)l * CFD_D : c->w->zeros512.as<float>();
         a.vb_stride[j] = stat ? nl * CFD_D : 0;
       }
       a.d_step = dstep;
-      a.wgs = c->xa_wgs.as<XaWg>(); a.segs = c->xa_segs.as<XaSeg>();
+      a.wgs = c->w->xa_wgs.as<XaWg>(); a.segs = c->w->xa_segs.as<XaSeg>();
 #if XA_STAMP
-      CHK(c->xa_stamps.ensure((size_t)p.xa_nwg * XA_WAVES * XA_NSTAMP * 8));
-      a.stamps = c->xa_stamps.as<long long>();
+      CHK(c->w->xa_stamps.ensure((size_t)p.xa_nwg * XA_WAVES * XA_NSTAMP * 8));
+      a.stamps = c->w->xa_stamps.as<long long>();
 #endif
       Bracket br(c, CFD_PROF_XATTN, st);
       hipLaunchKernelGGL(xattn_fused_kernel, dim3(p.xa_nwg), dim3(XA_WAVES * 64), XA_LDS, st, a);
       HIPCHK(hipGetLastError());
     } else {
-    CHK(ln(w.ln2g, w.ln2b, 0, 0, c->h_sp.as<char>(), M));
+    CHK(ln(w.ln2g, w.ln2b, 0, 0, c->w->h_sp.as<char>(), M));
     // Three-launch path (att_mats wanted): scores against the folded keys of every memory.  Long memories and short
     // (<= 64 keys) memories go to different tile shapes; rows in a shared-memory run of the largest memory use one
     // un-batched product per run.
@@ -1196,41 +1260,41 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       int n = 0;
       for (int j = 0; j < CFD_NMEM; ++j) {
         if ((p.Sp[j] <= 64) != small || j == skip_j) continue;
-        a.X[n] = c->kall_sp[j].as<char>() + (size_t)l * p.U[j] * p.Sp[j] * ROWB; a.ldx[n] = ROWB;
+        a.X[n] = c->w->kall_sp[j].as<char>() + (size_t)l * p.U[j] * p.Sp[j] * ROWB; a.ldx[n] = ROWB;
         a.xbs[n] = (long long)p.Sp[j] * ROWB; a.xmap[n] = mapj[j];
         a.I[n] = p.Sp[j]; a.Iclamp[n] = p.Sp[j]; a.kt[n] = CFD_D / 32;
-        e.goff[n] = p.off[j]; e.gbias[n] = c->cb[j].as<float>() + (size_t)l * p.U[j] * p.Sp[j]; e.gmap[n] = mapj[j]; e.gstride[n] = p.Sp[j];
+        e.goff[n] = p.off[j]; e.gbias[n] = c->w->cb[j].as<float>() + (size_t)l * p.U[j] * p.Sp[j]; e.gmap[n] = mapj[j]; e.gstride[n] = p.Sp[j];
         ++n;
       }
       if (!n || nb <= 0) return CFD_OK;
       a.nslot = n; a.brow = brow;
-      a.Y = c->h_sp.as<char>(); a.ldy = ROWB; a.ybs = (long long)L * ROWB; a.J = L; a.Jclamp = L;
-      e.out = c->sc.as<float>(); e.ldo = p.Sp_tot; e.obs = (long long)L * p.Sp_tot;
+      a.Y = c->w->h_sp.as<char>(); a.ldy = ROWB; a.ybs = (long long)L * ROWB; a.J = L; a.Jclamp = L;
+      e.out = c->w->sc.as<float>(); e.ldo = p.Sp_tot; e.obs = (long long)L * p.Sp_tot;
       return run_gemm<MODE_GROUPED>(c, CFD_PROF_GEMM_ATTN, a, e, nb, 1, st);
     };
     CHK(scores_grouped(true, -1, nullptr, Be));   // short memories
     if (!runs) {
       CHK(scores_grouped(false, -1, nullptr, Be));
     } else {
-      CHK(scores_grouped(false, -1, c->short_rows.as<int>(), p.nshort));
-      CHK(scores_grouped(false, p.jbig, c->long_rows.as<int>(), p.nlong));
+      CHK(scores_grouped(false, -1, c->w->short_rows.as<int>(), p.nshort));
+      CHK(scores_grouped(false, p.jbig, c->w->long_rows.as<int>(), p.nlong));
       const int j = p.jbig;
       for (int r = 0; r < p.nruns; ++r) {
         GemmArgs a = gemm_args();
-        a.X[0] = c->kall_sp[j].as<char>() + ((size_t)l * p.U[j] + p.run_u[r]) * p.Sp[j] * ROWB; a.ldx[0] = ROWB;
+        a.X[0] = c->w->kall_sp[j].as<char>() + ((size_t)l * p.U[j] + p.run_u[r]) * p.Sp[j] * ROWB; a.ldx[0] = ROWB;
         a.I[0] = p.Sp[j]; a.Iclamp[0] = p.Sp[j]; a.kt[0] = CFD_D / 32;
-        a.Y = c->h_sp.as<char>() + (size_t)p.run_row0[r] * L * ROWB; a.ldy = ROWB; a.J = p.run_len[r] * L; a.Jclamp = a.J;
+        a.Y = c->w->h_sp.as<char>() + (size_t)p.run_row0[r] * L * ROWB; a.ldy = ROWB; a.J = p.run_len[r] * L; a.Jclamp = a.J;
         EpiF32 e;
         memset(&e, 0, sizeof(e));
-        e.out = c->sc.as<float>() + (size_t)p.run_row0[r] * L * p.Sp_tot; e.ldo = p.Sp_tot; e.goff[0] = p.off[j];
-        e.gbias[0] = c->cb[j].as<float>() + ((size_t)l * p.U[j] + p.run_u[r]) * p.Sp[j]; e.gstride[0] = 0;
+        e.out = c->w->sc.as<float>() + (size_t)p.run_row0[r] * L * p.Sp_tot; e.ldo = p.Sp_tot; e.goff[0] = p.off[j];
+        e.gbias[0] = c->w->cb[j].as<float>() + ((size_t)l * p.U[j] + p.run_u[r]) * p.Sp[j]; e.gstride[0] = 0;
         CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_ATTN, a, e, 1, 1, st)));
       }
     }
     {
       SoftmaxArgs a;
       memset(&a, 0, sizeof(a));
-      a.sc = c->sc.as<float>(); a.P = c->p_sp.as<char>(); a.ld = p.Sp_tot; a.rows = M; a.rows_per_b = L; a.nseg = CFD_NMEM;
+      a.sc = c->w->sc.as<float>(); a.P = c->w->p_sp.as<char>(); a.ld = p.Sp_tot; a.rows = M; a.rows_per_b = L; a.nseg = CFD_NMEM;
       for (int j = 0; j < CFD_NMEM; ++j) {
         a.off[j] = p.off[j]; a.S[j] = p.S[j]; a.Sp[j] = p.Sp[j]; a.mask[j] = p.mask[j]; a.has_mask[j] = p.has_mask[j]; a.map[j] = mapj[j]; a.att[j] = attj[j];
       }
@@ -1244,53 +1308,53 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       int n = 0;
       for (int j = 0; j < CFD_NMEM; ++j) {
         if (j == skip_j) continue;
-        a.X[n] = c->vt_all[j].as<char>() + (size_t)l * p.U[j] * CFD_D * p.Sp[j] * 4; a.ldx[n] = (long long)p.Sp[j] * 4;
+        a.X[n] = c->w->vt_all[j].as<char>() + (size_t)l * p.U[j] * CFD_D * p.Sp[j] * 4; a.ldx[n] = (long long)p.Sp[j] * 4;
         a.xbs[n] = (long long)CFD_D * p.Sp[j] * 4; a.xmap[n] = mapj[j];
         a.kt[n] = p.Sp[j] / 32; a.yk0[n] = p.off[j] / 32;
         a.I[n] = CFD_D; a.Iclamp[n] = CFD_D;
         ++n;
       }
       a.nslot = n; a.brow = brow;
-      a.Y = c->p_sp.as<char>(); a.ldy = (long long)p.Sp_tot * 4; a.ybs = (long long)L * p.Sp_tot * 4; a.J = L; a.Jclamp = L;
-      EpiResid e{c->x.as<float>(), (long long)L * CFD_D, w.cross_bias.as<float>()};
+      a.Y = c->w->p_sp.as<char>(); a.ldy = (long long)p.Sp_tot * 4; a.ybs = (long long)L * p.Sp_tot * 4; a.J = L; a.Jclamp = L;
+      EpiResid e{c->w->x.as<float>(), (long long)L * CFD_D, w.cross_bias.as<float>()};
       return run_gemm<MODE_SEGK>(c, CFD_PROF_GEMM_ATTN, a, e, nb, 1, st);
     };
     if (!runs) {
       CHK(pv_segk(-1, nullptr, Be));
     } else {
-      CHK(pv_segk(-1, c->short_rows.as<int>(), p.nshort));   // short rows: all segments
-      CHK(pv_segk(p.jbig, c->long_rows.as<int>(), p.nlong));   // long rows: short segments first ...
+      CHK(pv_segk(-1, c->w->short_rows.as<int>(), p.nshort));   // short rows: all segments
+      CHK(pv_segk(p.jbig, c->w->long_rows.as<int>(), p.nlong));   // long rows: short segments first ...
       const int j = p.jbig;
       for (int r = 0; r < p.nruns; ++r) {   // ... then the shared audio memory, run by run (disjoint rows)
         GemmArgs a = gemm_args();
-        a.X[0] = c->vt_all[j].as<char>() + ((size_t)l * p.U[j] + p.run_u[r]) * CFD_D * p.Sp[j] * 4; a.ldx[0] = (long long)p.Sp[j] * 4;
+        a.X[0] = c->w->vt_all[j].as<char>() + ((size_t)l * p.U[j] + p.run_u[r]) * CFD_D * p.Sp[j] * 4; a.ldx[0] = (long long)p.Sp[j] * 4;
         a.I[0] = CFD_D; a.Iclamp[0] = CFD_D; a.kt[0] = p.Sp[j] / 32;
-        a.Y = c->p_sp.as<char>() + (size_t)p.run_row0[r] * L * p.Sp_tot * 4 + (size_t)(p.off[j] / 32) * 128;
+        a.Y = c->w->p_sp.as<char>() + (size_t)p.run_row0[r] * L * p.Sp_tot * 4 + (size_t)(p.off[j] / 32) * 128;
         a.ldy = (long long)p.Sp_tot * 4; a.J = p.run_len[r] * L; a.Jclamp = a.J;
-        EpiResid e{c->x.as<float>() + (size_t)p.run_row0[r] * L * CFD_D, 0, nullptr};
+        EpiResid e{c->w->x.as<float>() + (size_t)p.run_row0[r] * L * CFD_D, 0, nullptr};
         CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_ATTN, a, e, 1, 1, st)));
       }
     }
     }
     if (c->stop_stage == 4 + 4 * l) return CFD_OK;
     // ---- f. time block 2                                                        (:655)
-    CHK(ln(w.tb2g, w.tb2b, 1, 2 * l + 1, c->h_sp.as<char>(), M));
+    CHK(ln(w.tb2g, w.tb2b, 1, 2 * l + 1, c->w->h_sp.as<char>(), M));
     // time block 2's projection + residual, then norm3                           (:655, :659)
-    CHK(token_gemm_resid_ln(w.wtb2_sp, CFD_D, c->h_sp.as<char>(), w.btb2, M, w.ln3g, w.ln3b, 0, 0));
+    CHK(token_gemm_resid_ln(w.wtb2_sp, CFD_D, c->w->h_sp.as<char>(), w.btb2, M, w.ln3g, w.ln3b, 0, 0));
     // ---- g. FFN                                                                 (:659-661)
     {
       GemmArgs a = gemm_args();
       a.X[0] = w.w1_sp.as<char>(); a.ldx[0] = ROWB; a.I[0] = CFD_FF; a.Iclamp[0] = CFD_FF; a.kt[0] = CFD_D / 32;
-      a.Y = c->h_sp.as<char>(); a.ldy = ROWB; a.J = (int)M; a.Jclamp = (int)M;
-      EpiSplit e{c->u_sp.as<char>(), (long long)CFD_FF * 4, 0, 0, w.b1, 1, 0};
+      a.Y = c->w->h_sp.as<char>(); a.ldy = ROWB; a.J = (int)M; a.Jclamp = (int)M;
+      EpiSplit e{c->w->u_sp.as<char>(), (long long)CFD_FF * 4, 0, 0, w.b1, 1, 0};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
     }
     // second FFN product + residual, then the next layer's norm1 (or the decoder's final norm)   (:661, :568; :238-239)
     {
       const float* ng = l + 1 < nl ? c->lw[l + 1].ln1g : rawp(c, "decoder.norm.weight");
       const float* nb = l + 1 < nl ? c->lw[l + 1].ln1b : rawp(c, "decoder.norm.bias");
-      if (c->stop_stage == 5 + 4 * l) return token_gemm_resid(w.w2_sp, CFD_FF, c->u_sp.as<char>(), w.b2, M);
-      CHK(token_gemm_resid_ln(w.w2_sp, CFD_FF, c->u_sp.as<char>(), w.b2, M, ng, nb, 0, 0));
+      if (c->stop_stage == 5 + 4 * l) return token_gemm_resid(w.w2_sp, CFD_FF, c->w->u_sp.as<char>(), w.b2, M);
+      CHK(token_gemm_resid_ln(w.w2_sp, CFD_FF, c->w->u_sp.as<char>(), w.b2, M, ng, nb, 0, 0));
       h_ready = true;
     }
   }
@@ -1298,7 +1362,7 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
   {
     GemmArgs a = gemm_args();
     a.X[0] = c->wp_sp.as<char>(); a.ldx[0] = ROWB; a.I[0] = CFD_LAT; a.Iclamp[0] = CFD_LAT; a.kt[0] = CFD_D / 32;
-    a.Y = c->h_sp.as<char>(); a.ldy = ROWB; a.J = (int)M; a.Jclamp = (int)M;
+    a.Y = c->w->h_sp.as<char>(); a.ldy = ROWB; a.J = (int)M; a.Jclamp = (int)M;
     EpiF32 e;
     memset(&e, 0, sizeof(e));
     e.out = eps_out; e.ldo = CFD_LAT; e.bias = rawp(c, "latent_proj.bias");
@@ -1318,24 +1382,24 @@ extern "C" int cfd_forward(cfd_handle c, const float* sample, int Be, int L, con
   const int tmode = (n_t == 1) ? 0 : 1;
   CHK(setup_problem(c, Be, L, mem, att, tmode, n_t));
   // tmode 0 reads table row d_step[0] which must be 0 outside a sampling run
-  HIPCHK(hipMemsetAsync(c->d_step.p, 0, 16, st));
+  HIPCHK(hipMemsetAsync(c->w->d_step.p, 0, 16, st));
   CHK(build_time_tables(c, timesteps, n_t, st));
   {
     bool want_att = false;
     for (int j = 0; j < CFD_NMEM; ++j) want_att = want_att || (att && att[j]);
     CHK(prepare_static_memside(c, st, 0, want_att));
   }
-  const long long n = c->pb.M * (CFD_LAT / 8);
-  LAUNCH(CFD_PROF_OTHER, to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), st, sample, c->sample_sp.as<char>(), c->pb.M,
+  const long long n = c->w->pb.M * (CFD_LAT / 8);
+  LAUNCH(CFD_PROF_OTHER, to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), st, sample, c->w->sample_sp.as<char>(), c->w->pb.M,
          CFD_LAT, (long long)CFD_LAT, (long long)CFD_LAT * 4);
   CHK(enqueue_denoise(c, st));
-  HIPCHK(hipMemcpyAsync(out, c->eps.p, (size_t)c->pb.M * CFD_LAT * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(out, c->w->eps.p, (size_t)c->w->pb.M * CFD_LAT * 4, hipMemcpyDeviceToDevice, st));
   return CFD_OK;
 }
 
 extern "C" int cfd_profile_forward(cfd_handle c, float ms[CFD_PROF_NCLASS], int launches[CFD_PROF_NCLASS]) {
   if (!c || !ms || !launches) return fail(CFD_E_ARG, "null argument");
-  if (c->pb.Be == 0) return fail(CFD_E_STATE, "no problem configured (call cfd_forward or cfd_sample_begin first)");
+  if (c->w->pb.Be == 0) return fail(CFD_E_STATE, "no problem configured (call cfd_forward or cfd_sample_begin first)");
   HIPCHK(hipSetDevice(c->cfg.device));
   if (c->run_open && c->run_pos >= c->run_iters)
     return fail(CFD_E_STATE, "sampling run is complete; profile before the last iteration");
@@ -1387,18 +1451,18 @@ static void ddim_coef(const float* ac, int T, int n_inf, int t, float eta, int s
 static int enqueue_loop_iteration(Ctx* c, hipStream_t st) {
   const cfd_sample_args& s = c->sargs;
   const long long n8 = (long long)s.B * s.L * (CFD_LAT / 8);
-  BeginArgs ba{c->latents.as<float>(), c->sample_sp.as<char>(), s.B, s.L, s.G, s.preseq, c->inoise.as<float>(), s.preseq_len,
-               c->coef.as<StepCoef>(), c->d_step.as<int>()};
+  BeginArgs ba{c->latents.as<float>(), c->w->sample_sp.as<char>(), s.B, s.L, s.G, s.preseq, c->inoise.as<float>(), s.preseq_len,
+               c->coef.as<StepCoef>(), c->w->d_step.as<int>()};
   LAUNCH(CFD_PROF_OTHER, begin_step_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), st, ba);
   CHK(enqueue_denoise(c, st));
   CfgStepArgs ca;
   memset(&ca, 0, sizeof(ca));
-  ca.eps = c->eps.as<float>(); ca.latents = c->latents.as<float>(); ca.B = s.B; ca.L = s.L; ca.G = s.G;
+  ca.eps = c->w->eps.as<float>(); ca.latents = c->latents.as<float>(); ca.B = s.B; ca.L = s.L; ca.G = s.G;
   for (int k = 0; k < 8; ++k) { ca.w[k] = s.guidance_weight[k]; ca.pos[k] = c->chunk_pos[k]; }
-  ca.kind = s.scheduler; ca.clip = s.clip_sample; ca.coef = c->coef.as<StepCoef>(); ca.d_step = c->d_step.as<int>();
+  ca.kind = s.scheduler; ca.clip = s.clip_sample; ca.coef = c->coef.as<StepCoef>(); ca.d_step = c->w->d_step.as<int>();
   ca.noise = s.step_noise; ca.seed = s.seed; ca.utt0 = s.first_utterance;
   const long long n4 = (long long)s.B * s.L * CFD_LAT / 4;
-  ca.advance = c->d_step.as<int>();   // the last workgroup of cfg_step_kernel advances the loop index
+  ca.advance = c->w->d_step.as<int>();   // the last workgroup of cfg_step_kernel advances the loop index
   LAUNCH(CFD_PROF_OTHER, cfg_step_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), st, ca);
   return CFD_OK;
 }
@@ -1475,7 +1539,7 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
     }
   }
   CHK(setup_problem(c, Be, s.L, mem_in, nullptr, 0, N));
-  if (c->share0 && c->sargs.G > 1) c->pb.share_B = s.B;   // begin_step_kernel writes G identical copies of the B rows
+  if (c->share0 && c->sargs.G > 1) c->w->pb.share_B = s.B;   // begin_step_kernel writes G identical copies of the B rows
   // timesteps: (arange(N) * (T // N)).round()[::-1] (+ steps_offset for DDIM)
   std::vector<int32_t> ts(N);
   std::vector<StepCoef> coef(N);
@@ -1489,7 +1553,7 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
   }
   CHK(c->coef.ensure((size_t)N * sizeof(StepCoef)));
   HIPCHK(hipMemcpyAsync(c->coef.p, coef.data(), (size_t)N * sizeof(StepCoef), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemsetAsync(c->d_step.p, 0, 16, st));
+  HIPCHK(hipMemsetAsync(c->w->d_step.p, 0, 16, st));
   CHK(build_time_tables(c, ts.data(), N, st));
   CHK(prepare_static_memside(c, st, s.dynamic_memory_mask, false));
   HIPCHK(hipStreamSynchronize(st));  // ts / coef host vectors go out of scope
@@ -1524,7 +1588,7 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
     if (r != CFD_OK) return r;
     HIPCHK(hipMemcpyAsync(c->latents.p, save_lat.p, lat_bytes, hipMemcpyDeviceToDevice, st));
     if (s.preseq) HIPCHK(hipMemcpyAsync(c->inoise.p, save_in.p, c->inoise.bytes, hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemsetAsync(c->d_step.p, 0, 16, st));
+    HIPCHK(hipMemsetAsync(c->w->d_step.p, 0, 16, st));
     HIPCHK(hipStreamSynchronize(st));
     save_lat.release();
     save_in.release();
@@ -1677,6 +1741,8 @@ extern "C" int cfd_zero_rows(cfd_handle c, float* x, const uint8_t* keep, long l
 
 // ---- float32 pieces of the WEG gradient path (grad.hpp) and the whole evaluation (weg_eval.hpp) --------------------------
 #include "weg_eval.hpp"
+#include "rowtile_bwd.hpp"
+#include "weg_rt.hpp"
 
 extern "C" int cfd_gemm_f32(cfd_handle c, int M, int N, int K, int nb1, int nb2, const cfd_mat* A, const cfd_mat* B, const cfd_mat* Cm,
                             const float* bias, float alpha, int accumulate, void* stream) {
@@ -1804,21 +1870,42 @@ extern "C" int cfd_weg_eval(cfd_handle c, const cfd_weg_args* a, float* losses, 
     sig.push_back((long long)(size_t)a->mem[j].data);
   }
   weg::Ctx x{c, st, true, reinterpret_cast<char*>(256), 0, B, L, D, D, CFD_OK, std::string(), 0};
-  weg::run(x, wa);                                   // sizing pass
-  if (x.err) return fail(x.err, "missing tensor '%s' (state-dict key denoiser.%s)", x.missing.c_str(), x.missing.c_str());
-  if (x.off > c->weg_ws.bytes) HIPCHK(hipStreamSynchronize(st));
-  CHK(c->weg_ws.ensure(x.off));
-  sig.push_back((long long)(size_t)c->weg_ws.p);
-  sig.push_back((long long)x.off);
+  // small problems (the product shape) run on the row-tile kernels, everything else on the float32 launch sequence of weg_eval.hpp
+  const bool use_rt = wegrt::eligible(c, a);
+  const void* arena = nullptr;
+  if (use_rt) {
+    CHK(wegrt::prepare(c, a, st));
+    arena = c->weg_rt_ws.p;
+    sig.push_back((long long)(size_t)arena);
+    sig.push_back(-1);
+    c->weg_t_host = a->timestep;                     // in front of the launch sequence, outside any captured graph
+    HIPCHK(hipMemcpyAsync(c->wk[1].trows.p, &c->weg_t_host, 4, hipMemcpyHostToDevice, st));
+  } else {
+    weg::run(x, wa);                                 // sizing pass
+    if (x.err) return fail(x.err, "missing tensor '%s' (state-dict key denoiser.%s)", x.missing.c_str(), x.missing.c_str());
+    if (x.off > c->weg_ws.bytes) HIPCHK(hipStreamSynchronize(st));
+    CHK(c->weg_ws.ensure(x.off));
+    arena = c->weg_ws.p;
+    sig.push_back((long long)(size_t)arena);
+    sig.push_back((long long)x.off);
+  }
   x.dry = false;
   x.base = c->weg_ws.as<char>();
   x.off = 0;
   x.launches = 0;
   x.reuse = a->reuse_memory_side != 0 && sig == c->weg_sig;
   c->weg_sig.clear();
+  const wegrt::EvalArgs ea{io + o_lat, c->weg_tok.as<int32_t>(), c->weg_tok.as<int32_t>() + B + 1, a->last, nt_max,
+                           {a->kernel3[0], a->kernel3[1], a->kernel3[2]}, io + o_loss, io + o_max, io + o_grad};
+  auto run_eval = [&]() -> int {                     // the evaluation's launches (this is what a graph captures)
+    if (!use_rt) { weg::run(x, wa); return CFD_OK; }
+    const int r = wegrt::enqueue(c, st, !x.reuse, ea);
+    x.launches = c->wrt.launches;
+    return r;
+  };
   // everything the launch sequence and its (by-value) kernel arguments depend on, the timestep excepted (its row is staged)
   std::vector<long long> key = {B, L, a->last, nt_max, c->weg_tok_version, (long long)(size_t)c->weg_tok.p, (long long)(size_t)io, (long long)n_io,
-                                (long long)(size_t)c->weg_ws.p, (long long)x.reuse};
+                                (long long)(size_t)arena, (long long)x.reuse, (long long)use_rt};
   for (int j = 0; j < CFD_NMEM; ++j) {
     key.push_back(a->mem[j].S);
     key.push_back((long long)(size_t)a->mem[j].data);
@@ -1837,15 +1924,16 @@ extern "C" int cfd_weg_eval(cfd_handle c, const cfd_weg_args* a, float* losses, 
     x.launches = c->weg_launches;
   } else if (c->weg_graph_on && wg.uses >= 1) {       // second use of this key: capture, instantiate, launch
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    weg::run(x, wa);
+    const int rr = run_eval();
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(st, &g);
+    if (rr != CFD_OK) { if (g) (void)hipGraphDestroy(g); return rr; }
     if (e != hipSuccess) return fail(CFD_E_HIP, "capturing the WEG evaluation failed: %s", hipGetErrorString(e));
     wg.graph = g;
     HIPCHK(hipGraphInstantiate(&wg.exec, wg.graph, nullptr, nullptr, 0));
     HIPCHK(hipGraphLaunch(wg.exec, st));
   } else {
-    weg::run(x, wa);
+    CHK(run_eval());
   }
   ++wg.uses;
   HIPCHK(hipGetLastError());
@@ -1874,10 +1962,10 @@ extern "C" int cfd_sample_inpaint(cfd_handle c) {
   const cfd_sample_args& s = c->sargs;
   if (!s.preseq || s.preseq_len < 1) return CFD_OK;
   HIPCHK(hipSetDevice(c->cfg.device));
-  BeginArgs ba{c->latents.as<float>(), c->sample_sp.as<char>(), s.B, s.L, s.G, s.preseq, c->inoise.as<float>(), s.preseq_len,
-               c->coef.as<StepCoef>(), c->d_step.as<int>()};
+  BeginArgs ba{c->latents.as<float>(), c->w->sample_sp.as<char>(), s.B, s.L, s.G, s.preseq, c->inoise.as<float>(), s.preseq_len,
+               c->coef.as<StepCoef>(), c->w->d_step.as<int>()};
   const long long n = (long long)s.B * s.preseq_len * CFD_LAT;
-  hipLaunchKernelGGL(inpaint_now_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->run_stream, ba, c->d_step.as<int>());
+  hipLaunchKernelGGL(inpaint_now_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->run_stream, ba, c->w->d_step.as<int>());
   HIPCHK(hipGetLastError());
   return CFD_OK;
 }
@@ -1903,13 +1991,13 @@ extern "C" int cfd_debug_read(cfd_handle c, const char* what, float* dst_dev, si
   if (!c || !what || !dst_dev) return fail(CFD_E_ARG, "null argument");
   HIPCHK(hipSetDevice(c->cfg.device));
   const DBuf* b = nullptr;
-  if (!strcmp(what, "x")) b = &c->x;
-  else if (!strcmp(what, "temb")) b = &c->temb_tab;
-  else if (!strcmp(what, "ss")) b = &c->ss_tab;
-  else if (!strcmp(what, "eps")) b = &c->eps;
-  else if (!strcmp(what, "sc")) b = &c->sc;
-  else if (!strcmp(what, "ssc")) b = &c->ssc;
-  else if (!strcmp(what, "xa_stamps")) b = &c->xa_stamps;
+  if (!strcmp(what, "x")) b = &c->w->x;
+  else if (!strcmp(what, "temb")) b = &c->w->temb_tab;
+  else if (!strcmp(what, "ss")) b = &c->w->ss_tab;
+  else if (!strcmp(what, "eps")) b = &c->w->eps;
+  else if (!strcmp(what, "sc")) b = &c->w->sc;
+  else if (!strcmp(what, "ssc")) b = &c->w->ssc;
+  else if (!strcmp(what, "xa_stamps")) b = &c->w->xa_stamps;
   else return fail(CFD_E_ARG, "unknown buffer '%s'", what);
   if (numel * 4 > b->bytes) return fail(CFD_E_ARG, "buffer '%s' holds %zu bytes, asked for %zu", what, b->bytes, numel * 4);
   HIPCHK(hipDeviceSynchronize());

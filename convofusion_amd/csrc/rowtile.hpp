@@ -411,7 +411,8 @@ __global__ void __launch_bounds__(256) rt_selfattn_kernel(const RtSelfArgs a) {
 //   sc[token][off_j + s] = rs_s (q . KA_s + q . (A b_t)) + cbk_s
 // ------------------------------------------------------------------------------------------------
 struct RtXArgs {
-  float* x;                     // fp32 [M][512]
+  const float* x;               // fp32 [M][512]: the residual stream in front of the cross-attention block
+  float* xo;                    // where x + block(x) goes (xo == x: in place)
   const float* ln_g;            // norm2
   const float* ln_b;
   const float* bias;            // folded cross-attention bias [512]
@@ -663,7 +664,7 @@ __global__ void __launch_bounds__(NT) rt_xpv_kernel(const RtXArgs a) {
   }
   float4 r = ep_r;
   r.x = (r.x + ep_b.x) + o[0]; r.y = (r.y + ep_b.y) + o[1]; r.z = (r.z + ep_b.z) + o[2]; r.w = (r.w + ep_b.w) + o[3];
-  *reinterpret_cast<float4*>(a.x + (tok0 + l15) * CFD_D + fcol) = r;
+  *reinterpret_cast<float4*>(a.xo + (tok0 + l15) * CFD_D + fcol) = r;
 }
 
 // ------------------------------------------------------------------------------------------------

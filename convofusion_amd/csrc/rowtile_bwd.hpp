@@ -1,0 +1,550 @@
+// Row-tile backward sweep of the word-excitation-guidance gradient (convofusion.py:437-496, word_excitation_guidance.py:11-81): the
+// reverse of rowtile.hpp's forward on the text-only guidance chunk (one token tile per batch row at the product shape), in
+// the SAME folded formulation, so that the five cross-attentions cost two products per layer instead of five chains of four.
+//
+// Every backward product contracts over a weight's OUTPUT axis, i.e. reads W[k][n] with n contiguous -- the transpose of what
+// the split-pair kernels want -- and gradients span many binades, so the products run on the float32 matrix core
+// (v_mfma_f32_16x16x4_f32: exact float32 FMA chains, one scalar operand per lane and MFMA): lane (n, k) loads W[k][n] as it
+// lies, no transposed weight copies and no operand scaling.  The folded keys / values are read back from their split-pair form
+// (hi + lo is exact in float32).  Kernel shape as in rowtile.hpp: a workgroup = 16 tokens x 16 outputs, the K axis split over
+// its 8 waves, all operand loads issued up front, an LDS reduction over the waves; the row-complete steps of the backward
+// (LayerNorm backward, the TimeBlock's SiLU / modulation backward, the softmax backward) are PROLOGUES of the product that
+// consumes them, computed by every workgroup of the tile; workgroup 0 also writes the updated running gradient.
+//
+// Per layer (top down), g = gradient at the layer's output rows:
+//   B1  du = (g + LN1'(next layer's dy1)) W2         ; dh = du * gelu'(pre)            [16 x 1024]
+//   B2  dy3 = dh W1                                                                    [16 x 512]
+//   B3  dz2 = (g + LN3'(dy3)) Wtb2                   (writes g_a)
+//   B4  dP = ((g_a + TB2'(dz2)) (VA + VV b)^T) rs + d_att    (writes g_b; one workgroup per 16 keys)
+//   B5  dy2 = (softmax'(dP) rs) KA + (sum dS') (A b)                                   [16 x 512]
+//   B6  dz1 = (g_b + LN2'(dy2)) Wtb1                 (writes g_c)
+//   B7  dO = (g_c + TB1'(dz1)) Wo                    (writes g_d)
+//   B8  self-attention core backward per (row, head): dq | dk | dv                     [16 x 1536]
+//   B9  dy1 = [dq | dk | dv] Wqkv                                                      [16 x 512]
+// and at the bottom  grad = (g_d + LN1'(dy1)) We  [16 x 128].
+#pragma once
+#include "rowtile.hpp"
+
+#define RT_MFMA_F32 __builtin_amdgcn_mfma_f32_16x16x4f32
+
+__device__ __forceinline__ float rt_sp_f32(const char* p) {   // one element of an SP row: p points at its hi half
+  return (float)*reinterpret_cast<const sp_t*>(p) + (float)*reinterpret_cast<const sp_t*>(p + 64);
+}
+__device__ __forceinline__ float rt_gelu_grad(float y) {      // d/dy of the erf-form GELU (the formula of grad.hpp's EW_GELU_BWD)
+  return 0.5f * (1.0f + erff(y * 0.70710678118654752440f)) + y * expf(-0.5f * y * y) * 0.39894228040143267794f;
+}
+
+enum { RT_BPRO_ROWS = 0, RT_BPRO_LN = 1, RT_BPRO_TB = 2 };
+enum { RT_BEPI_F32 = 0, RT_BEPI_GELU = 1 };
+
+struct RtBwdArgs {
+  int L, tpr;
+  int K;                 // contraction length: 512 (LN / TB prologues), 1024, 1536
+  // prologue inputs
+  const float* a;        // ROWS: the operand rows fp32 [M][K];  LN / TB: dy, the gradient at the LayerNorm's / the TimeBlock linear's output [M][512]
+  const float* g;        // LN / TB: running gradient rows [M][512] (null: zero)
+  const float* x;        // LN / TB: the LayerNorm's input rows [M][512]
+  const float* gamma;    // LayerNorm weight
+  const float* beta;     // TB: LayerNorm bias
+  const float* ss;       // TB: (1 + scale | shift), row t at ss + t * ss_tstride
+  long long ss_tstride;
+  const int* d_step;
+  float* gout;           // LN / TB: the updated running gradient, written by workgroup x == 0
+  // weights: fp32 [K][ldw], outputs n contiguous
+  const float* w;
+  long long ldw;
+  // epilogue
+  float* out;            // fp32 [M][ldo]
+  long long ldo;
+  const float* pre;      // GELU: pre-activations [M][ldo]
+};
+
+// LayerNorm backward (+ optional TimeBlock SiLU / modulation backward in front of it) of one prologue row, 16 columns per lane
+// (c = 128 i + 4 plr .. + 3), 32 lanes per row.  In: dy (gradient at the LayerNorm output -- TB: at the linear's input side, i.e.
+// d/d SiLU output), x, g.  Out: gn = g + d/dx.  Same formulas and reduction structure as layernorm_bwd_f32_kernel (grad.hpp).
+template <bool TB>
+__device__ __forceinline__ void rt_ln_bwd_row(float (&dy)[4][4], float (&xv)[4][4], const float (&gv)[4][4], const float (&gam)[4][4],
+                                              const float (&bet)[4][4], const float (&s1)[4][4], const float (&sh)[4][4], float (&gn)[4][4]) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += xv[i][e];
+  const float mean = rt_row_sum<32>(s) * (1.0f / CFD_D);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { xv[i][e] -= mean; ss += xv[i][e] * xv[i][e]; }
+  const float rstd = 1.0f / sqrtf(rt_row_sum<32>(ss) * (1.0f / CFD_D) + 1e-5f);
+  float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      xv[i][e] *= rstd;                                   // x hat
+      float d = dy[i][e];
+      if constexpr (TB) {                                 // through SiLU and the modulation: h = LN(x) (1 + scale) + shift
+        const float h = (xv[i][e] * gam[i][e] + bet[i][e]) * s1[i][e] + sh[i][e];
+        const float sg = 1.0f / (1.0f + expf(-h));
+        d *= (sg * (1.0f + h * (1.0f - sg))) * s1[i][e];
+      }
+      d *= gam[i][e];
+      dy[i][e] = d;                                       // dh
+      a1 += d;
+      a2 = fmaf(d, xv[i][e], a2);
+    }
+  const float m1 = rt_row_sum<32>(a1) * (1.0f / CFD_D), m2 = rt_row_sum<32>(a2) * (1.0f / CFD_D);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gn[i][e] = gv[i][e] + rstd * (dy[i][e] - m1 - xv[i][e] * m2);
+}
+
+// loads of the LN / TB prologue for this lane's 16 columns of row `row` (global row index)
+struct RtBwdRow {
+  float dy[4][4], xv[4][4], gv[4][4], gam[4][4], bet[4][4], s1[4][4], sh[4][4];
+};
+template <bool TB>
+__device__ __forceinline__ void rt_bwd_row_load(RtBwdRow& r, const float* a, const float* g, const float* x, const float* gamma, const float* beta,
+                                                const float* sc, long long row, int plr) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = 128 * i + 4 * plr;
+    const float4 d = *reinterpret_cast<const float4*>(a + row * CFD_D + c);
+    const float4 xx = *reinterpret_cast<const float4*>(x + row * CFD_D + c);
+    const float4 gg = g ? *reinterpret_cast<const float4*>(g + row * CFD_D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+    r.dy[i][0] = d.x; r.dy[i][1] = d.y; r.dy[i][2] = d.z; r.dy[i][3] = d.w;
+    r.xv[i][0] = xx.x; r.xv[i][1] = xx.y; r.xv[i][2] = xx.z; r.xv[i][3] = xx.w;
+    r.gv[i][0] = gg.x; r.gv[i][1] = gg.y; r.gv[i][2] = gg.z; r.gv[i][3] = gg.w;
+    r.gam[i][0] = ga.x; r.gam[i][1] = ga.y; r.gam[i][2] = ga.z; r.gam[i][3] = ga.w;
+    if constexpr (TB) {
+      const float4 be = *reinterpret_cast<const float4*>(beta + c);
+      const float4 a1 = *reinterpret_cast<const float4*>(sc + c), a2 = *reinterpret_cast<const float4*>(sc + CFD_D + c);
+      r.bet[i][0] = be.x; r.bet[i][1] = be.y; r.bet[i][2] = be.z; r.bet[i][3] = be.w;
+      r.s1[i][0] = a1.x; r.s1[i][1] = a1.y; r.s1[i][2] = a1.z; r.s1[i][3] = a1.w;
+      r.sh[i][0] = a2.x; r.sh[i][1] = a2.y; r.sh[i][2] = a2.z; r.sh[i][3] = a2.w;
+    }
+  }
+}
+
+// float32 operand image of 16 rows in LDS: row stride K + 2 words (conflict-free ds_read_b32 of column k by 16 rows x 2 k's)
+#define RT_BSTRIDE(K) ((K) + 2)
+
+// sum over the waves (rt_reduce of rowtile.hpp with one block)
+template <int NW>
+__device__ __forceinline__ f32x4 rt_reduce1(char* red, int wid, int lane, f32x4 acc) {
+  const f32x4 part[1] = {acc};
+  return rt_reduce<NW, 1>(red, wid, lane, part);
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[16 tokens][16 outputs] = A[16][K] . W[K][n0 .. n0 + 15]      (B1, B2, B3, B6, B7, B9, the embedding's backward)
+// grid (N / 16, tiles), 512 threads; dynamic LDS = 16 * (K + 2) * 4 + 8 KB
+// ------------------------------------------------------------------------------------------------
+template <int PRO, int EPI, int MAXSTEP>
+__global__ void __launch_bounds__(512) rt_bwd_gemm_kernel(const RtBwdArgs a) {
+  constexpr int NW = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* img = reinterpret_cast<float*>(smem);
+  const int K = a.K, RS = RT_BSTRIDE(K);
+  char* red = smem + (size_t)16 * RS * 4;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int tile = blockIdx.y, n0 = blockIdx.x * 16;
+  const int b = tile / a.tpr, q0 = (tile - b * a.tpr) * 16, nq = min(16, a.L - q0);
+  const long long tok0 = (long long)b * a.L + q0;
+  const int pr = threadIdx.x >> 5, plr = threadIdx.x & 31;
+  const long long prow = tok0 + min(pr, nq - 1);
+
+  // ---- loads: prologue rows, then this wave's weight column ----------------------------------------------
+  RtBwdRow r;
+  constexpr int NR = PRO == RT_BPRO_ROWS ? MAXSTEP / 4 : 1;     // ROWS: K / 128 float4 per lane (12 for K = 1536)
+  float rows[NR][4];
+  if constexpr (PRO == RT_BPRO_ROWS) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+      if (128 * i < K) {
+        const float4 d = *reinterpret_cast<const float4*>(a.a + prow * K + 128 * i + 4 * plr);
+        rows[i][0] = d.x; rows[i][1] = d.y; rows[i][2] = d.z; rows[i][3] = d.w;
+      }
+  } else {
+    const float* sc = nullptr;
+    if constexpr (PRO == RT_BPRO_TB) sc = a.ss + (long long)(*a.d_step) * a.ss_tstride;
+    rt_bwd_row_load<PRO == RT_BPRO_TB>(r, a.a, a.g, a.x, a.gamma, a.beta, sc, prow, plr);
+  }
+  const int nstep = K / (4 * NW);                               // MFMAs of this wave: k = wid * (K / 8) + 4 i + q4
+  const int kbase = wid * (K / NW) + q4;
+  float wv[MAXSTEP];
+  {
+    const float* wp = a.w + (long long)kbase * a.ldw + n0 + l15;
+#pragma unroll
+    for (int i = 0; i < MAXSTEP; ++i)
+      if (i < nstep) wv[i] = wp[(long long)(4 * i) * a.ldw];
+  }
+  float4 ep_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (EPI == RT_BEPI_GELU) {
+    if (wid == 0) ep_pre = *reinterpret_cast<const float4*>(a.pre + (tok0 + min(l15, nq - 1)) * a.ldo + n0 + 4 * q4);
+  }
+
+  // ---- prologue -> float32 image ---------------------------------------------------------------------------
+  if constexpr (PRO == RT_BPRO_ROWS) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+      if (128 * i < K) {
+        *reinterpret_cast<float2*>(img + pr * RS + 128 * i + 4 * plr) = make_float2(rows[i][0], rows[i][1]);
+        *reinterpret_cast<float2*>(img + pr * RS + 128 * i + 4 * plr + 2) = make_float2(rows[i][2], rows[i][3]);
+      }
+  } else {
+    float gn[4][4];
+    rt_ln_bwd_row<PRO == RT_BPRO_TB>(r.dy, r.xv, r.gv, r.gam, r.bet, r.s1, r.sh, gn);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float2*>(img + pr * RS + 128 * i + 4 * plr) = make_float2(gn[i][0], gn[i][1]);
+      *reinterpret_cast<float2*>(img + pr * RS + 128 * i + 4 * plr + 2) = make_float2(gn[i][2], gn[i][3]);
+      if (blockIdx.x == 0 && pr < nq) *reinterpret_cast<float4*>(a.gout + (tok0 + pr) * CFD_D + 128 * i + 4 * plr) = make_float4(gn[i][0], gn[i][1], gn[i][2], gn[i][3]);
+    }
+  }
+  __syncthreads();
+
+  // ---- product ---------------------------------------------------------------------------------------------------
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* ap = img + l15 * RS + kbase;
+#pragma unroll
+  for (int i = 0; i < MAXSTEP; ++i)
+    if (i < nstep) acc = RT_MFMA_F32(wv[i], ap[4 * i], acc, 0, 0, 0);   // D[n][token]
+  acc = rt_reduce1<NW>(red, wid, lane, acc);
+  if (wid != 0 || l15 >= nq) return;
+  float4 o = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  if constexpr (EPI == RT_BEPI_GELU) {
+    o.x *= rt_gelu_grad(ep_pre.x); o.y *= rt_gelu_grad(ep_pre.y); o.z *= rt_gelu_grad(ep_pre.z); o.w *= rt_gelu_grad(ep_pre.w);
+  }
+  *reinterpret_cast<float4*>(a.out + (tok0 + l15) * a.ldo + n0 + 4 * q4) = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// B4: gradient at the cross-attention probabilities of 16 keys of one memory
+//   dP[token][s] = (gn . (VA_s + VV b_t)) rs_s + d_att[token][s]  (tlsn only),   gn = g + TB2'(dz)  (written by workgroup 0)
+// ------------------------------------------------------------------------------------------------
+struct RtXBwdArgs {
+  int L, tpr, nl, layer;
+  const int* d_step;
+  // TB prologue (B4)
+  const float* dz;
+  const float* g;
+  const float* x;
+  const float* gamma;
+  const float* beta;
+  const float* ss;
+  long long ss_tstride;
+  float* gout;
+  // memories
+  const char* K[CFD_NMEM];      // this layer's folded keys: SP [U_j * Sp_j][512]
+  const char* VT[CFD_NMEM];     // this layer's folded values^T: SP [U_j][512][Sp_j]
+  const float* kb[CFD_NMEM];    // A_l b_t
+  const float* vb[CFD_NMEM];    // VV_l b_t
+  long long kb_stride[CFD_NMEM], vb_stride[CFD_NMEM];
+  const int* map[CFD_NMEM];
+  int S[CFD_NMEM], Sp[CFD_NMEM], off[CFD_NMEM];
+  int blk0[CFD_NMEM + 1];
+  int Sp_tot;
+  const float* sc;              // this layer's scores [M][Sp_tot] (saved by the forward)
+  const float* rsp;             // per-key scales [M][Sp_tot]
+  const float* d_att;           // gradient at the tlsn probabilities [B][nl][L][S_2]
+  float* dP;                    // [M][Sp_tot]
+  int dp_from_datt;             // B5 of the top layer: dP is d_att alone (no B4 ran)
+  float* dy;                    // B5 output [M][512]
+};
+
+__global__ void __launch_bounds__(512) rt_xbwd_dp_kernel(const RtXBwdArgs a) {
+  constexpr int NW = 8, K = CFD_D, RS = RT_BSTRIDE(CFD_D), NSTEP = K / (4 * NW);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* img = reinterpret_cast<float*>(smem);
+  char* red = smem + 16 * RS * 4;
+  float* dvb = reinterpret_cast<float*>(red + NW * 1024);
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int tile = blockIdx.y;
+  const int b = tile / a.tpr, q0 = (tile - b * a.tpr) * 16, nq = min(16, a.L - q0);
+  const long long tok0 = (long long)b * a.L + q0;
+  int j = 0;
+#pragma unroll
+  for (int q = 1; q < CFD_NMEM; ++q)
+    if ((int)blockIdx.x >= a.blk0[q]) j = q;
+  int blk_first = 0;
+#pragma unroll
+  for (int q = 1; q < CFD_NMEM; ++q)
+    if (j == q) blk_first = a.blk0[q];
+  const int s0 = ((int)blockIdx.x - blk_first) * 16;
+  const int t = *a.d_step;
+  const int u = rt_sel(a.map, j)[b];
+  const int Sp = rt_sel(a.Sp, j);
+  const int pr = threadIdx.x >> 5, plr = threadIdx.x & 31;
+  const long long prow = tok0 + min(pr, nq - 1);
+  RtBwdRow r;
+  rt_bwd_row_load<true>(r, a.dz, a.g, a.x, a.gamma, a.beta, a.ss + (long long)t * a.ss_tstride, prow, plr);
+  const float* vbp = rt_sel(a.vb, j) + (long long)t * rt_sel(a.vb_stride, j);
+  float vbv[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 q = *reinterpret_cast<const float4*>(vbp + 128 * i + 4 * plr);
+    vbv[i][0] = q.x; vbv[i][1] = q.y; vbv[i][2] = q.z; vbv[i][3] = q.w;
+  }
+  // first operand: VA[s0 + l15][f] for f = wid * 64 + 4 i + q4, read from V^T [f][Sp] (split pairs, keys contiguous)
+  const int kbase = wid * (K / NW) + q4;
+  float wv[NSTEP];
+  {
+    const int sl = s0 + l15;
+    const char* vp = rt_sel(a.VT, j) + ((size_t)u * CFD_D + kbase) * ((size_t)Sp * 4) + (size_t)(sl >> 5) * 128 + (sl & 31) * 2;
+#pragma unroll
+    for (int i = 0; i < NSTEP; ++i) wv[i] = rt_sp_f32(vp + (size_t)(4 * i) * ((size_t)Sp * 4));
+  }
+  float4 e_rs = make_float4(0.f, 0.f, 0.f, 0.f), e_da = e_rs;
+  const long long so = (tok0 + min(l15, nq - 1)) * a.Sp_tot + rt_sel(a.off, j) + s0 + 4 * q4;
+  if (wid == 0) {
+    e_rs = *reinterpret_cast<const float4*>(a.rsp + so);
+    if (j == 2) {
+      const int S = a.S[2];
+      const float* dp = a.d_att + (((long long)b * a.nl + a.layer) * a.L + q0 + min(l15, nq - 1)) * S;
+      const int k0 = s0 + 4 * q4;
+      e_da.x = k0 < S ? dp[k0] : 0.f; e_da.y = k0 + 1 < S ? dp[k0 + 1] : 0.f; e_da.z = k0 + 2 < S ? dp[k0 + 2] : 0.f; e_da.w = k0 + 3 < S ? dp[k0 + 3] : 0.f;
+    }
+  }
+  float gn[4][4];
+  rt_ln_bwd_row<true>(r.dy, r.xv, r.gv, r.gam, r.bet, r.s1, r.sh, gn);
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *reinterpret_cast<float2*>(img + pr * RS + 128 * i + 4 * plr) = make_float2(gn[i][0], gn[i][1]);
+    *reinterpret_cast<float2*>(img + pr * RS + 128 * i + 4 * plr + 2) = make_float2(gn[i][2], gn[i][3]);
+    if (blockIdx.x == 0 && pr < nq) *reinterpret_cast<float4*>(a.gout + (tok0 + pr) * CFD_D + 128 * i + 4 * plr) = make_float4(gn[i][0], gn[i][1], gn[i][2], gn[i][3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dot = fmaf(gn[i][e], vbv[i][e], dot);
+  }
+  dot = rt_row_sum<32>(dot);
+  if (plr == 0) dvb[pr] = dot;
+  __syncthreads();
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* ap = img + l15 * RS + kbase;
+#pragma unroll
+  for (int i = 0; i < NSTEP; ++i) acc = RT_MFMA_F32(wv[i], ap[4 * i], acc, 0, 0, 0);   // D[key][token]
+  acc = rt_reduce1<NW>(red, wid, lane, acc);
+  if (wid != 0 || l15 >= nq) return;
+  const float d = dvb[l15];
+  *reinterpret_cast<float4*>(a.dP + so) = make_float4((acc[0] + d) * e_rs.x + e_da.x, (acc[1] + d) * e_rs.y + e_da.y, (acc[2] + d) * e_rs.z + e_da.z,
+                                                      (acc[3] + d) * e_rs.w + e_da.w);
+}
+
+// ------------------------------------------------------------------------------------------------
+// B5: softmax backward per memory, dS' = dS rs, and the gradient at the LayerNorm2 output
+//   dy[token][f] = sum_j ( sum_s dS'_s KA_j[s][f] + (sum_s dS'_s) (A b_t)_j[f] )
+// grid (32, tiles); dynamic LDS = 16 * (Sp_tot + 2) * 4 + 8 KB + Sp_tot * 8 + 16 * 8 * 4
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) rt_xbwd_dy_kernel(const RtXBwdArgs a) {
+  constexpr int NW = 8, LPR = 32;
+  constexpr int MAXC = RT_MAX_KEYS / 8 / LPR;                    // 8-key chunks per lane
+  constexpr int MAXSTEP = RT_MAX_KEYS / (4 * NW);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int KS = a.Sp_tot, RS = RT_BSTRIDE(KS);
+  float* img = reinterpret_cast<float*>(smem);
+  char* red = smem + (size_t)16 * RS * 4;
+  const char** krow = reinterpret_cast<const char**>(red + NW * 1024);   // [Sp_tot]: the key's row of its memory's folded keys
+  float* dcq = reinterpret_cast<float*>(red + NW * 1024 + (size_t)KS * 8);   // [16 tokens][8]
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int tile = blockIdx.y, f0 = blockIdx.x * 16;
+  const int b = tile / a.tpr, q0 = (tile - b * a.tpr) * 16, nq = min(16, a.L - q0);
+  const long long tok0 = (long long)b * a.L + q0;
+  const int t = *a.d_step;
+  // key -> row pointer table
+  for (int s = threadIdx.x; s < KS; s += 512) {
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < CFD_NMEM; ++q)
+      if (s >= a.off[q]) j = q;
+    const int sl = s - rt_sel(a.off, j);
+    krow[s] = rt_sel(a.K, j) + ((size_t)rt_sel(a.map, j)[b] * rt_sel(a.Sp, j) + sl) * (CFD_D * 4);
+  }
+  // prologue loads: scores, dP (or d_att), rs of this lane's chunks
+  const int pr = threadIdx.x / LPR, plr = threadIdx.x % LPR;
+  const long long prow = tok0 + min(pr, nq - 1);
+  float s[MAXC][8], dp[MAXC][8], rsv[MAXC][8];
+  int cj[MAXC];
+#pragma unroll
+  for (int n = 0; n < MAXC; ++n) {
+    const int c0 = (plr + LPR * n) * 8;
+    cj[n] = -1;
+    if (c0 < KS) {
+      int j = 0;
+#pragma unroll
+      for (int q = 1; q < CFD_NMEM; ++q)
+        if (c0 >= a.off[q]) j = q;
+      cj[n] = j;
+      const float* sp = a.sc + prow * KS + c0;
+      const float* rp = a.rsp + prow * KS + c0;
+      const float4 p0 = *reinterpret_cast<const float4*>(sp), p1 = *reinterpret_cast<const float4*>(sp + 4);
+      const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+      s[n][0] = p0.x; s[n][1] = p0.y; s[n][2] = p0.z; s[n][3] = p0.w; s[n][4] = p1.x; s[n][5] = p1.y; s[n][6] = p1.z; s[n][7] = p1.w;
+      rsv[n][0] = r0.x; rsv[n][1] = r0.y; rsv[n][2] = r0.z; rsv[n][3] = r0.w; rsv[n][4] = r1.x; rsv[n][5] = r1.y; rsv[n][6] = r1.z; rsv[n][7] = r1.w;
+      if (a.dp_from_datt) {
+        const int S2 = a.S[2], k0 = c0 - a.off[2];
+        const float* da = a.d_att + (((long long)b * a.nl + a.layer) * a.L + q0 + min(pr, nq - 1)) * S2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dp[n][e] = (j == 2 && k0 + e < S2) ? da[k0 + e] : 0.f;
+      } else {
+        const float* dq = a.dP + prow * KS + c0;
+        const float4 d0 = *reinterpret_cast<const float4*>(dq), d1 = *reinterpret_cast<const float4*>(dq + 4);
+        dp[n][0] = d0.x; dp[n][1] = d0.y; dp[n][2] = d0.z; dp[n][3] = d0.w; dp[n][4] = d1.x; dp[n][5] = d1.y; dp[n][6] = d1.z; dp[n][7] = d1.w;
+      }
+    }
+  }
+  const int fcol = f0 + 4 * q4;
+  float4 ep_kb[CFD_NMEM];
+  if (wid == 0) {
+#pragma unroll
+    for (int j = 0; j < CFD_NMEM; ++j) ep_kb[j] = *reinterpret_cast<const float4*>(a.kb[j] + (long long)t * a.kb_stride[j] + fcol);
+  }
+  // softmax (recomputed from the saved scores) and its backward, per memory
+#pragma unroll
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int n = 0; n < MAXC; ++n)
+      if (cj[n] == j) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, s[n][e]);
+      }
+    mx = rt_row_max<LPR>(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int n = 0; n < MAXC; ++n)
+      if (cj[n] == j) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[n][e] = __expf(s[n][e] - mx); sum += s[n][e]; }
+      }
+    sum = rt_row_sum<LPR>(sum);
+    const float inv = rt_rcp(sum);
+    float dot = 0.f;
+#pragma unroll
+    for (int n = 0; n < MAXC; ++n)
+      if (cj[n] == j) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[n][e] *= inv; dot = fmaf(dp[n][e], s[n][e], dot); }
+      }
+    dot = rt_row_sum<LPR>(dot);
+    float wsum = 0.f;
+#pragma unroll
+    for (int n = 0; n < MAXC; ++n)
+      if (cj[n] == j) {
+        const int c0 = (plr + LPR * n) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float ds = s[n][e] * (dp[n][e] - dot) * rsv[n][e];   // dS' = p (dP - sum dP p) rs
+          wsum += ds;
+          img[pr * RS + c0 + e] = ds;
+        }
+      }
+    wsum = rt_row_sum<LPR>(wsum);
+    if (plr == 0) dcq[pr * 8 + j] = wsum;
+  }
+  __syncthreads();
+  // product over the keys: this wave's range of Sp_tot / 8 keys
+  const int nstep = KS / (4 * NW);
+  const int kbase = wid * (KS / NW) + q4;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* ap = img + l15 * RS + kbase;
+  const int fo = ((f0 + l15) >> 5) * 128 + ((f0 + l15) & 31) * 2;   // this lane's feature inside an SP key row
+  float wv[MAXSTEP];
+#pragma unroll
+  for (int i = 0; i < MAXSTEP; ++i)
+    if (i < nstep) wv[i] = rt_sp_f32(krow[kbase + 4 * i] + fo);
+#pragma unroll
+  for (int i = 0; i < MAXSTEP; ++i)
+    if (i < nstep) acc = RT_MFMA_F32(wv[i], ap[4 * i], acc, 0, 0, 0);   // D[feature][token]
+  acc = rt_reduce1<NW>(red, wid, lane, acc);
+  if (wid != 0 || l15 >= nq) return;
+  float o[4] = {acc[0], acc[1], acc[2], acc[3]};
+#pragma unroll
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    const float w = dcq[l15 * 8 + j];
+    o[0] += w * ep_kb[j].x; o[1] += w * ep_kb[j].y; o[2] += w * ep_kb[j].z; o[3] += w * ep_kb[j].w;
+  }
+  *reinterpret_cast<float4*>(a.dy + (tok0 + l15) * CFD_D + fcol) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// B8: self-attention core backward of one (head, batch row), L <= 32 tokens, plain float32 out of LDS (a few hundred kFLOP):
+//   P = softmax(Q K^T) (recomputed), dP = dO V^T, dS = P (dP - rowsum(dP P)), dQ = dS K, dK = dS^T Q, dV = P^T dO
+// q is the pre-scaled query (the scale lives in the weights, so dQ is the gradient at the scaled projection's output).
+// ------------------------------------------------------------------------------------------------
+struct RtSelfBwdArgs {
+  const char* qk;     // SP [M][1024] saved by the forward
+  const char* vt;     // SP [Be][512][32]
+  const float* dO;    // [M][512]: gradient at the attention output (before the out-projection)
+  float* dqkv;        // [M][1536]: dq | dk | dv
+  int L;
+  float qscale;       // 1 / sqrt(head_dim): dq is handed on as the gradient at the UNSCALED query projection (the forward's weights carry the scale)
+};
+
+__global__ void __launch_bounds__(256) rt_selfattn_bwd_kernel(const RtSelfBwdArgs a) {
+  constexpr int HD = CFD_HD, RSD = HD + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Q = reinterpret_cast<float*>(smem);          // [32][129]
+  float* Kk = Q + RT_MAX_L * RSD;
+  float* V = Kk + RT_MAX_L * RSD;
+  float* dO = V + RT_MAX_L * RSD;
+  float* P = dO + RT_MAX_L * RSD;                      // [32][33]
+  float* dS = P + RT_MAX_L * (RT_MAX_L + 1);
+  const int h = blockIdx.x, b = blockIdx.y, L = a.L, tid = threadIdx.x;
+  const long long tok0 = (long long)b * L;
+  for (int e = tid; e < L * HD; e += 256) {
+    const int r = e / HD, d = e - r * HD;
+    const char* row = a.qk + (size_t)(tok0 + r) * 4096;
+    const int cq = h * HD + d;
+    Q[r * RSD + d] = rt_sp_f32(row + (cq >> 5) * 128 + (cq & 31) * 2);
+    Kk[r * RSD + d] = rt_sp_f32(row + (16 + (cq >> 5)) * 128 + (cq & 31) * 2);
+    V[r * RSD + d] = rt_sp_f32(a.vt + ((size_t)b * CFD_D + cq) * (RT_MAX_L * 4) + r * 2);
+    dO[r * RSD + d] = a.dO[(tok0 + r) * CFD_D + cq];
+  }
+  __syncthreads();
+  for (int e = tid; e < L * L; e += 256) {
+    const int q = e / L, k = e - q * L;
+    float sacc = 0.f, dacc = 0.f;
+    for (int d = 0; d < HD; ++d) {
+      sacc = fmaf(Q[q * RSD + d], Kk[k * RSD + d], sacc);
+      dacc = fmaf(dO[q * RSD + d], V[k * RSD + d], dacc);
+    }
+    P[q * (RT_MAX_L + 1) + k] = sacc;
+    dS[q * (RT_MAX_L + 1) + k] = dacc;
+  }
+  __syncthreads();
+  if (tid < L) {   // one query row per thread: softmax, then its backward in place
+    float* pr = P + tid * (RT_MAX_L + 1);
+    float* dr = dS + tid * (RT_MAX_L + 1);
+    float mx = -INFINITY;
+    for (int k = 0; k < L; ++k) mx = fmaxf(mx, pr[k]);
+    float sum = 0.f;
+    for (int k = 0; k < L; ++k) { pr[k] = expf(pr[k] - mx); sum += pr[k]; }
+    float dot = 0.f;
+    for (int k = 0; k < L; ++k) { pr[k] = pr[k] / sum; dot = fmaf(dr[k], pr[k], dot); }
+    for (int k = 0; k < L; ++k) dr[k] = pr[k] * (dr[k] - dot);
+  }
+  __syncthreads();
+  for (int e = tid; e < L * HD; e += 256) {
+    const int r = e / HD, d = e - r * HD;
+    float dq = 0.f, dk = 0.f, dv = 0.f;
+    for (int k = 0; k < L; ++k) {
+      dq = fmaf(dS[r * (RT_MAX_L + 1) + k], Kk[k * RSD + d], dq);
+      dk = fmaf(dS[k * (RT_MAX_L + 1) + r], Q[k * RSD + d], dk);
+      dv = fmaf(P[k * (RT_MAX_L + 1) + r], dO[k * RSD + d], dv);
+    }
+    float* o = a.dqkv + (tok0 + r) * (3 * CFD_D) + h * HD + d;
+    o[0] = dq * a.qscale;
+    o[CFD_D] = dk;
+    o[2 * CFD_D] = dv;
+  }
+}

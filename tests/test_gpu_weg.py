@@ -151,7 +151,10 @@ def test_gradient_matches_oracle_and_reference_autograd(name):
     assert float(fresh[0]) == float(reused[0]) and torch.equal(fresh[3], reused[3])
     # the launch-by-launch form of the same evaluation
     l3, _, _, g3 = weg.loss_and_grad_stepwise(m, to_dev(inp["sample"]), t, mems, masks, focus, neot, to_dev(eot))
-    assert abs(float(l3) - float(loss)) < 1e-6 and rel_l2(g3.cpu().numpy(), grad) < 1e-5
+    # (two implementations: the float32 launch sequence in the reference's unfolded formulation against the product path's
+    #  row-tile kernels -- split-pair forward in the folded formulation, float32-MFMA backward; both are held to the
+    #  reference's autograd gradient above)
+    assert abs(float(l3) - float(loss)) < 2e-6 and rel_l2(g3.cpu().numpy(), grad) < 1e-4
     # attention maps of the saved-activation forward against the reference's
     att, _ = weg.forward_saved(m, to_dev(inp["sample"]), t, mems, masks)
     assert np.abs(att.cpu().numpy() - g[name + ".att_tlsn"]).max() < (2e-4 if "sharp" in name else 1e-5)   # sharp: logits of +-40
