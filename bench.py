@@ -172,6 +172,132 @@ def cpu_baseline(model, n_warm=3, n_timed=10, budget_s=30.0):
             "single_utterance_s": t1, "b4_step_s": t4, "sample": sample}
 
 
+def secondary_configs(model, device):
+    """The BASELINE.json configurations that are not the headline line, on the same box and process (rank 0, N = 1): a few seconds each.
+      R   product shape (L=16, 161 audio tokens), B=32: the captured loop's steps/s
+      C1  ONE utterance at the product shape, the whole 1000-step DDPM run end to end (row-tile path), with the HBM roofline of
+          SURVEY.md section 8d's algorithmic bytes (float32 weights once per step + memories read by every layer + latents)
+      WEG one objective + gradient evaluation at that shape (cfd_weg_eval) and a guided single-utterance run
+      C4  50-step DDIM, B=32, headline shape: end-to-end latency through sample()
+      C5  dyadic reactive path, B=16 per side, headline shape: one lock-step iteration"""
+    global L, S
+    from convofusion_amd import scheduler, weg
+    from convofusion_amd.conditioning import default_fuser
+    from convofusion_amd.dyadic import DyadicRun
+    from convofusion_amd.sampler import SamplingRun, sample, sample_with_weg
+    sk = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=True)
+    ddpm = scheduler.DDPMScheduler(variance_type="fixed_small", **sk)
+    out = {}
+    L0, S0 = L, S
+
+    def sync():
+        torch.cuda.synchronize(device)
+    try:
+        # ---- C4 / C5 at the headline shape
+        mems, masks = make_inputs(B_PER_GPU, device, seed=1234)
+        ddim = scheduler.DDIMScheduler(set_alpha_to_one=True, steps_offset=0, **sk)
+        sample(model, ddim, mems, masks, B=B_PER_GPU, L=L, num_inference_steps=2, seed=0)
+        sync()
+        t0 = time.perf_counter()
+        sample(model, ddim, mems, masks, B=B_PER_GPU, L=L, num_inference_steps=50, eta=0.0, seed=1)
+        sync()
+        dt = time.perf_counter() - t0
+        out["c4_ddim50_b32"] = {"latency_s_end_to_end": dt, "steps_per_s": 50 / dt,
+                                "note": "sample(): de-duplication, tables, warm-up iteration, capture, 50 replays, read"}
+        del mems, masks
+        Bd = 16
+        g = torch.Generator().manual_seed(5)
+        cond = lambda: [torch.randn(Bd, L if j == 0 else S[j], 512, generator=g).to(device) for j in range(5)]   # noqa: E731
+        uncond = [torch.randn(1, L if j == 0 else S[j], 512, generator=g).to(device) for j in range(5)]
+        model_b = make_model(device)
+        ca, cb_, fus, c5 = cond(), cond(), default_fuser().to(device).eval(), {}
+        for key, mb, shared in (("two_handles", model_b, False), ("shared_weights_one_run", None, True)):
+            run = DyadicRun(model, mb, ddpm, fus, ca, cb_, uncond, Bd, L, 1000, seed=3, shared_weights=shared)
+            run.steps(3)
+            run.read()
+            t0 = time.perf_counter()
+            run.steps(10)
+            run.read()
+            sync()
+            c5[key] = (time.perf_counter() - t0) / 10
+            run.read(close=True)
+            del run
+        del model_b
+        out["c5_dyadic_b16x2"] = {"ms_per_lockstep_iteration": c5["shared_weights_one_run"] * 1e3, "iterations_per_s": 1 / c5["shared_weights_one_run"],
+                                  "ms_per_lockstep_iteration_two_handles": c5["two_handles"] * 1e3,
+                                  "note": "both sides share the denoiser's weights here: one captured iteration of the 32-utterance double batch + the "
+                                          "two partner projections per lock-step iteration (DyadicRun(shared_weights=True)); two_handles = two "
+                                          "denoisers, two 16-utterance graphs replayed one after the other on one stream"}
+        # ---- product shape
+        L, S = 16, (24, 161, 24, 8, 1)
+        mems, masks = make_inputs(B_PER_GPU, device, seed=1234)
+        run = SamplingRun(model, ddpm, mems, masks, B_PER_GPU, L, 1000, guidance_scale=7.5, seed=0)
+        run.steps(3)
+        run.read()
+        t0 = time.perf_counter()
+        run.steps(50)
+        run.read()
+        dt = time.perf_counter() - t0
+        run.close()
+        out["r_product_shape_b32"] = {"steps_per_s": 50 / dt, "ms_per_step": 1000 * dt / 50, "workload": f"B={B_PER_GPU}, L={L}, S={S}"}
+        mems, masks = make_inputs(1, device, seed=1234)
+        sample(model, ddpm, mems, masks, B=1, L=L, num_inference_steps=4, seed=0)
+        sync()
+        t0 = time.perf_counter()
+        sample(model, ddpm, mems, masks, B=1, L=L, num_inference_steps=1000, seed=0)
+        sync()
+        dt = time.perf_counter() - t0
+        # SURVEY.md section 8d, B = 1 at the product shape: float32 weights once per step + the memories read by each of the 9
+        # layers + the latents (in, 7 replicas of eps out)
+        n_w = sum(p.numel() for p in model.parameters()) * 4
+        alg_bytes = n_w + G * sum(S) * 512 * 4 * NL + (1 + G) * L * 128 * 4
+        ach = alg_bytes / (dt / 1000) / 1e9
+        out["c1_single_utterance"] = {"s_per_1000": dt, "steps_per_s": 1000 / dt, "launches_per_step": 85,
+                                      "workload": f"B=1 (denoiser batch {G}), L={L}, S={S}, 1000-step DDPM end to end through sample()",
+                                      "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                                                   "algorithmic_bytes_per_step": alg_bytes, "traffic": None,
+                                                   "note": "latency-bound: 85 dependent launches of ~5 us per step (rowtile.hpp); "
+                                                           "algorithmic bytes = SURVEY.md 8d (float32 weights + memories x 9 layers + latents)"}}
+        # ---- WEG at the product shape
+        gw = torch.Generator().manual_seed(9)
+        enc_w = [torch.randn(1, s, 512, generator=gw).to(device) for s in S]
+        mask_w = {"spkemb": None, "alsn": None, "apb": None, "lsnemb": None, "tlsn": (torch.arange(24) >= 17)[None].to(device)}
+        lat_w = torch.randn(1, L, 128, generator=gw).to(device)
+
+        def ev(same):
+            return weg.loss_and_grad(model, lat_w, 500, enc_w, mask_w, [[3, 9, 14]], same_conditioning=same)
+        for _ in range(3):
+            ev(False)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            ev(False)
+        sync()
+        t_full = (time.perf_counter() - t0) / 20
+        t0 = time.perf_counter()
+        for _ in range(20):
+            ev(True)
+        sync()
+        t_same = (time.perf_counter() - t0) / 20
+        g1 = torch.Generator().manual_seed(11)
+        cond1 = [torch.randn(1, s, 512, generator=g1) for s in S]
+        unc1 = [torch.randn(1, s, 512, generator=g1) for s in S]
+        pat = {0: (3, 6), 1: (2, 6), 2: (1, 6), 3: (4, 6), 4: (5, 6)}
+        enc7 = [torch.cat([(cond1[j] if c in pat[j] else unc1[j]) for c in range(G)], 0).to(device) for j in range(5)]
+        mask7 = {"spkemb": None, "alsn": None, "apb": None, "lsnemb": None, "tlsn": (torch.arange(24) >= 17)[None].expand(G, 24).contiguous().to(device)}
+        wp = dict(scale_factor=1000, scale_range=[1.0, 0.5], max_iter_to_alter=800, thresholds={0: 0.05, 200: 0.4, 400: 0.6, 600: 0.8}, max_refinement_steps=300)
+        sync()
+        t0 = time.perf_counter()
+        sample_with_weg(model, ddpm, enc7, mask7, [[3, 9, 14]], wp, B=1, L=L, num_inference_steps=1000, seed=1)
+        sync()
+        out["weg_b1_product_shape"] = {"eval_ms": t_full * 1e3, "eval_same_conditioning_ms": t_same * 1e3, "guided_utterance_s": time.perf_counter() - t0,
+                                       "note": "cfd_weg_eval on the row-tile kernels (forward with saved activations, objective, float32-MFMA reverse "
+                                               "sweep: ~160 launches); guided run = configs/assets.yaml:18-23 WEG parameters on random weights"}
+    finally:
+        L, S = L0, S0
+    return out
+
+
 def spawn_ranks(args):
     """``python bench.py --gpus N`` with N > 1 and no launcher environment: start N fresh worker processes (one per
     GPU, torch.distributed.run on 127.0.0.1) BEFORE anything in this process touches the GPU, forward their output
@@ -216,6 +342,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shape", default="C2", choices=["C2", "R"])
     ap.add_argument("--no-full-loop", action="store_true", help="skip the secondary whole-1000-step-run wall time")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configurations (R, C1, WEG, C4, C5) appended to the line")
     ap.add_argument("--selftest-cpu", action="store_true", help="exercise only the N-rank launch path on CPU (gloo); no measurement")
     args = ap.parse_args()
 
@@ -353,6 +480,13 @@ def main():
                           "achieved": xa_ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": xa_ach / PEAK_BF16_TFLOPS,
                           "frac_issued": 3.0 * xa_ach / PEAK_BF16_TFLOPS, "frac_of_issued_peak_div3": xa_ach / (PEAK_BF16_TFLOPS / 3.0),
                           "launches_per_step": xa_n, "avg_launch_ms": xa_ms / max(xa_n, 1), "traffic": xa_traffic}
+        # the same fractions on the REPLAYED graph's clock: the classes' shares of the eager, event-bracketed forward scaled to
+        # ms_per_step (the brackets and eager launch gaps inflate the class times; the shares are what rocprofv3 agrees with)
+        class_sum = sum(v[0] for v in prof.values())
+        scale = (1000.0 * dt / args.steps) / class_sum if class_sum > 0 else 1.0
+        achieved_replay, xa_replay = achieved / scale, xa_ach / scale
+        xattn_roofline.update({"achieved_replay": xa_replay, "frac_replay": xa_replay / PEAK_BF16_TFLOPS, "traffic_source": "profiles/hbm_traffic_gemm.json"
+                               if xa_traffic else None})
         mfma_ms = sum(prof[k][0] for k in ex)
         all_mfma = sum(ex.values()) / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
         out = {
@@ -380,12 +514,17 @@ def main():
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
                          "frac_issued": 3.0 * achieved / PEAK_BF16_TFLOPS,
                          "peak_div3": PEAK_BF16_TFLOPS / 3.0, "frac_of_issued_peak_div3": achieved / (PEAK_BF16_TFLOPS / 3.0),
+                         "achieved_replay": achieved_replay, "frac_replay": achieved_replay / PEAK_BF16_TFLOPS,
+                         "eager_to_replay_scale": scale,
                          "traffic": traffic,
+                         "traffic_source": "profiles/hbm_traffic_gemm.json (a committed rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE profile of this "
+                                           "command, not a quantity of this run)" if traffic else None,
                          "launches_per_step": dom_n, "avg_launch_ms": dom_ms / max(dom_n, 1),
                          "all_mfma_kernels_achieved": all_mfma, "all_mfma_kernels_frac": all_mfma / PEAK_BF16_TFLOPS,
-                         "note": "achieved = algorithmic (single-product) FLOPs of the launched GEMMs / their HIP-event time, taken "
-                                 "from ONE EAGER forward with every launch bracketed by an event pair (the class times sum to a few "
-                                 "per cent more than ms_per_step, which is the replayed hipGraph: the brackets cost that); "
+                         "note": "achieved / frac = algorithmic (single-product) FLOPs of the launched GEMMs / their HIP-event time, taken "
+                                 "from ONE EAGER forward with every launch bracketed by an event pair (the class times sum to more "
+                                 "than ms_per_step, which is the replayed hipGraph: the brackets cost that); achieved_replay / frac_replay = "
+                                 "the same FLOPs over the class's share of ms_per_step (what the committed rocprofv3 kernel stats give); "
                                  "each product is issued as 3 f16 MFMAs, so the MFMA pipe sees 3x this and the ceiling of the "
                                  "f16x3 instruction mix is peak / 3 = 833 TFLOP/s (frac_of_issued_peak_div3); traffic = mean HBM bytes "
                                  "per launch from rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE (profiles/)"},
@@ -393,6 +532,9 @@ def main():
             "kernel_classes": classes,
             "tflop_once_per_run_not_per_step": once_per_run,
         }
+        if world == 1 and not args.no_secondary and args.shape == "C2":
+            out["other_configs"] = secondary_configs(model, device)
+            out["c1_single_utterance"] = out["other_configs"].pop("c1_single_utterance")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(out))

@@ -22,7 +22,7 @@ SYMBOLS = [
     "cfd_sample_read", "cfd_scheduler_step", "cfd_add_noise", "cfd_philox_normal", "cfd_profile_forward",
     "cfd_test_gemm", "cfd_debug_stop_stage", "cfd_debug_read", "cfd_bench_gemm", "cfd_linear_act",
     "cfd_layer_norm", "cfd_mha", "cfd_add", "cfd_zero_rows", "cfd_gemm_f32", "cfd_softmax", "cfd_softmax_bwd",
-    "cfd_layer_norm_bwd", "cfd_ew", "cfd_weg_focus", "cfd_sample_write", "cfd_sample_inpaint", "cfd_weg_eval",
+    "cfd_layer_norm_bwd", "cfd_ew", "cfd_weg_focus", "cfd_sample_write", "cfd_sample_inpaint", "cfd_weg_eval", "cfd_dyadic_steps",
 ]
 
 
@@ -45,6 +45,11 @@ class Memory(C.Structure):
 class Mat(C.Structure):
     """cfd_mat: element (z1, z2, r, c) = p[z1*b1 + z2*b2 + r*rs + c*cs]."""
     _fields_ = [("p", C.c_void_p), ("rs", C.c_longlong), ("cs", C.c_longlong), ("b1", C.c_longlong), ("b2", C.c_longlong)]
+
+
+class DyadicProj(C.Structure):
+    _fields_ = [("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("hidden", C.c_int), ("out_dim", C.c_int),
+                ("spk_a", C.c_void_p), ("spk_b", C.c_void_p), ("tmp", C.c_void_p)]
 
 
 class SampleArgs(C.Structure):
@@ -158,6 +163,7 @@ def load():
     lib.cfd_sample_write.argtypes = [C.c_void_p, C.c_void_p]
     lib.cfd_sample_inpaint.argtypes = [C.c_void_p]
     lib.cfd_weg_eval.argtypes = [C.c_void_p, C.POINTER(WegArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_void_p]
+    lib.cfd_dyadic_steps.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(DyadicProj), C.c_int]
     lib.cfd_debug_stop_stage.argtypes = [C.c_void_p, C.c_int]
     lib.cfd_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
     for name in SYMBOLS:

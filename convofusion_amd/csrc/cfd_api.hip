@@ -998,8 +998,13 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
                                (RT_MAX_KEYS / 32) * 2048 + 8 * 1024 + 512));
     attr |= 1ull << (c->cfg.device & 63);
   }
+  // The residual stream alternates between two buffers: a time block's workgroups read COMPLETE rows (LayerNorm prologue) while the
+  // other workgroups of the tile write their 16 features of the sum, so it must not run in place.  x -> (time block 1) -> h ->
+  // (cross-attention) -> x -> (time block 2) -> h -> (FFN) -> x; the products whose prologue reads another matrix (out-projection,
+  // FFN2) and the cross-attention's second half touch only their own 16 features of the rows and may update in place.
   float* const xw = c->w->x.as<float>();
-  auto X = [&](int l, int k) -> float* { return sv ? sv->x[l][k] : xw; };
+  float* const hw = c->w->h_sp.as<float>();   // (the tile-kernel path's LayerNorm output: same bytes, unused here)
+  auto X = [&](int l, int k) -> float* { return sv ? sv->x[l][k] : ((k == 2 || k == 4) ? hw : xw); };
   RtGemmArgs base;
   memset(&base, 0, sizeof(base));
   base.L = L; base.tpr = tpr; base.d_step = dstep;
@@ -1062,7 +1067,10 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
     if (c->stop_stage == 2 + 4 * l) return CFD_OK;
     // ---- b. time block 1                                                        (:575, :426-439)
     CHK(time_block(w.wtb1_sp, w.tb1g, w.tb1b, w.btb1, 2 * l, X(l, 1), X(l, 2)));
-    if (c->stop_stage == 3 + 4 * l) return CFD_OK;
+    if (c->stop_stage == 3 + 4 * l) {   // (test hook: the tap is read from x)
+      if (!sv) HIPCHK(hipMemcpyAsync(xw, hw, (size_t)p.M * CFD_D * 4, hipMemcpyDeviceToDevice, st));
+      return CFD_OK;
+    }
     // ---- c-e. five cross attentions + fuser, folded                             (:578-652)
     {
       RtXArgs a = xa;
@@ -1618,6 +1626,54 @@ extern "C" int cfd_sample_steps(cfd_handle c, int n) {
   HIPCHK(hipSetDevice(c->cfg.device));
   for (int i = 0; i < n; ++i) HIPCHK(hipGraphLaunch(c->gexec, c->run_stream));
   c->run_pos += n;
+  return CFD_OK;
+}
+
+extern "C" int cfd_dyadic_steps(cfd_handle a, cfd_handle b, const cfd_dyadic_proj* pr, int n) {
+  if (!a || !pr || a == b) return fail(CFD_E_ARG, "side A's handle, the projection and (two-handle form) a distinct side B handle are needed");
+  if (!a->run_open || (b && !b->run_open)) return fail(CFD_E_STATE, "both sides need an open sampling run");
+  if (!pr->w1 || !pr->b1 || !pr->w2 || !pr->b2 || !pr->spk_a || !pr->spk_b || !pr->tmp || pr->hidden < 1 || pr->out_dim != CFD_D)
+    return fail(CFD_E_ARG, "bad partner projection");
+  const cfd_sample_args& sa = a->sargs;
+  if (!(sa.dynamic_memory_mask & 1) || (b && !(b->sargs.dynamic_memory_mask & 1)))
+    return fail(CFD_E_STATE, "the speaker memory of the run(s) must be declared dynamic");
+  if (b && (sa.B != b->sargs.B || sa.L != b->sargs.L || a->cfg.device != b->cfg.device)) return fail(CFD_E_ARG, "the two sides differ in batch, length or device");
+  if (!b && sa.B % 2) return fail(CFD_E_ARG, "merged form: the run holds side A's utterances followed by side B's (even batch)");
+  if (n < 0 || a->run_pos + n > a->run_iters || (b && b->run_pos + n > b->run_iters))
+    return fail(CFD_E_ARG, "run has %d of %d iterations done; cannot run %d more", a->run_pos, a->run_iters, n);
+  HIPCHK(hipSetDevice(a->cfg.device));
+  hipStream_t st = a->run_stream;
+  if (b) {
+    // side B's stream may still hold its set-up or an earlier read: everything below is ordered behind it, and side B's later reads
+    // behind everything below (events, no host wait)
+    HIPCHK(hipEventRecord(b->weg_ev, b->run_stream));
+    HIPCHK(hipStreamWaitEvent(st, b->weg_ev, 0));
+  }
+  const int Bs = b ? sa.B : sa.B / 2;                  // utterances per side
+  const long long rows = (long long)Bs * sa.L;
+  const dim3 blk(256);
+  const long long gy = (rows + 31) / 32;
+  if (gy > 65535) return fail(CFD_E_ARG, "too many rows for one launch (%lld)", rows);
+  auto project = [&](const float* lat, float* spk) {
+    hipLaunchKernelGGL(linear_act_kernel, dim3((unsigned)((pr->hidden + 63) / 64), (unsigned)gy), blk, 0, st, lat, rows, CFD_LAT, pr->w1, pr->b1, pr->hidden, 1, pr->tmp);
+    hipLaunchKernelGGL(linear_act_kernel, dim3((unsigned)((pr->out_dim + 63) / 64), (unsigned)gy), blk, 0, st, (const float*)pr->tmp, rows, pr->hidden, pr->w2, pr->b2,
+                       pr->out_dim, 1, spk);
+  };
+  const float* lat_a = a->latents.as<float>();
+  const float* lat_b = b ? b->latents.as<float>() : lat_a + rows * CFD_LAT;
+  for (int i = 0; i < n; ++i) {
+    project(lat_b, pr->spk_a);                         // A attends to B's latents as they stand at the start of the iteration ...
+    project(lat_a, pr->spk_b);                         // ... and B to A's
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipGraphLaunch(a->gexec, st));
+    if (b) HIPCHK(hipGraphLaunch(b->gexec, st));       // same queue, one after the other: no two-queue overlap
+  }
+  a->run_pos += n;
+  if (b) {
+    b->run_pos += n;
+    HIPCHK(hipEventRecord(a->weg_ev, st));
+    HIPCHK(hipStreamWaitEvent(b->run_stream, a->weg_ev, 0));
+  }
   return CFD_OK;
 }
 

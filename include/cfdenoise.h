@@ -140,6 +140,28 @@ int cfd_sample_begin(cfd_handle h, const cfd_sample_args* args, void* stream);
 int cfd_sample_steps(cfd_handle h, int n);
 /* Number of iterations executed so far in the open run. */
 int cfd_sample_position(cfd_handle h);
+
+/* Dyadic reactive path (BASELINE.json configs[4]; the partner projection is the reference's TextAudioMotionFuser.latent_proj,
+ * condfuser.py:22-27: Linear 128->128, GELU, Linear 128->out_dim, GELU): `n` lock-step iterations of two open sampling runs.
+ * Each iteration enqueues, on ONE stream (side A's) and with no host synchronisation, the projection of side B's current latents
+ * into side A's conditional speaker-memory rows `spk_a` [B][L][512], the projection of side A's latents into `spk_b`, side A's
+ * captured iteration and side B's captured iteration.  Both runs must have been opened with the speaker memory declared dynamic
+ * (cfd_sample_args.dynamic_memory_mask bit 0) and `spk_*` pointing into the memories they captured.  All pointers are device
+ * pointers; `tmp` holds B * L * hidden floats.
+ * Merged form (side_b == NULL), for two sides that share the denoiser's weights: ONE run of 2 B utterances -- side A's followed by
+ * side B's -- whose conditional speaker rows [0, B) are `spk_a` and [B, 2 B) are `spk_b`; an iteration is the two projections and one
+ * captured iteration of the double batch. */
+typedef struct {
+  const float* w1;  /* [hidden][latent_dim] */
+  const float* b1;  /* [hidden] */
+  const float* w2;  /* [out_dim][hidden] */
+  const float* b2;  /* [out_dim] */
+  int hidden, out_dim;
+  float* spk_a;
+  float* spk_b;
+  float* tmp;
+} cfd_dyadic_proj;
+int cfd_dyadic_steps(cfd_handle side_a, cfd_handle side_b, const cfd_dyadic_proj* proj, int n);
 /* Copies the current latents to `out` (dev [B][L][128]); with close != 0 also ends the run. */
 int cfd_sample_read(cfd_handle h, float* out, int close);
 

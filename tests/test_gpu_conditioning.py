@@ -95,7 +95,93 @@ def test_dyadic_loop_matches_oracle():
     ea, eb = rel(got_a.cpu().numpy(), want_a), rel(got_b.cpu().numpy(), want_b)
     print("dyadic vs oracle: rel L2", ea, eb)
     assert ea < 1e-3 and eb < 1e-3
+    # the merged form for two sides with the same weights: one run of 2 B utterances
+    got_a, got_b = sample_dyadic(ma, None, scheduler.DDPMScheduler(**SCHED_KW), _fuser(), [to_dev(x) for x in cond_a],
+                                 [to_dev(x) for x in cond_b], [to_dev(x) for x in uncond], B=B, L=L, num_inference_steps=n,
+                                 init_latents_a=to_dev(init_a), init_latents_b=to_dev(init_b), step_noise_a=to_dev(noise[0]),
+                                 step_noise_b=to_dev(noise[1]), shared_weights=True)
+    ea, eb = rel(got_a.cpu().numpy(), want_a), rel(got_b.cpu().numpy(), want_b)
+    print("merged dyadic vs oracle: rel L2", ea, eb)
+    assert ea < 1e-3 and eb < 1e-3
     # one open sampling run per handle: the same module on both sides is refused
     with pytest.raises(ValueError):
         sample_dyadic(ma, ma, scheduler.DDPMScheduler(**SCHED_KW), _fuser(), [to_dev(x) for x in cond_a], [to_dev(x) for x in cond_b],
                       [to_dev(x) for x in uncond], B=B, L=L, num_inference_steps=n)
+
+
+def test_dyadic_full_size_properties():
+    """BASELINE config 5 at its FULL size (B = 16 per side, L = 196, 1500 audio tokens) through size-independent properties of the
+    lock-step loop (the oracle case above is B = 2, L = 16): determinism (two runs, bit-identical), A / B symmetry (swapping the two
+    sides' inputs swaps the results bit for bit: the sides are processed one after the other with partner projections taken at the
+    START of the iteration), and shard independence (utterances 0-7 of both sides alone give the same latents as inside the batch of 16:
+    pairs only couple utterance u of A with utterance u of B)."""
+    import torch
+    from convofusion_amd import scheduler
+    from convofusion_amd.denoiser import Denoiser
+    from convofusion_amd.dyadic import DyadicRun
+    from tests.gpu_helpers import ABL, DENOISER_KW, SCHED_KW, hip_denoiser
+    B, L, n = 16, 196, 4
+    S = (L, 1500, 32, 8, 1)
+    ma = hip_denoiser(1234, 1.0)
+    mb = Denoiser(ablation=ABL, **DENOISER_KW)
+    mb.load_state_dict(ma.state_dict(), strict=True)
+    mb = mb.cuda().eval()
+    g = torch.Generator().manual_seed(17)
+    mk = lambda b: [torch.randn(b, S[j], 512, generator=g).cuda() for j in range(5)]   # noqa: E731
+    cond_a, cond_b, uncond = mk(B), mk(B), mk(1)
+    init = [torch.randn(B, L, 128, generator=g).cuda() for _ in range(2)]
+    noise = [torch.randn(n, B, L, 128, generator=g).cuda() for _ in range(2)]
+    sch = scheduler.DDPMScheduler(**SCHED_KW)
+
+    def go(ca, cb, ia, ib, na, nb, b=B, merged=False):
+        run = DyadicRun(ma, None if merged else mb, sch, _fuser(), ca, cb, uncond, b, L, n, init_latents_a=ia, init_latents_b=ib, step_noise_a=na,
+                        step_noise_b=nb, shared_weights=merged)
+        run.steps(1)
+        run.steps(n - 1)
+        assert run.position == n
+        return run.read(close=True)
+    a1, b1 = go(cond_a, cond_b, init[0], init[1], noise[0], noise[1])
+    a2, b2 = go(cond_a, cond_b, init[0], init[1], noise[0], noise[1])
+    assert torch.isfinite(a1).all() and torch.isfinite(b1).all()
+    assert torch.equal(a1, a2) and torch.equal(b1, b2)
+    bs, as_ = go(cond_b, cond_a, init[1], init[0], noise[1], noise[0])      # sides swapped
+    assert torch.equal(as_, a1) and torch.equal(bs, b1)
+    h = B // 2
+    cut = lambda xs: [x[:h].contiguous() for x in xs]   # noqa: E731
+    ah, bh = go(cut(cond_a), cut(cond_b), init[0][:h].contiguous(), init[1][:h].contiguous(), noise[0][:, :h].contiguous(),
+                noise[1][:, :h].contiguous(), b=h)
+    ea, eb = rel(ah.cpu().numpy(), a1[:h].cpu().numpy()), rel(bh.cpu().numpy(), b1[:h].cpu().numpy())
+    print("dyadic shard vs batch: rel L2", ea, eb)
+    assert ea < 1e-5 and eb < 1e-5      # (another batch size takes other tile shapes / work lists: rounding, not bit equality)
+    assert rel(a1.cpu().numpy(), b1.cpu().numpy()) > 1e-2   # the two sides are different problems
+    am, bm = go(cond_a, cond_b, init[0], init[1], noise[0], noise[1], merged=True)   # one run of 32 utterances (shared weights)
+    ea, eb = rel(am.cpu().numpy(), a1.cpu().numpy()), rel(bm.cpu().numpy(), b1.cpu().numpy())
+    print("merged vs two-handle dyadic: rel L2", ea, eb)
+    assert ea < 1e-5 and eb < 1e-5
+
+
+def test_dyadic_runs_every_iteration_of_a_non_dividing_step_count():
+    """The dyadic loop length is len(scheduler.timesteps), not num_inference_steps (300 of 1000 gives 334 iterations with
+    allow_unpinned_timesteps): sample_dyadic must reach t = 0."""
+    import torch
+    from convofusion_amd import scheduler
+    from convofusion_amd.denoiser import Denoiser
+    from convofusion_amd.dyadic import DyadicRun
+    from tests.gpu_helpers import ABL, DENOISER_KW, SCHED_KW, hip_denoiser, to_dev
+    B, L = 1, 16
+    S = (L, 20, 6, 8, 1)
+    ca = inputs.make_cfg_batch(seed=41, B=B, L=L, S=S)
+    cond = [to_dev(u[1:]) for u in ca["unique"]]
+    uncond = [to_dev(u[:1]) for u in ca["unique"]]
+    ma = hip_denoiser(1234, 1.0)
+    mb = Denoiser(ablation=ABL, **DENOISER_KW)
+    mb.load_state_dict(ma.state_dict(), strict=True)
+    mb = mb.cuda().eval()
+    sch = scheduler.DDPMScheduler(variance_type="fixed_small", allow_unpinned_timesteps=True, **SCHED_KW)
+    run = DyadicRun(ma, mb, sch, _fuser(), cond, cond, uncond, B, L, 300)
+    assert run.N == 334
+    run.steps(run.N)
+    with pytest.raises(Exception):
+        run.steps(1)
+    la, lb = run.read(close=True)
+    assert run.position == 334 and torch.isfinite(la).all() and torch.isfinite(lb).all()

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import denoiser_ref, inputs, philox_ref, sampler_ref, scheduler_ref
-from tests.helpers import load_golden, rel_l2, state_dict
+from tests.helpers import load_golden, max_abs, rel_l2, state_dict
 
 pytestmark = pytest.mark.gpu
 TRAJ_TOL = 1e-3
@@ -296,13 +296,14 @@ def test_ddim_with_eta_matches_oracle():
 
 
 @pytest.mark.parametrize("env", [{"CFD_NAIVE_GEMM": "1"}, {"CFD_RUNS": "0", "CFD_FUSED_XATTN": "0"}, {"CFD_FUSED_XATTN": "0"},
-                                 {"CFD_HOIST_MEMSIDE": "0"}])
+                                 {"CFD_HOIST_MEMSIDE": "0"}, {"CFD_ROWTILE": "0"}])
 def test_developer_knobs_keep_parity(env):
     """The debug switches that select another code path for the same arithmetic (read once at cfd_create) must not change
     results: CFD_NAIVE_GEMM=1 (one-thread-per-output products instead of the MFMA kernels, three-launch attention),
     CFD_FUSED_XATTN=0 (three-launch cross-attention everywhere, with its shared-memory runs), the same with
     CFD_RUNS=0 (per-row attention products only), CFD_HOIST_MEMSIDE=0 (fused cross-attention kernel fed by memory-side
-    projections made in every iteration instead of once per run).  Each leg runs the golden forward, the 20-step trajectory, the run-path
+    projections made in every iteration instead of once per run; it also turns the row-tile path off: that path needs the hoisted form),
+    CFD_ROWTILE=0 (small problems on the tile kernels instead of the row-tile kernels of rowtile.hpp).  Each leg runs the golden forward, the 20-step trajectory, the run-path
     test and the headline-shape loop rows in a child process."""
     import os
     import subprocess
@@ -489,39 +490,88 @@ def test_no_edit_installer_runs_the_fused_loop():
     assert tuple(r.shape) == (L, B, 128) and torch.equal(r, r2) and len(ratt) == 5
 
 
-def test_small_problems_take_the_three_launch_path_by_default():
-    """Default threshold (6 workgroups): a 2-utterance run (4 workgroups) goes through the three-launch cross-attention, the same run with the
-    threshold lifted through the fused kernel; both must agree to rounding (different summation orders) and the profile must
-    show which one ran."""
+def _handle_with_env(env):
+    """A Denoiser with the session's test weights whose library handle is created under `env` (the knobs are read at cfd_create)."""
     import os
     import torch
     from convofusion_amd.denoiser import Denoiser
+    from tests.gpu_helpers import ABL, DENOISER_KW, hip_denoiser
+    keep = {k: os.environ.get(k) for k in env}
+    try:
+        for k, v in env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        m = Denoiser(ablation=ABL, **DENOISER_KW)
+        m.load_state_dict(hip_denoiser(1234, 1.0).state_dict(), strict=True)
+        m = m.cuda().eval()
+        m.engine(torch.device("cuda"))
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return m
+
+
+def test_small_problems_take_the_row_tile_path_and_the_three_paths_agree():
+    """Path selection by SHAPE.  A 2-utterance run at the product shape (224 token rows of 16) takes the row-tile path (rowtile.hpp: two
+    cross-attention launches per layer, no row kernels); with CFD_ROWTILE=0 the same run goes through the tile kernels -- the
+    three-launch cross-attention at the default threshold (4 workgroups < 6), the fused kernel with the threshold lifted.  All three
+    must agree to rounding (different summation orders, hoisted / per-step memory LayerNorm) and the profile must show which ran."""
     from convofusion_amd.sampler import SamplingRun
-    from tests.gpu_helpers import ABL, DENOISER_KW, hip_denoiser, to_dev
+    from tests.gpu_helpers import hip_denoiser, to_dev
     B, L, S = 2, 16, (24, 161, 24, 8, 1)
     cb = inputs.make_cfg_batch(seed=5, B=B, L=L, S=S, pad_tail=(4, 0, 6, 0, 0))
     mems = [to_dev(x) for x in cb["memories"]]
     masks = {k: to_dev(v) for k, v in cb["masks"].items()}
-    m_fused = hip_denoiser(1234, 1.0)                   # conftest lifts the threshold for the session
-    keep = os.environ.pop("CFD_FUSED_XATTN_MIN_WGS")
-    try:
-        m_default = Denoiser(ablation=ABL, **DENOISER_KW)
-        m_default.load_state_dict(m_fused.state_dict(), strict=True)
-        m_default = m_default.cuda().eval()
-        m_default.engine(torch.device("cuda"))          # the knob is read when the handle is created
-    finally:
-        os.environ["CFD_FUSED_XATTN_MIN_WGS"] = keep
-    outs, launches = [], []
-    for m in (m_fused, m_default):
+    models = (hip_denoiser(1234, 1.0),                                                       # row-tile (default)
+              _handle_with_env({"CFD_ROWTILE": "0"}),                                        # tile kernels, fused cross-attention (conftest lifts the threshold)
+              _handle_with_env({"CFD_ROWTILE": "0", "CFD_FUSED_XATTN_MIN_WGS": None}))       # tile kernels, default threshold: three-launch
+    outs, prof = [], []
+    for m in models:
         run = SamplingRun(m, _sched("ddpm"), mems, masks, B, L, 4, guidance_scale=7.5, seed=11)
         run.steps(2)
-        launches.append(run.profile()["xattn"][1])
+        pf = run.profile()
+        prof.append((pf["xattn"][1], pf["rows"][1], sum(v[1] for v in pf.values())))
         run.steps(2)
         outs.append(run.read(close=True))
-    assert launches == [9, 0], launches
-    d = float((outs[0] - outs[1]).norm() / outs[1].norm())
-    print("fused vs three-launch cross-attention, 4 guided steps: rel L2", d)
-    assert d < 2e-4
+    print("launches (xattn class, row kernels, all) per path:", prof)
+    assert prof[0][:2] == (18, 0) and prof[0][2] == 83          # 9 layers x 9 launches + embedding + final projection
+    assert prof[1][0] == 9 and prof[2][0] == 0
+    for k in (1, 2):
+        d = float((outs[0] - outs[k]).norm() / outs[k].norm())
+        print("row-tile vs", ("fused", "three-launch")[k - 1], "tile-kernel path, 4 guided steps: rel L2", d)
+        assert d < 2e-4
+
+
+def test_row_tile_path_is_race_free_and_shape_general():
+    """The row-tile kernels hand data from launch to launch only (no workgroup reads what another workgroup of the same launch writes):
+    repeated forwards are bit-identical -- the time blocks' in-place update was a race before the residual stream alternated between two
+    buffers -- for one to five utterances, ragged last tiles (L = 20: a 4-token tile) and L = 32 (two full tiles, 32 keys)."""
+    import torch
+    from oracle import denoiser_ref
+    from tests.gpu_helpers import hip_denoiser, to_dev
+    m = hip_denoiser(1234, 1.0)
+    sd = state_dict(1234, 1.0)
+    for Be, L, S in ((7, 16, (24, 161, 24, 8, 1)), (35, 16, (6, 20, 6, 8, 1)), (3, 20, (5, 40, 3, 8, 1)), (2, 32, (33, 70, 12, 8, 1)), (1, 2, (1, 1, 1, 1, 1))):
+        inp = inputs.make_plain_batch(seed=50 + Be, Be=Be, L=L, S=S, pad_tail=(0, 0, 0, 0, 0), scale=1.0)
+        mems = [to_dev(x) for x in inp["memories"]]
+        x = to_dev(inp["sample"])
+        with torch.no_grad():
+            masks = {k: to_dev(v) for k, v in inp["masks"].items()}
+            first, att0 = m(x, torch.tensor(321), mems, mem_mask_dict=masks)
+            for _ in range(6):
+                again, att = m(x, torch.tensor(321), mems, mem_mask_dict=masks)
+                assert torch.equal(first, again) and all(torch.equal(p, q) for p, q in zip(att0, att))
+        want, watt = denoiser_ref.denoiser_forward(sd, inp["sample"], 321, inp["memories"], inp["masks"])
+        e = rel_l2(first.cpu().numpy(), want)
+        print(f"Be={Be} L={L} S={S}: forward vs oracle {e:.2e}")
+        assert e < 1e-4
+        for j in range(5):
+            assert max_abs(att0[j].cpu().numpy(), watt[j]) < 1e-4
 
 
 def test_static_and_dynamic_memory_declarations_agree_and_mean_what_they_say():
