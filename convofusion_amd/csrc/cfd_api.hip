@@ -217,6 +217,16 @@ struct cfd_handle_s {
 };
 typedef cfd_handle_s Ctx;
 
+// Saturation census (cfd_common.hpp): reads and clears the device counter.  Called where the stream is waited for anyway.
+static int check_saturation(const char* what) {
+  unsigned int n = 0, zero = 0;
+  HIPCHK(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_cfd_sat), sizeof(n)));
+  if (n == 0) return CFD_OK;
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_cfd_sat), &zero, sizeof(zero)));
+  return fail(CFD_E_RANGE, "%s: %u groups of values exceed +-65504, the range of the fp16 split-pair operands (weights, centred memories and their "
+                           "folded key / value projections must stay inside it); rescale the conditioning input", what, n);
+}
+
 static const float* rawp(Ctx* c, const std::string& name) {
   auto it = c->raw.find(name);
   return it == c->raw.end() ? nullptr : it->second.as<float>();
@@ -550,6 +560,7 @@ extern "C" int cfd_finalize_weights(cfd_handle c) {
     CHK(to_sp(c, wv_f[j].as<float>(), kfeat, D, c->wv_all_sp[j]));
   }
   HIPCHK(hipDeviceSynchronize());
+  CHK(check_saturation("cfd_finalize_weights (a weight or a folded weight product)"));
   for (int j = 0; j < CFD_NMEM; ++j) { wk_f[j].release(); wv_f[j].release(); }
   tmpf.release(); tmpd1.release(); tmpd2.release(); vd1.release(); vd2.release(); accd.release();
   c->finalized = true;
@@ -1396,6 +1407,10 @@ extern "C" int cfd_forward(cfd_handle c, const float* sample, int Be, int L, con
     bool want_att = false;
     for (int j = 0; j < CFD_NMEM; ++j) want_att = want_att || (att && att[j]);
     CHK(prepare_static_memside(c, st, 0, want_att));
+    if (c->w->pb.static_mask) {   // once-per-call projections of the caller's memories: the census is read before they are used
+      HIPCHK(hipStreamSynchronize(st));
+      CHK(check_saturation("cfd_forward (memories / their projections)"));
+    }
   }
   const long long n = c->w->pb.M * (CFD_LAT / 8);
   LAUNCH(CFD_PROF_OTHER, to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), st, sample, c->w->sample_sp.as<char>(), c->w->pb.M,
@@ -1565,6 +1580,7 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
   CHK(build_time_tables(c, ts.data(), N, st));
   CHK(prepare_static_memside(c, st, s.dynamic_memory_mask, false));
   HIPCHK(hipStreamSynchronize(st));  // ts / coef host vectors go out of scope
+  CHK(check_saturation("cfd_sample_begin (memories / their once-per-run projections)"));
   const size_t lat_bytes = (size_t)s.B * s.L * CFD_LAT * 4;
   CHK(c->latents.ensure(lat_bytes));
   if (s.init_latents) {
@@ -1687,6 +1703,7 @@ extern "C" int cfd_sample_read(cfd_handle c, float* out, int close) {
   HIPCHK(hipMemcpyAsync(out, c->latents.p, lat_bytes, hipMemcpyDeviceToDevice, c->run_stream));
   HIPCHK(hipStreamSynchronize(c->run_stream));
   if (close) c->run_open = false;
+  if (c->sargs.dynamic_memory_mask) CHK(check_saturation("sampling run (the per-step projections of a dynamic memory)"));
   return CFD_OK;
 }
 
@@ -2046,6 +2063,14 @@ extern "C" int cfd_debug_stop_stage(cfd_handle c, int stage) {
 extern "C" int cfd_debug_read(cfd_handle c, const char* what, float* dst_dev, size_t numel) {
   if (!c || !what || !dst_dev) return fail(CFD_E_ARG, "null argument");
   HIPCHK(hipSetDevice(c->cfg.device));
+  if (!strcmp(what, "sat")) {   // the saturation census as one float (not cleared)
+    unsigned int n = 0;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_cfd_sat), sizeof(n)));
+    const float f = (float)n;
+    HIPCHK(hipMemcpy(dst_dev, &f, 4, hipMemcpyHostToDevice));
+    return CFD_OK;
+  }
   const DBuf* b = nullptr;
   if (!strcmp(what, "x")) b = &c->w->x;
   else if (!strcmp(what, "temb")) b = &c->w->temb_tab;

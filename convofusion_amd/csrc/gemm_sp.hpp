@@ -227,6 +227,7 @@ struct EpiMemK {  // i < nfeat: K_layer[i/512][j][i%512] = split(v)  (one contig
     if (i + 8 <= nfeat) {   // (nfeat is a multiple of 512: 8 consecutive features never straddle a layer)
       const int layer = i >> 9, o = i & (CFD_D - 1);
       const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      sat_note<8>(v);
       sp_store8(kall + ((long long)layer * rows + j) * (CFD_D * 4), o, v);
     } else {
       (*this)(g, b, z, i, j, v0);
@@ -236,6 +237,8 @@ struct EpiMemK {  // i < nfeat: K_layer[i/512][j][i%512] = split(v)  (one contig
   __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
     if (i < nfeat) {
       const int layer = i >> 9, o = i & (CFD_D - 1);
+      const float vv[4] = {v[0], v[1], v[2], v[3]};
+      sat_note<4>(vv);
       sp_store4(kall + ((long long)layer * rows + j) * (CFD_D * 4), o, v[0], v[1], v[2], v[3]);
     } else {
       const int u = j / Sp, sk = j - u * Sp;
@@ -256,11 +259,14 @@ struct EpiMemV {  // V^T_layer_u[j/512][i/Sp][j%512][i%Sp] = split(v): one conti
     const int layer = j >> 9, f = j & (CFD_D - 1);
     const int u = i / Sp, s = i - u * Sp;   // (Sp is a multiple of 32: 8 consecutive rows belong to one memory)
     const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    sat_note<8>(v);
     sp_store8(vt + (((long long)layer * U + u) * CFD_D + f) * ((long long)Sp * 4), s, v);
   }
   __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
     const int layer = j >> 9, f = j & (CFD_D - 1);
     const int u = i / Sp, s = i - u * Sp;
+    const float vv[4] = {v[0], v[1], v[2], v[3]};
+    sat_note<4>(vv);
     sp_store4(vt + (((long long)layer * U + u) * CFD_D + f) * ((long long)Sp * 4), s, v[0], v[1], v[2], v[3]);
   }
 };

@@ -147,6 +147,7 @@ __global__ void __launch_bounds__(256) mem_center_kernel(const MemCenterArgs a) 
     for (int e = 0; e < 8; ++e) { v[e] -= mean; ss += v[e] * v[e]; }
     ss = wave_sum(ss);
   }
+  sat_note<8>(v);
   sp_store8(a.a_sp + row * (CFD_D * 4), lane * 8, v);
   if (lane == 0) a.asq[row] = ss;
 }
@@ -384,6 +385,7 @@ __global__ void to_split_kernel(const float* in, char* out, long long R, int K, 
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = in[r * ld_in + c + e];
+  sat_note<8>(v);
   sp_store8(out + r * ld_out_bytes, c, v);
 }
 

@@ -24,6 +24,9 @@ extern "C" {
 #define CFD_E_SHAPE (-2)    /* shape the reference also rejects: odd L, L/2 or S beyond the PE buffers */
 #define CFD_E_STATE (-3)    /* call order (weights not finalized, no sampling run open, ...) */
 #define CFD_E_HIP (-4)      /* HIP runtime error */
+#define CFD_E_RANGE (-5)    /* a weight, a centred memory row or a folded key / value projection of one exceeds +-65504, the range of the fp16
+                               split-pair operands: the engine would clamp it silently (the reference is float32 and has no such limit);
+                               rescale the offending conditioning input */
 
 #define CFD_NUM_MEM 5       /* memory tuple order: spkemb, alsn, tlsn, apb, lsnemb (denoiser.py:220) */
 

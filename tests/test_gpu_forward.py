@@ -198,3 +198,38 @@ def test_fused_cross_attention_with_several_long_memories_and_degenerate_rows():
         e = rel_l2(out.cpu().numpy(), want)
         print("t =", t, "rel L2 vs oracle", e)
         assert e < FWD_TOL
+
+
+def test_out_of_range_memories_are_refused_not_clamped():
+    """The split-pair operands saturate at +-65504 (fp16).  The products K = A a_s, V = VV a_s of the CENTRED raw memories follow the
+    caller's scale (the text encoder's projection is unbounded, t5.py:8-108).  Memories 1e3 times larger than the test inputs stay inside
+    the range and must still match the oracle (the memory LayerNorm makes the reference nearly scale-free, and so must we);
+    memories scaled into saturation must be REFUSED (CFD_E_RANGE) -- by Denoiser.forward and by the sampling run -- not clamped."""
+    import torch
+    from convofusion_amd._lib import CfdError
+    from convofusion_amd.sampler import SamplingRun
+    from oracle import denoiser_ref
+    from tests.gpu_helpers import SCHED_KW, dev_inputs, hip_denoiser, read_debug
+    from convofusion_amd import scheduler
+    sd, inp, t, g = forward_case("tiny")
+    m = hip_denoiser(1234, 1.0)
+    x = torch.from_numpy(inp["sample"]).cuda()
+    big = dict(inp, memories=[np.float32(1e3) * v for v in inp["memories"]])
+    want, _ = denoiser_ref.denoiser_forward(sd, big["sample"], t, big["memories"], big["masks"])
+    mems, masks = dev_inputs(big)
+    with torch.no_grad():
+        out, _ = m(x, torch.tensor(t), mems, mem_mask_dict=masks)
+    e = rel_l2(out.cpu().numpy(), want)
+    print("memories x 1e3: rel", e, "census", float(read_debug(m, "sat", (1,))[0]))
+    assert e < FWD_TOL and float(read_debug(m, "sat", (1,))[0]) == 0
+    huge = [np.float32(3e6) * v for v in inp["memories"]]
+    hm = [torch.from_numpy(v).cuda() for v in huge]
+    with pytest.raises(CfdError) as ei:
+        m(x, torch.tensor(t), hm, mem_mask_dict=masks)
+    assert ei.value.code == -5
+    with pytest.raises(CfdError) as ei:
+        SamplingRun(m, scheduler.DDPMScheduler(**SCHED_KW), hm, masks, inp["sample"].shape[0], inp["sample"].shape[1], 4, guidance_chunks=1, seed=0)
+    assert ei.value.code == -5
+    with torch.no_grad():   # the handle is usable afterwards
+        out2, _ = m(x, torch.tensor(t), mems, mem_mask_dict=masks)
+    assert torch.equal(out, out2)
