@@ -127,9 +127,10 @@ struct Work {
   DBuf xa_wgs, xa_segs, xa_stamps;
   DBuf d_step;  // [0] = loop index, [1] = constant 0, [2] = "this iteration's in-painting overwrite is done" (cfd_sample_inpaint)
   DBuf rt_vt, rt_cbt[CFD_NMEM];   // row-tile path: V^T of the self-attention, per-step key tables
+  DBuf rt_cur;                    // row-tile path, sampling run: this step's rows of every per-step table (rt_step_rows_kernel)
   void release() {
     DBuf* all[] = {&x, &h_sp, &qk_sp, &vts_sp, &ssc, &sp_sp, &o_sp, &u_sp, &sc, &p_sp, &eps, &sample_sp, &temb_tab, &h1_tab, &ss_tab, &trows, &iota,
-                   &long_rows, &short_rows, &zero_mask, &b_tab, &b_sp, &bsq, &zeros512, &xa_wgs, &xa_segs, &xa_stamps, &d_step, &rt_vt};
+                   &long_rows, &short_rows, &zero_mask, &b_tab, &b_sp, &bsq, &zeros512, &xa_wgs, &xa_segs, &xa_stamps, &d_step, &rt_vt, &rt_cur};
     for (DBuf* b : all) b->release();
     for (int j = 0; j < CFD_NMEM; ++j) {
       n_sp[j].release(); kall_sp[j].release(); cb[j].release(); vt_all[j].release(); ca[j].release(); asq[j].release(); kbtab[j].release();
@@ -1001,14 +1002,23 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
   const Problem& p = c->w->pb;
   const int nl = c->nl, L = p.L, tpr = (L + 15) / 16, ntile = p.Be * tpr;
   const int* dstep = c->w->d_step.as<int>();
-  constexpr int LDS_LN = 16 * 2048 + 8 * 1024, LDS_LN2 = 16 * 2048 + 16 * 1024, LDS_SP4 = 4 * 1024, LDS_SP8 = 8 * 1024;
-  const int lds_xs = 16 * 2048 + 8 * 1024 + 64, lds_xpv = (p.Sp_tot / 32) * 2048 + 8 * 1024 + 512;
+  const int lds_xpv = (p.Sp_tot / 32) * 2048 + 8 * (p.Sp_tot <= 512 ? 2 : 4) * 2048 + 512;
+#define RT_SET_LDS(kernel, bytes) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
   static unsigned long long attr = 0;
   if (!((attr >> (c->cfg.device & 63)) & 1ull)) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_xpv_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (RT_MAX_KEYS / 32) * 2048 + 8 * 1024 + 512));
+    RT_SET_LDS((rt_gemm_kernel<RT_PRO_SP, RT_EPI_EMBED, 256, CFD_LAT / 32, 1>), rt_gemm_lds(RT_PRO_SP, 256, CFD_LAT / 32, 1));
+    RT_SET_LDS((rt_gemm_kernel<RT_PRO_LN, RT_EPI_QKV, 512, CFD_D / 32, 3>), rt_gemm_lds(RT_PRO_LN, 512, CFD_D / 32, 3));
+    RT_SET_LDS((rt_gemm_kernel<RT_PRO_SP, RT_EPI_RESID, 256, CFD_D / 32, 1>), rt_gemm_lds(RT_PRO_SP, 256, CFD_D / 32, 1));
+    RT_SET_LDS((rt_gemm_kernel<RT_PRO_ADALN, RT_EPI_RESID, 512, CFD_D / 32, 1>), rt_gemm_lds(RT_PRO_ADALN, 512, CFD_D / 32, 1));
+    RT_SET_LDS((rt_gemm_kernel<RT_PRO_LN, RT_EPI_SPLIT, 512, CFD_D / 32, 2>), rt_gemm_lds(RT_PRO_LN, 512, CFD_D / 32, 2));
+    RT_SET_LDS((rt_gemm_kernel<RT_PRO_SP, RT_EPI_RESID, 512, CFD_FF / 32, 1>), rt_gemm_lds(RT_PRO_SP, 512, CFD_FF / 32, 1));
+    RT_SET_LDS((rt_gemm_kernel<RT_PRO_LN, RT_EPI_F32, 512, CFD_D / 32, 1>), rt_gemm_lds(RT_PRO_LN, 512, CFD_D / 32, 1));
+    RT_SET_LDS(rt_xscore_kernel, RT_XS_LDS);
+    RT_SET_LDS(rt_xpv_kernel<512>, (512 / 32) * 2048 + 8 * 2 * 2048 + 512);
+    RT_SET_LDS(rt_xpv_kernel<RT_MAX_KEYS>, (RT_MAX_KEYS / 32) * 2048 + 8 * 4 * 2048 + 512);
     attr |= 1ull << (c->cfg.device & 63);
   }
+#undef RT_SET_LDS
   // The residual stream alternates between two buffers: a time block's workgroups read COMPLETE rows (LayerNorm prologue) while the
   // other workgroups of the tile write their 16 features of the sum, so it must not run in place.  x -> (time block 1) -> h ->
   // (cross-attention) -> x -> (time block 2) -> h -> (FFN) -> x; the products whose prologue reads another matrix (out-projection,
@@ -1016,14 +1026,38 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
   float* const xw = c->w->x.as<float>();
   float* const hw = c->w->h_sp.as<float>();   // (the tile-kernel path's LayerNorm output: same bytes, unused here)
   auto X = [&](int l, int k) -> float* { return sv ? sv->x[l][k] : ((k == 2 || k == 4) ? hw : xw); };
+  // This step's rows of the per-step tables.  One table row (cfd_forward, the WEG evaluation): the tables themselves.  A sampling
+  // run: fixed buffers refreshed by ONE launch at the start of the iteration, so that no launch of the iteration has the step index
+  // as a dependent scalar load in front of its operand loads.
+  const float* ss_now = c->w->ss_tab.as<float>();
+  const float *kb_now[CFD_NMEM], *vb_now[CFD_NMEM], *cbt_now[CFD_NMEM];
+  for (int j = 0; j < CFD_NMEM; ++j) { kb_now[j] = c->w->kbtab[j].as<float>(); vb_now[j] = c->w->vbtab[j].as<float>(); cbt_now[j] = c->w->rt_cbt[j].as<float>(); }
+  if (p.T > 1) {
+    RtStepRowsArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    size_t off4 = 0;
+    int nt = 0, nwg = 0;
+    auto add = [&](const float*& now, int nfloat) {
+      float* dst = c->w->rt_cur.as<float>() + off4 * 4;
+      ra.src[nt] = now; ra.dst[nt] = dst; ra.n4[nt] = nfloat / 4; ra.first[nt] = nwg;
+      nwg += (nfloat / 4 + 255) / 256; off4 += (size_t)(nfloat / 4 + 63) / 64 * 64; ++nt;
+      now = dst;
+    };
+    size_t need4 = (size_t)(nl * 4 * CFD_D / 4 + 64);
+    for (int j = 0; j < CFD_NMEM; ++j) need4 += (size_t)((nl * CFD_D + 32) / 4 + 64) + (size_t)(nl * CFD_D / 4 + 64) + (size_t)((nl + 1) * p.U[j] * p.Sp[j] / 4 + 64);
+    CHK(c->w->rt_cur.ensure(need4 * 16));
+    add(ss_now, nl * 4 * CFD_D);
+    for (int j = 0; j < CFD_NMEM; ++j) { add(kb_now[j], nl * CFD_D + 32); add(vb_now[j], nl * CFD_D); add(cbt_now[j], (nl + 1) * p.U[j] * p.Sp[j]); }
+    ra.ntab = nt; ra.first[nt] = nwg; ra.d_step = dstep;
+    LAUNCH(CFD_PROF_OTHER, rt_step_rows_kernel, dim3(nwg), dim3(256), st, ra);
+  }
   RtGemmArgs base;
   memset(&base, 0, sizeof(base));
-  base.L = L; base.tpr = tpr; base.d_step = dstep;
-  base.ss_tstride = (long long)nl * 2 * 2 * CFD_D;
-#define RT_LAUNCH(cls, PRO, EPI, NT, KT, NFB, nfeat, lds, args)                                                   \
+  base.L = L; base.tpr = tpr;
+#define RT_LAUNCH(cls, PRO, EPI, NT, KT, NFB, nfeat, args)                                                        \
   do {                                                                                                          \
     Bracket _br(c, cls, st);                                                                                    \
-    hipLaunchKernelGGL((rt_gemm_kernel<PRO, EPI, NT, KT, NFB>), dim3((nfeat) / (16 * NFB), ntile), dim3(NT), lds, st, args); \
+    hipLaunchKernelGGL((rt_gemm_kernel<PRO, EPI, NT, KT, NFB>), dim3((nfeat) / (16 * NFB), ntile), dim3(NT), rt_gemm_lds(PRO, NT, KT, NFB), st, args); \
     hipError_t _e = hipGetLastError();                                                                          \
     if (_e != hipSuccess) return fail(CFD_E_HIP, "row-tile launch failed: %s", hipGetErrorString(_e));          \
   } while (0)
@@ -1032,29 +1066,29 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
     RtGemmArgs a = base;
     a.a_sp = c->w->sample_sp.as<char>(); a.w = c->we_sp.as<char>(); a.bias = rawp(c, "latent_embd.bias");
     a.bh = rawp(c, "bh_embedding.weight"); a.qpe = rawp(c, "query_pos.pe"); a.xo = X(0, 0);
-    RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_EMBED, 256, CFD_LAT / 32, 1, CFD_D, LDS_SP4, a);
+    RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_EMBED, 256, CFD_LAT / 32, 1, CFD_D, a);
   }
   if (c->stop_stage == 1) return CFD_OK;
   auto time_block = [&](const DBuf& w, const float* g, const float* b, const float* bias, int tbidx, const float* xin, float* xout) -> int {
     RtGemmArgs a = base;
     a.x = xin; a.xr = xin; a.xo = xout;
-    a.g = g; a.b = b; a.ss = c->w->ss_tab.as<float>() + (size_t)tbidx * 2 * CFD_D; a.w = w.as<char>(); a.bias = bias;
-    RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_ADALN, RT_EPI_RESID, 512, CFD_D / 32, 1, CFD_D, LDS_LN, a);
+    a.g = g; a.b = b; a.ss = ss_now + (size_t)tbidx * 2 * CFD_D; a.w = w.as<char>(); a.bias = bias;
+    RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_ADALN, RT_EPI_RESID, 512, CFD_D / 32, 1, CFD_D, a);
     return CFD_OK;
   };
   RtXArgs xa;
   memset(&xa, 0, sizeof(xa));
-  xa.L = L; xa.tpr = tpr; xa.nl = nl; xa.d_step = dstep; xa.Sp_tot = p.Sp_tot; xa.rsp = c->w->p_sp.as<float>();
+  xa.L = L; xa.tpr = tpr; xa.nl = nl; xa.Sp_tot = p.Sp_tot; xa.rsp = c->w->p_sp.as<float>();
   int nkb = 0;
   for (int j = 0; j < CFD_NMEM; ++j) {
     xa.map[j] = p.map[j]; xa.rows[j] = p.U[j] * p.Sp[j]; xa.S[j] = p.S[j]; xa.Sp[j] = p.Sp[j]; xa.off[j] = p.off[j];
-    xa.cbt[j] = c->w->rt_cbt[j].as<float>(); xa.att[j] = p.att[j];
-    xa.kb_stride[j] = nl * CFD_D + 32; xa.vb_stride[j] = nl * CFD_D;
+    xa.cbt[j] = cbt_now[j]; xa.att[j] = p.att[j];
     xa.blk0[j] = nkb; nkb += p.Sp[j] / 16;
   }
   xa.blk0[CFD_NMEM] = nkb;
+  static const bool exp_same_weights = getenv("CFD_RT_EXP_SAMEW") != nullptr;   // TIMING EXPERIMENT (garbage results): every layer reads layer 0's weights
   for (int l = 0; l < nl; ++l) {
-    const LayerW& w = c->lw[l];
+    const LayerW& w = c->lw[exp_same_weights ? 0 : l];
     char* qk = sv ? sv->qk[l] : c->w->qk_sp.as<char>();
     char* vt = sv ? sv->vt[l] : c->w->rt_vt.as<char>();
     // ---- a. self attention: x += Wo softmax(q k^T) v                         (cross_attention.py:568-572)
@@ -1063,17 +1097,19 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
       a.x = X(l, 0);
       a.g = w.ln1g; a.b = w.ln1b; a.w = w.wqk_sp.as<char>(); a.w2 = w.wv_sp.as<char>(); a.nfb_qk = 2 * CFD_D / 16;
       a.bias = w.bqk.as<float>(); a.o_sp = qk; a.ld_o = 2 * CFD_D * 4; a.vt = vt;
-      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_LN, RT_EPI_QKV, 512, CFD_D / 32, 2, 3 * CFD_D, LDS_LN2, a);
+      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_LN, RT_EPI_QKV, 512, CFD_D / 32, 3, 3 * CFD_D, a);
     }
     {
       RtSelfArgs a{qk, vt, c->w->o_sp.as<char>(), L, tpr};
-      LAUNCH(CFD_PROF_GEMM_ATTN, rt_selfattn_kernel, dim3(CFD_NHEAD, ntile), dim3(256), st, a);
+      Bracket br(c, CFD_PROF_GEMM_ATTN, st);
+      hipLaunchKernelGGL(rt_selfattn_kernel, dim3(CFD_NHEAD, ntile), dim3(256), 40960, st, a);
+      HIPCHK(hipGetLastError());
     }
     {
       RtGemmArgs a = base;   // out-projection + residual
       a.xr = X(l, 0); a.xo = X(l, 1);
       a.a_sp = c->w->o_sp.as<char>(); a.w = w.wo_sp.as<char>(); a.bias = w.bo2.as<float>();
-      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_RESID, 256, CFD_D / 32, 1, CFD_D, LDS_SP4, a);
+      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_RESID, 256, CFD_D / 32, 1, CFD_D, a);
     }
     if (c->stop_stage == 2 + 4 * l) return CFD_OK;
     // ---- b. time block 1                                                        (:575, :426-439)
@@ -1092,17 +1128,18 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
         const size_t rows = (size_t)p.U[j] * p.Sp[j];
         a.K[j] = c->w->kall_sp[j].as<char>() + (size_t)l * rows * CFD_D * 4;
         a.VT[j] = c->w->vt_all[j].as<char>() + (size_t)l * rows * CFD_D * 4;
-        a.kb[j] = c->w->kbtab[j].as<float>() + (size_t)l * CFD_D;
-        a.vb[j] = c->w->vbtab[j].as<float>() + (size_t)l * CFD_D;
+        a.kb[j] = kb_now[j] + (size_t)l * CFD_D;
+        a.vb[j] = vb_now[j] + (size_t)l * CFD_D;
       }
       {
         Bracket br(c, CFD_PROF_XATTN, st);
-        hipLaunchKernelGGL(rt_xscore_kernel<512>, dim3(nkb, ntile), dim3(512), lds_xs, st, a);
+        hipLaunchKernelGGL(rt_xscore_kernel, dim3(nkb, ntile), dim3(512), RT_XS_LDS, st, a);
         HIPCHK(hipGetLastError());
       }
       {
         Bracket br(c, CFD_PROF_XATTN, st);
-        hipLaunchKernelGGL(rt_xpv_kernel<512>, dim3(CFD_D / 16, ntile), dim3(512), lds_xpv, st, a);
+        if (p.Sp_tot <= 512) hipLaunchKernelGGL(rt_xpv_kernel<512>, dim3(CFD_D / 16, ntile), dim3(512), lds_xpv, st, a);
+        else hipLaunchKernelGGL(rt_xpv_kernel<RT_MAX_KEYS>, dim3(CFD_D / 16, ntile), dim3(512), lds_xpv, st, a);
         HIPCHK(hipGetLastError());
       }
     }
@@ -1116,13 +1153,13 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
       a.x = X(l, 4);
       a.g = w.ln3g; a.b = w.ln3b; a.w = w.w1_sp.as<char>(); a.bias = w.b1; a.o_sp = c->w->u_sp.as<char>(); a.ld_o = CFD_FF * 4; a.gelu = 1;
       a.pre = sv ? sv->pre[l] : nullptr;
-      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_LN, RT_EPI_SPLIT, 512, CFD_D / 32, 2, CFD_FF, LDS_LN2, a);
+      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_LN, RT_EPI_SPLIT, 512, CFD_D / 32, 2, CFD_FF, a);
     }
     {
       RtGemmArgs a = base;   // linear2 + residual
       a.xr = X(l, 4); a.xo = X(l + 1, 0);
       a.a_sp = c->w->u_sp.as<char>(); a.w = w.w2_sp.as<char>(); a.bias = w.b2;
-      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_RESID, 512, CFD_FF / 32, 1, CFD_D, LDS_SP8, a);
+      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_RESID, 512, CFD_FF / 32, 1, CFD_D, a);
     }
     if (c->stop_stage == 5 + 4 * l) return CFD_OK;
   }
@@ -1132,7 +1169,7 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
     a.x = X(nl, 0);
     a.g = rawp(c, "decoder.norm.weight"); a.b = rawp(c, "decoder.norm.bias"); a.w = c->wp_sp.as<char>();
     a.bias = rawp(c, "latent_proj.bias"); a.o_f32 = c->w->eps.as<float>(); a.ldo_f = CFD_LAT;
-    RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_LN, RT_EPI_F32, 512, CFD_D / 32, 1, CFD_LAT, LDS_LN, a);
+    RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_LN, RT_EPI_F32, 512, CFD_D / 32, 1, CFD_LAT, a);
   }
 #undef RT_LAUNCH
   return CFD_OK;
@@ -2071,6 +2108,15 @@ extern "C" int cfd_debug_read(cfd_handle c, const char* what, float* dst_dev, si
     HIPCHK(hipMemcpy(dst_dev, &f, 4, hipMemcpyHostToDevice));
     return CFD_OK;
   }
+#if RT_STAMP
+  if (!strcmp(what, "rt_ring")) {   // developer build: the launch time line (rowtile.hpp), 4 x 4096 64-bit words + the sequence counter
+    HIPCHK(hipDeviceSynchronize());
+    if (numel * 4 < sizeof(unsigned long long) * 4 * 4096 + 8) return fail(CFD_E_ARG, "rt_ring needs %zu bytes", sizeof(unsigned long long) * 4 * 4096 + 8);
+    HIPCHK(hipMemcpyFromSymbol(dst_dev, HIP_SYMBOL(g_rt_ring), sizeof(unsigned long long) * 4 * 4096, 0, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpyFromSymbol(reinterpret_cast<char*>(dst_dev) + sizeof(unsigned long long) * 4 * 4096, HIP_SYMBOL(g_rt_seq), 4, 0, hipMemcpyDeviceToDevice));
+    return CFD_OK;
+  }
+#endif
   const DBuf* b = nullptr;
   if (!strcmp(what, "x")) b = &c->w->x;
   else if (!strcmp(what, "temb")) b = &c->w->temb_tab;

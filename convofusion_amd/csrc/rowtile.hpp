@@ -28,6 +28,29 @@
 #pragma once
 #include "cfd_common.hpp"
 
+// Developer build (-DRT_STAMP=1, tools/rt_stamps.py): workgroup (0, 0) of every row-tile launch appends {kernel id, s_memrealtime at
+// entry, at operands-arrived, at exit} to a ring in device memory -- the time line of consecutive launches of a captured step.
+#ifndef RT_STAMP
+#define RT_STAMP 0
+#endif
+#if RT_STAMP
+__device__ unsigned long long g_rt_ring[4 * 4096];
+__device__ unsigned int g_rt_seq;
+#define RT_T(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
+#define RT_STAMP_OUT(id, t0, t1)                                                                     \
+  do {                                                                                               \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                                    \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
+      const unsigned long long t2_ = __builtin_amdgcn_s_memrealtime();                               \
+      const unsigned k_ = atomicAdd(&g_rt_seq, 1u) & 4095u;                                          \
+      g_rt_ring[4 * k_] = (id); g_rt_ring[4 * k_ + 1] = (t0); g_rt_ring[4 * k_ + 2] = (t1); g_rt_ring[4 * k_ + 3] = t2_; \
+    }                                                                                                \
+  } while (0)
+#else
+#define RT_T(var) do { } while (0)
+#define RT_STAMP_OUT(id, t0, t1) do { } while (0)
+#endif
+
 #define RT_MAX_L 32          // self-attention keys of a batch row fit one 32-deep k-step
 #define RT_MAX_KEYS 1024     // padded cross-attention keys of all five memories together
 
@@ -63,6 +86,21 @@ __device__ __forceinline__ void rt_lfrag(const char* img, int kt, int l15, int q
   hi = *reinterpret_cast<const spx8*>(p + ((q4 ^ sw) << 4));
   lo = *reinterpret_cast<const spx8*>(p + (((4 + q4) ^ sw) << 4));
 }
+// LDS-DMA of k-group kt of 16 SP rows (row r at base + min(r, rmax) * ld bytes) into the image slot `slot` (2 KB: [row 16][128 B]):
+// two wave-instructions of 8 rows x 128 B, i.e. whole cache lines per instruction (a direct 16-byte fragment load touches
+// sixteen HALF lines per instruction and runs at a quarter of the L1's rate: measured 1.5 us to issue 64 KB, tools/rt_stamps.py);
+// the swizzle is applied on the source address, as in gemm_sp.hpp.  The caller waits (vmcnt) before reading the slot.
+__device__ __forceinline__ void rt_dma_slice(char* slot, const char* base, long long ld, int rmax, int kt, int lane) {
+  const int cpos = lane & 7, rsub = lane >> 3;
+#pragma unroll
+  for (int pc = 0; pc < 2; ++pc) {
+    const int r = pc * 8 + rsub;
+    const char* src = base + (long long)min(r, rmax) * ld + (long long)kt * 128 + ((cpos ^ ((r >> 1) & 7)) << 4);
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slot + pc * 1024), 16, 0, 0);
+  }
+}
+#define RT_WAIT_VM0() do { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); } while (0)   /* vmcnt(0), lgkmcnt / expcnt untouched */
+
 // store 8 consecutive columns (c0 % 8 == 0) of row r into the image
 __device__ __forceinline__ void rt_lstore8(char* img, int r, int c0, const float* v) {
   spx8 h, l;
@@ -121,39 +159,91 @@ __device__ __forceinline__ float rt_rcp(float x) {
 }
 __device__ __forceinline__ float rt_silu(float x) { return x * rt_rcp(1.0f + __expf(-x)); }
 
-// sum of the waves' partial accumulators of NFB feature blocks (fixed order: bit-reproducible); block i's sum is returned in wave i
-template <int NW, int NFB>
-__device__ __forceinline__ f32x4 rt_reduce(char* red, int wid, int lane, const f32x4 (&acc)[NFB]) {
+// store 4 consecutive columns (c0 % 4 == 0) of row r into the image
+__device__ __forceinline__ void rt_lstore4(char* img, int r, int c0, const float* v) {
+  spx4 h, l;
 #pragma unroll
-  for (int i = 0; i < NFB; ++i) reinterpret_cast<f32x4*>(red)[(i * NW + wid) * 64 + lane] = acc[i];
+  for (int e = 0; e < 4; ++e) {
+    sp_t a, b;
+    split_f32(v[e], a, b);
+    h[e] = a;
+    l[e] = b;
+  }
+  const int sw = (r >> 1) & 7, ch = (c0 & 31) >> 3, half = ((c0 & 31) >> 2) & 1;
+  char* p = img + (c0 >> 5) * 2048 + r * 128 + half * 8;
+  *reinterpret_cast<spx4*>(p + ((ch ^ sw) << 4)) = h;
+  *reinterpret_cast<spx4*>(p + (((4 + ch) ^ sw) << 4)) = l;
+}
+// fragment of row `row` of a general image: [k-group][nrows][128 B] with the same swizzle (row index inside the image)
+__device__ __forceinline__ void rt_lfrag_row(const char* img, int kt, int nrows, int row, int q4, spx8& hi, spx8& lo) {
+  const int sw = (row >> 1) & 7;
+  const char* p = img + (kt * nrows + row) * 128;
+  hi = *reinterpret_cast<const spx8*>(p + ((q4 ^ sw) << 4));
+  lo = *reinterpret_cast<const spx8*>(p + (((4 + q4) ^ sw) << 4));
+}
+// one LDS-DMA piece: 8 rows x 128 B of k-group kt, rows r0 .. r0 + 7 of the image (source row = min(src_row0 + r, rmax))
+__device__ __forceinline__ void rt_dma_piece(char* img_rows0, const char* base, long long ld, int src_row0, int rmax, int r0, int kt, int lane) {
+  const int cpos = lane & 7, r = r0 + (lane >> 3);
+  const char* src = base + (long long)min(src_row0 + r, rmax) * ld + (long long)kt * 128 + ((cpos ^ ((r >> 1) & 7)) << 4);
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(img_rows0 + r0 * 128), 16, 0, 0);
+}
+
+// Sum of the waves' partial accumulators of NFB feature blocks (fixed order: bit-reproducible); block i's sum is returned in wave i.
+// Every wave parks its partials in ITS OWN staging region (dead once its fragments are in registers), `stride` bytes apart.
+template <int NW, int NFB>
+__device__ __forceinline__ f32x4 rt_reduce(char* stage0, int stride, int wid, int lane, const f32x4 (&acc)[NFB]) {
+#pragma unroll
+  for (int i = 0; i < NFB; ++i) reinterpret_cast<f32x4*>(stage0 + wid * stride + i * 1024)[lane] = acc[i];
   __syncthreads();
   f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
   if (wid < NFB) {
-    s = reinterpret_cast<const f32x4*>(red)[(wid * NW) * 64 + lane];
+    s = reinterpret_cast<const f32x4*>(stage0 + wid * 1024)[lane];
 #pragma unroll
     for (int w = 1; w < NW; ++w) {
-      const f32x4 t = reinterpret_cast<const f32x4*>(red)[(wid * NW + w) * 64 + lane];
+      const f32x4 t = reinterpret_cast<const f32x4*>(stage0 + w * stride + wid * 1024)[lane];
       s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
     }
   }
   return s;
 }
 
-// LayerNorm statistics of a prologue row: v (this lane's columns) is centred in place, returns 1 / sqrt(var + eps)
-template <int LPR, int CH>
-__device__ __forceinline__ float rt_ln_stats(float (&v)[CH][8]) {
+// LayerNorm prologue of a 512-thread workgroup: thread (row pr = tid / 32, lane plr = tid % 32) owns columns 128 i + 4 plr .. + 3,
+// i = 0..3 -- 16-byte loads that are contiguous across the row's lanes.  The per-column parameters (LayerNorm weight / bias, and
+// up to two more rows) go through LDS: ONE float4 per thread from global memory instead of every row's lanes loading all of them
+// (16 x the bytes through the L1, which is what bounds these kernels: tools/rt_stamps.py).
+#define RT_LPR 32
+__device__ __forceinline__ void rt_rows_load(const float* x, long long row, int plr, float (&v)[4][4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 q = *reinterpret_cast<const float4*>(x + row * CFD_D + 128 * i + 4 * plr);
+    v[i][0] = q.x; v[i][1] = q.y; v[i][2] = q.z; v[i][3] = q.w;
+  }
+}
+// parameter rows p0..p3 (512 floats each, null = unused) -> par[4][128] float4 in LDS; NPAR * 128 threads load one float4 each
+template <int NPAR>
+__device__ __forceinline__ float4 rt_par_fetch(const float* p0, const float* p1, const float* p2, const float* p3) {
+  const int arr = threadIdx.x >> 7, idx = threadIdx.x & 127;
+  const float* src = arr == 0 ? p0 : arr == 1 ? p1 : arr == 2 ? p2 : p3;
+  return (arr < NPAR) ? *reinterpret_cast<const float4*>(src + 4 * idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void rt_par_get(const char* par, int arr, int i, int plr, float (&o)[4]) {
+  const float4 q = reinterpret_cast<const float4*>(par)[arr * 128 + 32 * i + plr];
+  o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
+}
+// statistics of the row: v is centred in place, returns 1 / sqrt(var + eps)
+__device__ __forceinline__ float rt_ln_stats(float (&v)[4][4]) {
   float s = 0.f;
 #pragma unroll
-  for (int c = 0; c < CH; ++c)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s += v[c][e];
-  const float mean = rt_row_sum<LPR>(s) * (1.0f / CFD_D);
+    for (int e = 0; e < 4; ++e) s += v[i][e];
+  const float mean = rt_row_sum<RT_LPR>(s) * (1.0f / CFD_D);
   float ss = 0.f;
 #pragma unroll
-  for (int c = 0; c < CH; ++c)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { v[c][e] -= mean; ss += v[c][e] * v[c][e]; }
-  return 1.0f / sqrtf(rt_row_sum<LPR>(ss) * (1.0f / CFD_D) + 1e-5f);
+    for (int e = 0; e < 4; ++e) { v[i][e] -= mean; ss += v[i][e] * v[i][e]; }
+  return 1.0f / sqrtf(rt_row_sum<RT_LPR>(ss) * (1.0f / CFD_D) + 1e-5f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -169,12 +259,11 @@ struct RtGemmArgs {
   const char* a_sp;        // SP [M][K] (RT_PRO_SP)
   const float* g;          // LayerNorm weight / bias [512]
   const float* b;
-  const float* ss;         // AdaLN: (1 + scale | shift) of this time block, row t at ss + t * ss_tstride
-  long long ss_tstride;
-  const int* d_step;
+  const float* ss;         // AdaLN: (1 + scale | shift) of this time block AT THIS STEP [1024] (no step index on the device side: a
+                           // dependent scalar load in front of the parameter fetch costs every launch ~1 us, tools/rt_stamps.py)
   // W operand
   const char* w;           // SP [N][K]
-  const char* w2;          // RT_EPI_QKV: the value projection's weights (feature blocks >= nfb_qk, operand roles swapped)
+  const char* w2;          // RT_EPI_QKV: the value projection's weights (16-feature blocks >= nfb_qk, operand roles swapped)
   int nfb_qk;
   const float* bias;       // [N] or null
   // outputs
@@ -191,119 +280,138 @@ struct RtGemmArgs {
   const float* qpe;
 };
 
+// dynamic LDS of rt_gemm_kernel
+constexpr int rt_gemm_lds(int pro, int nt, int kt, int nfb) {
+  return (pro == RT_PRO_SP ? 0 : 16 * 2048 + 8192) + (nt / 64) * ((pro == RT_PRO_SP ? 1 : 0) + nfb) * (kt / (nt / 64)) * 2048;
+}
+
 template <int PRO, int EPI, int NT, int KT, int NFB>
-__global__ void __launch_bounds__(NT, NT / 128) rt_gemm_kernel(const RtGemmArgs a) {
+__global__ void __launch_bounds__(NT) rt_gemm_kernel(const RtGemmArgs a) {
   constexpr int NW = NT / 64;
   constexpr int NK = KT / NW;                // k-groups per wave: kt = wid + NW * n
-  constexpr int LPR = NT / 16;               // lanes per token row in the prologue
-  constexpr int CH = CFD_D / (LPR * 8);      // 8-column chunks per lane
   static_assert(KT % NW == 0 && NK >= 1, "the k-groups divide evenly over the waves");
-  static_assert(PRO == RT_PRO_SP || KT == CFD_D / 32, "LayerNorm prologues are 512 wide");
+  static_assert(PRO == RT_PRO_SP || (KT == CFD_D / 32 && NT == 512), "LayerNorm prologues: 512 columns, 512 threads");
+  static_assert(NFB <= NW, "wave i finishes feature block i");
+  RT_T(t_in);
+  // LDS map.  LN prologues: A image (16 k-groups x 2 KB, written by every wave) | parameter rows (8 KB) | staging.  Staging = per
+  // wave a PRIVATE region [A slices NK (SP prologue only) | W slices NFB x NK] x 2 KB, filled by that wave's own LDS-DMA and read
+  // back by it alone; afterwards the wave parks its partial sums there.
+  constexpr int NA = PRO == RT_PRO_SP ? NK : 0;
+  constexpr int STAGE_W = (NA + NFB * NK) * 2048;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* img = smem;                                              // A image (LN prologues): 16 k-groups x 2 KB
-  char* red = smem + (PRO == RT_PRO_SP ? 0 : 16 * 2048);         // reduction scratch: NFB x NW KB
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* img = smem;
+  char* par = smem + 16 * 2048;
+  char* stage0 = smem + (PRO == RT_PRO_SP ? 0 : 16 * 2048 + 8192);
+  char* wreg = stage0 + wid * STAGE_W;
   const int l15 = lane & 15, q4 = lane >> 4;
   const int tile = blockIdx.y;
   const int b = tile / a.tpr, q0 = (tile - b * a.tpr) * 16, nq = min(16, a.L - q0);
   const long long tok0 = (long long)b * a.L + q0;
   const int fb0 = blockIdx.x * NFB;                              // first 16-feature block of this workgroup
-  const bool swapped = EPI == RT_EPI_QKV && fb0 >= a.nfb_qk;     // workgroup-uniform (nfb_qk is a multiple of NFB)
-  const int f0 = (swapped ? fb0 - a.nfb_qk : fb0) * 16;
+  auto blk_swapped = [&](int i) __attribute__((always_inline)) { return EPI == RT_EPI_QKV && fb0 + i >= a.nfb_qk; };   // workgroup-uniform
+  auto blk_f0 = [&](int i) __attribute__((always_inline)) { return (blk_swapped(i) ? fb0 + i - a.nfb_qk : fb0 + i) * 16; };
 
   // ---- 1. every global load of the kernel is issued here ------------------------------------------------
-  // prologue rows first (vmcnt retires in order: the LayerNorm can start while the weight fragments are still in flight)
-  float v[CH][8];
-  float4 lg[CH][2], lb[CH][2], ls[CH][2], lh[CH][2];             // LayerNorm weight / bias, AdaLN (1 + scale) / shift of this lane's columns
-  const int pr = threadIdx.x / LPR, plr = threadIdx.x % LPR;     // prologue: row, lane in row
+  // prologue rows first (vmcnt retires in order: the LayerNorm can start while the weight slices are still in flight)
+  float v[4][4];
+  float4 parv = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int pr = threadIdx.x >> 5, plr = threadIdx.x & 31;      // prologue: row, lane in row
   if constexpr (PRO != RT_PRO_SP) {
-    const float* xr = a.x + (tok0 + min(pr, nq - 1)) * CFD_D + plr * 8;
+    rt_rows_load(a.x, tok0 + min(pr, nq - 1), plr, v);
+  } else {
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const float4 p0 = *reinterpret_cast<const float4*>(xr + c * (LPR * 8));
-      const float4 p1 = *reinterpret_cast<const float4*>(xr + c * (LPR * 8) + 4);
-      v[c][0] = p0.x; v[c][1] = p0.y; v[c][2] = p0.z; v[c][3] = p0.w; v[c][4] = p1.x; v[c][5] = p1.y; v[c][6] = p1.z; v[c][7] = p1.w;
-    }
-    const float* sc = nullptr;
-    if constexpr (PRO == RT_PRO_ADALN) sc = a.ss + (long long)(*a.d_step) * a.ss_tstride;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int c0 = c * (LPR * 8) + plr * 8;
-      lg[c][0] = *reinterpret_cast<const float4*>(a.g + c0); lg[c][1] = *reinterpret_cast<const float4*>(a.g + c0 + 4);
-      lb[c][0] = *reinterpret_cast<const float4*>(a.b + c0); lb[c][1] = *reinterpret_cast<const float4*>(a.b + c0 + 4);
-      if constexpr (PRO == RT_PRO_ADALN) {
-        ls[c][0] = *reinterpret_cast<const float4*>(sc + c0); ls[c][1] = *reinterpret_cast<const float4*>(sc + c0 + 4);
-        lh[c][0] = *reinterpret_cast<const float4*>(sc + CFD_D + c0); lh[c][1] = *reinterpret_cast<const float4*>(sc + CFD_D + c0 + 4);
-      }
-    }
+    for (int n = 0; n < NK; ++n) rt_dma_slice(wreg + n * 2048, a.a_sp + (size_t)tok0 * (KT * 128), KT * 128, nq - 1, wid + NW * n, lane);
   }
-  spx8 wh[NFB][NK], wl[NFB][NK], ah[NK], al[NK];
 #pragma unroll
   for (int i = 0; i < NFB; ++i) {
-    const char* wrow = (swapped ? a.w2 : a.w) + (size_t)(f0 + 16 * i + l15) * (KT * 128);
+    const char* wb = (blk_swapped(i) ? a.w2 : a.w) + (size_t)blk_f0(i) * (KT * 128);
 #pragma unroll
-    for (int n = 0; n < NK; ++n) rt_gfrag(wrow, wid + NW * n, q4, wh[i][n], wl[i][n]);
+    for (int n = 0; n < NK; ++n) rt_dma_slice(wreg + (NA + i * NK + n) * 2048, wb, KT * 128, 15, wid + NW * n, lane);
   }
-  if constexpr (PRO == RT_PRO_SP) {
-    const char* arow = a.a_sp + (size_t)(tok0 + min(l15, nq - 1)) * (KT * 128);
-#pragma unroll
-    for (int n = 0; n < NK; ++n) rt_gfrag(arow, wid + NW * n, q4, ah[n], al[n]);
+  if constexpr (PRO == RT_PRO_ADALN) {
+    parv = rt_par_fetch<4>(a.g, a.b, a.ss, a.ss + CFD_D);
+  } else if constexpr (PRO == RT_PRO_LN) {
+    parv = rt_par_fetch<2>(a.g, a.b, nullptr, nullptr);
   }
   // epilogue operands: wave i finishes feature block i
   float4 ep_r = make_float4(0.f, 0.f, 0.f, 0.f), ep_t = ep_r, ep_t1 = ep_r, ep_t2 = ep_r;
-  const int fcol = f0 + 16 * wid + 4 * q4;                       // standard roles: this lane's 4 features, token l15
+  const bool my_swapped = blk_swapped(wid);                       // (wave-uniform)
+  const int fcol = blk_f0(wid) + 4 * q4;                          // standard roles: this lane's 4 features, token l15
   if (wid < NFB) {
     if constexpr (EPI == RT_EPI_RESID) ep_r = *reinterpret_cast<const float4*>(a.xr + (tok0 + min(l15, nq - 1)) * CFD_D + fcol);
-    if (a.bias && !swapped) ep_t = *reinterpret_cast<const float4*>(a.bias + fcol);
+    if (a.bias && !my_swapped) ep_t = *reinterpret_cast<const float4*>(a.bias + fcol);
     if constexpr (EPI == RT_EPI_EMBED) {
       const int l = q0 + min(l15, nq - 1);
       ep_t1 = *reinterpret_cast<const float4*>(a.bh + (l & 1) * CFD_D + fcol);
       ep_t2 = *reinterpret_cast<const float4*>(a.qpe + (size_t)(l >> 1) * CFD_D + fcol);
     }
   }
+  RT_T(t_iss);
 
   // ---- 2. prologue: LayerNorm (+ AdaLN, SiLU) of the tile's rows -> split-pair image in LDS ---------------
   if constexpr (PRO != RT_PRO_SP) {
-    const float rstd = rt_ln_stats<LPR, CH>(v);
+    reinterpret_cast<float4*>(par)[threadIdx.x] = parv;
+    const float rstd = rt_ln_stats(v);
+    __syncthreads();                                            // the parameter rows are in LDS
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int c0 = c * (LPR * 8) + plr * 8;
-      const float gg[8] = {lg[c][0].x, lg[c][0].y, lg[c][0].z, lg[c][0].w, lg[c][1].x, lg[c][1].y, lg[c][1].z, lg[c][1].w};
-      const float bb[8] = {lb[c][0].x, lb[c][0].y, lb[c][0].z, lb[c][0].w, lb[c][1].x, lb[c][1].y, lb[c][1].z, lb[c][1].w};
+    for (int i = 0; i < 4; ++i) {
+      float gg[4], bb[4];
+      rt_par_get(par, 0, i, plr, gg);
+      rt_par_get(par, 1, i, plr, bb);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[c][e] = v[c][e] * rstd * gg[e] + bb[e];
+      for (int e = 0; e < 4; ++e) v[i][e] = v[i][e] * rstd * gg[e] + bb[e];
       if constexpr (PRO == RT_PRO_ADALN) {
-        const float sv[8] = {ls[c][0].x, ls[c][0].y, ls[c][0].z, ls[c][0].w, ls[c][1].x, ls[c][1].y, ls[c][1].z, ls[c][1].w};
-        const float hv[8] = {lh[c][0].x, lh[c][0].y, lh[c][0].z, lh[c][0].w, lh[c][1].x, lh[c][1].y, lh[c][1].z, lh[c][1].w};
+        float sv[4], hv[4];
+        rt_par_get(par, 2, i, plr, sv);
+        rt_par_get(par, 3, i, plr, hv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[c][e] = rt_silu(v[c][e] * sv[e] + hv[e]);
+        for (int e = 0; e < 4; ++e) v[i][e] = rt_silu(v[i][e] * sv[e] + hv[e]);
       }
-      rt_lstore8(img, pr, c0, v[c]);
+      rt_lstore4(img, pr, 128 * i + 4 * plr, v[i]);
     }
-    __syncthreads();
-#pragma unroll
-    for (int n = 0; n < NK; ++n) rt_lfrag(img, wid + NW * n, l15, q4, ah[n], al[n]);
   }
+  RT_WAIT_VM0();                                                  // this wave's slices have landed
+  if constexpr (PRO != RT_PRO_SP) __syncthreads();               // the A image is complete
+  spx8 wh[NFB][NK], wl[NFB][NK], ah[NK], al[NK];
+#pragma unroll
+  for (int n = 0; n < NK; ++n) {
+    if constexpr (PRO == RT_PRO_SP) rt_lfrag(wreg, n, l15, q4, ah[n], al[n]);
+    else rt_lfrag(img, wid + NW * n, l15, q4, ah[n], al[n]);
+  }
+#pragma unroll
+  for (int i = 0; i < NFB; ++i)
+#pragma unroll
+    for (int n = 0; n < NK; ++n) rt_lfrag(wreg + (NA + i * NK) * 2048, n, l15, q4, wh[i][n], wl[i][n]);
 
   // ---- 3. product over this wave's k-groups, then the sum over the waves -----------------------------------
+#if RT_STAMP
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+  RT_T(t_ops);
   f32x4 part[NFB];
 #pragma unroll
   for (int i = 0; i < NFB; ++i) {
     part[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool sw_i = blk_swapped(i);
 #pragma unroll
-    for (int n = 0; n < NK; ++n) part[i] = swapped ? rt_mma(ah[n], al[n], wh[i][n], wl[i][n], part[i]) : rt_mma(wh[i][n], wl[i][n], ah[n], al[n], part[i]);
+    for (int n = 0; n < NK; ++n) part[i] = sw_i ? rt_mma(ah[n], al[n], wh[i][n], wl[i][n], part[i]) : rt_mma(wh[i][n], wl[i][n], ah[n], al[n], part[i]);
   }
-  const f32x4 acc = rt_reduce<NW, NFB>(red, wid, lane, part);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // this wave's fragment reads are done: its staging region is free
+  const f32x4 acc = rt_reduce<NW, NFB>(stage0, STAGE_W, wid, lane, part);
   if (wid >= NFB) return;
+#if RT_STAMP
+  struct StampAtExit { unsigned long long a, b; int id; __device__ ~StampAtExit() { RT_STAMP_OUT(id, a, b); } } stamp_{t_in, t_ops, (int)(100 * PRO + 10 * EPI + (KT == 32 ? 1 : 0)) | (int)((t_iss - t_in) << 16)};
+#endif
 
   // ---- 4. epilogue (wave i: feature block i).  Standard roles: lane (token l15) holds features fcol .. fcol + 3 ---------------
   if constexpr (EPI == RT_EPI_QKV) {
-    if (swapped) {   // lane (feature f0 + 16 wid + l15) holds tokens q0 + 4 q4 .. + 3 of V^T; tokens beyond L are stored as zero
+    if (my_swapped) {   // lane (feature f0 + l15) holds tokens q0 + 4 q4 .. + 3 of V^T; tokens beyond L are stored as zero
       float o[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = (4 * q4 + r < nq) ? acc[r] : 0.f;
-      sp_store4(a.vt + ((size_t)b * CFD_D + f0 + 16 * wid + l15) * (RT_MAX_L * 4), q0 + 4 * q4, o[0], o[1], o[2], o[3]);
+      sp_store4(a.vt + ((size_t)b * CFD_D + blk_f0(wid) + l15) * (RT_MAX_L * 4), q0 + 4 * q4, o[0], o[1], o[2], o[3]);
       return;
     }
   }
@@ -337,9 +445,11 @@ __global__ void __launch_bounds__(NT, NT / 128) rt_gemm_kernel(const RtGemmArgs 
 
 // ------------------------------------------------------------------------------------------------
 // Self-attention core of one (head, token tile): o = softmax(q k^T) v for L <= 32 keys (cross_attention.py:568-572; q is
-// pre-scaled in the weights).  No LDS: every wave forms the 16 x 32 scores itself (S^T[key][query] = K . Q, 24 MFMAs) and
-// takes 2 of the head's 8 feature tiles of the P.V product.  The key rows are assigned to MFMA rows so that a lane's 8
-// score registers are keys 8 g .. 8 g + 7: exactly the k-slots it supplies as the second operand of P.V (as in attn_fused.hpp).
+// pre-scaled in the weights).  The head's q tile (8 KB), the row's keys (16 KB) and V^T (16 KB) come in by LDS-DMA, whole cache lines
+// per instruction; every wave then forms the 16 x 32 scores itself (S^T[key][query] = K . Q, 24 MFMAs) and takes 2 of the head's 8
+// feature tiles of the P.V product.  The key rows are assigned to MFMA rows so that a lane's 8 score registers are keys
+// 8 g .. 8 g + 7: exactly the k-slots it supplies as the second operand of P.V (as in attn_fused.hpp).
+// dynamic LDS: 40 KB
 // ------------------------------------------------------------------------------------------------
 struct RtSelfArgs {
   const char* qk;    // SP [M][1024]: q at k-groups 4 h .. 4 h + 3, k at 16 + 4 h ..
@@ -349,26 +459,44 @@ struct RtSelfArgs {
 };
 
 __global__ void __launch_bounds__(256) rt_selfattn_kernel(const RtSelfArgs a) {
+  RT_T(t_in);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* qimg = smem;                 // [4 k-groups][16 rows][128 B]
+  char* kimg = smem + 8192;          // [4 k-groups][32 rows][128 B]
+  char* vimg = smem + 8192 + 16384;  // [128 feature rows][128 B]
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l15 = lane & 15, q4 = lane >> 4;
   const int h = blockIdx.x, tile = blockIdx.y;
   const int b = tile / a.tpr, q0 = (tile - b * a.tpr) * 16, nq = min(16, a.L - q0);
   const long long tok0 = (long long)b * a.L;
-  const char* qrow = a.qk + (size_t)(tok0 + q0 + min(l15, nq - 1)) * 4096;
+  const char* rows0 = a.qk + (size_t)tok0 * 4096;
+  // 40 pieces of 8 rows x 128 B, 10 per wave: wave w takes k-group w of q (2) and of k (4), and feature rows 32 w .. of V^T (4)
+#pragma unroll
+  for (int pc = 0; pc < 2; ++pc) rt_dma_piece(qimg + wid * 2048, rows0, 4096, q0, a.L - 1, 8 * pc, 4 * h + wid, lane);
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) rt_dma_piece(kimg + wid * 4096, rows0, 4096, 0, a.L - 1, 8 * pc, 16 + 4 * h + wid, lane);
+  {
+    const char* vb = a.vt + ((size_t)b * CFD_D + h * CFD_HD) * (RT_MAX_L * 4);
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) rt_dma_piece(vimg, vb, RT_MAX_L * 4, 0, CFD_HD - 1, 32 * wid + 8 * pc, 0, lane);
+  }
+  RT_WAIT_VM0();
+  __syncthreads();
   const int key0 = 8 * (l15 >> 2) + (l15 & 3), key1 = key0 + 4;       // MFMA row l15 of key tile 0 / 1
-  const char* krow0 = a.qk + (size_t)(tok0 + min(key0, a.L - 1)) * 4096;
-  const char* krow1 = a.qk + (size_t)(tok0 + min(key1, a.L - 1)) * 4096;
   spx8 qh[4], ql[4], k0h[4], k0l[4], k1h[4], k1l[4], vh[2], vl[2];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    rt_gfrag(qrow, 4 * h + g, q4, qh[g], ql[g]);
-    rt_gfrag(krow0, 16 + 4 * h + g, q4, k0h[g], k0l[g]);
-    rt_gfrag(krow1, 16 + 4 * h + g, q4, k1h[g], k1l[g]);
+    rt_lfrag_row(qimg, g, 16, l15, q4, qh[g], ql[g]);
+    rt_lfrag_row(kimg, g, 32, key0, q4, k0h[g], k0l[g]);
+    rt_lfrag_row(kimg, g, 32, key1, q4, k1h[g], k1l[g]);
   }
 #pragma unroll
-  for (int n = 0; n < 2; ++n)
-    rt_gfrag(a.vt + ((size_t)b * CFD_D + h * CFD_HD + (2 * wid + n) * 16 + l15) * (RT_MAX_L * 4), 0, q4, vh[n], vl[n]);
+  for (int n = 0; n < 2; ++n) rt_lfrag_row(vimg, 0, CFD_HD, (2 * wid + n) * 16 + l15, q4, vh[n], vl[n]);
+#if RT_STAMP
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+  RT_T(t_ops);
   f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -389,11 +517,12 @@ __global__ void __launch_bounds__(256) rt_selfattn_kernel(const RtSelfArgs a) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) { p[e] = __expf(p[e] - mx); sum += p[e]; }
   sum = xlane_sum(sum);
+  const float inv = rt_rcp(sum);
   spx8 ph, pl;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     sp_t hi, lo;
-    split_f32(p[e] / sum, hi, lo);
+    split_f32(p[e] * inv, hi, lo);
     ph[e] = hi;
     pl[e] = lo;
   }
@@ -403,12 +532,14 @@ __global__ void __launch_bounds__(256) rt_selfattn_kernel(const RtSelfArgs a) {
     if (l15 < nq)
       sp_store4(a.o + (size_t)(tok0 + q0 + l15) * (CFD_D * 4), h * CFD_HD + (2 * wid + n) * 16 + 4 * q4, o[0], o[1], o[2], o[3]);
   }
+  RT_STAMP_OUT(1000, t_in, t_ops);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Cross-attention, first half: LayerNorm2 of the tile's rows and the scores against 16 folded keys of one memory
 // (cross_attention.py:578-652, folded + timestep-hoisted form, see the header):
 //   sc[token][off_j + s] = rs_s (q . KA_s + q . (A b_t)) + cbk_s
+// dynamic LDS: A image 32 KB | parameters 8 KB | 8 x 4 KB staging | c_q
 // ------------------------------------------------------------------------------------------------
 struct RtXArgs {
   const float* x;               // fp32 [M][512]: the residual stream in front of the cross-attention block
@@ -417,13 +548,11 @@ struct RtXArgs {
   const float* ln_b;
   const float* bias;            // folded cross-attention bias [512]
   int L, tpr, nl, layer;
-  const int* d_step;
   const char* K[CFD_NMEM];      // this layer's folded keys: SP [U_j * Sp_j][512]
   const char* VT[CFD_NMEM];     // this layer's folded values^T: SP [U_j][512][Sp_j]
-  const float* cbt[CFD_NMEM];   // per-step key tables [T][nl + 1][U_j * Sp_j]: plane l = cbk of layer l, plane nl = rs
-  const float* kb[CFD_NMEM];    // A_l b_t [512] at kb[j] + t * kb_stride
-  const float* vb[CFD_NMEM];    // VV_l b_t [512] at vb[j] + t * vb_stride
-  long long kb_stride[CFD_NMEM], vb_stride[CFD_NMEM];
+  const float* cbt[CFD_NMEM];   // THIS STEP's key tables [nl + 1][U_j * Sp_j]: plane l = cbk of layer l, plane nl = rs
+  const float* kb[CFD_NMEM];    // A_l b_t [512] of this layer at this step
+  const float* vb[CFD_NMEM];    // VV_l b_t [512] of this layer at this step
   const int* map[CFD_NMEM];     // batch row -> memory instance
   int rows[CFD_NMEM];           // U_j * Sp_j
   int S[CFD_NMEM], Sp[CFD_NMEM], off[CFD_NMEM];
@@ -434,20 +563,25 @@ struct RtXArgs {
   float* att[CFD_NMEM];         // optional att_mats [Be][nl][L][S_j]
 };
 
-template <int NT>
-__global__ void __launch_bounds__(NT) rt_xscore_kernel(const RtXArgs a) {
-  constexpr int NW = NT / 64, LPR = NT / 16, CH = CFD_D / (LPR * 8);
-  constexpr int NK = 16 / NW;                                    // k-groups per wave (K = 512)
+#define RT_XS_LDS (16 * 2048 + 8192 + 8 * 4096 + 64)
+__global__ void __launch_bounds__(512) rt_xscore_kernel(const RtXArgs a) {
+  constexpr int NW = 8, NK = 2, STAGE_W = NK * 2048;
+  RT_T(t_in);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* img = smem;
-  char* red = smem + 16 * 2048;
-  float* cq = reinterpret_cast<float*>(smem + 16 * 2048 + NW * 1024);
+  char* par = smem + 16 * 2048;
+  char* stage0 = smem + 16 * 2048 + 8192;
+  float* cq = reinterpret_cast<float*>(stage0 + NW * STAGE_W);
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* wreg = stage0 + wid * STAGE_W;
   const int l15 = lane & 15, q4 = lane >> 4;
   const int tile = blockIdx.y;
   const int b = tile / a.tpr, q0 = (tile - b * a.tpr) * 16, nq = min(16, a.L - q0);
   const long long tok0 = (long long)b * a.L + q0;
+  const int pr = threadIdx.x >> 5, plr = threadIdx.x & 31;
+  float v[4][4];
+  rt_rows_load(a.x, tok0 + min(pr, nq - 1), plr, v);   // (first: the rows depend on nothing but the tile)
   int j = 0;
 #pragma unroll
   for (int q = 1; q < CFD_NMEM; ++q)
@@ -457,71 +591,55 @@ __global__ void __launch_bounds__(NT) rt_xscore_kernel(const RtXArgs a) {
   for (int q = 1; q < CFD_NMEM; ++q)
     if (j == q) blk_first = a.blk0[q];
   const int s0 = ((int)blockIdx.x - blk_first) * 16;
-  const int t = *a.d_step;
   const int u = rt_sel(a.map, j)[b];
   const int rows = rt_sel(a.rows, j), Sp = rt_sel(a.Sp, j);
   const long long key0 = (long long)u * Sp + s0;
-
-  const int pr = threadIdx.x / LPR, plr = threadIdx.x % LPR;
-  float v[CH][8];
-  {
-    const float* xr = a.x + (tok0 + min(pr, nq - 1)) * CFD_D + plr * 8;
+  const float4 parv = rt_par_fetch<3>(a.ln_g, a.ln_b, rt_sel(a.kb, j), nullptr);
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const float4 p0 = *reinterpret_cast<const float4*>(xr + c * (LPR * 8));
-      const float4 p1 = *reinterpret_cast<const float4*>(xr + c * (LPR * 8) + 4);
-      v[c][0] = p0.x; v[c][1] = p0.y; v[c][2] = p0.z; v[c][3] = p0.w; v[c][4] = p1.x; v[c][5] = p1.y; v[c][6] = p1.z; v[c][7] = p1.w;
-    }
-  }
-  spx8 kh[NK], kl[NK], ah[NK], al[NK];
-  {
-    const char* krow = rt_sel(a.K, j) + (size_t)(key0 + l15) * (CFD_D * 4);
-#pragma unroll
-    for (int n = 0; n < NK; ++n) rt_gfrag(krow, wid + NW * n, q4, kh[n], kl[n]);
-  }
-  const float* kbp = rt_sel(a.kb, j) + (long long)t * rt_sel(a.kb_stride, j);
-  float4 lg[CH][2], lb[CH][2], lk[CH][2];
-#pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    const int c0 = c * (LPR * 8) + plr * 8;
-    lg[c][0] = *reinterpret_cast<const float4*>(a.ln_g + c0); lg[c][1] = *reinterpret_cast<const float4*>(a.ln_g + c0 + 4);
-    lb[c][0] = *reinterpret_cast<const float4*>(a.ln_b + c0); lb[c][1] = *reinterpret_cast<const float4*>(a.ln_b + c0 + 4);
-    lk[c][0] = *reinterpret_cast<const float4*>(kbp + c0); lk[c][1] = *reinterpret_cast<const float4*>(kbp + c0 + 4);
-  }
-  const float* tab = rt_sel(a.cbt, j) + (long long)t * (a.nl + 1) * rows;
+  for (int n = 0; n < NK; ++n) rt_dma_slice(wreg + n * 2048, rt_sel(a.K, j) + (size_t)key0 * (CFD_D * 4), CFD_D * 4, 15, wid + NW * n, lane);
+  const float* tab = rt_sel(a.cbt, j);
   float4 e_rs = make_float4(0.f, 0.f, 0.f, 0.f), e_cb = e_rs;
   if (wid == 0) {
     e_rs = *reinterpret_cast<const float4*>(tab + (long long)a.nl * rows + key0 + 4 * q4);
     e_cb = *reinterpret_cast<const float4*>(tab + (long long)a.layer * rows + key0 + 4 * q4);
   }
   // LayerNorm2 -> image; c_q = q . (A b_t)
-  {
-    const float rstd = rt_ln_stats<LPR, CH>(v);
-    float dot = 0.f;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int c0 = c * (LPR * 8) + plr * 8;
-      const float gg[8] = {lg[c][0].x, lg[c][0].y, lg[c][0].z, lg[c][0].w, lg[c][1].x, lg[c][1].y, lg[c][1].z, lg[c][1].w};
-      const float bb[8] = {lb[c][0].x, lb[c][0].y, lb[c][0].z, lb[c][0].w, lb[c][1].x, lb[c][1].y, lb[c][1].z, lb[c][1].w};
-      const float4 k0 = lk[c][0], k1 = lk[c][1];
-      const float kk[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[c][e] = v[c][e] * rstd * gg[e] + bb[e];
-        dot += v[c][e] * kk[e];
-      }
-      rt_lstore8(img, pr, c0, v[c]);
-    }
-    dot = rt_row_sum<LPR>(dot);
-    if (plr == 0) cq[pr] = dot;
-  }
+  reinterpret_cast<float4*>(par)[threadIdx.x] = parv;
+  const float rstd = rt_ln_stats(v);
   __syncthreads();
+  float dot = 0.f;
 #pragma unroll
-  for (int n = 0; n < NK; ++n) rt_lfrag(img, wid + NW * n, l15, q4, ah[n], al[n]);
+  for (int i = 0; i < 4; ++i) {
+    float gg[4], bb[4], kk[4];
+    rt_par_get(par, 0, i, plr, gg);
+    rt_par_get(par, 1, i, plr, bb);
+    rt_par_get(par, 2, i, plr, kk);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[i][e] = v[i][e] * rstd * gg[e] + bb[e];
+      dot += v[i][e] * kk[e];
+    }
+    rt_lstore4(img, pr, 128 * i + 4 * plr, v[i]);
+  }
+  dot = rt_row_sum<RT_LPR>(dot);
+  if (plr == 0) cq[pr] = dot;
+  RT_WAIT_VM0();
+  __syncthreads();
+  spx8 kh[NK], kl[NK], ah[NK], al[NK];
+#pragma unroll
+  for (int n = 0; n < NK; ++n) {
+    rt_lfrag(img, wid + NW * n, l15, q4, ah[n], al[n]);
+    rt_lfrag(wreg, n, l15, q4, kh[n], kl[n]);
+  }
+  RT_T(t_ops);
   f32x4 part[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
   for (int n = 0; n < NK; ++n) part[0] = rt_mma(kh[n], kl[n], ah[n], al[n], part[0]);   // S^T[key][token]
-  const f32x4 acc = rt_reduce<NW, 1>(red, wid, lane, part);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const f32x4 acc = rt_reduce<NW, 1>(stage0, STAGE_W, wid, lane, part);
+#if RT_STAMP
+  struct StampAtExit { unsigned long long a, b; __device__ ~StampAtExit() { RT_STAMP_OUT(2000, a, b); } } stamp_{t_in, t_ops};
+#endif
   if (wid != 0 || l15 >= nq) return;
   const float c_q = cq[l15];
   const float4 o = make_float4(e_rs.x * (acc[0] + c_q) + e_cb.x, e_rs.y * (acc[1] + c_q) + e_cb.y, e_rs.z * (acc[2] + c_q) + e_cb.z,
@@ -533,36 +651,41 @@ __global__ void __launch_bounds__(NT) rt_xscore_kernel(const RtXArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // Cross-attention, second half: softmax per memory, P' = p rs, x += sum_j (VA_j^T P'_j + (sum P'_j) VV_j b_t) + bias for 16 features
+// MAXKEYS: capacity in padded keys (512: the product shape's 320 keys; 1024).  Thread (row pr, lane plr) owns the 4-key chunks
+// plr + 32 n: 16-byte loads contiguous across the row's lanes.
+// dynamic LDS: P' image (Sp_tot / 32) x 2 KB | 8 x MAXN x 2 KB staging | sum_s P'_s [16][8]
 // ------------------------------------------------------------------------------------------------
-template <int NT>
-__global__ void __launch_bounds__(NT) rt_xpv_kernel(const RtXArgs a) {
-  constexpr int NW = NT / 64, LPR = NT / 16;
-  constexpr int MAXC = RT_MAX_KEYS / 8 / LPR;                    // 8-key chunks per lane
-  constexpr int MAXN = RT_MAX_KEYS / 32 / NW;                    // k-groups per wave
+template <int MAXKEYS>
+__global__ void __launch_bounds__(512) rt_xpv_kernel(const RtXArgs a) {
+  constexpr int NW = 8;
+  constexpr int MAXC = MAXKEYS / 4 / RT_LPR;                     // 4-key chunks per lane
+  constexpr int MAXN = MAXKEYS / 32 / NW;                        // k-groups per wave
+  constexpr int STAGE_W = MAXN * 2048;
+  RT_T(t_in);
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int KT = a.Sp_tot / 32;
   char* img = smem;                                              // P' image: Sp_tot / 32 k-groups x 2 KB
-  char* red = smem + (a.Sp_tot / 32) * 2048;
-  float* ws = reinterpret_cast<float*>(red + NW * 1024);         // [16 tokens][8]: sum_s P'_s per memory
+  char* stage0 = smem + KT * 2048;
+  float* ws = reinterpret_cast<float*>(stage0 + NW * STAGE_W);   // [16 tokens][8]: sum_s P'_s per memory
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* wreg = stage0 + wid * STAGE_W;
   const int l15 = lane & 15, q4 = lane >> 4;
   const int fb = blockIdx.x, tile = blockIdx.y, f0 = fb * 16;
   const int b = tile / a.tpr, q0 = (tile - b * a.tpr) * 16, nq = min(16, a.L - q0);
   const long long tok0 = (long long)b * a.L + q0;
-  const int t = *a.d_step;
-  const int KT = a.Sp_tot / 32;
   static_assert(CFD_NMEM == 5, "five named instance indices");
   const int u0 = a.map[0][b], u1 = a.map[1][b], u2 = a.map[2][b], u3 = a.map[3][b], u4 = a.map[4][b];   // (named scalars: a local array indexed through rt_sel goes to scratch)
   auto inst = [&](int j) __attribute__((always_inline)) { return j == 0 ? u0 : j == 1 ? u1 : j == 2 ? u2 : j == 3 ? u3 : u4; };
 
-  // ---- loads: the tile's scores and per-key scales (prologue lanes), the V^T fragments of this wave's k-groups --------
-  const int pr = threadIdx.x / LPR, plr = threadIdx.x % LPR;
-  float s[MAXC][8], rsv[MAXC][8];
+  // ---- loads: the tile's scores and per-key scales (prologue lanes), the V^T slices of this wave's k-groups --------
+  const int pr = threadIdx.x >> 5, plr = threadIdx.x & 31;
+  float s[MAXC][4], rsv[MAXC][4];
   int cj[MAXC];
-  const float* srow = a.sc + (tok0 + min(pr, nq - 1)) * a.Sp_tot;
+  const long long srow = (tok0 + min(pr, nq - 1)) * a.Sp_tot;
 #pragma unroll
   for (int n = 0; n < MAXC; ++n) {
-    const int c0 = (plr + LPR * n) * 8;
+    const int c0 = (plr + RT_LPR * n) * 4;
     cj[n] = -1;
     if (c0 < a.Sp_tot) {
       int j = 0;
@@ -570,14 +693,12 @@ __global__ void __launch_bounds__(NT) rt_xpv_kernel(const RtXArgs a) {
       for (int q = 1; q < CFD_NMEM; ++q)
         if (c0 >= a.off[q]) j = q;
       cj[n] = j;
-      const float4 p0 = *reinterpret_cast<const float4*>(srow + c0), p1 = *reinterpret_cast<const float4*>(srow + c0 + 4);
-      s[n][0] = p0.x; s[n][1] = p0.y; s[n][2] = p0.z; s[n][3] = p0.w; s[n][4] = p1.x; s[n][5] = p1.y; s[n][6] = p1.z; s[n][7] = p1.w;
-      const float* rp = a.rsp + (tok0 + min(pr, nq - 1)) * a.Sp_tot + c0;
-      const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
-      rsv[n][0] = r0.x; rsv[n][1] = r0.y; rsv[n][2] = r0.z; rsv[n][3] = r0.w; rsv[n][4] = r1.x; rsv[n][5] = r1.y; rsv[n][6] = r1.z; rsv[n][7] = r1.w;
+      const float4 p0 = *reinterpret_cast<const float4*>(a.sc + srow + c0);
+      const float4 r0 = *reinterpret_cast<const float4*>(a.rsp + srow + c0);
+      s[n][0] = p0.x; s[n][1] = p0.y; s[n][2] = p0.z; s[n][3] = p0.w;
+      rsv[n][0] = r0.x; rsv[n][1] = r0.y; rsv[n][2] = r0.z; rsv[n][3] = r0.w;
     }
   }
-  spx8 vh[MAXN], vl[MAXN], ph[MAXN], pl[MAXN];
   const int nk = (KT - wid + NW - 1) / NW;
 #pragma unroll
   for (int n = 0; n < MAXN; ++n) {
@@ -587,9 +708,8 @@ __global__ void __launch_bounds__(NT) rt_xpv_kernel(const RtXArgs a) {
 #pragma unroll
       for (int q = 1; q < CFD_NMEM; ++q)
         if (kt * 32 >= a.off[q]) j = q;
-      const int Sp = rt_sel(a.Sp, j);
-      const char* vrow = rt_sel(a.VT, j) + ((size_t)inst(j) * CFD_D + f0 + l15) * ((size_t)Sp * 4);
-      rt_gfrag(vrow, kt - rt_sel(a.off, j) / 32, q4, vh[n], vl[n]);
+      const long long ld = (long long)rt_sel(a.Sp, j) * 4;
+      rt_dma_slice(wreg + n * 2048, rt_sel(a.VT, j) + ((size_t)inst(j) * CFD_D + f0) * ld, ld, 15, kt - rt_sel(a.off, j) / 32, lane);
     }
   }
   const int fcol = f0 + 4 * q4;
@@ -599,62 +719,76 @@ __global__ void __launch_bounds__(NT) rt_xpv_kernel(const RtXArgs a) {
     ep_r = *reinterpret_cast<const float4*>(a.x + (tok0 + min(l15, nq - 1)) * CFD_D + fcol);
     ep_b = *reinterpret_cast<const float4*>(a.bias + fcol);
 #pragma unroll
-    for (int j = 0; j < CFD_NMEM; ++j) ep_vb[j] = *reinterpret_cast<const float4*>(a.vb[j] + (long long)t * a.vb_stride[j] + fcol);
+    for (int j = 0; j < CFD_NMEM; ++j) ep_vb[j] = *reinterpret_cast<const float4*>(a.vb[j] + fcol);
   }
 
+  RT_T(t_a);
   // ---- softmax per memory over the row's lanes; P' -> image; sum_s P'_s -> ws ----------------------------------
-#pragma unroll
+  // (a rolled loop: unrolled five times this was 29 KB of code)
+#pragma unroll 1
   for (int j = 0; j < CFD_NMEM; ++j) {
     float mx = -INFINITY;
 #pragma unroll
     for (int n = 0; n < MAXC; ++n)
       if (cj[n] == j) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, s[n][e]);
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[n][e]);
       }
-    mx = rt_row_max<LPR>(mx);
+    mx = rt_row_max<RT_LPR>(mx);
     float sum = 0.f;
 #pragma unroll
     for (int n = 0; n < MAXC; ++n)
       if (cj[n] == j) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s[n][e] = __expf(s[n][e] - mx); sum += s[n][e]; }   // all keys dead: NaN, as the reference
+        for (int e = 0; e < 4; ++e) { s[n][e] = __expf(s[n][e] - mx); sum += s[n][e]; }   // all keys dead: NaN, as the reference
       }
-    sum = rt_row_sum<LPR>(sum);
+    sum = rt_row_sum<RT_LPR>(sum);
     const float inv = rt_rcp(sum);
     float wsum = 0.f;
-    float* att = a.att[j];
-    const int S = a.S[j];
+    float* att = rt_sel(a.att, j);
+    const int S = rt_sel(a.S, j), offj = rt_sel(a.off, j);
 #pragma unroll
     for (int n = 0; n < MAXC; ++n)
       if (cj[n] == j) {
-        const int c0 = (plr + LPR * n) * 8;
+        const int c0 = (plr + RT_LPR * n) * 4;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[n][e] = s[n][e] * inv;
+        for (int e = 0; e < 4; ++e) s[n][e] = s[n][e] * inv;
         if (att && fb == 0 && pr < nq) {
           float* ap = att + (((long long)b * a.nl + a.layer) * a.L + q0 + pr) * S;
-          const int k0 = c0 - a.off[j];
+          const int k0 = c0 - offj;
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
+          for (int e = 0; e < 4; ++e)
             if (k0 + e < S) ap[k0 + e] = s[n][e];
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s[n][e] *= rsv[n][e]; wsum += s[n][e]; }
-        rt_lstore8(img, pr, c0, s[n]);
+        for (int e = 0; e < 4; ++e) { s[n][e] *= rsv[n][e]; wsum += s[n][e]; }
+        rt_lstore4(img, pr, c0, s[n]);
       }
-    wsum = rt_row_sum<LPR>(wsum);
+    wsum = rt_row_sum<RT_LPR>(wsum);
     if (plr == 0) ws[pr * 8 + j] = wsum;
   }
+  RT_T(t_b);
+  RT_WAIT_VM0();
   __syncthreads();
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  RT_T(t_ops);
+#if RT_STAMP
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // first record: entry, loads issued, softmax done
+    const unsigned k_ = atomicAdd(&g_rt_seq, 1u) & 4095u;
+    g_rt_ring[4 * k_] = 3001; g_rt_ring[4 * k_ + 1] = t_in; g_rt_ring[4 * k_ + 2] = t_a; g_rt_ring[4 * k_ + 3] = t_b;
+  }
+  struct StampAtExit { unsigned long long a, b; int id; __device__ ~StampAtExit() { RT_STAMP_OUT(id, a, b); } } stamp_{t_in, t_ops, 3000};
+#endif
+  f32x4 part[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
   for (int n = 0; n < MAXN; ++n)
     if (n < nk) {
-      rt_lfrag(img, wid + NW * n, l15, q4, ph[n], pl[n]);
-      acc = rt_mma(vh[n], vl[n], ph[n], pl[n], acc);   // O^T[feature][token]
+      spx8 ph, pl, vh, vl;
+      rt_lfrag(img, wid + NW * n, l15, q4, ph, pl);
+      rt_lfrag(wreg, n, l15, q4, vh, vl);
+      part[0] = rt_mma(vh, vl, ph, pl, part[0]);   // O^T[feature][token]
     }
-  const f32x4 part[1] = {acc};
-  acc = rt_reduce<NW, 1>(red, wid, lane, part);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const f32x4 acc = rt_reduce<NW, 1>(stage0, STAGE_W, wid, lane, part);
   if (wid != 0 || l15 >= nq) return;
   float o[4] = {acc[0], acc[1], acc[2], acc[3]};
 #pragma unroll
@@ -665,6 +799,34 @@ __global__ void __launch_bounds__(NT) rt_xpv_kernel(const RtXArgs a) {
   float4 r = ep_r;
   r.x = (r.x + ep_b.x) + o[0]; r.y = (r.y + ep_b.y) + o[1]; r.z = (r.z + ep_b.z) + o[2]; r.w = (r.w + ep_b.w) + o[3];
   *reinterpret_cast<float4*>(a.xo + (tok0 + l15) * CFD_D + fcol) = r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Start of a captured iteration on the row-tile path: row *d_step of every per-step table -> the fixed "this step" buffers the
+// launches of the iteration read (so that none of them has the step index as a dependent scalar load in front of its operands)
+// ------------------------------------------------------------------------------------------------
+#define RT_NTAB 16
+struct RtStepRowsArgs {
+  const float* src[RT_NTAB];    // table base; row t at src + t * n4 * 4 floats
+  float* dst[RT_NTAB];
+  int n4[RT_NTAB];              // float4 per row
+  int first[RT_NTAB + 1];       // first workgroup of table k
+  int ntab;
+  const int* d_step;
+};
+__global__ void __launch_bounds__(256) rt_step_rows_kernel(const RtStepRowsArgs a) {
+  int k = 0;
+#pragma unroll
+  for (int q = 1; q < RT_NTAB; ++q)
+    if (q < a.ntab && (int)blockIdx.x >= a.first[q]) k = q;
+  const float* src = a.src[0];
+  float* dst = a.dst[0];
+  int n4 = a.n4[0], first = 0;
+#pragma unroll
+  for (int q = 1; q < RT_NTAB; ++q)
+    if (k == q) { src = a.src[q]; dst = a.dst[q]; n4 = a.n4[q]; first = a.first[q]; }
+  const int i = ((int)blockIdx.x - first) * 256 + threadIdx.x;
+  if (i < n4) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[(long long)(*a.d_step) * n4 + i];
 }
 
 // ------------------------------------------------------------------------------------------------

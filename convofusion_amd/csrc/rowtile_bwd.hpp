@@ -46,9 +46,7 @@ struct RtBwdArgs {
   const float* x;        // LN / TB: the LayerNorm's input rows [M][512]
   const float* gamma;    // LayerNorm weight
   const float* beta;     // TB: LayerNorm bias
-  const float* ss;       // TB: (1 + scale | shift), row t at ss + t * ss_tstride
-  long long ss_tstride;
-  const int* d_step;
+  const float* ss;       // TB: (1 + scale | shift) of this time block at this step [1024]
   float* gout;           // LN / TB: the updated running gradient, written by workgroup x == 0
   // weights: fp32 [K][ldw], outputs n contiguous
   const float* w;
@@ -136,7 +134,7 @@ __device__ __forceinline__ void rt_bwd_row_load(RtBwdRow& r, const float* a, con
 template <int NW>
 __device__ __forceinline__ f32x4 rt_reduce1(char* red, int wid, int lane, f32x4 acc) {
   const f32x4 part[1] = {acc};
-  return rt_reduce<NW, 1>(red, wid, lane, part);
+  return rt_reduce<NW, 1>(red, 1024, wid, lane, part);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -171,9 +169,7 @@ __global__ void __launch_bounds__(512) rt_bwd_gemm_kernel(const RtBwdArgs a) {
         rows[i][0] = d.x; rows[i][1] = d.y; rows[i][2] = d.z; rows[i][3] = d.w;
       }
   } else {
-    const float* sc = nullptr;
-    if constexpr (PRO == RT_BPRO_TB) sc = a.ss + (long long)(*a.d_step) * a.ss_tstride;
-    rt_bwd_row_load<PRO == RT_BPRO_TB>(r, a.a, a.g, a.x, a.gamma, a.beta, sc, prow, plr);
+    rt_bwd_row_load<PRO == RT_BPRO_TB>(r, a.a, a.g, a.x, a.gamma, a.beta, a.ss, prow, plr);
   }
   const int nstep = K / (4 * NW);                               // MFMAs of this wave: k = wid * (K / 8) + 4 i + q4
   const int kbase = wid * (K / NW) + q4;
@@ -230,22 +226,19 @@ __global__ void __launch_bounds__(512) rt_bwd_gemm_kernel(const RtBwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 struct RtXBwdArgs {
   int L, tpr, nl, layer;
-  const int* d_step;
   // TB prologue (B4)
   const float* dz;
   const float* g;
   const float* x;
   const float* gamma;
   const float* beta;
-  const float* ss;
-  long long ss_tstride;
+  const float* ss;              // time block 2's (1 + scale | shift) at this step
   float* gout;
   // memories
   const char* K[CFD_NMEM];      // this layer's folded keys: SP [U_j * Sp_j][512]
   const char* VT[CFD_NMEM];     // this layer's folded values^T: SP [U_j][512][Sp_j]
-  const float* kb[CFD_NMEM];    // A_l b_t
+  const float* kb[CFD_NMEM];    // A_l b_t of this layer at this step
   const float* vb[CFD_NMEM];    // VV_l b_t
-  long long kb_stride[CFD_NMEM], vb_stride[CFD_NMEM];
   const int* map[CFD_NMEM];
   int S[CFD_NMEM], Sp[CFD_NMEM], off[CFD_NMEM];
   int blk0[CFD_NMEM + 1];
@@ -279,14 +272,13 @@ __global__ void __launch_bounds__(512) rt_xbwd_dp_kernel(const RtXBwdArgs a) {
   for (int q = 1; q < CFD_NMEM; ++q)
     if (j == q) blk_first = a.blk0[q];
   const int s0 = ((int)blockIdx.x - blk_first) * 16;
-  const int t = *a.d_step;
   const int u = rt_sel(a.map, j)[b];
   const int Sp = rt_sel(a.Sp, j);
   const int pr = threadIdx.x >> 5, plr = threadIdx.x & 31;
   const long long prow = tok0 + min(pr, nq - 1);
   RtBwdRow r;
-  rt_bwd_row_load<true>(r, a.dz, a.g, a.x, a.gamma, a.beta, a.ss + (long long)t * a.ss_tstride, prow, plr);
-  const float* vbp = rt_sel(a.vb, j) + (long long)t * rt_sel(a.vb_stride, j);
+  rt_bwd_row_load<true>(r, a.dz, a.g, a.x, a.gamma, a.beta, a.ss, prow, plr);
+  const float* vbp = rt_sel(a.vb, j);
   float vbv[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -359,7 +351,6 @@ __global__ void __launch_bounds__(512) rt_xbwd_dy_kernel(const RtXBwdArgs a) {
   const int tile = blockIdx.y, f0 = blockIdx.x * 16;
   const int b = tile / a.tpr, q0 = (tile - b * a.tpr) * 16, nq = min(16, a.L - q0);
   const long long tok0 = (long long)b * a.L + q0;
-  const int t = *a.d_step;
   // key -> row pointer table
   for (int s = threadIdx.x; s < KS; s += 512) {
     int j = 0;
@@ -406,7 +397,7 @@ __global__ void __launch_bounds__(512) rt_xbwd_dy_kernel(const RtXBwdArgs a) {
   float4 ep_kb[CFD_NMEM];
   if (wid == 0) {
 #pragma unroll
-    for (int j = 0; j < CFD_NMEM; ++j) ep_kb[j] = *reinterpret_cast<const float4*>(a.kb[j] + (long long)t * a.kb_stride[j] + fcol);
+    for (int j = 0; j < CFD_NMEM; ++j) ep_kb[j] = *reinterpret_cast<const float4*>(a.kb[j] + fcol);
   }
   // softmax (recomputed from the saved scores) and its backward, per memory
 #pragma unroll

@@ -133,18 +133,16 @@ static int enqueue(Ctx* c, hipStream_t st, bool full, const EvalArgs& e) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_selfattn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_sa));
     attr |= 1ull << (c->cfg.device & 63);
   }
-  const int* dstep = w->d_step.as<int>();
   RtBwdArgs base;
   memset(&base, 0, sizeof(base));
-  base.L = L; base.tpr = tpr; base.d_step = dstep; base.ss_tstride = (long long)nl * 2 * 2 * CFD_D;
+  base.L = L; base.tpr = tpr;
   RtXBwdArgs xb;
   memset(&xb, 0, sizeof(xb));
-  xb.L = L; xb.tpr = tpr; xb.nl = nl; xb.d_step = dstep; xb.ss_tstride = base.ss_tstride; xb.Sp_tot = p.Sp_tot;
+  xb.L = L; xb.tpr = tpr; xb.nl = nl; xb.Sp_tot = p.Sp_tot;   // (one table row: T = 1, the tables ARE this step's rows)
   xb.rsp = w->p_sp.as<float>(); xb.d_att = s.d_att; xb.dP = s.dP; xb.dy = s.dy;
   int nkb = 0;
   for (int j = 0; j < CFD_NMEM; ++j) {
     xb.map[j] = p.map[j]; xb.S[j] = p.S[j]; xb.Sp[j] = p.Sp[j]; xb.off[j] = p.off[j];
-    xb.kb_stride[j] = nl * CFD_D + 32; xb.vb_stride[j] = nl * CFD_D;
     xb.blk0[j] = nkb; nkb += p.Sp[j] / 16;
   }
   xb.blk0[CFD_NMEM] = nkb;

@@ -539,7 +539,7 @@ def test_small_problems_take_the_row_tile_path_and_the_three_paths_agree():
         run.steps(2)
         outs.append(run.read(close=True))
     print("launches (xattn class, row kernels, all) per path:", prof)
-    assert prof[0][:2] == (18, 0) and prof[0][2] == 83          # 9 layers x 9 launches + embedding + final projection
+    assert prof[0][:2] == (18, 0) and prof[0][2] == 84          # this step's table rows + embedding + 9 layers x 9 launches + final projection
     assert prof[1][0] == 9 and prof[2][0] == 0
     for k in (1, 2):
         d = float((outs[0] - outs[k]).norm() / outs[k].norm())
