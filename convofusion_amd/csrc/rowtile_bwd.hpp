@@ -337,37 +337,46 @@ __global__ void __launch_bounds__(512) rt_xbwd_dp_kernel(const RtXBwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(512) rt_xbwd_dy_kernel(const RtXBwdArgs a) {
   constexpr int NW = 8, LPR = 32;
-  constexpr int MAXC = RT_MAX_KEYS / 8 / LPR;                    // 8-key chunks per lane
+  constexpr int MAXC = RT_MAX_KEYS / 4 / LPR;                    // 4-key chunks per lane
   constexpr int MAXSTEP = RT_MAX_KEYS / (4 * NW);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int KS = a.Sp_tot, RS = RT_BSTRIDE(KS);
   float* img = reinterpret_cast<float*>(smem);
   char* red = smem + (size_t)16 * RS * 4;
-  const char** krow = reinterpret_cast<const char**>(red + NW * 1024);   // [Sp_tot]: the key's row of its memory's folded keys
-  float* dcq = reinterpret_cast<float*>(red + NW * 1024 + (size_t)KS * 8);   // [16 tokens][8]
+  float* dcq = reinterpret_cast<float*>(red + NW * 1024);   // [16 tokens][8]
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l15 = lane & 15, q4 = lane >> 4;
   const int tile = blockIdx.y, f0 = blockIdx.x * 16;
   const int b = tile / a.tpr, q0 = (tile - b * a.tpr) * 16, nq = min(16, a.L - q0);
   const long long tok0 = (long long)b * a.L + q0;
-  // key -> row pointer table
-  for (int s = threadIdx.x; s < KS; s += 512) {
-    int j = 0;
+  // this wave's operand: KA[key][f0 + l15] for its keys kbase + 4 i, read from the folded keys (split pairs) -- requested before the
+  // prologue, so that the loads run under the softmax backward
+  static_assert(CFD_NMEM == 5, "five named instance indices");
+  const int u0 = a.map[0][b], u1 = a.map[1][b], u2 = a.map[2][b], u3 = a.map[3][b], u4 = a.map[4][b];
+  const int nstep = KS / (4 * NW);
+  const int kbase = wid * (KS / NW) + q4;
+  const int fo = ((f0 + l15) >> 5) * 128 + ((f0 + l15) & 31) * 2;   // this lane's feature inside an SP key row
+  float wv[MAXSTEP];
 #pragma unroll
-    for (int q = 1; q < CFD_NMEM; ++q)
-      if (s >= a.off[q]) j = q;
-    const int sl = s - rt_sel(a.off, j);
-    krow[s] = rt_sel(a.K, j) + ((size_t)rt_sel(a.map, j)[b] * rt_sel(a.Sp, j) + sl) * (CFD_D * 4);
-  }
-  // prologue loads: scores, dP (or d_att), rs of this lane's chunks
+  for (int i = 0; i < MAXSTEP; ++i)
+    if (i < nstep) {
+      const int key = kbase + 4 * i;
+      int j = 0;
+#pragma unroll
+      for (int q = 1; q < CFD_NMEM; ++q)
+        if (key >= a.off[q]) j = q;
+      const int u = j == 0 ? u0 : j == 1 ? u1 : j == 2 ? u2 : j == 3 ? u3 : u4;
+      wv[i] = rt_sp_f32(rt_sel(a.K, j) + ((size_t)u * rt_sel(a.Sp, j) + (key - rt_sel(a.off, j))) * (CFD_D * 4) + fo);
+    }
+  // prologue loads: scores, dP (or d_att), rs of this lane's 4-key chunks plr + 32 n (16-byte loads contiguous across the row's lanes)
   const int pr = threadIdx.x / LPR, plr = threadIdx.x % LPR;
   const long long prow = tok0 + min(pr, nq - 1);
-  float s[MAXC][8], dp[MAXC][8], rsv[MAXC][8];
+  float s[MAXC][4], dp[MAXC][4], rsv[MAXC][4];
   int cj[MAXC];
 #pragma unroll
   for (int n = 0; n < MAXC; ++n) {
-    const int c0 = (plr + LPR * n) * 8;
+    const int c0 = (plr + LPR * n) * 4;
     cj[n] = -1;
     if (c0 < KS) {
       int j = 0;
@@ -375,21 +384,18 @@ __global__ void __launch_bounds__(512) rt_xbwd_dy_kernel(const RtXBwdArgs a) {
       for (int q = 1; q < CFD_NMEM; ++q)
         if (c0 >= a.off[q]) j = q;
       cj[n] = j;
-      const float* sp = a.sc + prow * KS + c0;
-      const float* rp = a.rsp + prow * KS + c0;
-      const float4 p0 = *reinterpret_cast<const float4*>(sp), p1 = *reinterpret_cast<const float4*>(sp + 4);
-      const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
-      s[n][0] = p0.x; s[n][1] = p0.y; s[n][2] = p0.z; s[n][3] = p0.w; s[n][4] = p1.x; s[n][5] = p1.y; s[n][6] = p1.z; s[n][7] = p1.w;
-      rsv[n][0] = r0.x; rsv[n][1] = r0.y; rsv[n][2] = r0.z; rsv[n][3] = r0.w; rsv[n][4] = r1.x; rsv[n][5] = r1.y; rsv[n][6] = r1.z; rsv[n][7] = r1.w;
+      const float4 p0 = *reinterpret_cast<const float4*>(a.sc + prow * KS + c0);
+      const float4 r0 = *reinterpret_cast<const float4*>(a.rsp + prow * KS + c0);
+      s[n][0] = p0.x; s[n][1] = p0.y; s[n][2] = p0.z; s[n][3] = p0.w;
+      rsv[n][0] = r0.x; rsv[n][1] = r0.y; rsv[n][2] = r0.z; rsv[n][3] = r0.w;
       if (a.dp_from_datt) {
         const int S2 = a.S[2], k0 = c0 - a.off[2];
         const float* da = a.d_att + (((long long)b * a.nl + a.layer) * a.L + q0 + min(pr, nq - 1)) * S2;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dp[n][e] = (j == 2 && k0 + e < S2) ? da[k0 + e] : 0.f;
+        for (int e = 0; e < 4; ++e) dp[n][e] = (j == 2 && k0 + e < S2) ? da[k0 + e] : 0.f;
       } else {
-        const float* dq = a.dP + prow * KS + c0;
-        const float4 d0 = *reinterpret_cast<const float4*>(dq), d1 = *reinterpret_cast<const float4*>(dq + 4);
-        dp[n][0] = d0.x; dp[n][1] = d0.y; dp[n][2] = d0.z; dp[n][3] = d0.w; dp[n][4] = d1.x; dp[n][5] = d1.y; dp[n][6] = d1.z; dp[n][7] = d1.w;
+        const float4 d0 = *reinterpret_cast<const float4*>(a.dP + prow * KS + c0);
+        dp[n][0] = d0.x; dp[n][1] = d0.y; dp[n][2] = d0.z; dp[n][3] = d0.w;
       }
     }
   }
@@ -399,15 +405,15 @@ __global__ void __launch_bounds__(512) rt_xbwd_dy_kernel(const RtXBwdArgs a) {
 #pragma unroll
     for (int j = 0; j < CFD_NMEM; ++j) ep_kb[j] = *reinterpret_cast<const float4*>(a.kb[j] + fcol);
   }
-  // softmax (recomputed from the saved scores) and its backward, per memory
-#pragma unroll
+  // softmax (recomputed from the saved scores) and its backward, per memory (a rolled loop: see rt_xpv_kernel)
+#pragma unroll 1
   for (int j = 0; j < CFD_NMEM; ++j) {
     float mx = -INFINITY;
 #pragma unroll
     for (int n = 0; n < MAXC; ++n)
       if (cj[n] == j) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, s[n][e]);
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[n][e]);
       }
     mx = rt_row_max<LPR>(mx);
     float sum = 0.f;
@@ -415,7 +421,7 @@ __global__ void __launch_bounds__(512) rt_xbwd_dy_kernel(const RtXBwdArgs a) {
     for (int n = 0; n < MAXC; ++n)
       if (cj[n] == j) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s[n][e] = __expf(s[n][e] - mx); sum += s[n][e]; }
+        for (int e = 0; e < 4; ++e) { s[n][e] = __expf(s[n][e] - mx); sum += s[n][e]; }
       }
     sum = rt_row_sum<LPR>(sum);
     const float inv = rt_rcp(sum);
@@ -424,35 +430,30 @@ __global__ void __launch_bounds__(512) rt_xbwd_dy_kernel(const RtXBwdArgs a) {
     for (int n = 0; n < MAXC; ++n)
       if (cj[n] == j) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s[n][e] *= inv; dot = fmaf(dp[n][e], s[n][e], dot); }
+        for (int e = 0; e < 4; ++e) { s[n][e] *= inv; dot = fmaf(dp[n][e], s[n][e], dot); }
       }
     dot = rt_row_sum<LPR>(dot);
     float wsum = 0.f;
 #pragma unroll
     for (int n = 0; n < MAXC; ++n)
       if (cj[n] == j) {
-        const int c0 = (plr + LPR * n) * 8;
+        const int c0 = (plr + LPR * n) * 4;
+        float ds[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float ds = s[n][e] * (dp[n][e] - dot) * rsv[n][e];   // dS' = p (dP - sum dP p) rs
-          wsum += ds;
-          img[pr * RS + c0 + e] = ds;
+        for (int e = 0; e < 4; ++e) {
+          ds[e] = s[n][e] * (dp[n][e] - dot) * rsv[n][e];   // dS' = p (dP - sum dP p) rs
+          wsum += ds[e];
         }
+        *reinterpret_cast<float2*>(img + pr * RS + c0) = make_float2(ds[0], ds[1]);
+        *reinterpret_cast<float2*>(img + pr * RS + c0 + 2) = make_float2(ds[2], ds[3]);
       }
     wsum = rt_row_sum<LPR>(wsum);
     if (plr == 0) dcq[pr * 8 + j] = wsum;
   }
   __syncthreads();
   // product over the keys: this wave's range of Sp_tot / 8 keys
-  const int nstep = KS / (4 * NW);
-  const int kbase = wid * (KS / NW) + q4;
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* ap = img + l15 * RS + kbase;
-  const int fo = ((f0 + l15) >> 5) * 128 + ((f0 + l15) & 31) * 2;   // this lane's feature inside an SP key row
-  float wv[MAXSTEP];
-#pragma unroll
-  for (int i = 0; i < MAXSTEP; ++i)
-    if (i < nstep) wv[i] = rt_sp_f32(krow[kbase + 4 * i] + fo);
 #pragma unroll
   for (int i = 0; i < MAXSTEP; ++i)
     if (i < nstep) acc = RT_MFMA_F32(wv[i], ap[4 * i], acc, 0, 0, 0);   // D[feature][token]
@@ -492,14 +493,33 @@ __global__ void __launch_bounds__(256) rt_selfattn_bwd_kernel(const RtSelfBwdArg
   float* dS = P + RT_MAX_L * (RT_MAX_L + 1);
   const int h = blockIdx.x, b = blockIdx.y, L = a.L, tid = threadIdx.x;
   const long long tok0 = (long long)b * L;
-  for (int e = tid; e < L * HD; e += 256) {
-    const int r = e / HD, d = e - r * HD;
-    const char* row = a.qk + (size_t)(tok0 + r) * 4096;
-    const int cq = h * HD + d;
-    Q[r * RSD + d] = rt_sp_f32(row + (cq >> 5) * 128 + (cq & 31) * 2);
-    Kk[r * RSD + d] = rt_sp_f32(row + (16 + (cq >> 5)) * 128 + (cq & 31) * 2);
-    V[r * RSD + d] = rt_sp_f32(a.vt + ((size_t)b * CFD_D + cq) * (RT_MAX_L * 4) + r * 2);
-    dO[r * RSD + d] = a.dO[(tok0 + r) * CFD_D + cq];
+  // operands into LDS as float32, 16-byte loads: 8 consecutive features of a q / k row (hi and lo chunk), 8 consecutive keys of a
+  // V^T feature row, 4 consecutive features of a dO row  (element by element this phase was most of the kernel's 15 us)
+  for (int e = tid; e < L * (HD / 8); e += 256) {
+    const int r = e / (HD / 8), c8 = (e - r * (HD / 8)) * 8, cq = h * HD + c8;
+    const char* row = a.qk + (size_t)(tok0 + r) * 4096 + (cq & 31) * 2;
+    const spx8 qh = *reinterpret_cast<const spx8*>(row + (cq >> 5) * 128), ql = *reinterpret_cast<const spx8*>(row + (cq >> 5) * 128 + 64);
+    const spx8 kh = *reinterpret_cast<const spx8*>(row + (16 + (cq >> 5)) * 128), kl = *reinterpret_cast<const spx8*>(row + (16 + (cq >> 5)) * 128 + 64);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      Q[r * RSD + c8 + i] = (float)qh[i] + (float)ql[i];
+      Kk[r * RSD + c8 + i] = (float)kh[i] + (float)kl[i];
+    }
+  }
+  for (int e = tid; e < HD * (RT_MAX_L / 8); e += 256) {
+    const int d = e / (RT_MAX_L / 8), k8 = (e - d * (RT_MAX_L / 8)) * 8;
+    if (k8 < L) {
+      const char* vr = a.vt + ((size_t)b * CFD_D + h * HD + d) * (RT_MAX_L * 4) + k8 * 2;
+      const spx8 vh = *reinterpret_cast<const spx8*>(vr), vl = *reinterpret_cast<const spx8*>(vr + 64);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (k8 + i < L) V[(k8 + i) * RSD + d] = (float)vh[i] + (float)vl[i];
+    }
+  }
+  for (int e = tid; e < L * (HD / 4); e += 256) {
+    const int r = e / (HD / 4), c4 = (e - r * (HD / 4)) * 4;
+    const float4 q = *reinterpret_cast<const float4*>(a.dO + (tok0 + r) * CFD_D + h * HD + c4);
+    dO[r * RSD + c4] = q.x; dO[r * RSD + c4 + 1] = q.y; dO[r * RSD + c4 + 2] = q.z; dO[r * RSD + c4 + 3] = q.w;
   }
   __syncthreads();
   for (int e = tid; e < L * L; e += 256) {
