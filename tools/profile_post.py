@@ -75,6 +75,20 @@ def publish():
         p = os.path.join(OUT, src)
         if os.path.exists(p):
             shutil.copy(p, os.path.join(PROF, dst))
+    for src, dst in ((f"{tag}_c1_kernel_stats.csv", f"{tag}_c1_single_utterance_kernel_stats.csv"), (f"{tag}_weg_kernel_stats.csv", f"{tag}_weg_eval_kernel_stats.csv"),
+                     (f"{tag}_c1.txt", f"{tag}_c1_single_utterance_summary.txt"), (f"{tag}_weg.txt", f"{tag}_weg_eval_summary.txt")):
+        p = os.path.join(OUT, src)
+        if os.path.exists(p):
+            shutil.copy(p, os.path.join(PROF, dst))
+    b = os.path.join(OUT, f"{tag}_bench_c2.json")
+    if os.path.exists(b):     # the other BASELINE configurations travel inside the bench line since round 4
+        try:
+            d = json.loads(open(b).read().strip().splitlines()[-1])
+            oc = dict(d.get("other_configs") or {})
+            oc["c1_single_utterance"] = d.get("c1_single_utterance")
+            json.dump(oc, open(os.path.join(PROF, f"{tag}_other_configs.json"), "w"), indent=1)
+        except Exception as e:
+            print("other_configs not extracted:", e)
     stats = glob.glob(os.path.join(OUT, f"{tag}_stats", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
         shutil.copy(stats[0], os.path.join(PROF, f"{tag}_bench_c2_kernel_stats.csv"))
