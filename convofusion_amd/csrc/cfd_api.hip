@@ -96,13 +96,16 @@ struct Problem {
   int static_mask = 0;
   // small problems (rowtile.hpp): every launch of the forward is a grid of 16-token x 16-feature workgroups; needs every memory static
   bool rt = false;
+  int rt_use_inst = 0;                              // the row maps fit the kernel arguments (<= RT_ARG_ROWS rows, instances < 256)
+  unsigned char rt_inst[CFD_NMEM][RT_ARG_ROWS];
 };
 
 struct RtSave {
   float* x[CFD_MAX_LAYERS + 1][5];   // [l][0] layer input, [1] after self-attention, [2] after time block 1, [3] after cross-attention, [4] after time block 2
   char* qk[CFD_MAX_LAYERS];
   char* vt[CFD_MAX_LAYERS];
-  float* sc[CFD_MAX_LAYERS];
+  float* sc[CFD_MAX_LAYERS];    // e_s of the cross-attention (rowtile.hpp: rt_xscore_kernel) ...
+  float* cst[CFD_MAX_LAYERS];   // ... and its cell statistics
   float* pre[CFD_MAX_LAYERS];
 };
 
@@ -775,6 +778,17 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
   }
   p.rt = c->rt_on && tmode == 0 && !g_cfd_naive_gemm && L <= RT_MAX_L && p.M <= c->rt_max_rows && p.Sp_tot <= RT_MAX_KEYS && c->hoist_memside;
   if (p.rt) {
+    p.rt_use_inst = Be <= RT_ARG_ROWS;
+    for (int j = 0; j < CFD_NMEM && p.rt_use_inst; ++j) {
+      std::vector<int> hm(Be);
+      if (mem[j].row_map) HIPCHK(hipMemcpy(hm.data(), mem[j].row_map, (size_t)Be * 4, hipMemcpyDeviceToHost));
+      else for (int b = 0; b < Be; ++b) hm[b] = b;
+      for (int b = 0; b < Be; ++b) {
+        if (hm[b] < 0 || hm[b] >= p.U[j]) return fail(CFD_E_ARG, "memory %s: row_map[%d] = %d outside [0, %d)", MEM_NAMES[j], b, hm[b], p.U[j]);
+        if (hm[b] > 255) p.rt_use_inst = 0;
+        p.rt_inst[j][b] = (unsigned char)hm[b];
+      }
+    }
     CHK(c->w->rt_vt.ensure((size_t)Be * CFD_D * RT_MAX_L * 4));
     HIPCHK(hipMemset(c->w->rt_vt.p, 0, (size_t)Be * CFD_D * RT_MAX_L * 4));   // keys beyond L stay zero
   }
@@ -1002,7 +1016,7 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
   const Problem& p = c->w->pb;
   const int nl = c->nl, L = p.L, tpr = (L + 15) / 16, ntile = p.Be * tpr;
   const int* dstep = c->w->d_step.as<int>();
-  const int lds_xpv = (p.Sp_tot / 32) * 2048 + 8 * (p.Sp_tot <= 512 ? 2 : 4) * 2048 + 512;
+  const int lds_xpv = (p.Sp_tot / 32) * 2048 + 8 * (p.Sp_tot <= 512 ? 2 : 4) * 2048 + 16 * 32 * 16 + 512 + 2048;
 #define RT_SET_LDS(kernel, bytes) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
   static unsigned long long attr = 0;
   if (!((attr >> (c->cfg.device & 63)) & 1ull)) {
@@ -1014,8 +1028,8 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
     RT_SET_LDS((rt_gemm_kernel<RT_PRO_SP, RT_EPI_RESID, 512, CFD_FF / 32, 1>), rt_gemm_lds(RT_PRO_SP, 512, CFD_FF / 32, 1));
     RT_SET_LDS((rt_gemm_kernel<RT_PRO_LN, RT_EPI_F32, 512, CFD_D / 32, 1>), rt_gemm_lds(RT_PRO_LN, 512, CFD_D / 32, 1));
     RT_SET_LDS(rt_xscore_kernel, RT_XS_LDS);
-    RT_SET_LDS(rt_xpv_kernel<512>, (512 / 32) * 2048 + 8 * 2 * 2048 + 512);
-    RT_SET_LDS(rt_xpv_kernel<RT_MAX_KEYS>, (RT_MAX_KEYS / 32) * 2048 + 8 * 4 * 2048 + 512);
+    RT_SET_LDS(rt_xpv_kernel<512>, (512 / 32) * 2048 + 8 * 2 * 2048 + 16 * 32 * 16 + 512 + 2048);
+    RT_SET_LDS(rt_xpv_kernel<RT_MAX_KEYS>, (RT_MAX_KEYS / 32) * 2048 + 8 * 4 * 2048 + 16 * 32 * 16 + 512 + 2048);
     attr |= 1ull << (c->cfg.device & 63);
   }
 #undef RT_SET_LDS
@@ -1083,6 +1097,7 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
   for (int j = 0; j < CFD_NMEM; ++j) {
     xa.map[j] = p.map[j]; xa.rows[j] = p.U[j] * p.Sp[j]; xa.S[j] = p.S[j]; xa.Sp[j] = p.Sp[j]; xa.off[j] = p.off[j];
     xa.cbt[j] = cbt_now[j]; xa.att[j] = p.att[j];
+    memcpy(xa.inst[j], p.rt_inst[j], RT_ARG_ROWS);
     xa.blk0[j] = nkb; nkb += p.Sp[j] / 16;
   }
   xa.blk0[CFD_NMEM] = nkb;
@@ -1123,6 +1138,7 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
       RtXArgs a = xa;
       a.x = X(l, 2); a.xo = X(l, 3);
       a.sc = sv ? sv->sc[l] : c->w->sc.as<float>();
+      a.cst = sv ? sv->cst[l] : c->w->ssc.as<float>();   // (the tile-kernel path's self-attention score buffer: >= M x 32 float4, unused here)
       a.ln_g = w.ln2g; a.ln_b = w.ln2b; a.bias = w.cross_bias.as<float>(); a.layer = l;
       for (int j = 0; j < CFD_NMEM; ++j) {
         const size_t rows = (size_t)p.U[j] * p.Sp[j];
@@ -1133,7 +1149,7 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
       }
       {
         Bracket br(c, CFD_PROF_XATTN, st);
-        hipLaunchKernelGGL(rt_xscore_kernel, dim3(nkb, ntile), dim3(512), RT_XS_LDS, st, a);
+        hipLaunchKernelGGL(rt_xscore_kernel, dim3(p.Sp_tot / 32, ntile), dim3(512), RT_XS_LDS, st, a);
         HIPCHK(hipGetLastError());
       }
       {

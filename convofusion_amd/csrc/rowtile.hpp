@@ -52,6 +52,7 @@ __device__ unsigned int g_rt_seq;
 #endif
 
 #define RT_MAX_L 32          // self-attention keys of a batch row fit one 32-deep k-step
+#define RT_ARG_ROWS 64       // batch rows whose memory instances travel inside the kernel arguments
 #define RT_MAX_KEYS 1024     // padded cross-attention keys of all five memories together
 
 template <class T>
@@ -536,10 +537,10 @@ __global__ void __launch_bounds__(256) rt_selfattn_kernel(const RtSelfArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Cross-attention, first half: LayerNorm2 of the tile's rows and the scores against 16 folded keys of one memory
+// Cross-attention, first half: LayerNorm2 of the tile's rows and the scores against one CELL of 32 folded keys of one memory
 // (cross_attention.py:578-652, folded + timestep-hoisted form, see the header):
-//   sc[token][off_j + s] = rs_s (q . KA_s + q . (A b_t)) + cbk_s
-// dynamic LDS: A image 32 KB | parameters 8 KB | 8 x 4 KB staging | c_q
+//   score_s = rs_s (q . KA_s + q . (A b_t)) + cbk_s;   out: e_s = exp(score_s - max over the cell), the cell's (max, sum e, sum e rs)
+// dynamic LDS: A image 32 KB | parameters 8 KB | 8 x 8 KB staging | c_q, exchange
 // ------------------------------------------------------------------------------------------------
 struct RtXArgs {
   const float* x;               // fp32 [M][512]: the residual stream in front of the cross-attention block
@@ -553,30 +554,47 @@ struct RtXArgs {
   const float* cbt[CFD_NMEM];   // THIS STEP's key tables [nl + 1][U_j * Sp_j]: plane l = cbk of layer l, plane nl = rs
   const float* kb[CFD_NMEM];    // A_l b_t [512] of this layer at this step
   const float* vb[CFD_NMEM];    // VV_l b_t [512] of this layer at this step
-  const int* map[CFD_NMEM];     // batch row -> memory instance
+  const int* map[CFD_NMEM];     // batch row -> memory instance (used when the batch has more than RT_ARG_ROWS rows)
+  int use_inst;                 // 1: inst[j][b] below holds map[j][b] (a kernel-argument read instead of a dependent global load in
+  unsigned char inst[CFD_NMEM][RT_ARG_ROWS];   // front of the operand fetch; instances < 256, <= RT_ARG_ROWS batch rows)
   int rows[CFD_NMEM];           // U_j * Sp_j
   int S[CFD_NMEM], Sp[CFD_NMEM], off[CFD_NMEM];
-  int blk0[CFD_NMEM + 1];       // first 16-key block of memory j in the score launch's grid
+  int blk0[CFD_NMEM + 1];       // (unused since the score launch works on 32-key cells of the concatenated key axis)
   int Sp_tot;
-  float* sc;                    // fp32 [M][Sp_tot] scores
+  float* sc;                    // fp32 [M][Sp_tot]: e_s = exp(score_s - its cell's maximum)
+  float* cst;                   // float4 [M][Sp_tot / 32]: per (token, cell) maximum, sum e_s, sum e_s rs_s
   float* rsp;                   // fp32 [M][Sp_tot]: rs of every key, repeated per token by the score launch
   float* att[CFD_NMEM];         // optional att_mats [Be][nl][L][S_j]
 };
 
-#define RT_XS_LDS (16 * 2048 + 8192 + 8 * 4096 + 64)
+// The softmax of a memory is assembled from CELLS of 32 keys: the score launch leaves e_s = exp(score_s - m_c) and, per (token, cell),
+// (m_c, l_c = sum e_s, sum e_s rs_s); the probability of key s is then e_s * factor, factor = exp(m_c - M) / sum_c' l_c' exp(m_c' - M)
+// over the cells [cb, ce) of the key's memory, M their largest m -- no reduction over lanes in the launch that consumes it
+// (its 32 feature-block workgroups per tile each computed the whole five-memory softmax before: 3 of that launch's 7.6 us).
+__device__ __forceinline__ float rt_cell_scale(const float4* cst, int c, int cb, int ce, float& inv_l) {
+  float M = -INFINITY;
+  for (int k = cb; k < ce; ++k) M = fmaxf(M, cst[k].x);
+  float l = 0.f;
+  for (int k = cb; k < ce; ++k) l = fmaf(cst[k].y, __expf(cst[k].x - M), l);
+  inv_l = rt_rcp(l);                                  // all keys of the memory dead: M = -inf, NaN like the reference's softmax
+  return __expf(cst[c].x - M) * inv_l;
+}
+
+#define RT_XS_LDS (16 * 2048 + 8192 + 8 * 8192 + 64 + 512)
 __global__ void __launch_bounds__(512) rt_xscore_kernel(const RtXArgs a) {
-  constexpr int NW = 8, NK = 2, STAGE_W = NK * 2048;
+  constexpr int NW = 8, NK = 2, STAGE_W = 2 * NK * 2048;     // per wave: 2 key tiles x NK k-groups
   RT_T(t_in);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* img = smem;
   char* par = smem + 16 * 2048;
   char* stage0 = smem + 16 * 2048 + 8192;
   float* cq = reinterpret_cast<float*>(stage0 + NW * STAGE_W);
+  float* xch = cq + 16;                                        // [2 tiles][16 tokens] x (max, l, l_rs) exchange
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   char* wreg = stage0 + wid * STAGE_W;
   const int l15 = lane & 15, q4 = lane >> 4;
-  const int tile = blockIdx.y;
+  const int tile = blockIdx.y, cell = blockIdx.x;
   const int b = tile / a.tpr, q0 = (tile - b * a.tpr) * 16, nq = min(16, a.L - q0);
   const long long tok0 = (long long)b * a.L + q0;
   const int pr = threadIdx.x >> 5, plr = threadIdx.x & 31;
@@ -585,23 +603,22 @@ __global__ void __launch_bounds__(512) rt_xscore_kernel(const RtXArgs a) {
   int j = 0;
 #pragma unroll
   for (int q = 1; q < CFD_NMEM; ++q)
-    if ((int)blockIdx.x >= a.blk0[q]) j = q;
-  int blk_first = 0;
-#pragma unroll
-  for (int q = 1; q < CFD_NMEM; ++q)
-    if (j == q) blk_first = a.blk0[q];
-  const int s0 = ((int)blockIdx.x - blk_first) * 16;
-  const int u = rt_sel(a.map, j)[b];
+    if (cell * 32 >= a.off[q]) j = q;
+  const int s0 = cell * 32 - rt_sel(a.off, j);
+  const int u = a.use_inst ? (int)a.inst[j][b] : rt_sel(a.map, j)[b];
   const int rows = rt_sel(a.rows, j), Sp = rt_sel(a.Sp, j);
   const long long key0 = (long long)u * Sp + s0;
   const float4 parv = rt_par_fetch<3>(a.ln_g, a.ln_b, rt_sel(a.kb, j), nullptr);
 #pragma unroll
-  for (int n = 0; n < NK; ++n) rt_dma_slice(wreg + n * 2048, rt_sel(a.K, j) + (size_t)key0 * (CFD_D * 4), CFD_D * 4, 15, wid + NW * n, lane);
+  for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+    for (int n = 0; n < NK; ++n)
+      rt_dma_slice(wreg + (t2 * NK + n) * 2048, rt_sel(a.K, j) + (size_t)(key0 + 16 * t2) * (CFD_D * 4), CFD_D * 4, 15, wid + NW * n, lane);
   const float* tab = rt_sel(a.cbt, j);
   float4 e_rs = make_float4(0.f, 0.f, 0.f, 0.f), e_cb = e_rs;
-  if (wid == 0) {
-    e_rs = *reinterpret_cast<const float4*>(tab + (long long)a.nl * rows + key0 + 4 * q4);
-    e_cb = *reinterpret_cast<const float4*>(tab + (long long)a.layer * rows + key0 + 4 * q4);
+  if (wid < 2) {                                        // wave t finishes key tile t
+    e_rs = *reinterpret_cast<const float4*>(tab + (long long)a.nl * rows + key0 + 16 * wid + 4 * q4);
+    e_cb = *reinterpret_cast<const float4*>(tab + (long long)a.layer * rows + key0 + 16 * wid + 4 * q4);
   }
   // LayerNorm2 -> image; c_q = q . (A b_t)
   reinterpret_cast<float4*>(par)[threadIdx.x] = parv;
@@ -625,35 +642,65 @@ __global__ void __launch_bounds__(512) rt_xscore_kernel(const RtXArgs a) {
   if (plr == 0) cq[pr] = dot;
   RT_WAIT_VM0();
   __syncthreads();
-  spx8 kh[NK], kl[NK], ah[NK], al[NK];
+  spx8 kh[2][NK], kl[2][NK], ah[NK], al[NK];
 #pragma unroll
   for (int n = 0; n < NK; ++n) {
     rt_lfrag(img, wid + NW * n, l15, q4, ah[n], al[n]);
-    rt_lfrag(wreg, n, l15, q4, kh[n], kl[n]);
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) rt_lfrag(wreg + t2 * NK * 2048, n, l15, q4, kh[t2][n], kl[t2][n]);
   }
   RT_T(t_ops);
-  f32x4 part[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 part[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-  for (int n = 0; n < NK; ++n) part[0] = rt_mma(kh[n], kl[n], ah[n], al[n], part[0]);   // S^T[key][token]
+  for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+    for (int n = 0; n < NK; ++n) part[t2] = rt_mma(kh[t2][n], kl[t2][n], ah[n], al[n], part[t2]);   // S^T[key][token]
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const f32x4 acc = rt_reduce<NW, 1>(stage0, STAGE_W, wid, lane, part);
+  const f32x4 acc = rt_reduce<NW, 2>(stage0, STAGE_W, wid, lane, part);
 #if RT_STAMP
   struct StampAtExit { unsigned long long a, b; __device__ ~StampAtExit() { RT_STAMP_OUT(2000, a, b); } } stamp_{t_in, t_ops};
 #endif
-  if (wid != 0 || l15 >= nq) return;
-  const float c_q = cq[l15];
-  const float4 o = make_float4(e_rs.x * (acc[0] + c_q) + e_cb.x, e_rs.y * (acc[1] + c_q) + e_cb.y, e_rs.z * (acc[2] + c_q) + e_cb.z,
-                               e_rs.w * (acc[3] + c_q) + e_cb.w);
-  const long long so = (tok0 + l15) * a.Sp_tot + rt_sel(a.off, j) + s0 + 4 * q4;
-  *reinterpret_cast<float4*>(a.sc + so) = o;
-  *reinterpret_cast<float4*>(a.rsp + so) = e_rs;   // the keys' scales next to the scores: the second half then has no load that waits for another
+  // waves 0 / 1: the scores of their 16 keys, the cell's maximum (both tiles), e = exp(score - max) and the cell sums
+  float sc4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  const float rs4[4] = {e_rs.x, e_rs.y, e_rs.z, e_rs.w};
+  if (wid < 2) {
+    const float c_q = cq[l15];
+    const float cb4[4] = {e_cb.x, e_cb.y, e_cb.z, e_cb.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sc4[r] = rs4[r] * (acc[r] + c_q) + cb4[r];
+    const float m16 = xlane_max(fmaxf(fmaxf(sc4[0], sc4[1]), fmaxf(sc4[2], sc4[3])));
+    if (q4 == 0) xch[wid * 16 + l15] = m16;
+  }
+  __syncthreads();
+  float e4[4] = {0.f, 0.f, 0.f, 0.f};
+  float mcell = 0.f;
+  if (wid < 2) {
+    mcell = fmaxf(xch[l15], xch[16 + l15]);
+    float l4 = 0.f, lr4 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      e4[r] = (mcell == -INFINITY) ? 0.f : __expf(sc4[r] - mcell);
+      l4 += e4[r];
+      lr4 = fmaf(e4[r], rs4[r], lr4);
+    }
+    l4 = xlane_sum(l4);
+    lr4 = xlane_sum(lr4);
+    if (q4 == 0) { xch[32 + wid * 16 + l15] = l4; xch[64 + wid * 16 + l15] = lr4; }
+  }
+  __syncthreads();
+  if (wid >= 2 || l15 >= nq) return;
+  const long long so = (tok0 + l15) * a.Sp_tot + cell * 32 + 16 * wid + 4 * q4;
+  *reinterpret_cast<float4*>(a.sc + so) = make_float4(e4[0], e4[1], e4[2], e4[3]);
+  *reinterpret_cast<float4*>(a.rsp + so) = e_rs;   // the keys' scales next to them: the second half then has no load that waits for another
+  if (wid == 0 && q4 == 0)
+    reinterpret_cast<float4*>(a.cst)[(tok0 + l15) * (a.Sp_tot / 32) + cell] = make_float4(mcell, xch[32 + l15] + xch[48 + l15], xch[64 + l15] + xch[80 + l15], 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Cross-attention, second half: softmax per memory, P' = p rs, x += sum_j (VA_j^T P'_j + (sum P'_j) VV_j b_t) + bias for 16 features
-// MAXKEYS: capacity in padded keys (512: the product shape's 320 keys; 1024).  Thread (row pr, lane plr) owns the 4-key chunks
-// plr + 32 n: 16-byte loads contiguous across the row's lanes.
-// dynamic LDS: P' image (Sp_tot / 32) x 2 KB | 8 x MAXN x 2 KB staging | sum_s P'_s [16][8]
+// Cross-attention, second half: P' = p rs from the cells' statistics, x += sum_j (VA_j^T P'_j + (sum P'_j) VV_j b_t) + bias for 16
+// features.  MAXKEYS: capacity in padded keys (512: the product shape's 320 keys; 1024).  Thread (row pr, lane plr) owns the 4-key
+// chunks plr + 32 n: 16-byte loads contiguous across the row's lanes.
+// dynamic LDS: P' image (Sp_tot / 32) x 2 KB | 8 x MAXN x 2 KB staging | cell statistics [16][32] float4 | sum_s P'_s [16][8]
 // ------------------------------------------------------------------------------------------------
 template <int MAXKEYS>
 __global__ void __launch_bounds__(512) rt_xpv_kernel(const RtXArgs a) {
@@ -666,7 +713,8 @@ __global__ void __launch_bounds__(512) rt_xpv_kernel(const RtXArgs a) {
   const int KT = a.Sp_tot / 32;
   char* img = smem;                                              // P' image: Sp_tot / 32 k-groups x 2 KB
   char* stage0 = smem + KT * 2048;
-  float* ws = reinterpret_cast<float*>(stage0 + NW * STAGE_W);   // [16 tokens][8]: sum_s P'_s per memory
+  float4* cst = reinterpret_cast<float4*>(stage0 + NW * STAGE_W);   // [16 tokens][32 cells]
+  float* ws = reinterpret_cast<float*>(cst + 16 * 32);           // [16 tokens][8]: sum_s P'_s per memory
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   char* wreg = stage0 + wid * STAGE_W;
@@ -675,30 +723,28 @@ __global__ void __launch_bounds__(512) rt_xpv_kernel(const RtXArgs a) {
   const int b = tile / a.tpr, q0 = (tile - b * a.tpr) * 16, nq = min(16, a.L - q0);
   const long long tok0 = (long long)b * a.L + q0;
   static_assert(CFD_NMEM == 5, "five named instance indices");
-  const int u0 = a.map[0][b], u1 = a.map[1][b], u2 = a.map[2][b], u3 = a.map[3][b], u4 = a.map[4][b];   // (named scalars: a local array indexed through rt_sel goes to scratch)
+  int u0, u1, u2, u3, u4;   // (named scalars: a local array indexed through rt_sel goes to scratch)
+  if (a.use_inst) { u0 = a.inst[0][b]; u1 = a.inst[1][b]; u2 = a.inst[2][b]; u3 = a.inst[3][b]; u4 = a.inst[4][b]; }
+  else { u0 = a.map[0][b]; u1 = a.map[1][b]; u2 = a.map[2][b]; u3 = a.map[3][b]; u4 = a.map[4][b]; }
   auto inst = [&](int j) __attribute__((always_inline)) { return j == 0 ? u0 : j == 1 ? u1 : j == 2 ? u2 : j == 3 ? u3 : u4; };
 
-  // ---- loads: the tile's scores and per-key scales (prologue lanes), the V^T slices of this wave's k-groups --------
+  // ---- loads: the tile's e_s, per-key scales and cell statistics (prologue lanes), the V^T slices of this wave's k-groups --------
   const int pr = threadIdx.x >> 5, plr = threadIdx.x & 31;
   float s[MAXC][4], rsv[MAXC][4];
-  int cj[MAXC];
   const long long srow = (tok0 + min(pr, nq - 1)) * a.Sp_tot;
 #pragma unroll
   for (int n = 0; n < MAXC; ++n) {
     const int c0 = (plr + RT_LPR * n) * 4;
-    cj[n] = -1;
     if (c0 < a.Sp_tot) {
-      int j = 0;
-#pragma unroll
-      for (int q = 1; q < CFD_NMEM; ++q)
-        if (c0 >= a.off[q]) j = q;
-      cj[n] = j;
       const float4 p0 = *reinterpret_cast<const float4*>(a.sc + srow + c0);
       const float4 r0 = *reinterpret_cast<const float4*>(a.rsp + srow + c0);
       s[n][0] = p0.x; s[n][1] = p0.y; s[n][2] = p0.z; s[n][3] = p0.w;
       rsv[n][0] = r0.x; rsv[n][1] = r0.y; rsv[n][2] = r0.z; rsv[n][3] = r0.w;
     }
   }
+  RT_T(t_x1);
+  if (plr < KT) cst[pr * 32 + plr] = reinterpret_cast<const float4*>(a.cst)[(tok0 + min(pr, nq - 1)) * KT + plr];
+  RT_T(t_x2);
   const int nk = (KT - wid + NW - 1) / NW;
 #pragma unroll
   for (int n = 0; n < MAXN; ++n) {
@@ -712,6 +758,7 @@ __global__ void __launch_bounds__(512) rt_xpv_kernel(const RtXArgs a) {
       rt_dma_slice(wreg + n * 2048, rt_sel(a.VT, j) + ((size_t)inst(j) * CFD_D + f0) * ld, ld, 15, kt - rt_sel(a.off, j) / 32, lane);
     }
   }
+  RT_T(t_x3);
   const int fcol = f0 + 4 * q4;
   float4 ep_r = make_float4(0.f, 0.f, 0.f, 0.f), ep_b = ep_r;
   float4 ep_vb[CFD_NMEM];
@@ -721,51 +768,60 @@ __global__ void __launch_bounds__(512) rt_xpv_kernel(const RtXArgs a) {
 #pragma unroll
     for (int j = 0; j < CFD_NMEM; ++j) ep_vb[j] = *reinterpret_cast<const float4*>(a.vb[j] + fcol);
   }
-
   RT_T(t_a);
-  // ---- softmax per memory over the row's lanes; P' -> image; sum_s P'_s -> ws ----------------------------------
-  // (a rolled loop: unrolled five times this was 29 KB of code)
-#pragma unroll 1
-  for (int j = 0; j < CFD_NMEM; ++j) {
-    float mx = -INFINITY;
+#if RT_STAMP
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    const unsigned k_ = atomicAdd(&g_rt_seq, 1u) & 4095u;
+    g_rt_ring[4 * k_] = 3002; g_rt_ring[4 * k_ + 1] = t_x1 - t_in; g_rt_ring[4 * k_ + 2] = t_x2 - t_in; g_rt_ring[4 * k_ + 3] = t_x3 - t_in;
+  }
+#endif
+  __syncthreads();                                                // the cell statistics are in LDS
+  // per (token, memory): M, 1 / sum_c l_c exp(m_c - M), sum_s P'_s -- once, by 80 threads (serial walks over a memory's cells by every
+  // lane cost more than the softmax they replaced)
+  float4* seg = reinterpret_cast<float4*>(ws + 16 * 8);           // [16 tokens][8]
+  if (threadIdx.x < 16 * CFD_NMEM) {
+    const int r = threadIdx.x / CFD_NMEM, j = threadIdx.x - r * CFD_NMEM;
+    const float4* cr = cst + r * 32;
+    const int offj = rt_sel(a.off, j), cb = offj >> 5, ce = (offj + rt_sel(a.Sp, j)) >> 5;
+    float M = -INFINITY, l = 0.f, w = 0.f;
+    for (int k = cb; k < ce; ++k) M = fmaxf(M, cr[k].x);
+    for (int k = cb; k < ce; ++k) {
+      const float ex = __expf(cr[k].x - M);
+      l = fmaf(cr[k].y, ex, l);
+      w = fmaf(cr[k].z, ex, w);
+    }
+    const float il = rt_rcp(l);                                   // all keys of the memory dead: NaN like the reference's softmax
+    seg[r * 8 + j] = make_float4(M, il, 0.f, 0.f);
+    ws[r * 8 + j] = w * il;
+  }
+  __syncthreads();
+  // ---- probabilities from the cells' statistics; P' -> image ----------------------------------
+  const float4* crow = cst + pr * 32;
 #pragma unroll
-    for (int n = 0; n < MAXC; ++n)
-      if (cj[n] == j) {
+  for (int n = 0; n < MAXC; ++n) {
+    const int c0 = (plr + RT_LPR * n) * 4;
+    if (c0 < a.Sp_tot) {
+      int j = 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[n][e]);
+      for (int q = 1; q < CFD_NMEM; ++q)
+        if (c0 >= a.off[q]) j = q;
+      const int offj = rt_sel(a.off, j), S = rt_sel(a.S, j);
+      const float4 sg = seg[pr * 8 + j];
+      const float f = __expf(crow[c0 >> 5].x - sg.x) * sg.y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[n][e] *= f;
+      float* att = rt_sel(a.att, j);
+      if (att && fb == 0 && pr < nq) {
+        float* ap = att + (((long long)b * a.nl + a.layer) * a.L + q0 + pr) * S;
+        const int k0 = c0 - offj;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k0 + e < S) ap[k0 + e] = s[n][e];
       }
-    mx = rt_row_max<RT_LPR>(mx);
-    float sum = 0.f;
 #pragma unroll
-    for (int n = 0; n < MAXC; ++n)
-      if (cj[n] == j) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { s[n][e] = __expf(s[n][e] - mx); sum += s[n][e]; }   // all keys dead: NaN, as the reference
-      }
-    sum = rt_row_sum<RT_LPR>(sum);
-    const float inv = rt_rcp(sum);
-    float wsum = 0.f;
-    float* att = rt_sel(a.att, j);
-    const int S = rt_sel(a.S, j), offj = rt_sel(a.off, j);
-#pragma unroll
-    for (int n = 0; n < MAXC; ++n)
-      if (cj[n] == j) {
-        const int c0 = (plr + RT_LPR * n) * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s[n][e] = s[n][e] * inv;
-        if (att && fb == 0 && pr < nq) {
-          float* ap = att + (((long long)b * a.nl + a.layer) * a.L + q0 + pr) * S;
-          const int k0 = c0 - offj;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (k0 + e < S) ap[k0 + e] = s[n][e];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { s[n][e] *= rsv[n][e]; wsum += s[n][e]; }
-        rt_lstore4(img, pr, c0, s[n]);
-      }
-    wsum = rt_row_sum<RT_LPR>(wsum);
-    if (plr == 0) ws[pr * 8 + j] = wsum;
+      for (int e = 0; e < 4; ++e) s[n][e] *= rsv[n][e];
+      rt_lstore4(img, pr, c0, s[n]);
+    }
   }
   RT_T(t_b);
   RT_WAIT_VM0();

@@ -240,10 +240,13 @@ struct RtXBwdArgs {
   const float* kb[CFD_NMEM];    // A_l b_t of this layer at this step
   const float* vb[CFD_NMEM];    // VV_l b_t
   const int* map[CFD_NMEM];
+  int use_inst;                 // as RtXArgs
+  unsigned char inst[CFD_NMEM][RT_ARG_ROWS];
   int S[CFD_NMEM], Sp[CFD_NMEM], off[CFD_NMEM];
   int blk0[CFD_NMEM + 1];
   int Sp_tot;
-  const float* sc;              // this layer's scores [M][Sp_tot] (saved by the forward)
+  const float* sc;              // this layer's e_s = exp(score - cell maximum) [M][Sp_tot] (saved by the forward)
+  const float* cst;             // this layer's cell statistics, float4 [M][Sp_tot / 32] (rowtile.hpp, rt_cell_scale)
   const float* rsp;             // per-key scales [M][Sp_tot]
   const float* d_att;           // gradient at the tlsn probabilities [B][nl][L][S_2]
   float* dP;                    // [M][Sp_tot]
@@ -272,7 +275,7 @@ __global__ void __launch_bounds__(512) rt_xbwd_dp_kernel(const RtXBwdArgs a) {
   for (int q = 1; q < CFD_NMEM; ++q)
     if (j == q) blk_first = a.blk0[q];
   const int s0 = ((int)blockIdx.x - blk_first) * 16;
-  const int u = rt_sel(a.map, j)[b];
+  const int u = a.use_inst ? (int)a.inst[j][b] : rt_sel(a.map, j)[b];
   const int Sp = rt_sel(a.Sp, j);
   const int pr = threadIdx.x >> 5, plr = threadIdx.x & 31;
   const long long prow = tok0 + min(pr, nq - 1);
@@ -344,6 +347,7 @@ __global__ void __launch_bounds__(512) rt_xbwd_dy_kernel(const RtXBwdArgs a) {
   float* img = reinterpret_cast<float*>(smem);
   char* red = smem + (size_t)16 * RS * 4;
   float* dcq = reinterpret_cast<float*>(red + NW * 1024);   // [16 tokens][8]
+  float4* cst = reinterpret_cast<float4*>(red + NW * 1024 + 512);   // [16 tokens][32 cells]
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l15 = lane & 15, q4 = lane >> 4;
@@ -353,7 +357,9 @@ __global__ void __launch_bounds__(512) rt_xbwd_dy_kernel(const RtXBwdArgs a) {
   // this wave's operand: KA[key][f0 + l15] for its keys kbase + 4 i, read from the folded keys (split pairs) -- requested before the
   // prologue, so that the loads run under the softmax backward
   static_assert(CFD_NMEM == 5, "five named instance indices");
-  const int u0 = a.map[0][b], u1 = a.map[1][b], u2 = a.map[2][b], u3 = a.map[3][b], u4 = a.map[4][b];
+  int u0, u1, u2, u3, u4;
+  if (a.use_inst) { u0 = a.inst[0][b]; u1 = a.inst[1][b]; u2 = a.inst[2][b]; u3 = a.inst[3][b]; u4 = a.inst[4][b]; }
+  else { u0 = a.map[0][b]; u1 = a.map[1][b]; u2 = a.map[2][b]; u3 = a.map[3][b]; u4 = a.map[4][b]; }
   const int nstep = KS / (4 * NW);
   const int kbase = wid * (KS / NW) + q4;
   const int fo = ((f0 + l15) >> 5) * 128 + ((f0 + l15) & 31) * 2;   // this lane's feature inside an SP key row
@@ -405,32 +411,26 @@ __global__ void __launch_bounds__(512) rt_xbwd_dy_kernel(const RtXBwdArgs a) {
 #pragma unroll
     for (int j = 0; j < CFD_NMEM; ++j) ep_kb[j] = *reinterpret_cast<const float4*>(a.kb[j] + fcol);
   }
-  // softmax (recomputed from the saved scores) and its backward, per memory (a rolled loop: see rt_xpv_kernel)
+  if (plr < KS / 32) cst[pr * 32 + plr] = reinterpret_cast<const float4*>(a.cst)[prow * (KS / 32) + plr];
+  __syncthreads();
+  // the probabilities from the saved e_s and cell statistics (as rt_xpv_kernel makes them), then the softmax backward per memory
+#pragma unroll
+  for (int n = 0; n < MAXC; ++n)
+    if (cj[n] >= 0) {
+      const int c0 = (plr + LPR * n) * 4, j = cj[n], offj = rt_sel(a.off, j);
+      float inv_l;
+      const float f = rt_cell_scale(cst + pr * 32, c0 >> 5, offj >> 5, (offj + rt_sel(a.Sp, j)) >> 5, inv_l);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[n][e] *= f;
+    }
 #pragma unroll 1
   for (int j = 0; j < CFD_NMEM; ++j) {
-    float mx = -INFINITY;
-#pragma unroll
-    for (int n = 0; n < MAXC; ++n)
-      if (cj[n] == j) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[n][e]);
-      }
-    mx = rt_row_max<LPR>(mx);
-    float sum = 0.f;
-#pragma unroll
-    for (int n = 0; n < MAXC; ++n)
-      if (cj[n] == j) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { s[n][e] = __expf(s[n][e] - mx); sum += s[n][e]; }
-      }
-    sum = rt_row_sum<LPR>(sum);
-    const float inv = rt_rcp(sum);
     float dot = 0.f;
 #pragma unroll
     for (int n = 0; n < MAXC; ++n)
       if (cj[n] == j) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { s[n][e] *= inv; dot = fmaf(dp[n][e], s[n][e], dot); }
+        for (int e = 0; e < 4; ++e) dot = fmaf(dp[n][e], s[n][e], dot);
       }
     dot = rt_row_sum<LPR>(dot);
     float wsum = 0.f;
@@ -522,40 +522,70 @@ __global__ void __launch_bounds__(256) rt_selfattn_bwd_kernel(const RtSelfBwdArg
     dO[r * RSD + c4] = q.x; dO[r * RSD + c4 + 1] = q.y; dO[r * RSD + c4 + 2] = q.z; dO[r * RSD + c4 + 3] = q.w;
   }
   __syncthreads();
-  for (int e = tid; e < L * L; e += 256) {
-    const int q = e / L, k = e - q * L;
-    float sacc = 0.f, dacc = 0.f;
-    for (int d = 0; d < HD; ++d) {
-      sacc = fmaf(Q[q * RSD + d], Kk[k * RSD + d], sacc);
-      dacc = fmaf(dO[q * RSD + d], V[k * RSD + d], dacc);
+  // scores and dP on the float32 matrix core: wave w takes (query tile w & 1, key tile w >> 1); D[key][query], 32 steps over d
+  const int lane = tid & 63, wid = tid >> 6, l15 = lane & 15, q4 = lane >> 4;
+  const int nqt = (L + 15) / 16;
+  {
+    const int qt = wid & 1, kt = wid >> 1;
+    if (qt < nqt && kt < nqt) {
+      const float* qrow = Q + min(qt * 16 + l15, L - 1) * RSD + q4;
+      const float* orow = dO + min(qt * 16 + l15, L - 1) * RSD + q4;
+      const float* krow = Kk + min(kt * 16 + l15, L - 1) * RSD + q4;
+      const float* vrow = V + min(kt * 16 + l15, L - 1) * RSD + q4;
+      f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, da = sa;
+#pragma unroll 8
+      for (int st = 0; st < HD / 4; ++st) {
+        sa = RT_MFMA_F32(krow[4 * st], qrow[4 * st], sa, 0, 0, 0);
+        da = RT_MFMA_F32(vrow[4 * st], orow[4 * st], da, 0, 0, 0);
+      }
+      const int q = qt * 16 + l15;
+      if (q < L) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = kt * 16 + 4 * q4 + r;
+          if (k < L) { P[q * (RT_MAX_L + 1) + k] = sa[r]; dS[q * (RT_MAX_L + 1) + k] = da[r]; }
+        }
+      }
     }
-    P[q * (RT_MAX_L + 1) + k] = sacc;
-    dS[q * (RT_MAX_L + 1) + k] = dacc;
   }
   __syncthreads();
-  if (tid < L) {   // one query row per thread: softmax, then its backward in place
-    float* pr = P + tid * (RT_MAX_L + 1);
-    float* dr = dS + tid * (RT_MAX_L + 1);
-    float mx = -INFINITY;
-    for (int k = 0; k < L; ++k) mx = fmaxf(mx, pr[k]);
-    float sum = 0.f;
-    for (int k = 0; k < L; ++k) { pr[k] = expf(pr[k] - mx); sum += pr[k]; }
-    float dot = 0.f;
-    for (int k = 0; k < L; ++k) { pr[k] = pr[k] / sum; dot = fmaf(dr[k], pr[k], dot); }
-    for (int k = 0; k < L; ++k) dr[k] = pr[k] * (dr[k] - dot);
+  // softmax of every query row and its backward, in place: 16 lanes per row (keys lane16 and lane16 + 16), 16 rows per pass
+  for (int r0 = 0; r0 < L; r0 += 16) {
+    const int q = r0 + (tid >> 4), k0 = tid & 15, k1 = k0 + 16;
+    const bool qok = q < L, ok0 = qok && k0 < L, ok1 = qok && k1 < L;
+    float* pr = P + min(q, L - 1) * (RT_MAX_L + 1);
+    float* dr = dS + min(q, L - 1) * (RT_MAX_L + 1);
+    const float s0 = ok0 ? pr[k0] : -INFINITY, s1 = ok1 ? pr[k1] : -INFINITY;
+    const float mx = rt_row_max<16>(fmaxf(s0, s1));
+    const float e0 = ok0 ? expf(s0 - mx) : 0.f, e1 = ok1 ? expf(s1 - mx) : 0.f;
+    const float sum = rt_row_sum<16>(e0 + e1);
+    const float p0 = e0 / sum, p1 = e1 / sum;
+    const float d0 = ok0 ? dr[k0] : 0.f, d1 = ok1 ? dr[k1] : 0.f;
+    const float dot = rt_row_sum<16>(fmaf(d0, p0, d1 * p1));
+    if (ok0) { pr[k0] = p0; dr[k0] = p0 * (d0 - dot); }
+    if (ok1) { pr[k1] = p1; dr[k1] = p1 * (d1 - dot); }
   }
   __syncthreads();
-  for (int e = tid; e < L * HD; e += 256) {
-    const int r = e / HD, d = e - r * HD;
-    float dq = 0.f, dk = 0.f, dv = 0.f;
-    for (int k = 0; k < L; ++k) {
-      dq = fmaf(dS[r * (RT_MAX_L + 1) + k], Kk[k * RSD + d], dq);
-      dk = fmaf(dS[k * (RT_MAX_L + 1) + r], Q[k * RSD + d], dk);
-      dv = fmaf(P[k * (RT_MAX_L + 1) + r], dO[k * RSD + d], dv);
+  // dQ = dS K, dK = dS^T Q, dV = P^T dO: output tiles [16 features][16 rows] (lane: 4 consecutive features of row l15), contraction
+  // over the other row axis (L / 4 steps); 3 products x nqt row tiles x 8 feature tiles dealt to the 4 waves
+  const int nsteps = (L + 3) / 4;
+  for (int item = wid; item < 3 * nqt * 8; item += 4) {
+    const int prod = item / (nqt * 8), rt = (item / 8) % nqt, ft = item & 7;
+    const float* X = prod == 0 ? Kk : (prod == 1 ? Q : dO);           // first operand: X[kk][feature]
+    const float* Y = prod == 2 ? P : dS;                                // second operand: dQ: dS[row][kk]; dK, dV: Y[kk][row] (transposed use)
+    const int row = rt * 16 + l15;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int st = 0; st < nsteps; ++st) {
+      const int kk = 4 * st + q4;
+      const bool ok = kk < L;
+      const float xv = ok ? X[kk * RSD + ft * 16 + l15] : 0.f;
+      const float yv = (ok && row < L) ? (prod == 0 ? Y[row * (RT_MAX_L + 1) + kk] : Y[kk * (RT_MAX_L + 1) + row]) : 0.f;
+      acc = RT_MFMA_F32(xv, yv, acc, 0, 0, 0);
     }
-    float* o = a.dqkv + (tok0 + r) * (3 * CFD_D) + h * HD + d;
-    o[0] = dq * a.qscale;
-    o[CFD_D] = dk;
-    o[2 * CFD_D] = dv;
+    if (row < L) {
+      const float sc = prod == 0 ? a.qscale : 1.0f;
+      float* o = a.dqkv + (tok0 + row) * (3 * CFD_D) + prod * CFD_D + h * HD + ft * 16 + 4 * q4;
+      *reinterpret_cast<float4*>(o) = make_float4(acc[0] * sc, acc[1] * sc, acc[2] * sc, acc[3] * sc);
+    }
   }
 }

@@ -40,7 +40,8 @@ static int prepare(Ctx* c, const cfd_weg_args* a, hipStream_t st) {
   auto al = [](size_t n) { return (n + 63) & ~(size_t)63; };   // floats, 256-byte granules
   size_t n = 0;
   const size_t n_x = al(M * CFD_D), n_qk = al(M * 2 * CFD_D), n_vt = al((size_t)B * CFD_D * RT_MAX_L), n_sc = al(M * spt), n_pre = al(M * CFD_FF);
-  n += (size_t)(nl + 1) * 5 * n_x + (size_t)nl * (n_qk + n_vt + n_sc + n_pre);
+  const size_t n_cst = al(M * 32 * 4);
+  n += (size_t)(nl + 1) * 5 * n_x + (size_t)nl * (n_qk + n_vt + n_sc + n_pre + n_cst);
   const size_t n_att = al((size_t)B * nl * L * St), n_fws = al((size_t)B * (3 * (size_t)L * St + 3 * St + 64));
   n += 2 * n_att + n_fws + n_sc + 3 * n_x + 2 * n_x + n_pre + n_x + al(M * 3 * CFD_D);
   CHK(c->weg_rt_ws.ensure(n * 4));
@@ -53,6 +54,7 @@ static int prepare(Ctx* c, const cfd_weg_args* a, hipStream_t st) {
     s.sv.vt[l] = reinterpret_cast<char*>(take(n_vt));
     HIPCHK(hipMemset(s.sv.vt[l], 0, n_vt * 4));   // keys beyond L stay zero
     s.sv.sc[l] = take(n_sc);
+    s.sv.cst[l] = take(n_cst);
     s.sv.pre[l] = take(n_pre);
   }
   s.att = take(n_att); s.d_att = take(n_att); s.fws = take(n_fws); s.dP = take(n_sc);
@@ -125,11 +127,11 @@ static int enqueue(Ctx* c, hipStream_t st, bool full, const EvalArgs& e) {
   // ---- reverse sweep (rowtile_bwd.hpp) -----------------------------------------------------------------------
   static unsigned long long attr = 0;
   const int lds_dp = 16 * RT_BSTRIDE(CFD_D) * 4 + 8 * 1024 + 64;
-  const int lds_dy = 16 * RT_BSTRIDE(p.Sp_tot) * 4 + 8 * 1024 + p.Sp_tot * 8 + 512;
+  const int lds_dy = 16 * RT_BSTRIDE(p.Sp_tot) * 4 + 8 * 1024 + 512 + 16 * 32 * 16;
   const int lds_sa = (4 * RT_MAX_L * (CFD_HD + 1) + 2 * RT_MAX_L * (RT_MAX_L + 1)) * 4;
   if (!((attr >> (c->cfg.device & 63)) & 1ull)) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_xbwd_dy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               16 * RT_BSTRIDE(RT_MAX_KEYS) * 4 + 8 * 1024 + RT_MAX_KEYS * 8 + 512));
+                               16 * RT_BSTRIDE(RT_MAX_KEYS) * 4 + 8 * 1024 + 512 + 16 * 32 * 16));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_selfattn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_sa));
     attr |= 1ull << (c->cfg.device & 63);
   }
@@ -144,8 +146,10 @@ static int enqueue(Ctx* c, hipStream_t st, bool full, const EvalArgs& e) {
   for (int j = 0; j < CFD_NMEM; ++j) {
     xb.map[j] = p.map[j]; xb.S[j] = p.S[j]; xb.Sp[j] = p.Sp[j]; xb.off[j] = p.off[j];
     xb.blk0[j] = nkb; nkb += p.Sp[j] / 16;
+    memcpy(xb.inst[j], p.rt_inst[j], RT_ARG_ROWS);
   }
   xb.blk0[CFD_NMEM] = nkb;
+  xb.use_inst = p.rt_use_inst;
   auto Wraw = [&](int l, const char* name) -> const float* { return rawp(c, "decoder.layers." + std::to_string(l) + "." + name); };
   int gi = 0;                 // G[gi] holds the running gradient (valid once have_g)
   bool have_g = false;
@@ -153,7 +157,7 @@ static int enqueue(Ctx* c, hipStream_t st, bool full, const EvalArgs& e) {
   for (int l = nl - 1; l >= 0; --l) {
     const LayerW& lw = c->lw[l];
     RtXBwdArgs x5 = xb;
-    x5.layer = l; x5.sc = s.sv.sc[l];
+    x5.layer = l; x5.sc = s.sv.sc[l]; x5.cst = s.sv.cst[l];
     for (int j = 0; j < CFD_NMEM; ++j) {
       const size_t rows = (size_t)p.U[j] * p.Sp[j];
       x5.K[j] = w->kall_sp[j].as<char>() + (size_t)l * rows * CFD_D * 4;

@@ -31,7 +31,7 @@ ring = np.frombuffer(raw[:4 * 4096 * 8], dtype=np.uint64).reshape(4096, 4)
 seq = int(np.frombuffer(raw[4 * 4096 * 8:4 * 4096 * 8 + 4], dtype=np.uint32)[0])
 n = min(seq, 4096)
 rows = ring[:n] if seq <= 4096 else np.roll(ring, -(seq % 4096), axis=0)
-rows = rows[-92 * 3:]                       # the last three steps
+rows = rows[-101 * 3:]                       # the last three steps
 names = {0: "oproj", 1: "ffn2", 30: "embed", 110: "ffn1", 120: "final", 140: "qkv", 200: "timeblock", 1000: "selfattn", 2000: "xscore", 3000: "xpv"}
 t0 = int(rows[0, 1])
 prev_exit = None
@@ -39,6 +39,9 @@ agg = {}
 for kid, a, b, c in rows:
     kid, a, b, c = int(kid), int(a), int(b), int(c)
     iss, kid = (kid >> 16) / 100.0, kid & 0xFFFF      # (product kernels: entry -> all loads issued, in the id's upper half)
+    if kid == 3002:                                   # xpv: entry -> scores requested, cell statistics requested, V^T slices requested
+        agg.setdefault("xpv-issue", []).append((0.0, a / 100.0, b / 100.0, c / 100.0))
+        continue
     if kid == 3001:                                   # xpv's first record: entry, loads issued, softmax done
         agg.setdefault("xpv-pro", []).append((0.0, (b - a) / 100.0, (c - a) / 100.0, 0.0))
         continue
