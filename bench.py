@@ -537,8 +537,11 @@ def main():
             "tflop_once_per_run_not_per_step": once_per_run,
         }
         if world == 1 and not args.no_secondary and args.shape == "C2":
-            out["other_configs"] = secondary_configs(model, device)
-            out["c1_single_utterance"] = out["other_configs"].pop("c1_single_utterance")
+            try:                      # (secondary measurements never take the headline line down with them)
+                out["other_configs"] = secondary_configs(model, device)
+                out["c1_single_utterance"] = out["other_configs"].pop("c1_single_utterance")
+            except Exception as e:    # noqa: BLE001
+                out["other_configs"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(out))
