@@ -91,6 +91,7 @@ struct Problem {
   int run_row0[8], run_len[8], run_u[8];
   // fused cross-attention (xattn_fused.hpp): workgroups of the work list, 0 = the list was not built
   int xa_nwg = 0;
+  int xa0_nwg_a = 0, xa0_nwg_b = 0;   // layer-0 de-duplication lists (build_xattn_layer0_lists); 0: one launch
   // memories (bit j) whose folded projections were computed once for the run from the centred static part of the memory
   // (prepare_static_memside); per step they only get their per-key scale and bias (mem_scale_kernel)
   int static_mask = 0;
@@ -127,13 +128,13 @@ struct Work {
   // timestep-independent memory-side projections (rows.hpp mem_center_kernel): per memory the dot products c_l . a_s (ca), |a_s|^2 (asq)
   // and, per table row t, A_l b_t / c_l . b_t (kbtab) and VV_l b_t (vbtab); b_t = centred timestep embedding.  CFD_HOIST_MEMSIDE=0: off.
   DBuf ca[CFD_NMEM], asq[CFD_NMEM], kbtab[CFD_NMEM], vbtab[CFD_NMEM], b_tab, b_sp, bsq, zeros512;
-  DBuf xa_wgs, xa_segs, xa_stamps;
+  DBuf xa_wgs, xa_segs, xa_stamps, xa0_wgs_a, xa0_segs_a, xa0_wgs_b, xa0_segs_b, xa_dedup;
   DBuf d_step;  // [0] = loop index, [1] = constant 0, [2] = "this iteration's in-painting overwrite is done" (cfd_sample_inpaint)
   DBuf rt_vt, rt_cbt[CFD_NMEM];   // row-tile path: V^T of the self-attention, per-step key tables
   DBuf rt_cur;                    // row-tile path, sampling run: this step's rows of every per-step table (rt_step_rows_kernel)
   void release() {
     DBuf* all[] = {&x, &h_sp, &qk_sp, &vts_sp, &ssc, &sp_sp, &o_sp, &u_sp, &sc, &p_sp, &eps, &sample_sp, &temb_tab, &h1_tab, &ss_tab, &trows, &iota,
-                   &long_rows, &short_rows, &zero_mask, &b_tab, &b_sp, &bsq, &zeros512, &xa_wgs, &xa_segs, &xa_stamps, &d_step, &rt_vt, &rt_cur};
+                   &long_rows, &short_rows, &zero_mask, &b_tab, &b_sp, &bsq, &zeros512, &xa_wgs, &xa_segs, &xa_stamps, &xa0_wgs_a, &xa0_segs_a, &xa0_wgs_b, &xa0_segs_b, &xa_dedup, &d_step, &rt_vt, &rt_cur};
     for (DBuf* b : all) b->release();
     for (int j = 0; j < CFD_NMEM; ++j) {
       n_sp[j].release(); kall_sp[j].release(); cb[j].release(); vt_all[j].release(); ca[j].release(); asq[j].release(); kbtab[j].release();
@@ -167,6 +168,7 @@ struct cfd_handle_s {
   // the three-launch path everywhere (parity A/B of the two paths).
   bool fused_xattn = true;
   int fused_xattn_min_wgs = 6;
+  int l0_dedup = 1;             // CFD_L0_DEDUP=0: layer 0's cross-attention as one launch over all rows (build_xattn_layer0_lists)
   // Row-tile path for small problems (rowtile.hpp): chosen by SHAPE -- at most rt_max_rows token rows of at most RT_MAX_L tokens per batch
   // row, one timestep for all rows, no dynamic memories.  CFD_ROWTILE=0 turns it off (parity A/B against the tile kernels),
   // CFD_ROWTILE_MAX_ROWS moves the threshold.
@@ -319,6 +321,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   c->fused_xattn = !(env && atoi(env) == 0);
   env = getenv("CFD_FUSED_XATTN_MIN_WGS");
   if (env) c->fused_xattn_min_wgs = atoi(env);
+  env = getenv("CFD_L0_DEDUP");
+  if (env) c->l0_dedup = atoi(env) != 0;
   env = getenv("CFD_ROWTILE");
   c->rt_on = !(env && atoi(env) == 0);
   env = getenv("CFD_WEG_ROWTILE");
@@ -590,60 +594,62 @@ extern "C" int cfd_set_timestep_table(cfd_handle c, const float* rows, int n_row
 //  * memories longer than one 32-key tile come first (online softmax; a flush of the accumulator between two of them);
 //  * workgroups that read the same instance are placed on one XCD (block id % 8) next to each other so the stream is
 //    fetched into that XCD's L2 once; big groups are dealt over all XCDs.
-static int build_xattn_worklist(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
-  Problem& p = c->w->pb;
-  p.xa_nwg = 0;
-  if (!c->fused_xattn) return CFD_OK;
-  const int Be = p.Be, L = p.L, nqt = (L + 15) / 16;
-  std::vector<std::vector<int>> hm(CFD_NMEM, std::vector<int>(Be));
-  for (int j = 0; j < CFD_NMEM; ++j) {
-    if (mem[j].row_map) HIPCHK(hipMemcpy(hm[j].data(), mem[j].row_map, (size_t)Be * 4, hipMemcpyDeviceToHost));
-    else for (int b = 0; b < Be; ++b) hm[j][b] = b;
-    for (int b = 0; b < Be; ++b)
-      if (hm[j][b] < 0 || hm[j][b] >= p.U[j]) return fail(CFD_E_ARG, "memory %s: row_map[%d] = %d outside [0, %d)", MEM_NAMES[j], b, hm[j][b], p.U[j]);
-  }
+struct XaRow {      // one row of a work list
+  int xrow;           // row of the residual stream (queries read from it; updated unless the list stores to xa_dedup)
+  int inst[CFD_NMEM]; // memory instance per memory
+  int aux;            // row of xa_dedup this row's tiles store to / add (-1: none)
+};
+
+static void make_xattn_worklist(const Problem& p, const std::vector<XaRow>& rows, int mem_mask, std::vector<XaWg>& wgs, std::vector<XaSeg>& segs,
+                                size_t& n_active) {
+  const int L = p.L, nqt = (L + 15) / 16;
+  wgs.clear(); segs.clear(); n_active = 0;
   // memory order: long (online) memories first, longest first; then the single-tile ones
-  int order[CFD_NMEM], n_online = 0;
-  for (int j = 0; j < CFD_NMEM; ++j) order[j] = j;
-  std::stable_sort(order, order + CFD_NMEM, [&](int a, int b) { return p.Sp[a] > p.Sp[b]; });
-  for (int j = 0; j < CFD_NMEM; ++j) n_online += p.Sp[j] > XA_KEYS;
+  int order[CFD_NMEM], n_mem = 0, n_online = 0;
+  for (int j = 0; j < CFD_NMEM; ++j)
+    if ((mem_mask >> j) & 1) order[n_mem++] = j;
+  if (n_mem == 0 || rows.empty()) return;
+  std::stable_sort(order, order + n_mem, [&](int a, int b) { return p.Sp[a] > p.Sp[b]; });
+  for (int oi = 0; oi < n_mem; ++oi) n_online += p.Sp[order[oi]] > XA_KEYS;
   const int jg = order[0];
   // groups of rows by instance of memory jg, in order of first appearance
   std::vector<int> inst_group(p.U[jg], -1);
   std::vector<std::vector<int>> groups;
-  for (int b = 0; b < Be; ++b) {
-    int& g = inst_group[hm[jg][b]];
+  for (size_t r = 0; r < rows.size(); ++r) {
+    int& g = inst_group[rows[r].inst[jg]];
     if (g < 0) { g = (int)groups.size(); groups.emplace_back(); }
-    groups[g].push_back(b);
+    groups[g].push_back((int)r);
   }
-  std::vector<XaSeg> segs;
   std::vector<std::vector<XaWg>> group_wgs(groups.size());
   for (size_t g = 0; g < groups.size(); ++g) {
-    std::vector<std::pair<int, int>> tiles;   // (row, first query)
-    for (int b : groups[g])
-      for (int t = 0; t < nqt; ++t) tiles.emplace_back(b, t * 16);
+    std::vector<std::pair<int, int>> tiles;   // (row of `rows`, first query)
+    for (int r : groups[g])
+      for (int t = 0; t < nqt; ++t) tiles.emplace_back(r, t * 16);
     for (size_t t0 = 0; t0 < tiles.size(); t0 += XA_TILES) {
       XaWg w;
       memset(&w, 0, sizeof(w));
+      int vr[XA_TILES];
       for (int k = 0; k < XA_TILES; ++k) {
         const bool on = t0 + k < tiles.size();
-        w.row[k] = on ? tiles[t0 + k].first : -1;
+        vr[k] = on ? tiles[t0 + k].first : -1;
+        w.row[k] = on ? rows[vr[k]].xrow : -1;
+        w.aux[k] = on ? rows[vr[k]].aux : -1;
         w.q0[k] = on ? tiles[t0 + k].second : 0;
       }
       w.seg0 = (int)segs.size();
       int online_seen = 0;
-      for (int oi = 0; oi < CFD_NMEM; ++oi) {
+      for (int oi = 0; oi < n_mem; ++oi) {
         const int j = order[oi];
         const bool online = p.Sp[j] > XA_KEYS;
         online_seen += online;
         int done = 0;
         size_t first_seg = segs.size();
         for (int k = 0; k < XA_TILES; ++k) {
-          if (w.row[k] < 0 || (done >> k) & 1) continue;
+          if (vr[k] < 0 || (done >> k) & 1) continue;
           XaSeg sg;
-          sg.j = j; sg.u = hm[j][w.row[k]]; sg.wmask = 0; sg.flags = online ? XA_ONLINE : 0;
+          sg.j = j; sg.u = rows[vr[k]].inst[j]; sg.wmask = 0; sg.flags = online ? XA_ONLINE : 0;
           for (int k2 = k; k2 < XA_TILES; ++k2)
-            if (w.row[k2] >= 0 && hm[j][w.row[k2]] == sg.u) sg.wmask |= 1 << k2;
+            if (vr[k2] >= 0 && rows[vr[k2]].inst[j] == sg.u) sg.wmask |= 1 << k2;
           done |= sg.wmask;
           segs.push_back(sg);
         }
@@ -681,10 +687,49 @@ static int build_xattn_worklist(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
   for (int x = 0; x < 8; ++x) qlen = std::max(qlen, queue[x].size());
   XaWg idle;
   memset(&idle, 0, sizeof(idle));
-  for (int k = 0; k < XA_TILES; ++k) idle.row[k] = -1;
-  std::vector<XaWg> wgs(qlen * 8, idle);
-  for (int x = 0; x < 8; ++x)
+  for (int k = 0; k < XA_TILES; ++k) { idle.row[k] = -1; idle.aux[k] = -1; }
+  wgs.assign(qlen * 8, idle);
+  for (int x = 0; x < 8; ++x) {
     for (size_t i = 0; i < queue[x].size(); ++i) wgs[i * 8 + x] = queue[x][i];
+    n_active += queue[x].size();
+  }
+}
+
+static int read_row_maps(Ctx* c, const cfd_memory mem[CFD_NMEM], std::vector<std::vector<int>>& hm) {
+  const Problem& p = c->w->pb;
+  hm.assign(CFD_NMEM, std::vector<int>(p.Be));
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    if (mem[j].row_map) HIPCHK(hipMemcpy(hm[j].data(), mem[j].row_map, (size_t)p.Be * 4, hipMemcpyDeviceToHost));
+    else for (int b = 0; b < p.Be; ++b) hm[j][b] = b;
+    for (int b = 0; b < p.Be; ++b)
+      if (hm[j][b] < 0 || hm[j][b] >= p.U[j]) return fail(CFD_E_ARG, "memory %s: row_map[%d] = %d outside [0, %d)", MEM_NAMES[j], b, hm[j][b], p.U[j]);
+  }
+  return CFD_OK;
+}
+
+static int upload_worklist(DBuf& dw, DBuf& ds, const std::vector<XaWg>& wgs, const std::vector<XaSeg>& segs) {
+  CHK(dw.ensure(wgs.size() * sizeof(XaWg)));
+  CHK(ds.ensure(segs.size() * sizeof(XaSeg)));
+  HIPCHK(hipMemcpy(dw.p, wgs.data(), wgs.size() * sizeof(XaWg), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ds.p, segs.data(), segs.size() * sizeof(XaSeg), hipMemcpyHostToDevice));
+  return CFD_OK;
+}
+
+static int build_xattn_worklist(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
+  Problem& p = c->w->pb;
+  p.xa_nwg = 0; p.xa0_nwg_a = 0; p.xa0_nwg_b = 0;
+  if (!c->fused_xattn) return CFD_OK;
+  std::vector<std::vector<int>> hm;
+  CHK(read_row_maps(c, mem, hm));
+  std::vector<XaRow> rows(p.Be);
+  for (int b = 0; b < p.Be; ++b) {
+    rows[b].xrow = b; rows[b].aux = -1;
+    for (int j = 0; j < CFD_NMEM; ++j) rows[b].inst[j] = hm[j][b];
+  }
+  std::vector<XaWg> wgs;
+  std::vector<XaSeg> segs;
+  size_t n_active = 0;
+  make_xattn_worklist(p, rows, (1 << CFD_NMEM) - 1, wgs, segs, n_active);
   if (wgs.empty() || segs.empty()) return CFD_OK;
   // A handful of workgroups cannot hide their serial walk over the key tiles (3 barriers and a fill round trip per 32 keys
   // with nothing else on the chip).  Round-2 measurements at the product shape, 1000 steps, since the memory-side projections
@@ -692,14 +737,69 @@ static int build_xattn_worklist(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
   // 1.318 s three-launch, four utterances (7 workgroups) 1.370 against 1.404, 16 (28 workgroups, one shard of the product-shape
   // benchmark) 470 against 465 steps/s.  Below 6 workgroups the three-launch path stays (CFD_FUSED_XATTN_MIN_WGS overrides;
   // the test suite sets 0 and runs its small cases through the fused kernel).
-  size_t n_active = 0;
-  for (int x = 0; x < 8; ++x) n_active += queue[x].size();
   if ((int)n_active < c->fused_xattn_min_wgs) return CFD_OK;
-  CHK(c->w->xa_wgs.ensure(wgs.size() * sizeof(XaWg)));
-  CHK(c->w->xa_segs.ensure(segs.size() * sizeof(XaSeg)));
-  HIPCHK(hipMemcpy(c->w->xa_wgs.p, wgs.data(), wgs.size() * sizeof(XaWg), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->w->xa_segs.p, segs.data(), segs.size() * sizeof(XaSeg), hipMemcpyHostToDevice));
+  CHK(upload_worklist(c->w->xa_wgs, c->w->xa_segs, wgs, segs));
   p.xa_nwg = (int)wgs.size();
+  return CFD_OK;
+}
+
+// Layer 0 of the sampling loop: the G guidance chunks of an utterance enter the first cross-attention with the SAME state (the
+// replica-independent head, Problem::share_B), so the attention of that state against one memory instance is the same in every
+// chunk that uses the instance.  For the longest memory (audio: 1 500 of the 1 573 keys at the benchmark shape) the 7 chunks of an
+// utterance use 2 instances -- its own and the shared unconditional one -- so 2 evaluations replace 7:
+//   list A  one row per distinct (utterance, instance of the longest memory): that memory only, result (incl. its rank-one
+//           timestep term, without the bias) STORED to xa_dedup[aux]
+//   list B  every row, the other memories, and x += ... + xa_dedup[aux(row)]
+// Exact in real arithmetic; the summation order over the memories differs from the one-launch form (CFD_L0_DEDUP=0), so the G
+// chunks of an utterance still leave layer 0 bit-identical where their memories are identical, but a run differs from the
+// one-launch form by rounding (measured 2e-5 relative on final latents).
+static int build_xattn_layer0_lists(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
+  Problem& p = c->w->pb;
+  p.xa0_nwg_a = p.xa0_nwg_b = 0;
+  if (!c->l0_dedup || p.xa_nwg == 0 || p.share_B <= 0 || p.Be % p.share_B || p.Be == p.share_B) return CFD_OK;
+  const int B = p.share_B, G = p.Be / B;
+  std::vector<std::vector<int>> hm;
+  CHK(read_row_maps(c, mem, hm));
+  int jg = 0;
+  for (int j = 1; j < CFD_NMEM; ++j)
+    if (p.Sp[j] > p.Sp[jg]) jg = j;
+  if (p.Sp[jg] < 256) return CFD_OK;   // nothing worth a second launch
+  std::vector<XaRow> ra, rb(p.Be);
+  std::vector<int> aux_of(p.Be, -1);
+  for (int b = 0; b < B; ++b) {
+    std::vector<std::pair<int, int>> seen;   // (instance, index in ra)
+    for (int g = 0; g < G; ++g) {
+      const int row = g * B + b, u = hm[jg][row];
+      int idx = -1;
+      for (auto& sn : seen)
+        if (sn.first == u) idx = sn.second;
+      if (idx < 0) {
+        idx = (int)ra.size();
+        XaRow r;
+        r.xrow = row; r.aux = idx;
+        for (int j = 0; j < CFD_NMEM; ++j) r.inst[j] = hm[j][row];
+        ra.push_back(r);
+        seen.emplace_back(u, idx);
+      }
+      aux_of[row] = idx;
+    }
+  }
+  if (ra.size() * 2 > (size_t)p.Be) return CFD_OK;   // too little repetition
+  for (int b = 0; b < p.Be; ++b) {
+    rb[b].xrow = b; rb[b].aux = aux_of[b];
+    for (int j = 0; j < CFD_NMEM; ++j) rb[b].inst[j] = hm[j][b];
+  }
+  std::vector<XaWg> wa, wb;
+  std::vector<XaSeg> sa, sb;
+  size_t na = 0, nb = 0;
+  make_xattn_worklist(p, ra, 1 << jg, wa, sa, na);
+  make_xattn_worklist(p, rb, ((1 << CFD_NMEM) - 1) & ~(1 << jg), wb, sb, nb);
+  if (wa.empty() || wb.empty()) return CFD_OK;
+  CHK(upload_worklist(c->w->xa0_wgs_a, c->w->xa0_segs_a, wa, sa));
+  CHK(upload_worklist(c->w->xa0_wgs_b, c->w->xa0_segs_b, wb, sb));
+  CHK(c->w->xa_dedup.ensure(ra.size() * (size_t)p.L * CFD_D * 4));
+  p.xa0_nwg_a = (int)wa.size();
+  p.xa0_nwg_b = (int)wb.size();
   return CFD_OK;
 }
 
@@ -1317,8 +1417,20 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       a.stamps = c->w->xa_stamps.as<long long>();
 #endif
       Bracket br(c, CFD_PROF_XATTN, st);
-      hipLaunchKernelGGL(xattn_fused_kernel, dim3(p.xa_nwg), dim3(XA_WAVES * 64), XA_LDS, st, a);
-      HIPCHK(hipGetLastError());
+      if (l == 0 && share && p.xa0_nwg_a > 0) {   // layer-0 de-duplication (build_xattn_layer0_lists): the longest memory once per distinct (utterance, instance) ...
+        XAttnArgs a0 = a;
+        a0.wgs = c->w->xa0_wgs_a.as<XaWg>(); a0.segs = c->w->xa0_segs_a.as<XaSeg>(); a0.dd_out = c->w->xa_dedup.as<float>(); a0.stamps = nullptr;
+        hipLaunchKernelGGL(xattn_fused_kernel, dim3(p.xa0_nwg_a), dim3(XA_WAVES * 64), XA_LDS, st, a0);
+        HIPCHK(hipGetLastError());
+        // ... then the other memories for every row, which also adds the stored results
+        a0.wgs = c->w->xa0_wgs_b.as<XaWg>(); a0.segs = c->w->xa0_segs_b.as<XaSeg>(); a0.dd_out = nullptr; a0.dd_in = c->w->xa_dedup.as<float>();
+        hipLaunchKernelGGL(xattn_fused_kernel, dim3(p.xa0_nwg_b), dim3(XA_WAVES * 64), XA_LDS, st, a0);
+        HIPCHK(hipGetLastError());
+        if (c->prof) c->prof_n[CFD_PROF_XATTN] += 1;   // (two launches under one bracket)
+      } else {
+        hipLaunchKernelGGL(xattn_fused_kernel, dim3(p.xa_nwg), dim3(XA_WAVES * 64), XA_LDS, st, a);
+        HIPCHK(hipGetLastError());
+      }
     } else {
     CHK(ln(w.ln2g, w.ln2b, 0, 0, c->w->h_sp.as<char>(), M));
     // Three-launch path (att_mats wanted): scores against the folded keys of every memory.  Long memories and short
@@ -1616,6 +1728,7 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
   }
   CHK(setup_problem(c, Be, s.L, mem_in, nullptr, 0, N));
   if (c->share0 && c->sargs.G > 1) c->w->pb.share_B = s.B;   // begin_step_kernel writes G identical copies of the B rows
+  CHK(build_xattn_layer0_lists(c, mem_in));
   // timesteps: (arange(N) * (T // N)).round()[::-1] (+ steps_offset for DDIM)
   std::vector<int32_t> ts(N);
   std::vector<StepCoef> coef(N);

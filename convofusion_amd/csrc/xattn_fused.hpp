@@ -86,6 +86,7 @@ enum { XA_ONLINE = 1, XA_FLUSH = 2 };
 struct XaWg {
   int row[XA_TILES];   // effective-batch row of query tile t, or -1 (idle)
   int q0[XA_TILES];    // first query (token index inside the row) of tile t
+  int aux[XA_TILES];   // layer-0 de-duplication: row of XAttnArgs::dd_out this tile's result is stored to / of dd_in it adds (-1: none)
   int seg0, nseg;
   int pf_slot, pf_n;   // L2 prefetch share (used by the archived role-split kernel, tools/experiments/r03_variants/xattn_role.hpp): this workgroup is number pf_slot of pf_n that stream the same instance of the
                        // longest memory on one XCD at about the same time (0, 0: no prefetch)
@@ -108,6 +109,10 @@ struct XAttnArgs {
   int L;
   const XaWg* wgs;
   const XaSeg* segs;
+  // layer-0 de-duplication (cfd_api.hip, build_xattn_layer0_lists).  dd_out: the tiles' results (accumulated memories + their rank-one
+  // terms, no bias) are STORED to dd_out[aux][query][512] and x is left alone.  dd_in: x += ... + dd_in[aux][query][512].
+  float* dd_out;
+  const float* dd_in;
   long long* stamps;          // XA_STAMP builds only (tools/xa_stamps.py): per wave, cycles per section of the kernel
 };
 
@@ -164,6 +169,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   const XaWg* wgp = a.wgs + blockIdx.x;
   const int my_row = wgp->row[tile];
   const int my_q0 = wgp->q0[tile];
+  const int my_aux = wgp->aux[tile];
   const int seg0 = wgp->seg0, nseg = wgp->nseg;
   const bool active = my_row >= 0;                     // wave-uniform
   const long long tok0 = active ? (long long)my_row * a.L + my_q0 : 0;
@@ -343,11 +349,20 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
         vbv[j] = *reinterpret_cast<const float4*>(ka->vb[j] + (long long)trow * ka->vb_stride[j] + half * 256 + lane * 4);
     }
     float* xp = ka->x + tok0 * CFD_D + half * 256 + lane * 4;
+    float* const dd_out = ka->dd_out;
+    const float* const dd_in = ka->dd_in;
+    const bool store_only = add_bias && dd_out != nullptr;                      // (wave-uniform)
+    const bool add_extra = add_bias && dd_in != nullptr && my_aux >= 0;
+    const long long dd_off = ((long long)max(my_aux, 0) * a.L + my_q0) * CFD_D + half * 256 + lane * 4;
     // all 16 rows are requested before the first is used: one exposed memory round trip per flush instead of four
-    float4 old[16];
+    float4 old[16], extra[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if (r < nq) old[r] = *reinterpret_cast<const float4*>(xp + (long long)r * CFD_D);
+    for (int r = 0; r < 16; ++r) {
+      old[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      extra[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < nq && !store_only) old[r] = *reinterpret_cast<const float4*>(xp + (long long)r * CFD_D);
+      if (r < nq && add_extra) extra[r] = *reinterpret_cast<const float4*>(dd_in + dd_off + (long long)r * CFD_D);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(strip + r * RS + lane * 16);
@@ -361,8 +376,13 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
             c.x += wj * vbv[j].x; c.y += wj * vbv[j].y; c.z += wj * vbv[j].z; c.w += wj * vbv[j].w;
           }
         }
-        t.x = (t.x + bv.x) + c.x; t.y = (t.y + bv.y) + c.y; t.z = (t.z + bv.z) + c.z; t.w = (t.w + bv.w) + c.w;
-        *reinterpret_cast<float4*>(xp + (long long)r * CFD_D) = t;
+        if (store_only) {
+          *reinterpret_cast<float4*>(dd_out + dd_off + (long long)r * CFD_D) = c;
+        } else {
+          const float4 e = extra[r];
+          t.x = ((t.x + bv.x) + e.x) + c.x; t.y = ((t.y + bv.y) + e.y) + c.y; t.z = ((t.z + bv.z) + e.z) + c.z; t.w = ((t.w + bv.w) + e.w) + c.w;
+          *reinterpret_cast<float4*>(xp + (long long)r * CFD_D) = t;
+        }
       }
     }
 #pragma unroll
