@@ -268,8 +268,8 @@ def secondary_configs(model, device):
         mask_w = {"spkemb": None, "alsn": None, "apb": None, "lsnemb": None, "tlsn": (torch.arange(24) >= 17)[None].to(device)}
         lat_w = torch.randn(1, L, 128, generator=gw).to(device)
 
-        def ev(same):
-            return weg.loss_and_grad(model, lat_w, 500, enc_w, mask_w, [[3, 9, 14]], same_conditioning=same)
+        def ev(same, t=500):
+            return weg.loss_and_grad(model, lat_w, t, enc_w, mask_w, [[3, 9, 14]], same_conditioning=same)
         for _ in range(3):
             ev(False)
         sync()
@@ -283,6 +283,14 @@ def secondary_configs(model, device):
             ev(True)
         sync()
         t_same = (time.perf_counter() - t0) / 20
+        for k in range(3):       # the guided loop's case: one evaluation per iteration, same conditioning, a new timestep every time
+            ev("memories", 999 - k)
+        sync()
+        t0 = time.perf_counter()
+        for k in range(20):
+            ev("memories", 900 - 7 * k)
+        sync()
+        t_newt = (time.perf_counter() - t0) / 20
         g1 = torch.Generator().manual_seed(11)
         cond1 = [torch.randn(1, s, 512, generator=g1) for s in S]
         unc1 = [torch.randn(1, s, 512, generator=g1) for s in S]
@@ -294,9 +302,12 @@ def secondary_configs(model, device):
         t0 = time.perf_counter()
         sample_with_weg(model, ddpm, enc7, mask7, [[3, 9, 14]], wp, B=1, L=L, num_inference_steps=1000, seed=1)
         sync()
-        out["weg_b1_product_shape"] = {"eval_ms": t_full * 1e3, "eval_same_conditioning_ms": t_same * 1e3, "guided_utterance_s": time.perf_counter() - t0,
+        out["weg_b1_product_shape"] = {"eval_ms": t_full * 1e3, "eval_same_conditioning_ms": t_same * 1e3, "eval_new_timestep_same_memories_ms": t_newt * 1e3,
+                                       "guided_utterance_s": time.perf_counter() - t0,
                                        "note": "cfd_weg_eval on the row-tile kernels (forward with saved activations, objective, float32-MFMA reverse "
-                                               "sweep: ~160 launches); guided run = configs/assets.yaml:18-23 WEG parameters on random weights"}
+                                               "sweep: ~160 launches); eval_ms = new memories (their projections and one timestep's tables are made: ~50 launches more), "
+                                               "eval_new_timestep_same_memories_ms = what the guided loop does once per iteration (tables over all timesteps, built once); "
+                                               "guided run = configs/assets.yaml:18-23 WEG parameters on random weights"}
     finally:
         L, S = L0, S0
     return out

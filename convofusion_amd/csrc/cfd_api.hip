@@ -117,6 +117,7 @@ struct WegRtState {
   float *att = nullptr, *d_att = nullptr, *fws = nullptr, *dP = nullptr, *G[3] = {nullptr, nullptr, nullptr}, *dz = nullptr, *dy = nullptr,
         *dh = nullptr, *dO = nullptr, *dqkv = nullptr;
   int launches = 0;
+  int T = 1;                    // rows of wk[1]'s per-timestep tables: 1 (this evaluation's timestep) or every timestep (cfd_weg_args::reuse_memory_side == 2)
 };
 
 // One problem's device workspace: everything setup_problem / prepare_static_memside allocate and the launches of a forward touch.
@@ -132,6 +133,11 @@ struct Work {
   DBuf d_step;  // [0] = loop index, [1] = constant 0, [2] = "this iteration's in-painting overwrite is done" (cfd_sample_inpaint)
   DBuf rt_vt, rt_cbt[CFD_NMEM];   // row-tile path: V^T of the self-attention, per-step key tables
   DBuf rt_cur;                    // row-tile path, sampling run: this step's rows of every per-step table (rt_step_rows_kernel)
+  // row-tile path: where the launches of the current problem find this step's AdaLN rows and A b / VV b vectors (the tables themselves
+  // when they have one row, rt_cur otherwise); set by enqueue_rows_rt, read by the WEG reverse sweep (weg_rt.hpp)
+  const float* now_ss = nullptr;
+  const float* now_kb[CFD_NMEM] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  const float* now_vb[CFD_NMEM] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   void release() {
     DBuf* all[] = {&x, &h_sp, &qk_sp, &vts_sp, &ssc, &sp_sp, &o_sp, &u_sp, &sc, &p_sp, &eps, &sample_sp, &temb_tab, &h1_tab, &ss_tab, &trows, &iota,
                    &long_rows, &short_rows, &zero_mask, &b_tab, &b_sp, &bsq, &zeros512, &xa_wgs, &xa_segs, &xa_stamps, &xa0_wgs_a, &xa0_segs_a, &xa0_wgs_b, &xa0_segs_b, &xa_dedup, &d_step, &rt_vt, &rt_cur};
@@ -187,7 +193,8 @@ struct cfd_handle_s {
   bool weg_rt_on = true;
   DBuf weg_rt_ws;
   WegRtState wrt;
-  int weg_t_host = 0;   // the evaluation's timestep, copied to wk[1].trows in front of every launch sequence
+  int weg_t_host = 0;   // the evaluation's timestep, copied to wk[1].trows in front of every launch sequence (one-row tables)
+  int weg_dstep_host = 0;   // ... and the table row it selects, copied to wk[1].d_step (0 for one-row tables, the timestep for full tables)
   bool weg_graph_on = true;
   struct WegGraph { std::vector<long long> key; int uses = 0; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
   WegGraph weg_graph[2];
@@ -1165,6 +1172,8 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
     ra.ntab = nt; ra.first[nt] = nwg; ra.d_step = dstep;
     LAUNCH(CFD_PROF_OTHER, rt_step_rows_kernel, dim3(nwg), dim3(256), st, ra);
   }
+  c->w->now_ss = ss_now;
+  for (int j = 0; j < CFD_NMEM; ++j) { c->w->now_kb[j] = kb_now[j]; c->w->now_vb[j] = vb_now[j]; }
   RtGemmArgs base;
   memset(&base, 0, sizeof(base));
   base.L = L; base.tpr = tpr;
@@ -2103,23 +2112,38 @@ extern "C" int cfd_weg_eval(cfd_handle c, const cfd_weg_args* a, float* losses, 
                a->last, nt_max, {a->kernel3[0], a->kernel3[1], a->kernel3[2]}, io + o_loss, io + o_max, io + o_grad};
   // what the memory-side / time-only part of an evaluation depends on: with args->reuse_memory_side the caller states that the
   // memories' CONTENTS are unchanged too (a refinement loop at one timestep), and those launches are skipped
-  std::vector<long long> sig = {B, L, a->timestep};
+  // What the memory-side / time-only part of an evaluation depends on.  With args->reuse_memory_side the caller states that the
+  // memories' CONTENTS are unchanged too, and those launches are skipped: 1 = same timestep as well (a refinement loop at one
+  // timestep), 2 = the timestep may differ (the guided sampling loop: one evaluation per iteration, same conditioning).  The
+  // row-tile path serves 2 from tables over ALL timesteps, built at the first such call (row t = timestep t, one launch per
+  // evaluation copies the row); the float32 launch sequence treats 2 with a new timestep as 0.
+  const bool use_rt = wegrt::eligible(c, a);
+  std::vector<long long> sig = {B, L};
   for (int j = 0; j < CFD_NMEM; ++j) {
     sig.push_back(a->mem[j].S);
     sig.push_back((long long)(size_t)a->mem[j].data);
   }
   weg::Ctx x{c, st, true, reinterpret_cast<char*>(256), 0, B, L, D, D, CFD_OK, std::string(), 0};
   // small problems (the product shape) run on the row-tile kernels, everything else on the float32 launch sequence of weg_eval.hpp
-  const bool use_rt = wegrt::eligible(c, a);
   const void* arena = nullptr;
+  bool reuse = false;
   if (use_rt) {
-    CHK(wegrt::prepare(c, a, st));
+    const bool had_full = c->wrt.T > 1;
+    // tables over all timesteps stay while the caller keeps stating that the conditioning is unchanged
+    const int T = a->reuse_memory_side == 2 || (a->reuse_memory_side == 1 && had_full) ? c->tsin_rows : 1;
+    CHK(wegrt::prepare(c, a, T, st));
     arena = c->weg_rt_ws.p;
     sig.push_back((long long)(size_t)arena);
-    sig.push_back(-1);
+    sig.push_back(-(long long)T);
+    if (T == 1) sig.push_back(a->timestep);
+    reuse = a->reuse_memory_side != 0 && sig == c->weg_sig;
+    c->wrt.T = T;
     c->weg_t_host = a->timestep;                     // in front of the launch sequence, outside any captured graph
-    HIPCHK(hipMemcpyAsync(c->wk[1].trows.p, &c->weg_t_host, 4, hipMemcpyHostToDevice, st));
+    c->weg_dstep_host = T > 1 ? a->timestep : 0;
+    if (T == 1) HIPCHK(hipMemcpyAsync(c->wk[1].trows.p, &c->weg_t_host, 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->wk[1].d_step.p, &c->weg_dstep_host, 4, hipMemcpyHostToDevice, st));
   } else {
+    sig.push_back(a->timestep);
     weg::run(x, wa);                                 // sizing pass
     if (x.err) return fail(x.err, "missing tensor '%s' (state-dict key denoiser.%s)", x.missing.c_str(), x.missing.c_str());
     if (x.off > c->weg_ws.bytes) HIPCHK(hipStreamSynchronize(st));
@@ -2127,12 +2151,13 @@ extern "C" int cfd_weg_eval(cfd_handle c, const cfd_weg_args* a, float* losses, 
     arena = c->weg_ws.p;
     sig.push_back((long long)(size_t)arena);
     sig.push_back((long long)x.off);
+    reuse = a->reuse_memory_side != 0 && sig == c->weg_sig;
   }
   x.dry = false;
   x.base = c->weg_ws.as<char>();
   x.off = 0;
   x.launches = 0;
-  x.reuse = a->reuse_memory_side != 0 && sig == c->weg_sig;
+  x.reuse = reuse;
   c->weg_sig.clear();
   const wegrt::EvalArgs ea{io + o_lat, c->weg_tok.as<int32_t>(), c->weg_tok.as<int32_t>() + B + 1, a->last, nt_max,
                            {a->kernel3[0], a->kernel3[1], a->kernel3[2]}, io + o_loss, io + o_max, io + o_grad};
@@ -2144,7 +2169,7 @@ extern "C" int cfd_weg_eval(cfd_handle c, const cfd_weg_args* a, float* losses, 
   };
   // everything the launch sequence and its (by-value) kernel arguments depend on, the timestep excepted (its row is staged)
   std::vector<long long> key = {B, L, a->last, nt_max, c->weg_tok_version, (long long)(size_t)c->weg_tok.p, (long long)(size_t)io, (long long)n_io,
-                                (long long)(size_t)arena, (long long)x.reuse, (long long)use_rt};
+                                (long long)(size_t)arena, (long long)x.reuse, (long long)use_rt, (long long)(use_rt ? c->wrt.T : 0)};
   for (int j = 0; j < CFD_NMEM; ++j) {
     key.push_back(a->mem[j].S);
     key.push_back((long long)(size_t)a->mem[j].data);

@@ -22,10 +22,10 @@ static bool eligible(Ctx* c, const cfd_weg_args* a) {
 }
 
 // (Re)build the evaluation's problem and arena when shapes or pointers change.  Host work only (allocations, row maps): never captured.
-static int prepare(Ctx* c, const cfd_weg_args* a, hipStream_t st) {
+static int prepare(Ctx* c, const cfd_weg_args* a, int T, hipStream_t st) {
   WegRtState& s = c->wrt;
   const int B = a->B, L = a->L, nl = c->nl;
-  std::vector<long long> sig = {B, L, nl};
+  std::vector<long long> sig = {B, L, nl, T};
   int spt = 0;
   for (int j = 0; j < CFD_NMEM; ++j) {
     sig.push_back(a->mem[j].S);
@@ -65,7 +65,12 @@ static int prepare(Ctx* c, const cfd_weg_args* a, hipStream_t st) {
     cfd_memory mem[CFD_NMEM];
     float* att[CFD_NMEM] = {nullptr, nullptr, s.att, nullptr, nullptr};
     for (int j = 0; j < CFD_NMEM; ++j) mem[j] = a->mem[j];
-    CHK(setup_problem(c, B, L, mem, att, 0, 1));
+    CHK(setup_problem(c, B, L, mem, att, 0, T));
+    if (T > 1) {   // full tables: row t belongs to timestep t
+      std::vector<int32_t> iota(T);
+      for (int t = 0; t < T; ++t) iota[t] = t;
+      HIPCHK(hipMemcpy(c->w->trows.p, iota.data(), (size_t)T * 4, hipMemcpyHostToDevice));
+    }
     if (!c->w->pb.rt) return fail(CFD_E_STATE, "row-tile WEG evaluation: the problem does not qualify for the row-tile path");
   }
   s.sig = sig;
@@ -106,7 +111,7 @@ static int enqueue(Ctx* c, hipStream_t st, bool full, const EvalArgs& e) {
   const int nl = c->nl, B = p.Be, L = p.L, tpr = (L + 15) / 16, ntile = B * tpr, St = p.S[2];
   const long long M = p.M;
   if (full) {
-    CHK(enqueue_time_tables(c, 1, st));        // the timestep index is in w->trows (copied in front of the launch sequence)
+    CHK(enqueue_time_tables(c, p.T, st));      // one row: the timestep index is in w->trows (copied in front of the launch sequence); full tables: row t = timestep t
     CHK(prepare_static_memside(c, st, 0, true));
     if (!p.rt) return fail(CFD_E_STATE, "row-tile WEG evaluation lost its path");
     s.launches += 20 + 5 * 6 + 2;
@@ -140,7 +145,7 @@ static int enqueue(Ctx* c, hipStream_t st, bool full, const EvalArgs& e) {
   base.L = L; base.tpr = tpr;
   RtXBwdArgs xb;
   memset(&xb, 0, sizeof(xb));
-  xb.L = L; xb.tpr = tpr; xb.nl = nl; xb.Sp_tot = p.Sp_tot;   // (one table row: T = 1, the tables ARE this step's rows)
+  xb.L = L; xb.tpr = tpr; xb.nl = nl; xb.Sp_tot = p.Sp_tot;   // (this step's table rows: Work::now_*, set by the forward)
   xb.rsp = w->p_sp.as<float>(); xb.d_att = s.d_att; xb.dP = s.dP; xb.dy = s.dy;
   int nkb = 0;
   for (int j = 0; j < CFD_NMEM; ++j) {
@@ -162,8 +167,8 @@ static int enqueue(Ctx* c, hipStream_t st, bool full, const EvalArgs& e) {
       const size_t rows = (size_t)p.U[j] * p.Sp[j];
       x5.K[j] = w->kall_sp[j].as<char>() + (size_t)l * rows * CFD_D * 4;
       x5.VT[j] = w->vt_all[j].as<char>() + (size_t)l * rows * CFD_D * 4;
-      x5.kb[j] = w->kbtab[j].as<float>() + (size_t)l * CFD_D;
-      x5.vb[j] = w->vbtab[j].as<float>() + (size_t)l * CFD_D;
+      x5.kb[j] = w->now_kb[j] + (size_t)l * CFD_D;
+      x5.vb[j] = w->now_vb[j] + (size_t)l * CFD_D;
     }
     if (l < nl - 1) {
       const LayerW& up = c->lw[l + 1];
@@ -189,7 +194,7 @@ static int enqueue(Ctx* c, hipStream_t st, bool full, const EvalArgs& e) {
       {   // B4: time block 2's SiLU / modulation / norm, then the probabilities' gradient
         RtXBwdArgs a = x5;
         a.dz = s.dz; a.g = s.G[gi]; a.x = s.sv.x[l][3]; a.gamma = lw.tb2g; a.beta = lw.tb2b;
-        a.ss = w->ss_tab.as<float>() + (size_t)(2 * l + 1) * 2 * CFD_D; a.gout = s.G[(gi + 1) % 3];
+        a.ss = w->now_ss + (size_t)(2 * l + 1) * 2 * CFD_D; a.gout = s.G[(gi + 1) % 3];
         hipLaunchKernelGGL(rt_xbwd_dp_kernel, dim3(nkb, ntile), dim3(512), lds_dp, st, a);
         HIPCHK(hipGetLastError());
         ++s.launches;
@@ -214,7 +219,7 @@ static int enqueue(Ctx* c, hipStream_t st, bool full, const EvalArgs& e) {
     {   // B7: time block 1, then the attention's output projection
       RtBwdArgs a = base;
       a.K = CFD_D; a.a = s.dz; a.g = s.G[gi]; a.x = s.sv.x[l][1]; a.gamma = lw.tb1g; a.beta = lw.tb1b;
-      a.ss = w->ss_tab.as<float>() + (size_t)(2 * l) * 2 * CFD_D; a.gout = s.G[(gi + 1) % 3];
+      a.ss = w->now_ss + (size_t)(2 * l) * 2 * CFD_D; a.gout = s.G[(gi + 1) % 3];
       a.w = Wraw(l, "self_attn.out_proj.weight"); a.ldw = CFD_D; a.out = s.dO; a.ldo = CFD_D;
       CHK((bwd_gemm<RT_BPRO_TB, RT_BEPI_F32, 16>(c, st, a, CFD_D, ntile)));
       gi = (gi + 1) % 3;

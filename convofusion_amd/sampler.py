@@ -378,6 +378,7 @@ def sample_with_weg(denoiser, scheduler, encoder_hidden_states, cond_masks, focu
         thresholds = dict(weg_parameters["thresholds"])
         timesteps = run.timesteps
         carry = [weg_parameters["scale_range"][0], weg_parameters["scale_range"][1]] if carry_scale_range else None   # :395
+        guided = 0                            # evaluations of the objective so far (their conditioning never changes inside the loop)
         every = return_attention == "all"     # the reference's dict: one entry per iteration (convofusion.py:517-523)
         att = {} if every else None
 
@@ -395,7 +396,8 @@ def sample_with_weg(denoiser, scheduler, encoder_hidden_states, cond_masks, focu
             else:
                 run.inpaint()   # rollout: the re-noised previous window goes in before the WEG update (unbounded_synthesis.py:70-76)
                 lat, _ = weg.weg_update(denoiser, run.read(), i, t, text_states, text_masks, focus_indices, weg_parameters, len(timesteps),
-                                        scale_carry=carry)
+                                        scale_carry=carry, same_memories=guided > 0)
+                guided += 1
                 run.write(lat)
             if every:
                 att[int(t)] = maps(t)

@@ -378,8 +378,9 @@ def loss_and_grad(denoiser, latents, timestep, encoder_hidden_states, cond_masks
                   same_conditioning=False):
     """One evaluation of the WEG objective on the text-only chunk (convofusion.py:447-471) and d(loss)/d(latents) --
     ``cfd_weg_eval``: forward with saved activations, objective and backward sweep enqueued by the library.
-    ``same_conditioning``: timestep, memories and masks are those of the previous call (only the latents moved): the
-    memory-side LayerNorms / key-value projections and the time embeddings are reused.
+    ``same_conditioning``: True = timestep, memories and masks are those of the previous call (only the latents moved): the
+    memory-side LayerNorms / key-value projections and the time embeddings are reused; ``"memories"`` = memories and masks are
+    the previous call's, the timestep may differ (one evaluation per loop iteration: the library keeps per-timestep tables).
     Returns (loss 0-d tensor, losses [B], max_attention_at_indices, grad [B, L, 128])."""
     if not isinstance(denoiser, Denoiser):
         raise TypeError("denoiser must be a convofusion_amd.denoiser.Denoiser")
@@ -399,7 +400,7 @@ def loss_and_grad(denoiser, latents, timestep, encoder_hidden_states, cond_masks
     a.B, a.L, a.timestep, a.latents, a.mem = B, L, int(timestep), lat.data_ptr(), marr
     a.tok_off, a.tok_idx, a.last = off.ctypes.data, flat.ctypes.data, last
     a.kernel3 = (C.c_float * 3)(*gaussian_kernel3())
-    a.reuse_memory_side = 1 if same_conditioning else 0
+    a.reuse_memory_side = 2 if same_conditioning == "memories" else (1 if same_conditioning else 0)
     losses = torch.empty(B, dtype=torch.float32, device=dev)
     max_att = torch.empty(max(1, int(off[-1])), dtype=torch.float32, device=dev)
     grad = torch.empty_like(lat)
@@ -432,12 +433,13 @@ def update_latent(latents, grad, lr, denoiser):
 
 
 def iterative_refinement_step(denoiser, latents, indices_to_alter, loss, threshold, encoder_hidden_states, cond_masks, step_size, t,
-                              max_refinement_steps=400, normalize_eot=False, eot_indices=()):
+                              max_refinement_steps=400, normalize_eot=False, eot_indices=(), conditioning_seen=False):
     """``Convofusion.iterative_refinement_step`` (convofusion.py:298-388): repeat the update at one timestep until the
-    objective falls below ``1 - threshold``.  Returns (loss, latents, max_attention_at_indices, grad at the returned latents)."""
+    objective falls below ``1 - threshold``.  ``conditioning_seen``: the caller's previous evaluation was at this timestep with
+    these memories (``weg_update``).  Returns (loss, latents, max_attention_at_indices, grad at the returned latents)."""
     iteration = 0
     target_loss = max(0, 1.0 - threshold)
-    same = False      # the loop stays at one timestep with the same memories: from the second evaluation on only the latents differ
+    same = bool(conditioning_seen)   # the loop stays at one timestep with the same memories: from the second evaluation on only the latents differ
     while loss > target_loss:
         iteration += 1
         loss, _, _, grad = loss_and_grad(denoiser, latents, t, encoder_hidden_states, cond_masks, indices_to_alter, normalize_eot, eot_indices,
@@ -469,18 +471,22 @@ def scale_range_schedule(weg_parameters, num_steps, i, carry=None):
     return sr
 
 
-def weg_update(denoiser, latents, i, t, text_only_states, text_only_masks, focus_indices, weg_parameters, num_steps, scale_carry=None):
+def weg_update(denoiser, latents, i, t, text_only_states, text_only_masks, focus_indices, weg_parameters, num_steps, scale_carry=None,
+               same_memories=False):
     """The WEG branch of loop iteration ``i`` at timestep ``t`` (convofusion.py:437-496).  ``text_only_*``: chunk 1 of
     the 7-way guidance batch (:447-448).  ``scale_carry``: see ``scale_range_schedule`` (a list threaded through the loop
-    for ``_diffusion_reverse``; None for the rollout).  Returns (latents, loss)."""
+    for ``_diffusion_reverse``; None for the rollout).  ``same_memories``: the memories and masks are the ones the previous
+    ``weg_update`` of this loop was given (every iteration but the first).  Returns (latents, loss)."""
     scale_range = scale_range_schedule(weg_parameters, num_steps, i, scale_carry)                                # :442-444
     eot = torch.argmax(text_only_masks["tlsn"].int(), dim=1) - 1                                                  # :460
     step_size = weg_parameters["scale_factor"] * np.sqrt(scale_range[i])
-    loss, _, _, grad = loss_and_grad(denoiser, latents, t, text_only_states, text_only_masks, focus_indices, True, eot)
+    loss, _, _, grad = loss_and_grad(denoiser, latents, t, text_only_states, text_only_masks, focus_indices, True, eot,
+                                     same_conditioning="memories" if same_memories else False)
     thresholds = weg_parameters["thresholds"]
     if i in thresholds and loss > 1.0 - thresholds[i]:                                                            # :474-487
         loss, latents, _, grad = iterative_refinement_step(denoiser, latents, focus_indices, loss, thresholds[i], text_only_states,
-                                                           text_only_masks, step_size, t, weg_parameters["max_refinement_steps"], True, eot)
+                                                           text_only_masks, step_size, t, weg_parameters["max_refinement_steps"], True, eot,
+                                                           conditioning_seen=True)
     if i < weg_parameters["max_iter_to_alter"] and loss != 0:                                                     # :490-495
         latents = update_latent(latents, grad, step_size, denoiser)
     return latents, float(loss)

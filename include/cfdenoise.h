@@ -253,9 +253,14 @@ typedef struct {
   const int32_t* tok_idx;        /* HOST focus token positions (text positions, BOS = 0), each in [1, last) */
   int last;                      /* text slice [1, last): eot index (normalize_eot) or S_text - 1 */
   float kernel3[3];              /* {corner, edge, centre} of GaussianSmoothing(1, 3, 0.5, dim=2).weight */
-  int reuse_memory_side;         /* != 0: timestep and memory CONTENTS are those of the previous call (the refinement loop at one
-                                    timestep, convofusion.py:322-346): their time embedding, memory LayerNorms and key / value
-                                    projections are taken from the previous evaluation (ignored when shapes / pointers differ) */
+  int reuse_memory_side;         /* != 0: the memory CONTENTS (and masks) are those of the previous call, so their LayerNorms and
+                                    key / value projections are taken from it (ignored when shapes / pointers differ).
+                                    1: the timestep is the previous call's too (the refinement loop at one timestep,
+                                       convofusion.py:322-346): its time embedding is reused as well.
+                                    2: the timestep may differ (the guided sampling loop evaluates the objective once per
+                                       iteration with the same conditioning, convofusion.py:437-471): small problems keep
+                                       per-timestep tables for every timestep, built at the first such call (a few ms), and an
+                                       evaluation selects its row; larger problems treat a new timestep like 0. */
 } cfd_weg_args;
 int cfd_weg_eval(cfd_handle h, const cfd_weg_args* args, float* losses, float* max_att, float* grad, float* loss_host, void* stream);
 int cfd_sample_write(cfd_handle h, const float* latents);

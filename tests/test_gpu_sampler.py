@@ -572,8 +572,13 @@ def test_row_tile_path_is_race_free_and_shape_general():
     from tests.gpu_helpers import hip_denoiser, to_dev
     m = hip_denoiser(1234, 1.0)
     sd = state_dict(1234, 1.0)
-    for Be, L, S in ((7, 16, (24, 161, 24, 8, 1)), (35, 16, (6, 20, 6, 8, 1)), (3, 20, (5, 40, 3, 8, 1)), (2, 32, (33, 70, 12, 8, 1)), (1, 2, (1, 1, 1, 1, 1))):
-        inp = inputs.make_plain_batch(seed=50 + Be, Be=Be, L=L, S=S, pad_tail=(0, 0, 0, 0, 0), scale=1.0)
+    # ... and the edges of the path's eligibility: 800 token rows exactly, 1024 padded keys exactly (the 1024-key instantiation of
+    # the second cross-attention launch), both with padded tails in the key masks
+    shapes = ((7, 16, (24, 161, 24, 8, 1), None), (35, 16, (6, 20, 6, 8, 1), None), (3, 20, (5, 40, 3, 8, 1), None),
+              (2, 32, (33, 70, 12, 8, 1), None), (1, 2, (1, 1, 1, 1, 1), None),
+              (25, 32, (32, 700, 32, 8, 1), (3, 100, 5, 0, 0)), (2, 16, (32, 890, 32, 8, 1), (0, 37, 31, 0, 0)))
+    for Be, L, S, pad in shapes:
+        inp = inputs.make_plain_batch(seed=50 + Be, Be=Be, L=L, S=S, pad_tail=pad or (0, 0, 0, 0, 0), scale=1.0)
         mems = [to_dev(x) for x in inp["memories"]]
         x = to_dev(inp["sample"])
         with torch.no_grad():

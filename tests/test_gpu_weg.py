@@ -149,6 +149,15 @@ def test_gradient_matches_oracle_and_reference_autograd(name):
     weg.loss_and_grad(m, to_dev(inp["sample"]), t, mems, masks, focus, neot, to_dev(eot))
     reused = weg.loss_and_grad(m, lat2, t, mems, masks, focus, neot, to_dev(eot), same_conditioning=True)
     assert float(fresh[0]) == float(reused[0]) and torch.equal(fresh[3], reused[3])
+    # the guided loop's case: same memories, another timestep every call -- served from tables over all timesteps (built at the
+    # first such call), bit-identical to fresh evaluations; a refinement call at one of them (same_conditioning=True) stays on them
+    for t2 in (t, 3, 999, t):
+        fresh = weg.loss_and_grad(m, lat2, t2, mems, masks, focus, neot, to_dev(eot))
+        weg.loss_and_grad(m, to_dev(inp["sample"]), t, mems, masks, focus, neot, to_dev(eot), same_conditioning="memories")
+        tabled = weg.loss_and_grad(m, lat2, t2, mems, masks, focus, neot, to_dev(eot), same_conditioning="memories")
+        again = weg.loss_and_grad(m, lat2, t2, mems, masks, focus, neot, to_dev(eot), same_conditioning=True)
+        assert float(fresh[0]) == float(tabled[0]) == float(again[0]), t2
+        assert torch.equal(fresh[3], tabled[3]) and torch.equal(fresh[3], again[3]), t2
     # the launch-by-launch form of the same evaluation
     l3, _, _, g3 = weg.loss_and_grad_stepwise(m, to_dev(inp["sample"]), t, mems, masks, focus, neot, to_dev(eot))
     # (two implementations: the float32 launch sequence in the reference's unfolded formulation against the product path's

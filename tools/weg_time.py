@@ -37,6 +37,8 @@ def timeit(fn, n=50):
 out = {"rowtile": os.environ.get("CFD_WEG_ROWTILE", "1")}
 out["eval_ms"] = timeit(lambda: weg.loss_and_grad(model, lat_w, 500, enc_w, mask_w, focus_w))
 out["eval_same_conditioning_ms"] = timeit(lambda: weg.loss_and_grad(model, lat_w, 500, enc_w, mask_w, focus_w, same_conditioning=True))
+ts = iter(range(999, 0, -1))
+out["eval_new_timestep_same_memories_ms"] = timeit(lambda: weg.loss_and_grad(model, lat_w, next(ts), enc_w, mask_w, focus_w, same_conditioning="memories"))
 if len(sys.argv) > 1 and sys.argv[1] == "guided":
     g1 = torch.Generator().manual_seed(11)
     cond1 = [torch.randn(1, s, 512, generator=g1) for s in Sw]
