@@ -542,6 +542,23 @@ __global__ void __launch_bounds__(256) rt_selfattn_kernel(const RtSelfArgs a) {
 //   score_s = rs_s (q . KA_s + q . (A b_t)) + cbk_s;   out: e_s = exp(score_s - max over the cell), the cell's (max, sum e, sum e rs)
 // dynamic LDS: A image 32 KB | parameters 8 KB | 8 x 8 KB staging | c_q, exchange
 // ------------------------------------------------------------------------------------------------
+// Per-memory scalars of a kernel's arguments, chosen per lane.  Written as a select over the argument ARRAY (rt_sel) the compiler turns
+// `select(j == q, load arr[q], ...)` into ONE load at a per-lane address of the kernel-argument segment -- a vector-memory round trip in
+// the middle of a prologue, behind a barrier.  Values pinned in scalar registers first stay selects.
+#define RT_PIN_S(x) asm volatile("" : "+s"(x))
+template <class T>
+__device__ __forceinline__ T rt_pick5(int j, T v0, T v1, T v2, T v3, T v4) {
+  return j == 0 ? v0 : j == 1 ? v1 : j == 2 ? v2 : j == 3 ? v3 : v4;
+}
+
+// Entry b of a memory's instance table in the kernel-argument segment (RtXArgs::inst[j], RtXBwdArgs::inst[j]), b wave-uniform: fetched
+// as the aligned dword that holds it, which is a SCALAR load (there is no scalar byte load on gfx9: indexed as bytes the table was read
+// with a vector load per memory, and every operand load whose address depends on the instance waited a vector-memory round trip for it).
+__device__ __forceinline__ int rt_inst_get(const unsigned char (&tab)[64], int b) {
+  const unsigned w = reinterpret_cast<const unsigned*>(&tab[0])[b >> 2];
+  return (int)((w >> (8 * (b & 3))) & 255u);
+}
+
 struct RtXArgs {
   const float* x;               // fp32 [M][512]: the residual stream in front of the cross-attention block
   float* xo;                    // where x + block(x) goes (xo == x: in place)
@@ -556,7 +573,7 @@ struct RtXArgs {
   const float* vb[CFD_NMEM];    // VV_l b_t [512] of this layer at this step
   const int* map[CFD_NMEM];     // batch row -> memory instance (used when the batch has more than RT_ARG_ROWS rows)
   int use_inst;                 // 1: inst[j][b] below holds map[j][b] (a kernel-argument read instead of a dependent global load in
-  unsigned char inst[CFD_NMEM][RT_ARG_ROWS];   // front of the operand fetch; instances < 256, <= RT_ARG_ROWS batch rows)
+  alignas(4) unsigned char inst[CFD_NMEM][RT_ARG_ROWS];   // front of the operand fetch; instances < 256, <= RT_ARG_ROWS batch rows; read with rt_inst_get)
   int rows[CFD_NMEM];           // U_j * Sp_j
   int S[CFD_NMEM], Sp[CFD_NMEM], off[CFD_NMEM];
   int blk0[CFD_NMEM + 1];       // (unused since the score launch works on 32-key cells of the concatenated key axis)
@@ -605,7 +622,7 @@ __global__ void __launch_bounds__(512) rt_xscore_kernel(const RtXArgs a) {
   for (int q = 1; q < CFD_NMEM; ++q)
     if (cell * 32 >= a.off[q]) j = q;
   const int s0 = cell * 32 - rt_sel(a.off, j);
-  const int u = a.use_inst ? (int)a.inst[j][b] : rt_sel(a.map, j)[b];
+  const int u = a.use_inst ? rt_inst_get(a.inst[j], b) : rt_sel(a.map, j)[b];
   const int rows = rt_sel(a.rows, j), Sp = rt_sel(a.Sp, j);
   const long long key0 = (long long)u * Sp + s0;
   const float4 parv = rt_par_fetch<3>(a.ln_g, a.ln_b, rt_sel(a.kb, j), nullptr);
@@ -724,40 +741,48 @@ __global__ void __launch_bounds__(512) rt_xpv_kernel(const RtXArgs a) {
   const long long tok0 = (long long)b * a.L + q0;
   static_assert(CFD_NMEM == 5, "five named instance indices");
   int u0, u1, u2, u3, u4;   // (named scalars: a local array indexed through rt_sel goes to scratch)
-  if (a.use_inst) { u0 = a.inst[0][b]; u1 = a.inst[1][b]; u2 = a.inst[2][b]; u3 = a.inst[3][b]; u4 = a.inst[4][b]; }
+  if (a.use_inst) { u0 = rt_inst_get(a.inst[0], b); u1 = rt_inst_get(a.inst[1], b); u2 = rt_inst_get(a.inst[2], b); u3 = rt_inst_get(a.inst[3], b); u4 = rt_inst_get(a.inst[4], b); }
   else { u0 = a.map[0][b]; u1 = a.map[1][b]; u2 = a.map[2][b]; u3 = a.map[3][b]; u4 = a.map[4][b]; }
   auto inst = [&](int j) __attribute__((always_inline)) { return j == 0 ? u0 : j == 1 ? u1 : j == 2 ? u2 : j == 3 ? u3 : u4; };
 
-  // ---- loads: the tile's e_s, per-key scales and cell statistics (prologue lanes), the V^T slices of this wave's k-groups --------
-  const int pr = threadIdx.x >> 5, plr = threadIdx.x & 31;
-  float s[MAXC][4], rsv[MAXC][4];
-  const long long srow = (tok0 + min(pr, nq - 1)) * a.Sp_tot;
-#pragma unroll
-  for (int n = 0; n < MAXC; ++n) {
-    const int c0 = (plr + RT_LPR * n) * 4;
-    if (c0 < a.Sp_tot) {
-      const float4 p0 = *reinterpret_cast<const float4*>(a.sc + srow + c0);
-      const float4 r0 = *reinterpret_cast<const float4*>(a.rsp + srow + c0);
-      s[n][0] = p0.x; s[n][1] = p0.y; s[n][2] = p0.z; s[n][3] = p0.w;
-      rsv[n][0] = r0.x; rsv[n][1] = r0.y; rsv[n][2] = r0.z; rsv[n][3] = r0.w;
-    }
-  }
-  RT_T(t_x1);
-  if (plr < KT) cst[pr * 32 + plr] = reinterpret_cast<const float4*>(a.cst)[(tok0 + min(pr, nq - 1)) * KT + plr];
-  RT_T(t_x2);
+  // per-memory scalars (see RT_PIN_S)
+  int o1 = a.off[1], o2 = a.off[2], o3 = a.off[3], o4 = a.off[4];
+  int sp0 = a.Sp[0], sp1 = a.Sp[1], sp2 = a.Sp[2], sp3 = a.Sp[3], sp4 = a.Sp[4];
+  int sz0 = a.S[0], sz1 = a.S[1], sz2 = a.S[2], sz3 = a.S[3], sz4 = a.S[4];
+  RT_PIN_S(o1); RT_PIN_S(o2); RT_PIN_S(o3); RT_PIN_S(o4);
+  RT_PIN_S(sp0); RT_PIN_S(sp1); RT_PIN_S(sp2); RT_PIN_S(sp3); RT_PIN_S(sp4);
+  RT_PIN_S(sz0); RT_PIN_S(sz1); RT_PIN_S(sz2); RT_PIN_S(sz3); RT_PIN_S(sz4);
+  const bool any_att = a.att[0] || a.att[1] || a.att[2] || a.att[3] || a.att[4];   // (attention maps wanted: cfd_forward, the WEG evaluation)
+  auto mem_of = [&](int key) __attribute__((always_inline)) { return key >= o4 ? 4 : key >= o3 ? 3 : key >= o2 ? 2 : key >= o1 ? 1 : 0; };
+
+  // ---- loads, all requested before anything waits: the V^T slices of this wave's k-groups (LDS-DMA), the tile's e_s and per-key
+  // scales (prologue lanes; chunks past the last key load the last chunk and are ignored), the cell statistics, the epilogue's operands.
+  // (The statistics used to be loaded AND stored to LDS in front of the DMA: the store waited for every load before it, and the slices
+  //  were requested one round trip late.)
   const int nk = (KT - wid + NW - 1) / NW;
 #pragma unroll
   for (int n = 0; n < MAXN; ++n) {
     if (n < nk) {
       const int kt = wid + NW * n;
-      int j = 0;
-#pragma unroll
-      for (int q = 1; q < CFD_NMEM; ++q)
-        if (kt * 32 >= a.off[q]) j = q;
-      const long long ld = (long long)rt_sel(a.Sp, j) * 4;
-      rt_dma_slice(wreg + n * 2048, rt_sel(a.VT, j) + ((size_t)inst(j) * CFD_D + f0) * ld, ld, 15, kt - rt_sel(a.off, j) / 32, lane);
+      const int j = mem_of(kt * 32);
+      const long long ld = (long long)rt_pick5(j, sp0, sp1, sp2, sp3, sp4) * 4;
+      rt_dma_slice(wreg + n * 2048, rt_sel(a.VT, j) + ((size_t)inst(j) * CFD_D + f0) * ld, ld, 15, kt - rt_pick5(j, 0, o1, o2, o3, o4) / 32, lane);
     }
   }
+  RT_T(t_x1);
+  const int pr = threadIdx.x >> 5, plr = threadIdx.x & 31;
+  float s[MAXC][4], rsv[MAXC][4];
+  const long long srow = (tok0 + min(pr, nq - 1)) * a.Sp_tot;
+#pragma unroll
+  for (int n = 0; n < MAXC; ++n) {
+    const int c0 = min((plr + RT_LPR * n) * 4, a.Sp_tot - 4);
+    const float4 p0 = *reinterpret_cast<const float4*>(a.sc + srow + c0);
+    const float4 r0 = *reinterpret_cast<const float4*>(a.rsp + srow + c0);
+    s[n][0] = p0.x; s[n][1] = p0.y; s[n][2] = p0.z; s[n][3] = p0.w;
+    rsv[n][0] = r0.x; rsv[n][1] = r0.y; rsv[n][2] = r0.z; rsv[n][3] = r0.w;
+  }
+  RT_T(t_x2);
+  const float4 cst_mine = reinterpret_cast<const float4*>(a.cst)[(tok0 + min(pr, nq - 1)) * KT + min(plr, KT - 1)];
   RT_T(t_x3);
   const int fcol = f0 + 4 * q4;
   float4 ep_r = make_float4(0.f, 0.f, 0.f, 0.f), ep_b = ep_r;
@@ -768,7 +793,9 @@ __global__ void __launch_bounds__(512) rt_xpv_kernel(const RtXArgs a) {
 #pragma unroll
     for (int j = 0; j < CFD_NMEM; ++j) ep_vb[j] = *reinterpret_cast<const float4*>(a.vb[j] + fcol);
   }
+  __builtin_amdgcn_sched_barrier(0);
   RT_T(t_a);
+  if (plr < KT) cst[pr * 32 + plr] = cst_mine;
 #if RT_STAMP
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     const unsigned k_ = atomicAdd(&g_rt_seq, 1u) & 4095u;
@@ -782,7 +809,7 @@ __global__ void __launch_bounds__(512) rt_xpv_kernel(const RtXArgs a) {
   if (threadIdx.x < 16 * CFD_NMEM) {
     const int r = threadIdx.x / CFD_NMEM, j = threadIdx.x - r * CFD_NMEM;
     const float4* cr = cst + r * 32;
-    const int offj = rt_sel(a.off, j), cb = offj >> 5, ce = (offj + rt_sel(a.Sp, j)) >> 5;
+    const int offj = rt_pick5(j, 0, o1, o2, o3, o4), cb = offj >> 5, ce = (offj + rt_pick5(j, sp0, sp1, sp2, sp3, sp4)) >> 5;
     float M = -INFINITY, l = 0.f, w = 0.f;
     for (int k = cb; k < ce; ++k) M = fmaxf(M, cr[k].x);
     for (int k = cb; k < ce; ++k) {
@@ -801,22 +828,21 @@ __global__ void __launch_bounds__(512) rt_xpv_kernel(const RtXArgs a) {
   for (int n = 0; n < MAXC; ++n) {
     const int c0 = (plr + RT_LPR * n) * 4;
     if (c0 < a.Sp_tot) {
-      int j = 0;
-#pragma unroll
-      for (int q = 1; q < CFD_NMEM; ++q)
-        if (c0 >= a.off[q]) j = q;
-      const int offj = rt_sel(a.off, j), S = rt_sel(a.S, j);
+      const int j = mem_of(c0);
       const float4 sg = seg[pr * 8 + j];
       const float f = __expf(crow[c0 >> 5].x - sg.x) * sg.y;
 #pragma unroll
       for (int e = 0; e < 4; ++e) s[n][e] *= f;
-      float* att = rt_sel(a.att, j);
-      if (att && fb == 0 && pr < nq) {
-        float* ap = att + (((long long)b * a.nl + a.layer) * a.L + q0 + pr) * S;
-        const int k0 = c0 - offj;
+      if (any_att && fb == 0 && pr < nq) {
+        float* att = rt_sel(a.att, j);
+        if (att) {
+          const int S = rt_pick5(j, sz0, sz1, sz2, sz3, sz4);
+          float* ap = att + (((long long)b * a.nl + a.layer) * a.L + q0 + pr) * S;
+          const int k0 = c0 - rt_pick5(j, 0, o1, o2, o3, o4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (k0 + e < S) ap[k0 + e] = s[n][e];
+          for (int e = 0; e < 4; ++e)
+            if (k0 + e < S) ap[k0 + e] = s[n][e];
+        }
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) s[n][e] *= rsv[n][e];

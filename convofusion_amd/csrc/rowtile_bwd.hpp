@@ -106,12 +106,16 @@ struct RtBwdRow {
 template <bool TB>
 __device__ __forceinline__ void rt_bwd_row_load(RtBwdRow& r, const float* a, const float* g, const float* x, const float* gamma, const float* beta,
                                                 const float* sc, long long row, int plr) {
+  // every load unconditional and in one basic block: a load inside `g ? ... : 0` is a block of its own, the loads behind it cannot move
+  // in front of it, and the ones inside wait for themselves
+  const float* gp = g ? g : a;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = 128 * i + 4 * plr;
     const float4 d = *reinterpret_cast<const float4*>(a + row * CFD_D + c);
     const float4 xx = *reinterpret_cast<const float4*>(x + row * CFD_D + c);
-    const float4 gg = g ? *reinterpret_cast<const float4*>(g + row * CFD_D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gg = *reinterpret_cast<const float4*>(gp + row * CFD_D + c);   // (no running gradient yet: a valid row, zeroed by the select below)
+    if (!g) gg = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
     r.dy[i][0] = d.x; r.dy[i][1] = d.y; r.dy[i][2] = d.z; r.dy[i][3] = d.w;
     r.xv[i][0] = xx.x; r.xv[i][1] = xx.y; r.xv[i][2] = xx.z; r.xv[i][3] = xx.w;
@@ -146,7 +150,9 @@ __global__ void __launch_bounds__(512) rt_bwd_gemm_kernel(const RtBwdArgs a) {
   constexpr int NW = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* img = reinterpret_cast<float*>(smem);
-  const int K = a.K, RS = RT_BSTRIDE(K);
+  // K is the kernel instance's (the host checks a.K == MAXSTEP * 32): with a run-time K every load of the unrolled loops below sat in
+  // a conditional block of its own, next to its use, and waited for its own round trip -- 16 to 48 of them in a row
+  constexpr int K = MAXSTEP * 32, RS = RT_BSTRIDE(K);
   char* red = smem + (size_t)16 * RS * 4;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -156,30 +162,29 @@ __global__ void __launch_bounds__(512) rt_bwd_gemm_kernel(const RtBwdArgs a) {
   const long long tok0 = (long long)b * a.L + q0;
   const int pr = threadIdx.x >> 5, plr = threadIdx.x & 31;
   const long long prow = tok0 + min(pr, nq - 1);
+  RT_T(t_in);
 
-  // ---- loads: prologue rows, then this wave's weight column ----------------------------------------------
+  // ---- loads: the prologue's rows (they lead to the barrier), then this wave's weight column, all requested before anything waits ----
   RtBwdRow r;
   constexpr int NR = PRO == RT_BPRO_ROWS ? MAXSTEP / 4 : 1;     // ROWS: K / 128 float4 per lane (12 for K = 1536)
   float rows[NR][4];
   if constexpr (PRO == RT_BPRO_ROWS) {
 #pragma unroll
-    for (int i = 0; i < NR; ++i)
-      if (128 * i < K) {
-        const float4 d = *reinterpret_cast<const float4*>(a.a + prow * K + 128 * i + 4 * plr);
-        rows[i][0] = d.x; rows[i][1] = d.y; rows[i][2] = d.z; rows[i][3] = d.w;
-      }
+    for (int i = 0; i < NR; ++i) {
+      const float4 d = *reinterpret_cast<const float4*>(a.a + prow * K + 128 * i + 4 * plr);
+      rows[i][0] = d.x; rows[i][1] = d.y; rows[i][2] = d.z; rows[i][3] = d.w;
+    }
   } else {
     rt_bwd_row_load<PRO == RT_BPRO_TB>(r, a.a, a.g, a.x, a.gamma, a.beta, a.ss, prow, plr);
   }
-  const int nstep = K / (4 * NW);                               // MFMAs of this wave: k = wid * (K / 8) + 4 i + q4
-  const int kbase = wid * (K / NW) + q4;
+  const int kbase = wid * (K / NW) + q4;                        // MFMAs of this wave: k = wid * (K / 8) + 4 i + q4, i < MAXSTEP
   float wv[MAXSTEP];
   {
     const float* wp = a.w + (long long)kbase * a.ldw + n0 + l15;
 #pragma unroll
-    for (int i = 0; i < MAXSTEP; ++i)
-      if (i < nstep) wv[i] = wp[(long long)(4 * i) * a.ldw];
+    for (int i = 0; i < MAXSTEP; ++i) wv[i] = wp[(long long)(4 * i) * a.ldw];
   }
+  __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler sinks the weight loads behind the prologue's waits: a second round trip)
   float4 ep_pre = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (EPI == RT_BEPI_GELU) {
     if (wid == 0) ep_pre = *reinterpret_cast<const float4*>(a.pre + (tok0 + min(l15, nq - 1)) * a.ldo + n0 + 4 * q4);
@@ -188,11 +193,10 @@ __global__ void __launch_bounds__(512) rt_bwd_gemm_kernel(const RtBwdArgs a) {
   // ---- prologue -> float32 image ---------------------------------------------------------------------------
   if constexpr (PRO == RT_BPRO_ROWS) {
 #pragma unroll
-    for (int i = 0; i < NR; ++i)
-      if (128 * i < K) {
-        *reinterpret_cast<float2*>(img + pr * RS + 128 * i + 4 * plr) = make_float2(rows[i][0], rows[i][1]);
-        *reinterpret_cast<float2*>(img + pr * RS + 128 * i + 4 * plr + 2) = make_float2(rows[i][2], rows[i][3]);
-      }
+    for (int i = 0; i < NR; ++i) {
+      *reinterpret_cast<float2*>(img + pr * RS + 128 * i + 4 * plr) = make_float2(rows[i][0], rows[i][1]);
+      *reinterpret_cast<float2*>(img + pr * RS + 128 * i + 4 * plr + 2) = make_float2(rows[i][2], rows[i][3]);
+    }
   } else {
     float gn[4][4];
     rt_ln_bwd_row<PRO == RT_BPRO_TB>(r.dy, r.xv, r.gv, r.gam, r.bet, r.s1, r.sh, gn);
@@ -206,11 +210,15 @@ __global__ void __launch_bounds__(512) rt_bwd_gemm_kernel(const RtBwdArgs a) {
   __syncthreads();
 
   // ---- product ---------------------------------------------------------------------------------------------------
+#if RT_STAMP
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  RT_T(t_ops);
+  struct StampAtExit { unsigned long long a, b; int id; __device__ ~StampAtExit() { RT_STAMP_OUT(id, a, b); } } stamp_{t_in, t_ops, 5000 + 100 * PRO + 10 * EPI + (MAXSTEP == 16 ? 0 : MAXSTEP == 32 ? 1 : 2)};
+#endif
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* ap = img + l15 * RS + kbase;
 #pragma unroll
-  for (int i = 0; i < MAXSTEP; ++i)
-    if (i < nstep) acc = RT_MFMA_F32(wv[i], ap[4 * i], acc, 0, 0, 0);   // D[n][token]
+  for (int i = 0; i < MAXSTEP; ++i) acc = RT_MFMA_F32(wv[i], ap[4 * i], acc, 0, 0, 0);   // D[n][token]
   acc = rt_reduce1<NW>(red, wid, lane, acc);
   if (wid != 0 || l15 >= nq) return;
   float4 o = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -241,7 +249,7 @@ struct RtXBwdArgs {
   const float* vb[CFD_NMEM];    // VV_l b_t
   const int* map[CFD_NMEM];
   int use_inst;                 // as RtXArgs
-  unsigned char inst[CFD_NMEM][RT_ARG_ROWS];
+  alignas(4) unsigned char inst[CFD_NMEM][RT_ARG_ROWS];
   int S[CFD_NMEM], Sp[CFD_NMEM], off[CFD_NMEM];
   int blk0[CFD_NMEM + 1];
   int Sp_tot;
@@ -275,10 +283,11 @@ __global__ void __launch_bounds__(512) rt_xbwd_dp_kernel(const RtXBwdArgs a) {
   for (int q = 1; q < CFD_NMEM; ++q)
     if (j == q) blk_first = a.blk0[q];
   const int s0 = ((int)blockIdx.x - blk_first) * 16;
-  const int u = a.use_inst ? (int)a.inst[j][b] : rt_sel(a.map, j)[b];
+  const int u = a.use_inst ? rt_inst_get(a.inst[j], b) : rt_sel(a.map, j)[b];
   const int Sp = rt_sel(a.Sp, j);
   const int pr = threadIdx.x >> 5, plr = threadIdx.x & 31;
   const long long prow = tok0 + min(pr, nq - 1);
+  RT_T(t_in);
   RtBwdRow r;
   rt_bwd_row_load<true>(r, a.dz, a.g, a.x, a.gamma, a.beta, a.ss, prow, plr);
   const float* vbp = rt_sel(a.vb, j);
@@ -288,15 +297,21 @@ __global__ void __launch_bounds__(512) rt_xbwd_dp_kernel(const RtXBwdArgs a) {
     const float4 q = *reinterpret_cast<const float4*>(vbp + 128 * i + 4 * plr);
     vbv[i][0] = q.x; vbv[i][1] = q.y; vbv[i][2] = q.z; vbv[i][3] = q.w;
   }
-  // first operand: VA[s0 + l15][f] for f = wid * 64 + 4 i + q4, read from V^T [f][Sp] (split pairs, keys contiguous)
+  // first operand: VA[s0 + l15][f] for f = wid * 64 + 4 i + q4, read from V^T [f][Sp] (split pairs, keys contiguous) -- kept as halves
+  // until the product (a conversion next to its load waits for it), and requested before the prologue waits for its rows
   const int kbase = wid * (K / NW) + q4;
-  float wv[NSTEP];
+  sp_t whi[NSTEP], wlo[NSTEP];
   {
     const int sl = s0 + l15;
     const char* vp = rt_sel(a.VT, j) + ((size_t)u * CFD_D + kbase) * ((size_t)Sp * 4) + (size_t)(sl >> 5) * 128 + (sl & 31) * 2;
 #pragma unroll
-    for (int i = 0; i < NSTEP; ++i) wv[i] = rt_sp_f32(vp + (size_t)(4 * i) * ((size_t)Sp * 4));
+    for (int i = 0; i < NSTEP; ++i) {
+      const char* p = vp + (size_t)(4 * i) * ((size_t)Sp * 4);
+      whi[i] = *reinterpret_cast<const sp_t*>(p);
+      wlo[i] = *reinterpret_cast<const sp_t*>(p + 64);
+    }
   }
+  __builtin_amdgcn_sched_barrier(0);
   float4 e_rs = make_float4(0.f, 0.f, 0.f, 0.f), e_da = e_rs;
   const long long so = (tok0 + min(l15, nq - 1)) * a.Sp_tot + rt_sel(a.off, j) + s0 + 4 * q4;
   if (wid == 0) {
@@ -322,10 +337,15 @@ __global__ void __launch_bounds__(512) rt_xbwd_dp_kernel(const RtXBwdArgs a) {
   dot = rt_row_sum<32>(dot);
   if (plr == 0) dvb[pr] = dot;
   __syncthreads();
+#if RT_STAMP
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  RT_T(t_ops);
+  struct StampAtExit { unsigned long long a, b; int id; __device__ ~StampAtExit() { RT_STAMP_OUT(id, a, b); } } stamp_{t_in, t_ops, 6000};
+#endif
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* ap = img + l15 * RS + kbase;
 #pragma unroll
-  for (int i = 0; i < NSTEP; ++i) acc = RT_MFMA_F32(wv[i], ap[4 * i], acc, 0, 0, 0);   // D[key][token]
+  for (int i = 0; i < NSTEP; ++i) acc = RT_MFMA_F32((float)whi[i] + (float)wlo[i], ap[4 * i], acc, 0, 0, 0);   // D[key][token]
   acc = rt_reduce1<NW>(red, wid, lane, acc);
   if (wid != 0 || l15 >= nq) return;
   const float d = dvb[l15];
@@ -336,12 +356,13 @@ __global__ void __launch_bounds__(512) rt_xbwd_dp_kernel(const RtXBwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // B5: softmax backward per memory, dS' = dS rs, and the gradient at the LayerNorm2 output
 //   dy[token][f] = sum_j ( sum_s dS'_s KA_j[s][f] + (sum_s dS'_s) (A b_t)_j[f] )
-// grid (32, tiles); dynamic LDS = 16 * (Sp_tot + 2) * 4 + 8 KB + Sp_tot * 8 + 16 * 8 * 4
+// grid (32, tiles); dynamic LDS = 16 * (Sp_tot + 2) * 4 (dS image) + 8 KB (reduction) + 512 (sums) + 8 KB (cell statistics) + 1 KB (per-memory statistics)
 // ------------------------------------------------------------------------------------------------
+template <int MAXKEYS>
 __global__ void __launch_bounds__(512) rt_xbwd_dy_kernel(const RtXBwdArgs a) {
   constexpr int NW = 8, LPR = 32;
-  constexpr int MAXC = RT_MAX_KEYS / 4 / LPR;                    // 4-key chunks per lane
-  constexpr int MAXSTEP = RT_MAX_KEYS / (4 * NW);
+  constexpr int MAXC = MAXKEYS / 4 / LPR;                        // 4-key chunks per lane
+  constexpr int MAXSTEP = MAXKEYS / (4 * NW);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int KS = a.Sp_tot, RS = RT_BSTRIDE(KS);
   float* img = reinterpret_cast<float*>(smem);
@@ -354,27 +375,29 @@ __global__ void __launch_bounds__(512) rt_xbwd_dy_kernel(const RtXBwdArgs a) {
   const int tile = blockIdx.y, f0 = blockIdx.x * 16;
   const int b = tile / a.tpr, q0 = (tile - b * a.tpr) * 16, nq = min(16, a.L - q0);
   const long long tok0 = (long long)b * a.L + q0;
+  RT_T(t_in);
   // this wave's operand: KA[key][f0 + l15] for its keys kbase + 4 i, read from the folded keys (split pairs) -- requested before the
-  // prologue, so that the loads run under the softmax backward
+  // prologue, so that the loads run under the softmax backward.  The row of concatenated key k of memory j starts at kb_j + k * 2048
+  // with kb_j wave-uniform (the instance of the batch row), so a load's address costs one select chain over four boundaries and one
+  // multiply-add.  (With the memory, instance and row length selected per lane and step -- the first version -- ISSUING the loads was
+  // 9.3 us of this kernel's 14 us in front of its first MFMA: ~100 vector instructions for each of the 32 unrolled steps.)
   static_assert(CFD_NMEM == 5, "five named instance indices");
   int u0, u1, u2, u3, u4;
-  if (a.use_inst) { u0 = a.inst[0][b]; u1 = a.inst[1][b]; u2 = a.inst[2][b]; u3 = a.inst[3][b]; u4 = a.inst[4][b]; }
+  if (a.use_inst) { u0 = rt_inst_get(a.inst[0], b); u1 = rt_inst_get(a.inst[1], b); u2 = rt_inst_get(a.inst[2], b); u3 = rt_inst_get(a.inst[3], b); u4 = rt_inst_get(a.inst[4], b); }
   else { u0 = a.map[0][b]; u1 = a.map[1][b]; u2 = a.map[2][b]; u3 = a.map[3][b]; u4 = a.map[4][b]; }
+  const long long ROWB = CFD_D * 4;
+  const char* const kb0 = a.K[0] + ((long long)u0 * a.Sp[0] - a.off[0]) * ROWB;
+  const char* const kb1 = a.K[1] + ((long long)u1 * a.Sp[1] - a.off[1]) * ROWB;
+  const char* const kb2 = a.K[2] + ((long long)u2 * a.Sp[2] - a.off[2]) * ROWB;
+  const char* const kb3 = a.K[3] + ((long long)u3 * a.Sp[3] - a.off[3]) * ROWB;
+  const char* const kb4 = a.K[4] + ((long long)u4 * a.Sp[4] - a.off[4]) * ROWB;
+  int o1 = a.off[1], o2 = a.off[2], o3 = a.off[3], o4 = a.off[4];
+  int sp0 = a.Sp[0], sp1 = a.Sp[1], sp2 = a.Sp[2], sp3 = a.Sp[3], sp4 = a.Sp[4];
+  RT_PIN_S(o1); RT_PIN_S(o2); RT_PIN_S(o3); RT_PIN_S(o4);      // (per-lane choices below stay selects: rowtile.hpp, RT_PIN_S)
+  RT_PIN_S(sp0); RT_PIN_S(sp1); RT_PIN_S(sp2); RT_PIN_S(sp3); RT_PIN_S(sp4);
   const int nstep = KS / (4 * NW);
   const int kbase = wid * (KS / NW) + q4;
   const int fo = ((f0 + l15) >> 5) * 128 + ((f0 + l15) & 31) * 2;   // this lane's feature inside an SP key row
-  float wv[MAXSTEP];
-#pragma unroll
-  for (int i = 0; i < MAXSTEP; ++i)
-    if (i < nstep) {
-      const int key = kbase + 4 * i;
-      int j = 0;
-#pragma unroll
-      for (int q = 1; q < CFD_NMEM; ++q)
-        if (key >= a.off[q]) j = q;
-      const int u = j == 0 ? u0 : j == 1 ? u1 : j == 2 ? u2 : j == 3 ? u3 : u4;
-      wv[i] = rt_sp_f32(rt_sel(a.K, j) + ((size_t)u * rt_sel(a.Sp, j) + (key - rt_sel(a.off, j))) * (CFD_D * 4) + fo);
-    }
   // prologue loads: scores, dP (or d_att), rs of this lane's 4-key chunks plr + 32 n (16-byte loads contiguous across the row's lanes)
   const int pr = threadIdx.x / LPR, plr = threadIdx.x % LPR;
   const long long prow = tok0 + min(pr, nq - 1);
@@ -382,27 +405,28 @@ __global__ void __launch_bounds__(512) rt_xbwd_dy_kernel(const RtXBwdArgs a) {
   int cj[MAXC];
 #pragma unroll
   for (int n = 0; n < MAXC; ++n) {
-    const int c0 = (plr + LPR * n) * 4;
-    cj[n] = -1;
-    if (c0 < KS) {
-      int j = 0;
+    const int c0r = (plr + LPR * n) * 4, c0 = min(c0r, KS - 4);   // (chunks past the last key load the last chunk and are ignored: cj = -1)
+    const int j = c0 >= o4 ? 4 : c0 >= o3 ? 3 : c0 >= o2 ? 2 : c0 >= o1 ? 1 : 0;
+    cj[n] = c0r < KS ? j : -1;
+    const float4 p0 = *reinterpret_cast<const float4*>(a.sc + prow * KS + c0);
+    const float4 r0 = *reinterpret_cast<const float4*>(a.rsp + prow * KS + c0);
+    s[n][0] = p0.x; s[n][1] = p0.y; s[n][2] = p0.z; s[n][3] = p0.w;
+    rsv[n][0] = r0.x; rsv[n][1] = r0.y; rsv[n][2] = r0.z; rsv[n][3] = r0.w;
+  }
+  if (!a.dp_from_datt) {        // (one block of loads per case: the branch is outside the unrolled loop)
 #pragma unroll
-      for (int q = 1; q < CFD_NMEM; ++q)
-        if (c0 >= a.off[q]) j = q;
-      cj[n] = j;
-      const float4 p0 = *reinterpret_cast<const float4*>(a.sc + prow * KS + c0);
-      const float4 r0 = *reinterpret_cast<const float4*>(a.rsp + prow * KS + c0);
-      s[n][0] = p0.x; s[n][1] = p0.y; s[n][2] = p0.z; s[n][3] = p0.w;
-      rsv[n][0] = r0.x; rsv[n][1] = r0.y; rsv[n][2] = r0.z; rsv[n][3] = r0.w;
-      if (a.dp_from_datt) {
-        const int S2 = a.S[2], k0 = c0 - a.off[2];
-        const float* da = a.d_att + (((long long)b * a.nl + a.layer) * a.L + q0 + min(pr, nq - 1)) * S2;
+    for (int n = 0; n < MAXC; ++n) {
+      const float4 d0 = *reinterpret_cast<const float4*>(a.dP + prow * KS + min((plr + LPR * n) * 4, KS - 4));
+      dp[n][0] = d0.x; dp[n][1] = d0.y; dp[n][2] = d0.z; dp[n][3] = d0.w;
+    }
+  } else {                      // the top layer: dP is d_att alone (tlsn keys), element by element (S_2 need not be a multiple of 4)
+    const int S2 = a.S[2];
+    const float* da = a.d_att + (((long long)b * a.nl + a.layer) * a.L + q0 + min(pr, nq - 1)) * S2;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dp[n][e] = (j == 2 && k0 + e < S2) ? da[k0 + e] : 0.f;
-      } else {
-        const float4 d0 = *reinterpret_cast<const float4*>(a.dP + prow * KS + c0);
-        dp[n][0] = d0.x; dp[n][1] = d0.y; dp[n][2] = d0.z; dp[n][3] = d0.w;
-      }
+    for (int n = 0; n < MAXC; ++n) {
+      const int k0 = min((plr + LPR * n) * 4, KS - 4) - o2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dp[n][e] = (cj[n] == 2 && k0 + e < S2) ? da[min(max(k0 + e, 0), S2 - 1)] : 0.f;
     }
   }
   const int fcol = f0 + 4 * q4;
@@ -411,18 +435,45 @@ __global__ void __launch_bounds__(512) rt_xbwd_dy_kernel(const RtXBwdArgs a) {
 #pragma unroll
     for (int j = 0; j < CFD_NMEM; ++j) ep_kb[j] = *reinterpret_cast<const float4*>(a.kb[j] + fcol);
   }
+  // (unconditional loads at clamped keys, converted behind the prologue: a load inside `if (i < nstep)` is a block of its own together
+  //  with its conversion, and each step then waits for its own round trip)
+  sp_t whi[MAXSTEP], wlo[MAXSTEP];
+#pragma unroll
+  for (int i = 0; i < MAXSTEP; ++i) {
+    const int key = min(kbase + 4 * i, KS - 1);
+    const char* base = key >= o4 ? kb4 : key >= o3 ? kb3 : key >= o2 ? kb2 : key >= o1 ? kb1 : kb0;
+    const char* p = base + (long long)key * ROWB + fo;
+    whi[i] = *reinterpret_cast<const sp_t*>(p);
+    wlo[i] = *reinterpret_cast<const sp_t*>(p + 64);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  RT_T(t_iss);
   if (plr < KS / 32) cst[pr * 32 + plr] = reinterpret_cast<const float4*>(a.cst)[prow * (KS / 32) + plr];
   __syncthreads();
-  // the probabilities from the saved e_s and cell statistics (as rt_xpv_kernel makes them), then the softmax backward per memory
+  RT_T(t_s1);
+  // the probabilities from the saved e_s and cell statistics (as rt_xpv_kernel makes them: per (token, memory) the maximum and
+  // 1 / sum once, by 80 threads), then the softmax backward per memory
+  float2* seg = reinterpret_cast<float2*>(cst + 16 * 32);   // [16 tokens][8]
+  if (threadIdx.x < 16 * CFD_NMEM) {
+    const int r = threadIdx.x / CFD_NMEM, j = threadIdx.x - r * CFD_NMEM;
+    const float4* cr = cst + r * 32;
+    const int offj = rt_pick5(j, 0, o1, o2, o3, o4), cb = offj >> 5, ce = (offj + rt_pick5(j, sp0, sp1, sp2, sp3, sp4)) >> 5;
+    float M = -INFINITY, l = 0.f;
+    for (int k = cb; k < ce; ++k) M = fmaxf(M, cr[k].x);
+    for (int k = cb; k < ce; ++k) l = fmaf(cr[k].y, __expf(cr[k].x - M), l);
+    seg[r * 8 + j] = make_float2(M, rt_rcp(l));
+  }
+  __syncthreads();
 #pragma unroll
   for (int n = 0; n < MAXC; ++n)
     if (cj[n] >= 0) {
-      const int c0 = (plr + LPR * n) * 4, j = cj[n], offj = rt_sel(a.off, j);
-      float inv_l;
-      const float f = rt_cell_scale(cst + pr * 32, c0 >> 5, offj >> 5, (offj + rt_sel(a.Sp, j)) >> 5, inv_l);
+      const int c0 = (plr + LPR * n) * 4;
+      const float2 sg = seg[pr * 8 + cj[n]];
+      const float f = __expf(cst[pr * 32 + (c0 >> 5)].x - sg.x) * sg.y;
 #pragma unroll
       for (int e = 0; e < 4; ++e) s[n][e] *= f;
     }
+  RT_T(t_cs);
 #pragma unroll 1
   for (int j = 0; j < CFD_NMEM; ++j) {
     float dot = 0.f;
@@ -451,12 +502,23 @@ __global__ void __launch_bounds__(512) rt_xbwd_dy_kernel(const RtXBwdArgs a) {
     if (plr == 0) dcq[pr * 8 + j] = wsum;
   }
   __syncthreads();
+#if RT_STAMP
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  RT_T(t_ops);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // first record: entry -> loads issued, first barrier passed, cell scales applied
+    const unsigned k_ = atomicAdd(&g_rt_seq, 1u) & 4095u;
+    g_rt_ring[4 * k_] = 6101; g_rt_ring[4 * k_ + 1] = t_iss - t_in; g_rt_ring[4 * k_ + 2] = t_s1 - t_in; g_rt_ring[4 * k_ + 3] = t_cs - t_in;
+  }
+  struct StampAtExit { unsigned long long a, b; int id; __device__ ~StampAtExit() { RT_STAMP_OUT(id, a, b); } } stamp_{t_in, t_ops, 6100};
+#endif
   // product over the keys: this wave's range of Sp_tot / 8 keys
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* ap = img + l15 * RS + kbase;
 #pragma unroll
-  for (int i = 0; i < MAXSTEP; ++i)
-    if (i < nstep) acc = RT_MFMA_F32(wv[i], ap[4 * i], acc, 0, 0, 0);   // D[feature][token]
+  for (int i = 0; i < MAXSTEP; ++i) {
+    const float wv = i < nstep ? (float)whi[i] + (float)wlo[i] : 0.f;   // (a select, not a branch: see the loads; steps past the last
+    acc = RT_MFMA_F32(wv, ap[4 * min(i, nstep - 1)], acc, 0, 0, 0);     //  key multiply a valid image element by zero)  D[feature][token]
+  }
   acc = rt_reduce1<NW>(red, wid, lane, acc);
   if (wid != 0 || l15 >= nq) return;
   float o[4] = {acc[0], acc[1], acc[2], acc[3]};
@@ -493,6 +555,7 @@ __global__ void __launch_bounds__(256) rt_selfattn_bwd_kernel(const RtSelfBwdArg
   float* dS = P + RT_MAX_L * (RT_MAX_L + 1);
   const int h = blockIdx.x, b = blockIdx.y, L = a.L, tid = threadIdx.x;
   const long long tok0 = (long long)b * L;
+  RT_T(t_in);
   // operands into LDS as float32, 16-byte loads: 8 consecutive features of a q / k row (hi and lo chunk), 8 consecutive keys of a
   // V^T feature row, 4 consecutive features of a dO row  (element by element this phase was most of the kernel's 15 us)
   for (int e = tid; e < L * (HD / 8); e += 256) {
@@ -522,6 +585,10 @@ __global__ void __launch_bounds__(256) rt_selfattn_bwd_kernel(const RtSelfBwdArg
     dO[r * RSD + c4] = q.x; dO[r * RSD + c4 + 1] = q.y; dO[r * RSD + c4 + 2] = q.z; dO[r * RSD + c4 + 3] = q.w;
   }
   __syncthreads();
+#if RT_STAMP
+  RT_T(t_ops);
+  struct StampAtExit { unsigned long long a, b; int id; __device__ ~StampAtExit() { RT_STAMP_OUT(id, a, b); } } stamp_{t_in, t_ops, 6200};
+#endif
   // scores and dP on the float32 matrix core: wave w takes (query tile w & 1, key tile w >> 1); D[key][query], 32 steps over d
   const int lane = tid & 63, wid = tid >> 6, l15 = lane & 15, q4 = lane >> 4;
   const int nqt = (L + 15) / 16;

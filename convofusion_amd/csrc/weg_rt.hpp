@@ -132,11 +132,13 @@ static int enqueue(Ctx* c, hipStream_t st, bool full, const EvalArgs& e) {
   // ---- reverse sweep (rowtile_bwd.hpp) -----------------------------------------------------------------------
   static unsigned long long attr = 0;
   const int lds_dp = 16 * RT_BSTRIDE(CFD_D) * 4 + 8 * 1024 + 64;
-  const int lds_dy = 16 * RT_BSTRIDE(p.Sp_tot) * 4 + 8 * 1024 + 512 + 16 * 32 * 16;
+  const int lds_dy = 16 * RT_BSTRIDE(p.Sp_tot) * 4 + 8 * 1024 + 512 + 16 * 32 * 16 + 16 * 8 * 8;
   const int lds_sa = (4 * RT_MAX_L * (CFD_HD + 1) + 2 * RT_MAX_L * (RT_MAX_L + 1)) * 4;
   if (!((attr >> (c->cfg.device & 63)) & 1ull)) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_xbwd_dy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               16 * RT_BSTRIDE(RT_MAX_KEYS) * 4 + 8 * 1024 + 512 + 16 * 32 * 16));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_xbwd_dy_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               16 * RT_BSTRIDE(512) * 4 + 8 * 1024 + 512 + 16 * 32 * 16 + 16 * 8 * 8));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_xbwd_dy_kernel<RT_MAX_KEYS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               16 * RT_BSTRIDE(RT_MAX_KEYS) * 4 + 8 * 1024 + 512 + 16 * 32 * 16 + 16 * 8 * 8));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_selfattn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_sa));
     attr |= 1ull << (c->cfg.device & 63);
   }
@@ -204,7 +206,8 @@ static int enqueue(Ctx* c, hipStream_t st, bool full, const EvalArgs& e) {
     {   // B5: softmax backward and the folded keys
       RtXBwdArgs a = x5;
       a.dp_from_datt = have_g || l < nl - 1 ? 0 : 1;
-      hipLaunchKernelGGL(rt_xbwd_dy_kernel, dim3(CFD_D / 16, ntile), dim3(512), lds_dy, st, a);
+      if (p.Sp_tot <= 512) hipLaunchKernelGGL(rt_xbwd_dy_kernel<512>, dim3(CFD_D / 16, ntile), dim3(512), lds_dy, st, a);
+      else hipLaunchKernelGGL(rt_xbwd_dy_kernel<RT_MAX_KEYS>, dim3(CFD_D / 16, ntile), dim3(512), lds_dy, st, a);
       HIPCHK(hipGetLastError());
       ++s.launches;
     }
