@@ -644,3 +644,112 @@ __global__ void __launch_bounds__(256) weg_focus_kernel(const float* att, const 
     }
   }
 }
+
+// The same objective for small maps (L * (last - 1) <= WEG_SMALL_CELLS cells, <= WEG_SMALL_TOK focus tokens per sample: the product shape is
+// 16 x 16): the three maps live in LDS, every phase but the two row-serial ones runs one thread per cell, and the layers are read and
+// written along the key axis.  Operation for operation the arithmetic of weg_focus_kernel (same summation orders: the results are
+// bit-identical); 34 -> ~6 us at the product shape, where the general kernel's 16 active threads walk global memory serially.
+#define WEG_SMALL_CELLS 1024
+#define WEG_SMALL_TOK 64
+__global__ void __launch_bounds__(256) weg_focus_small_kernel(const float* att, const int* tok_off, const int* tok_idx, int B, int NL, int L, int S,
+                                                              int last, float k00, float k01, float k11, float* losses, float* max_att,
+                                                              float* d_att) {
+  __shared__ float sm[WEG_SMALL_CELLS], sg[WEG_SMALL_CELLS], dsm[WEG_SMALL_CELLS];
+  __shared__ float tok_g[WEG_SMALL_TOK], dots[64];
+  __shared__ int tok_l[WEG_SMALL_TOK], tok_w[WEG_SMALL_TOK];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int W = last - 1, LW = L * W;
+  const float* ab = att + (long long)b * NL * L * S;
+  // 1. layer mean over the slice [1, last) (a thread per cell), softmax over the slice (a thread per frame)
+  for (int e = tid; e < LW; e += 256) {
+    const int l = e / W, w = e - l * W;
+    float m = 0.f;
+    for (int n = 0; n < NL; ++n) m += ab[((long long)n * L + l) * S + 1 + w];
+    sm[e] = m / (float)NL;
+  }
+  __syncthreads();
+  for (int l = tid; l < L; l += 256) {
+    float mx = -INFINITY;
+    for (int w = 0; w < W; ++w) mx = fmaxf(mx, sm[l * W + w]);
+    float sum = 0.f;
+    for (int w = 0; w < W; ++w) {
+      const float e = expf(sm[l * W + w] - mx);
+      sm[l * W + w] = e;
+      sum += e;
+    }
+    for (int w = 0; w < W; ++w) sm[l * W + w] /= sum;
+  }
+  __syncthreads();
+  // 2. 3 x 3 Gaussian correlation over the reflect-padded map
+  const float kk[3][3] = {{k00, k01, k00}, {k01, k11, k01}, {k00, k01, k00}};
+  for (int e = tid; e < LW; e += 256) {
+    const int l = e / W, w = e - l * W;
+    float v = 0.f;
+    for (int a = 0; a < 3; ++a)
+      for (int c = 0; c < 3; ++c) {
+        int ll = l + a - 1, ww = w + c - 1;
+        ll = ll < 0 ? 1 : (ll >= L ? L - 2 : ll);
+        ww = ww < 0 ? 1 : (ww >= W ? W - 2 : ww);
+        v += kk[a][c] * sm[ll * W + ww];
+      }
+    sg[e] = v;
+  }
+  __syncthreads();
+  // 3. per focus token: max over frames, hinge
+  const int t0 = tok_off[b], nt = tok_off[b + 1] - t0;
+  for (int t = tid; t < nt; t += 256) {
+    const int w = tok_idx[t0 + t] - 1;
+    float best = -INFINITY;
+    int bl = 0;
+    for (int l = 0; l < L; ++l) {
+      const float v = sg[l * W + w];
+      if (v > best) { best = v; bl = l; }
+    }
+    max_att[t0 + t] = best;
+    tok_l[t] = bl;
+    tok_w[t] = w;
+    tok_g[t] = (1.0f - best > 0.f) ? -1.0f / ((float)nt * (float)B) : 0.f;
+    dots[t] = fmaxf(0.f, 1.0f - best);   // (hinge terms, summed in token order below)
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+    for (int t = 0; t < nt; ++t) s += dots[t];
+    losses[b] = nt > 0 ? s / (float)nt : 0.f;
+  }
+  // 4. adjoint of the padded correlation, gathered per cell over the (few) tokens: deterministic, no atomics
+  for (int e = tid; e < LW; e += 256) {
+    const int l = e / W, w = e - l * W;
+    float v = 0.f;
+    for (int t = 0; t < nt; ++t) {
+      const float g = tok_g[t];
+      if (g == 0.f) continue;
+      for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) {
+          int ll = tok_l[t] + a - 1, ww = tok_w[t] + c - 1;
+          ll = ll < 0 ? 1 : (ll >= L ? L - 2 : ll);
+          ww = ww < 0 ? 1 : (ww >= W ? W - 2 : ww);
+          if (ll == l && ww == w) v += kk[a][c] * g;
+        }
+    }
+    dsm[e] = v;
+  }
+  __syncthreads();
+  // 5. softmax backward (the row's dot product by a thread per frame), spread over the layers (mean) and written into the full-width maps
+  for (int l = tid; l < L; l += 256) {
+    float dot = 0.f;
+    for (int w = 0; w < W; ++w) dot = fmaf(dsm[l * W + w], sm[l * W + w], dot);
+    dots[l] = dot;
+  }
+  __syncthreads();
+  float* db = d_att + (long long)b * NL * L * S;
+  for (int e = tid; e < L * S; e += 256) {
+    const int l = e / S, s = e - l * S;
+    float v = 0.f;
+    if (s >= 1 && s < last) {
+      const int w = s - 1;
+      v = sm[l * W + w] * (dsm[l * W + w] - dots[l]) / (float)NL;
+    }
+    for (int n = 0; n < NL; ++n) db[((long long)n * L + l) * S + s] = v;
+  }
+}

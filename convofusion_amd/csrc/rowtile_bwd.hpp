@@ -320,7 +320,10 @@ __global__ void __launch_bounds__(512) rt_xbwd_dp_kernel(const RtXBwdArgs a) {
       const int S = a.S[2];
       const float* dp = a.d_att + (((long long)b * a.nl + a.layer) * a.L + q0 + min(l15, nq - 1)) * S;
       const int k0 = s0 + 4 * q4;
-      e_da.x = k0 < S ? dp[k0] : 0.f; e_da.y = k0 + 1 < S ? dp[k0 + 1] : 0.f; e_da.z = k0 + 2 < S ? dp[k0 + 2] : 0.f; e_da.w = k0 + 3 < S ? dp[k0 + 3] : 0.f;
+      // (loads at clamped indices, zeroed by selects: four conditional loads are four blocks that each wait for their own round trip,
+      //  and the workgroups of this memory then ran 2 us behind the others of the launch)
+      const float d0 = dp[min(k0, S - 1)], d1 = dp[min(k0 + 1, S - 1)], d2 = dp[min(k0 + 2, S - 1)], d3 = dp[min(k0 + 3, S - 1)];
+      e_da.x = k0 < S ? d0 : 0.f; e_da.y = k0 + 1 < S ? d1 : 0.f; e_da.z = k0 + 2 < S ? d2 : 0.f; e_da.w = k0 + 3 < S ? d3 : 0.f;
     }
   }
   float gn[4][4];
@@ -640,14 +643,23 @@ __global__ void __launch_bounds__(256) rt_selfattn_bwd_kernel(const RtSelfBwdArg
     const int prod = item / (nqt * 8), rt = (item / 8) % nqt, ft = item & 7;
     const float* X = prod == 0 ? Kk : (prod == 1 ? Q : dO);           // first operand: X[kk][feature]
     const float* Y = prod == 2 ? P : dS;                                // second operand: dQ: dS[row][kk]; dK, dV: Y[kk][row] (transposed use)
-    const int row = rt * 16 + l15;
+    const int row = rt * 16 + l15, rowc = min(row, L - 1);
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int st = 0; st < nsteps; ++st) {
-      const int kk = 4 * st + q4;
-      const bool ok = kk < L;
-      const float xv = ok ? X[kk * RSD + ft * 16 + l15] : 0.f;
-      const float yv = (ok && row < L) ? (prod == 0 ? Y[row * (RT_MAX_L + 1) + kk] : Y[kk * (RT_MAX_L + 1) + row]) : 0.f;
-      acc = RT_MFMA_F32(xv, yv, acc, 0, 0, 0);
+    // (LDS reads at clamped indices, zeroed by selects, in one block: a read inside a condition waits for itself before the next is issued)
+    const float* xp = X + ft * 16 + l15;
+    const float* yp = prod == 0 ? Y + rowc * (RT_MAX_L + 1) : Y + rowc;
+    const int ystep = prod == 0 ? 1 : RT_MAX_L + 1;
+    float xv[RT_MAX_L / 4], yv[RT_MAX_L / 4];
+#pragma unroll
+    for (int st = 0; st < RT_MAX_L / 4; ++st) {
+      const int kk = min(4 * st + q4, L - 1);
+      xv[st] = xp[kk * RSD];
+      yv[st] = yp[kk * ystep];
+    }
+#pragma unroll
+    for (int st = 0; st < RT_MAX_L / 4; ++st) {
+      const bool ok = 4 * st + q4 < L;
+      if (st < nsteps) acc = RT_MFMA_F32(ok ? xv[st] : 0.f, (ok && row < L) ? yv[st] : 0.f, acc, 0, 0, 0);
     }
     if (row < L) {
       const float sc = prod == 0 ? a.qscale : 1.0f;

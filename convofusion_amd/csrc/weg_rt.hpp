@@ -124,8 +124,12 @@ static int enqueue(Ctx* c, hipStream_t st, bool full, const EvalArgs& e) {
   }
   CHK(enqueue_rows_rt(c, st, &s.sv));
   s.launches += 2 + 9 * nl - 3;
-  hipLaunchKernelGGL(weg_focus_kernel, dim3((unsigned)B), dim3(256), 0, st, s.att, e.tok_off, e.tok_idx, B, nl, L, St, e.last, e.nt_max, e.k3[0], e.k3[1],
-                     e.k3[2], s.fws, e.losses, e.max_att, s.d_att);
+  if (L * (e.last - 1) <= WEG_SMALL_CELLS && e.nt_max <= WEG_SMALL_TOK && L <= 64)
+    hipLaunchKernelGGL(weg_focus_small_kernel, dim3((unsigned)B), dim3(256), 0, st, s.att, e.tok_off, e.tok_idx, B, nl, L, St, e.last, e.k3[0], e.k3[1],
+                       e.k3[2], e.losses, e.max_att, s.d_att);
+  else
+    hipLaunchKernelGGL(weg_focus_kernel, dim3((unsigned)B), dim3(256), 0, st, s.att, e.tok_off, e.tok_idx, B, nl, L, St, e.last, e.nt_max, e.k3[0], e.k3[1],
+                       e.k3[2], s.fws, e.losses, e.max_att, s.d_att);
   HIPCHK(hipGetLastError());
   ++s.launches;
 
