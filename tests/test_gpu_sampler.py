@@ -595,6 +595,37 @@ def test_row_tile_path_is_race_free_and_shape_general():
             assert max_abs(att0[j].cpu().numpy(), watt[j]) < 1e-4
 
 
+def test_row_tile_path_agrees_with_the_tile_kernels_on_random_shapes():
+    """Random shapes inside the row-tile path's eligibility (batch rows, even L <= 32, memory lengths, padded tails, timestep) through both
+    implementations of the forward -- the row-tile kernels (default) and the tile kernels (CFD_ROWTILE=0): latents to 1e-4 relative,
+    attention maps to 1e-4 absolute, including rows whose key masks leave a single live key."""
+    import torch
+    from tests.gpu_helpers import hip_denoiser, to_dev
+    rng = np.random.Generator(np.random.PCG64(2024))
+    m_rt = hip_denoiser(1234, 1.0)
+    m_tile = _handle_with_env({"CFD_ROWTILE": "0"})
+    worst = 0.0
+    for case in range(12):
+        L = int(rng.choice([2, 4, 6, 10, 16, 18, 24, 32]))
+        Be = int(rng.integers(1, max(2, min(20, 800 // L))))
+        S = (int(rng.integers(1, 40)), int(rng.integers(1, 600)), int(rng.integers(1, 40)), int(rng.integers(1, 12)), int(rng.integers(1, 3)))
+        pad = tuple(int(rng.integers(0, max(1, s // 2))) if rng.random() < 0.5 else 0 for s in S)
+        t = int(rng.integers(0, 1000))
+        inp = inputs.make_plain_batch(seed=900 + case, Be=Be, L=L, S=S, pad_tail=pad, scale=float(rng.choice([0.5, 1.0, 2.0])))
+        mems = [to_dev(x) for x in inp["memories"]]
+        masks = {k: to_dev(v) for k, v in inp["masks"].items()}
+        x = to_dev(inp["sample"])
+        with torch.no_grad():
+            a, att_a = m_rt(x, torch.tensor(t), mems, mem_mask_dict=masks)
+            b, att_b = m_tile(x, torch.tensor(t), mems, mem_mask_dict=masks)
+        e = float((a - b).norm() / b.norm())
+        ea = max(float((p - q).abs().max()) for p, q in zip(att_a, att_b))
+        worst = max(worst, e)
+        print(f"case {case}: Be={Be} L={L} S={S} pad={pad} t={t}: latents {e:.2e}, attention {ea:.2e}")
+        assert torch.isfinite(a).all() and e < 1e-4 and ea < 1e-4
+    print("worst", worst)
+
+
 def test_static_and_dynamic_memory_declarations_agree_and_mean_what_they_say():
     """cfd_sample_args.dynamic_memory_mask.  Memories are constants of a reference sampling run (convofusion.py:391-549), so by
     default the library projects the timestep-independent part of every memory once at cfd_sample_begin and never reads the
