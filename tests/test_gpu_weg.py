@@ -259,6 +259,35 @@ def test_gradient_at_the_synthetic_shape_matches_oracle():
     np.testing.assert_allclose([float(v) for s in mx for v in s], [float(v) for s in mo for v in s], rtol=2e-5)
 
 
+def test_gradient_on_random_small_shapes_matches_oracle():
+    """The row-tile evaluation (cfd_weg_eval's path for small problems) on random shapes inside its eligibility -- batch 1 .. 3, even
+    L <= 32 including ragged tiles, memory lengths with padded tails, several focus tokens -- against the numpy oracle's backward."""
+    from convofusion_amd import weg
+    from tests.gpu_helpers import dev_inputs, hip_denoiser, to_dev
+    rng = np.random.Generator(np.random.PCG64(77))
+    sd = state_dict(1234, 1.0)
+    m = hip_denoiser(1234, 1.0)
+    for case in range(6):
+        B = (1, 2, 1, 3, 1, 2)[case]
+        L = int(rng.choice([4, 10, 16, 20, 32]))
+        St = int(rng.integers(8, 33))
+        S = (int(rng.integers(2, 33)), int(rng.integers(4, 300)), St, int(rng.integers(1, 10)), 1)
+        pad = (int(rng.integers(0, 2)), int(rng.integers(0, S[1] // 2)), int(rng.integers(1, St // 2)), 0, 0)
+        t = int(rng.integers(0, 1000))
+        inp = inputs.make_plain_batch(seed=700 + case, Be=B, L=L, S=S, pad_tail=pad)
+        eot = np.argmax(inp["masks"]["tlsn"].astype(np.int64), axis=1) - 1
+        neot = B == 1     # (the end-of-text normalisation needs batch 1, like the reference: word_excitation_guidance.py:25)
+        top = int(eot.min()) if neot else St - 1
+        focus = [sorted(set(int(v) for v in rng.integers(1, max(2, top), size=int(rng.integers(1, 4))))) for b in range(B)]
+        lo, _, mo, go = weg_ref.loss_and_grad(sd, inp["sample"], t, inp["memories"], inp["masks"], focus, neot, eot)
+        mems, masks = dev_inputs(inp)
+        loss, _, mx, grad = weg.loss_and_grad(m, to_dev(inp["sample"]), t, mems, masks, focus, neot, to_dev(eot))
+        e = rel_l2(grad.cpu().numpy(), go)
+        print(f"case {case}: B={B} L={L} S={S} pad={pad} t={t} focus={focus}: loss {float(loss):.6f} (oracle {float(lo):.6f}), grad {e:.2e}")
+        assert abs(float(loss) - float(lo)) < 2e-6 and e < 1e-3
+        np.testing.assert_allclose([float(v) for s in mx for v in s], [float(v) for s in mo for v in s], rtol=2e-5)
+
+
 def test_eval_rejects_what_the_reference_cannot_run():
     import torch
     from convofusion_amd import _lib, weg
