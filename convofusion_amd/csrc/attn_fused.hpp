@@ -15,7 +15,7 @@
 
 struct SelfAttnArgs {
   const char* qk;   // SP [M][1024]: q at columns h*128.., k at columns 512 + h*128..
-  const char* vts;  // SP [Be][512][Lv]: V^T per batch row, keys permuted inside every 32-block, Lv = roundup(L, 64)
+  const char* vts;  // SP [Be][512][Lv]: V^T per batch row, keys permuted inside every 32-block, Lv = roundup(L, 32)
   char* o;          // SP [M][512]
   int L, Lv;
 };

@@ -1369,7 +1369,7 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     // (norm1 of layers 1.. is made by the previous layer's last residual product when that ran row-complete: `h_ready`)
     if (!h_ready) CHK(ln(w.ln1g, w.ln1b, 0, 0, c->w->h_sp.as<char>(), Ma));
     h_ready = false;
-    const int Lv = (L + 63) / 64 * 64;
+    const int Lv = (L + 31) / 32 * 32;   // (whole 32-key blocks: at L = 16 a 64-key pitch made the v^T product twice the work of the q | k one)
     {
       // q (pre-scaled) and k, token-major ...
       GemmArgs a = gemm_args();
