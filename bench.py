@@ -505,7 +505,8 @@ def main():
         mfma_ms = sum(prof[k][0] for k in ex)
         all_mfma = sum(ex.values()) / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
         out = {
-            "metric": "denoise-steps/sec (B=32 per GPU, 196-token latent, 1500 audio tokens, 1000-step DDPM schedule)",
+            "metric": ("denoise-steps/sec (B=32 per GPU, 196-token latent, 1500 audio tokens, 1000-step DDPM schedule)" if args.shape == "C2" else
+                       f"denoise-steps/sec at the product shape (NOT the BASELINE metric: B=32 per GPU, L={L}, S={S}, 1000-step DDPM schedule)"),
             "value": world * args.steps / dt,
             "unit": "denoise-steps/s (32-utterance batches, summed over GPUs)",
             "n_gpus": world, "ranks_seen": ranks_seen, "rank_ms_per_step": [round(x, 4) for x in rank_ms],
@@ -514,7 +515,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16x3 (fp16 hi/lo split operands, 3 MFMAs per product, f32 accumulate; f32-equivalent)",
             "data": "synthetic",
-            "config": {"workload": f"configs[1]: B={B_PER_GPU}/GPU synthetic, L={L}, S={S}, 7-way guidance (denoiser batch {Be}), "
+            "config": {"workload": f"{'configs[1]' if args.shape == 'C2' else 'product shape (developer flag --shape R)'}: B={B_PER_GPU}/GPU synthetic, L={L}, S={S}, 7-way guidance (denoiser batch {Be}), "
                                    f"DDPM 1000-step schedule, {args.steps} timed iterations of the hipGraph-captured loop",
                        "shape": args.shape,
                        "parallelism": f"batch-shard x{world}, one all_gather of latents"},
