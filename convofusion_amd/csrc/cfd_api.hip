@@ -93,7 +93,7 @@ struct Problem {
   int xa_nwg = 0;
   int xa0_nwg_a = 0, xa0_nwg_b = 0;   // layer-0 de-duplication lists (build_xattn_layer0_lists); 0: one launch
   // memories (bit j) whose folded projections were computed once for the run from the centred static part of the memory
-  // (prepare_static_memside); per step they only get their per-key scale and bias (mem_scale_kernel)
+  // (prepare_static_memside); per step they only get their per-key scale and bias (mem_scale_all_kernel)
   int static_mask = 0;
   // small problems (rowtile.hpp): every launch of the forward is a grid of 16-token x 16-feature workgroups; needs every memory static
   bool rt = false;
@@ -975,7 +975,7 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
   const int nl = c->nl;
   const long long ROWB = CFD_D * 4;
   p.static_mask = 0;
-  for (int j = 0; j < CFD_NMEM; ++j) {   // scale plane = 1 unless mem_scale_kernel writes it
+  for (int j = 0; j < CFD_NMEM; ++j) {   // scale plane = 1 unless mem_scale_all_kernel writes it
     const long long rows = (long long)p.U[j] * p.Sp[j];
     LAUNCH(CFD_PROF_OTHER, fill_f32_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), st, c->w->cb[j].as<float>() + (size_t)nl * rows, rows, 1.0f);
   }
@@ -1039,7 +1039,7 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
     }
     p.static_mask |= 1 << j;
   }
-  if (p.rt) {   // per-key scale and key bias of every step of the run (the tile-kernel path makes one step's per iteration: mem_scale_kernel)
+  if (p.rt) {   // per-key scale and key bias of every step of the run (the tile-kernel path makes one step's per iteration: mem_scale_all_kernel)
     for (int j = 0; j < CFD_NMEM; ++j) {
       const long long rows = (long long)p.U[j] * p.Sp[j];
       CHK(c->w->rt_cbt[j].ensure((size_t)T * (nl + 1) * rows * 4));
@@ -1064,14 +1064,23 @@ static int enqueue_memside(Ctx* c, hipStream_t st) {
   const long long ROWB = CFD_D * 4;
   const dim3 blk(256);
   // memories whose projections were made once for the run: this step's per-key scale and key bias
-  for (int j = 0; j < CFD_NMEM; ++j) {
-    if (!((p.static_mask >> j) & 1)) continue;
-    const long long rows = (long long)p.U[j] * p.Sp[j];
-    const int NK = nl * CFD_D + 32;
-    MemScaleArgs a{c->w->n_sp[j].as<char>(), c->w->asq[j].as<float>(), rows, c->w->b_tab.as<float>(), c->w->bsq.as<float>(), c->w->ca[j].as<float>(),
-                   c->w->kbtab[j].as<float>() + (size_t)nl * CFD_D, (long long)NK, dstep, nl, c->w->cb[j].as<float>() + (size_t)nl * rows,
-                   c->w->cb[j].as<float>()};
-    LAUNCH(CFD_PROF_ROWS, mem_scale_kernel, dim3((unsigned)((rows + 3) / 4)), blk, st, a);
+  {
+    MemScaleAllArgs g;
+    memset(&g, 0, sizeof(g));
+    int nwg = 0;
+    for (int j = 0; j < CFD_NMEM; ++j) {
+      if (!((p.static_mask >> j) & 1)) continue;
+      const long long rows = (long long)p.U[j] * p.Sp[j];
+      const int NK = nl * CFD_D + 32;
+      g.m[g.n] = MemScaleArgs{c->w->n_sp[j].as<char>(), c->w->asq[j].as<float>(), rows, c->w->b_tab.as<float>(), c->w->bsq.as<float>(), c->w->ca[j].as<float>(),
+                              c->w->kbtab[j].as<float>() + (size_t)nl * CFD_D, (long long)NK, dstep, nl, c->w->cb[j].as<float>() + (size_t)nl * rows,
+                              c->w->cb[j].as<float>()};
+      g.first[g.n] = nwg;
+      nwg += (int)((rows + 3) / 4);
+      ++g.n;
+    }
+    g.first[g.n] = nwg;
+    if (g.n > 0) LAUNCH(CFD_PROF_ROWS, mem_scale_all_kernel, dim3((unsigned)nwg), blk, st, g);
   }
   // 2. memories: + temb + condition id + PE, normalise           (denoiser.py:223-261,332-353)
   for (int j = 0; j < CFD_NMEM; ++j) {

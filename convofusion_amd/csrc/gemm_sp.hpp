@@ -490,6 +490,17 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
       }
   }
 
+  // the bias of a lane's 8 output columns (split-pair stores): requested here, so that its round trip runs under the K loop -- it used
+  // to be the first thing the epilogue waited for.  (-DCFD_BIAS8_LATE=1: the old place, for the A/B.)
+#ifndef CFD_BIAS8_LATE
+#define CFD_BIAS8_LATE 0
+#endif
+  float4 s8_t0 = make_float4(0.f, 0.f, 0.f, 0.f), s8_t1 = s8_t0;
+  if constexpr (WIDE && !CFD_BIAS8_LATE && EpiHasStore8<Epi>::value && EpiHasBias8<Epi>::value) {
+    const int i8 = i0 + wi * TI * 16 + (lane % (TI * 2)) * 8;   // (a lane's columns do not depend on the band)
+    epi.tile_bias8(min(i8, Ig - 8), s8_t0, s8_t1);
+  }
+
   auto compute2 = [&](const char* sbx, const char* sby) __attribute__((always_inline)) {   // sby: the Y tile's base MINUS BI * 128
     spx8 xh[TI], xl[TI], yh[TJ], yl[TJ];
 #pragma unroll
@@ -570,8 +581,7 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
         band_r[it] = epi.band_load(g, b, z, min(i, Ig - 4), min(j, a.J - 1));
       }
     }
-    float4 s8_t0 = make_float4(0.f, 0.f, 0.f, 0.f), s8_t1 = s8_t0;
-    if constexpr (EpiHasStore8<Epi>::value && EpiHasBias8<Epi>::value) {
+    if constexpr (CFD_BIAS8_LATE && EpiHasStore8<Epi>::value && EpiHasBias8<Epi>::value) {
       const int i8 = i0 + wi * TI * 16 + (lane % (TI * 2)) * 8;   // (a lane's columns do not depend on the band)
       if (i8 + 8 <= Ig) epi.tile_bias8(i8, s8_t0, s8_t1);
     }

@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) mem_prep_kernel(const MemPrepArgs a) {
 // a_s = m_s - mean(m_s) and b = temb(t) - mean(temb(t)):   v_s - mean(v_s) = a_s + b,
 //   var_s = (|a_s|^2 + 2 a_s.b + |b|^2) / 512,   n_s = (a_s + b) * rstd_s,   rstd_s = 1 / sqrt(var_s + eps)
 // so every folded projection W n_s = rstd_s (W a_s + W b): the big products W a_s are computed ONCE per run from a_s (this
-// kernel's output), W b is one vector per timestep, and rstd_s is one scalar per key and step (mem_scale_kernel).
+// kernel's output), W b is one vector per timestep, and rstd_s is one scalar per key and step (mem_scale_all_kernel).
 //   a[u][s][:] = m - mean(m)  as SP,  asq[u][s] = |a|^2   (rows s >= S: zero)
 // ------------------------------------------------------------------------------------------------
 struct MemCenterArgs {
@@ -171,10 +171,35 @@ struct MemScaleArgs {
   float* cbk;          // [nl][rows]
 };
 
-__global__ void __launch_bounds__(256) mem_scale_kernel(const MemScaleArgs a) {
-  const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+// every static memory of a step in ONE launch (five launches of this size were five launch latencies: four of them have a few hundred rows)
+struct MemScaleAllArgs {
+  MemScaleArgs m[CFD_NMEM];
+  int first[CFD_NMEM + 1];   // first workgroup of memory slot k (slots packed: n of them)
+  int n;
+};
+
+__device__ __forceinline__ void mem_scale_rows(const MemScaleArgs& a, long long row, int lane);
+
+__global__ void __launch_bounds__(256) mem_scale_all_kernel(const MemScaleAllArgs g) {
+  int k = 0;
+#pragma unroll
+  for (int q = 1; q < CFD_NMEM; ++q)
+    if (q < g.n && (int)blockIdx.x >= g.first[q]) k = q;
+  // (copies of the chosen slot's fields: a select per field, no indexing of the argument struct)
+  MemScaleArgs a = g.m[0];
+#pragma unroll
+  for (int q = 1; q < CFD_NMEM; ++q)
+    if (k == q) a = g.m[q];
+  int first = 0;
+#pragma unroll
+  for (int q = 1; q < CFD_NMEM; ++q)
+    if (k == q) first = g.first[q];
+  const long long row = (long long)((int)blockIdx.x - first) * 4 + (threadIdx.x >> 6);
   if (row >= a.rows) return;
+  mem_scale_rows(a, row, threadIdx.x & 63);
+}
+
+__device__ __forceinline__ void mem_scale_rows(const MemScaleArgs& a, long long row, int lane) {
   const int t = *a.d_step;
   const char* ap = a.a_sp + row * (CFD_D * 4) + (size_t)(lane >> 2) * 128 + (lane & 3) * 16;   // 8 consecutive columns: lane * 8
   const spx8 h = *reinterpret_cast<const spx8*>(ap);

@@ -912,7 +912,7 @@ __global__ void __launch_bounds__(256) rt_step_rows_kernel(const RtStepRowsArgs 
 }
 
 // ------------------------------------------------------------------------------------------------
-// mem_scale_kernel (rows.hpp) for EVERY step of a run at once: table[t][l][key] = cbk, table[t][nl][key] = rs
+// mem_scale_all_kernel (rows.hpp) for EVERY step of a run at once: table[t][l][key] = cbk, table[t][nl][key] = rs
 // grid (ceil(rows / 4), T)
 // ------------------------------------------------------------------------------------------------
 struct MemScaleTabArgs {

@@ -52,7 +52,7 @@
 // per-step part itself:
 //   score(q, s) = rs_s (S_raw(q, s) + c_q) + cbk_s        c_q = q . (A b): per query and memory, made in the prologue
 //   O += VA^T P',  P' = p_s rs_s                           and   x += (sum_s P'_s) VV b   in the epilogue (rank one)
-// rs_s and cbk_s (one scalar per key each, mem_scale_kernel) arrive together in the tile's key-bias piece.  A memory whose
+// rs_s and cbk_s (one scalar per key each, mem_scale_all_kernel) arrive together in the tile's key-bias piece.  A memory whose
 // projections are still made per step (dynamic memories of the dyadic rollout, per-row timesteps) passes rs = 1, A b = VV b = 0:
 // same code, the extra terms vanish exactly.
 //
