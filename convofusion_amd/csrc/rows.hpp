@@ -602,22 +602,24 @@ __global__ void cfg_step_kernel(const CfgStepArgs a) {
   const StepCoef c = a.coef[i];
   const long long e0 = idx * 4;
   const long long chunk = (long long)a.B * per_utt;
-  const float4 u4 = *reinterpret_cast<const float4*>(a.eps + a.pos[0] * chunk + e0);
-  const float u[4] = {u4.x, u4.y, u4.z, u4.w};
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  if (a.G > 1) {
-    // reference association: ((((text + audio) + spk) + apb) + lsnid) + all, each = (g*w)*(e_k - e_0)
-    for (int k = 1; k < a.G; ++k) {
-      const float4 e4 = *reinterpret_cast<const float4*>(a.eps + a.pos[k] * chunk + e0);
-      const float e[4] = {e4.x, e4.y, e4.z, e4.w};
+  // every chunk's prediction is requested before the first is used (chunks past G re-read the last one and are ignored): in a loop
+  // of run-time length each load sat next to its use and the G round trips ran one after the other -- 28 us at the benchmark shape
+  float4 e4[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float term = a.w[k] * (e[q] - u[q]);
-        acc[q] = (k == 1) ? term : acc[q] + term;
-      }
+  for (int k = 0; k < 8; ++k) e4[k] = *reinterpret_cast<const float4*>(a.eps + a.pos[min(k, a.G - 1)] * chunk + e0);
+  float4 x4 = *reinterpret_cast<const float4*>(a.latents + e0);
+  const float u[4] = {e4[0].x, e4[0].y, e4[0].z, e4[0].w};
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // reference association: ((((text + audio) + spk) + apb) + lsnid) + all, each = (g*w)*(e_k - e_0)
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    const float e[4] = {e4[k].x, e4[k].y, e4[k].z, e4[k].w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float term = a.w[k] * (e[q] - u[q]);
+      acc[q] = (k == 1) ? (a.G > 1 ? term : 0.f) : (k < a.G ? acc[q] + term : acc[q]);
     }
   }
-  float4 x4 = *reinterpret_cast<const float4*>(a.latents + e0);
   float x[4] = {x4.x, x4.y, x4.z, x4.w};
   float z[4] = {0.f, 0.f, 0.f, 0.f};
   if (c.use_noise != 0.f) {
