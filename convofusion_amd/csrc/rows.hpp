@@ -28,12 +28,22 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const LnArgs a) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.M) return;
   const float* xr = a.x + row * CFD_D + lane * 8;
-  float v[8];
-  {
-    const float4 p = *reinterpret_cast<const float4*>(xr);
-    const float4 q = *reinterpret_cast<const float4*>(xr + 4);
-    v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
-  }
+  // every operand is requested before the first is used: the AdaLN rows used to be loaded inside `if (a.adaln)`, behind the statistics,
+  // i.e. a second round trip per row (half of the launches of a step are AdaLN ones)
+  const long long trow = a.tmode ? (a.trow0 + row / a.L) : (long long)(*a.d_step);
+  const float* sc = a.adaln ? a.ss + trow * a.ss_tstride + lane * 8 : a.g + lane * 8;   // (plain LayerNorm: a valid address, values unused)
+  const float* sh = a.adaln ? sc + CFD_D : sc;
+  const float4 p = *reinterpret_cast<const float4*>(xr), q = *reinterpret_cast<const float4*>(xr + 4);
+  const float4 g0 = *reinterpret_cast<const float4*>(a.g + lane * 8), g1 = *reinterpret_cast<const float4*>(a.g + lane * 8 + 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(a.b + lane * 8), b1 = *reinterpret_cast<const float4*>(a.b + lane * 8 + 4);
+  const float4 s0 = *reinterpret_cast<const float4*>(sc), s1 = *reinterpret_cast<const float4*>(sc + 4);
+  const float4 h0 = *reinterpret_cast<const float4*>(sh), h1 = *reinterpret_cast<const float4*>(sh + 4);
+  __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the parameter loads behind the wait for x)
+  float v[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+  const float gp[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+  const float bp[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+  const float shv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
   float s = 0.f;
 #pragma unroll
   for (int e = 0; e < 8; ++e) s += v[e];
@@ -43,15 +53,11 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const LnArgs a) {
   for (int e = 0; e < 8; ++e) { v[e] -= mean; ss += v[e] * v[e]; }
   const float var = wave_sum(ss) * (1.0f / CFD_D);
   const float rstd = 1.0f / sqrtf(var + 1e-5f);
-  const float* gp = a.g + lane * 8;
-  const float* bp = a.b + lane * 8;
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = v[e] * rstd * gp[e] + bp[e];
   if (a.adaln) {
-    const long long trow = a.tmode ? (a.trow0 + row / a.L) : (long long)(*a.d_step);
-    const float* sc = a.ss + trow * a.ss_tstride + lane * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e] * sc[e] + sc[CFD_D + e]);
+    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e] * scv[e] + shv[e]);
   }
   sp_store8(a.out + row * (CFD_D * 4), lane * 8, v);
 }
@@ -205,14 +211,22 @@ __device__ __forceinline__ void mem_scale_rows(const MemScaleArgs& a, long long 
   const spx8 h = *reinterpret_cast<const spx8*>(ap);
   const spx8 l = *reinterpret_cast<const spx8*>(ap + 64);
   const float* bp = a.btab + (long long)t * CFD_D + lane * 8;
+  const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+  // (the scalars of the row and the layers' terms are requested with the row, at clamped lanes: loaded where they are used they
+  //  were a second and a third round trip behind the reduction)
+  const int ll = min(lane, a.nl - 1);
+  const float asq = a.asq[row], bsq = a.bsq[t];
+  const float ca = a.ca[(long long)ll * a.rows + row], cbb = a.cbb[(long long)t * a.cbb_tstride + ll];
+  __builtin_amdgcn_sched_barrier(0);
+  const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
   float dot = 0.f;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) dot += ((float)h[e] + (float)l[e]) * bp[e];
+  for (int e = 0; e < 8; ++e) dot += ((float)h[e] + (float)l[e]) * bv[e];
   dot = wave_sum(dot);
-  const float var = (a.asq[row] + 2.0f * dot + a.bsq[t]) * (1.0f / CFD_D);
+  const float var = (asq + 2.0f * dot + bsq) * (1.0f / CFD_D);
   const float rstd = 1.0f / sqrtf(var + 1e-5f);
   if (lane == 0) a.rs[row] = rstd;
-  if (lane < a.nl) a.cbk[(long long)lane * a.rows + row] = rstd * (a.ca[(long long)lane * a.rows + row] + a.cbb[(long long)t * a.cbb_tstride + lane]);
+  if (lane < a.nl) a.cbk[(long long)lane * a.rows + row] = rstd * (ca + cbb);
 }
 
 // b[t][:] = temb[t][:] - mean(temb[t]) as fp32 and SP, bsq[t] = |b|^2   (one wave per table row)
