@@ -72,12 +72,6 @@ __device__ __forceinline__ f32x4 rt_mma(const spx8 xh, const spx8 xl, const spx8
   return acc;
 }
 
-// fragment of k-group kt of an SP row in global memory (row_base points at the row): lane q4 takes k = 8 q4 .. 8 q4 + 7
-__device__ __forceinline__ void rt_gfrag(const char* row_base, int kt, int q4, spx8& hi, spx8& lo) {
-  const char* p = row_base + (size_t)kt * 128 + q4 * 16;
-  hi = *reinterpret_cast<const spx8*>(p);
-  lo = *reinterpret_cast<const spx8*>(p + 64);
-}
 
 // LDS image of a 16-row SP operand: [k-group][row 16][128 B], 16-byte chunk c of a row stored at position c ^ ((row >> 1) & 7)
 // (the swizzle of gemm_sp.hpp: conflict-free ds_read_b128 fragment reads)
@@ -102,21 +96,6 @@ __device__ __forceinline__ void rt_dma_slice(char* slot, const char* base, long 
 }
 #define RT_WAIT_VM0() do { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); } while (0)   /* vmcnt(0), lgkmcnt / expcnt untouched */
 
-// store 8 consecutive columns (c0 % 8 == 0) of row r into the image
-__device__ __forceinline__ void rt_lstore8(char* img, int r, int c0, const float* v) {
-  spx8 h, l;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    sp_t a, b;
-    split_f32(v[e], a, b);
-    h[e] = a;
-    l[e] = b;
-  }
-  const int sw = (r >> 1) & 7, ch = (c0 & 31) >> 3;
-  char* p = img + (c0 >> 5) * 2048 + r * 128;
-  *reinterpret_cast<spx8*>(p + ((ch ^ sw) << 4)) = h;
-  *reinterpret_cast<spx8*>(p + (((4 + ch) ^ sw) << 4)) = l;
-}
 
 // Reductions over the LPR lanes that share a prologue row (LPR = 16: one DPP row; 32: two adjacent DPP rows), in the vector ALU:
 // quad permutes, row_half_mirror and row_mirror (each lane ends with the value of its whole 16-lane row), then
@@ -588,14 +567,8 @@ struct RtXArgs {
 // (m_c, l_c = sum e_s, sum e_s rs_s); the probability of key s is then e_s * factor, factor = exp(m_c - M) / sum_c' l_c' exp(m_c' - M)
 // over the cells [cb, ce) of the key's memory, M their largest m -- no reduction over lanes in the launch that consumes it
 // (its 32 feature-block workgroups per tile each computed the whole five-memory softmax before: 3 of that launch's 7.6 us).
-__device__ __forceinline__ float rt_cell_scale(const float4* cst, int c, int cb, int ce, float& inv_l) {
-  float M = -INFINITY;
-  for (int k = cb; k < ce; ++k) M = fmaxf(M, cst[k].x);
-  float l = 0.f;
-  for (int k = cb; k < ce; ++k) l = fmaf(cst[k].y, __expf(cst[k].x - M), l);
-  inv_l = rt_rcp(l);                                  // all keys of the memory dead: M = -inf, NaN like the reference's softmax
-  return __expf(cst[c].x - M) * inv_l;
-}
+// (M and 1 / sum per (token, memory) are made once per workgroup by 80 threads -- rt_xpv_kernel, rt_xbwd_dy_kernel -- and a key's factor
+//  is then exp(m_c - M) / sum.)
 
 #define RT_XS_LDS (16 * 2048 + 8192 + 8 * 8192 + 64 + 512)
 __global__ void __launch_bounds__(512) rt_xscore_kernel(const RtXArgs a) {

@@ -27,9 +27,6 @@
 
 #define RT_MFMA_F32 __builtin_amdgcn_mfma_f32_16x16x4f32
 
-__device__ __forceinline__ float rt_sp_f32(const char* p) {   // one element of an SP row: p points at its hi half
-  return (float)*reinterpret_cast<const sp_t*>(p) + (float)*reinterpret_cast<const sp_t*>(p + 64);
-}
 __device__ __forceinline__ float rt_gelu_grad(float y) {      // d/dy of the erf-form GELU (the formula of grad.hpp's EW_GELU_BWD)
   return 0.5f * (1.0f + erff(y * 0.70710678118654752440f)) + y * expf(-0.5f * y * y) * 0.39894228040143267794f;
 }
@@ -254,7 +251,7 @@ struct RtXBwdArgs {
   int blk0[CFD_NMEM + 1];
   int Sp_tot;
   const float* sc;              // this layer's e_s = exp(score - cell maximum) [M][Sp_tot] (saved by the forward)
-  const float* cst;             // this layer's cell statistics, float4 [M][Sp_tot / 32] (rowtile.hpp, rt_cell_scale)
+  const float* cst;             // this layer's cell statistics, float4 [M][Sp_tot / 32] (rowtile.hpp, RtXArgs::cst)
   const float* rsp;             // per-key scales [M][Sp_tot]
   const float* d_att;           // gradient at the tlsn probabilities [B][nl][L][S_2]
   float* dP;                    // [M][Sp_tot]
