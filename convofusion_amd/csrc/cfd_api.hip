@@ -1219,9 +1219,8 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
     xa.blk0[j] = nkb; nkb += p.Sp[j] / 16;
   }
   xa.blk0[CFD_NMEM] = nkb;
-  static const bool exp_same_weights = getenv("CFD_RT_EXP_SAMEW") != nullptr;   // TIMING EXPERIMENT (garbage results): every layer reads layer 0's weights
   for (int l = 0; l < nl; ++l) {
-    const LayerW& w = c->lw[exp_same_weights ? 0 : l];
+    const LayerW& w = c->lw[l];
     char* qk = sv ? sv->qk[l] : c->w->qk_sp.as<char>();
     char* vt = sv ? sv->vt[l] : c->w->rt_vt.as<char>();
     // ---- a. self attention: x += Wo softmax(q k^T) v                         (cross_attention.py:568-572)
