@@ -244,6 +244,16 @@ def secondary_configs(model, device):
         run = SamplingRun(model, ddpm, mems, masks, 1, L, 1000, guidance_scale=7.5, seed=0)
         run.steps(2)
         c1_launches = sum(v[1] for v in run.profile().values()) + 2     # + begin_step / cfg_step around the forward
+        # host against GPU: how long the replays of 900 iterations take to ENQUEUE (hipGraphLaunch per iteration) and to finish
+        run.steps(8)
+        run.read()
+        sync()
+        t0 = time.perf_counter()
+        run.steps(900)
+        t_enq = time.perf_counter() - t0
+        run.read()
+        sync()
+        t_gpu = time.perf_counter() - t0
         run.close()
         sample(model, ddpm, mems, masks, B=1, L=L, num_inference_steps=4, seed=0)
         sync()
@@ -257,6 +267,7 @@ def secondary_configs(model, device):
         alg_bytes = n_w + G * sum(S) * 512 * 4 * NL + (1 + G) * L * 128 * 4
         ach = alg_bytes / (dt / 1000) / 1e9
         out["c1_single_utterance"] = {"s_per_1000": dt, "steps_per_s": 1000 / dt, "launches_per_step": c1_launches,
+                                      "gpu_us_per_step": t_gpu / 900 * 1e6, "host_enqueue_us_per_step": t_enq / 900 * 1e6,
                                       "workload": f"B=1 (denoiser batch {G}), L={L}, S={S}, 1000-step DDPM end to end through sample()",
                                       "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                                                    "algorithmic_bytes_per_step": alg_bytes, "traffic": None,
