@@ -92,6 +92,7 @@ struct Problem {
   // fused cross-attention (xattn_fused.hpp): workgroups of the work list, 0 = the list was not built
   int xa_nwg = 0;
   int xa0_nwg_a = 0, xa0_nwg_b = 0;   // layer-0 de-duplication lists (build_xattn_layer0_lists); 0: one launch
+  int xa_one = -1;                     // the one-key memory the fused cross-attention adds as a vector (xattn_fused.hpp, XAttnArgs::one_j), or -1
   // memories (bit j) whose folded projections were computed once for the run from the centred static part of the memory
   // (prepare_static_memside); per step they only get their per-key scale and bias (mem_scale_all_kernel)
   int static_mask = 0;
@@ -129,7 +130,7 @@ struct Work {
   // timestep-independent memory-side projections (rows.hpp mem_center_kernel): per memory the dot products c_l . a_s (ca), |a_s|^2 (asq)
   // and, per table row t, A_l b_t / c_l . b_t (kbtab) and VV_l b_t (vbtab); b_t = centred timestep embedding.  CFD_HOIST_MEMSIDE=0: off.
   DBuf ca[CFD_NMEM], asq[CFD_NMEM], kbtab[CFD_NMEM], vbtab[CFD_NMEM], b_tab, b_sp, bsq, zeros512;
-  DBuf xa_wgs, xa_segs, xa_stamps, xa0_wgs_a, xa0_segs_a, xa0_wgs_b, xa0_segs_b, xa_dedup;
+  DBuf xa_wgs, xa_segs, xa_stamps, xa0_wgs_a, xa0_segs_a, xa0_wgs_b, xa0_segs_b, xa_dedup, xa_one_va;
   DBuf d_step;  // [0] = loop index, [1] = constant 0, [2] = "this iteration's in-painting overwrite is done" (cfd_sample_inpaint)
   DBuf rt_vt, rt_cbt[CFD_NMEM];   // row-tile path: V^T of the self-attention, per-step key tables
   DBuf rt_cur;                    // row-tile path, sampling run: this step's rows of every per-step table (rt_step_rows_kernel)
@@ -140,7 +141,7 @@ struct Work {
   const float* now_vb[CFD_NMEM] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   void release() {
     DBuf* all[] = {&x, &h_sp, &qk_sp, &vts_sp, &ssc, &sp_sp, &o_sp, &u_sp, &sc, &p_sp, &eps, &sample_sp, &temb_tab, &h1_tab, &ss_tab, &trows, &iota,
-                   &long_rows, &short_rows, &zero_mask, &b_tab, &b_sp, &bsq, &zeros512, &xa_wgs, &xa_segs, &xa_stamps, &xa0_wgs_a, &xa0_segs_a, &xa0_wgs_b, &xa0_segs_b, &xa_dedup, &d_step, &rt_vt, &rt_cur};
+                   &long_rows, &short_rows, &zero_mask, &b_tab, &b_sp, &bsq, &zeros512, &xa_wgs, &xa_segs, &xa_stamps, &xa0_wgs_a, &xa0_segs_a, &xa0_wgs_b, &xa0_segs_b, &xa_dedup, &xa_one_va, &d_step, &rt_vt, &rt_cur};
     for (DBuf* b : all) b->release();
     for (int j = 0; j < CFD_NMEM; ++j) {
       n_sp[j].release(); kall_sp[j].release(); cb[j].release(); vt_all[j].release(); ca[j].release(); asq[j].release(); kbtab[j].release();
@@ -174,6 +175,7 @@ struct cfd_handle_s {
   // the three-launch path everywhere (parity A/B of the two paths).
   bool fused_xattn = true;
   int fused_xattn_min_wgs = 6;
+  int one_key = 1;              // CFD_ONE_KEY=0: a one-key memory (lsnemb) keeps its 32-key tile step in the fused cross-attention
   int l0_dedup = 1;             // CFD_L0_DEDUP=0: layer 0's cross-attention as one launch over all rows (build_xattn_layer0_lists)
   // Row-tile path for small problems (rowtile.hpp): chosen by SHAPE -- at most rt_max_rows token rows of at most RT_MAX_L tokens per batch
   // row, one timestep for all rows, no dynamic memories.  CFD_ROWTILE=0 turns it off (parity A/B against the tile kernels),
@@ -330,6 +332,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   if (env) c->fused_xattn_min_wgs = atoi(env);
   env = getenv("CFD_L0_DEDUP");
   if (env) c->l0_dedup = atoi(env) != 0;
+  env = getenv("CFD_ONE_KEY");
+  if (env) c->one_key = atoi(env) != 0;
   env = getenv("CFD_ROWTILE");
   c->rt_on = !(env && atoi(env) == 0);
   env = getenv("CFD_WEG_ROWTILE");
@@ -605,6 +609,7 @@ struct XaRow {      // one row of a work list
   int xrow;           // row of the residual stream (queries read from it; updated unless the list stores to xa_dedup)
   int inst[CFD_NMEM]; // memory instance per memory
   int aux;            // row of xa_dedup this row's tiles store to / add (-1: none)
+  int one;            // instance of the one-key memory (Problem::xa_one), or -1
 };
 
 static void make_xattn_worklist(const Problem& p, const std::vector<XaRow>& rows, int mem_mask, std::vector<XaWg>& wgs, std::vector<XaSeg>& segs,
@@ -641,6 +646,7 @@ static void make_xattn_worklist(const Problem& p, const std::vector<XaRow>& rows
         vr[k] = on ? tiles[t0 + k].first : -1;
         w.row[k] = on ? rows[vr[k]].xrow : -1;
         w.aux[k] = on ? rows[vr[k]].aux : -1;
+        w.one[k] = on ? rows[vr[k]].one : -1;
         w.q0[k] = on ? tiles[t0 + k].second : 0;
       }
       w.seg0 = (int)segs.size();
@@ -694,7 +700,7 @@ static void make_xattn_worklist(const Problem& p, const std::vector<XaRow>& rows
   for (int x = 0; x < 8; ++x) qlen = std::max(qlen, queue[x].size());
   XaWg idle;
   memset(&idle, 0, sizeof(idle));
-  for (int k = 0; k < XA_TILES; ++k) { idle.row[k] = -1; idle.aux[k] = -1; }
+  for (int k = 0; k < XA_TILES; ++k) { idle.row[k] = -1; idle.aux[k] = -1; idle.one[k] = -1; }
   wgs.assign(qlen * 8, idle);
   for (int x = 0; x < 8; ++x) {
     for (size_t i = 0; i < queue[x].size(); ++i) wgs[i * 8 + x] = queue[x][i];
@@ -728,15 +734,31 @@ static int build_xattn_worklist(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
   if (!c->fused_xattn) return CFD_OK;
   std::vector<std::vector<int>> hm;
   CHK(read_row_maps(c, mem, hm));
+  // A memory of ONE key whose key no instance masks is added as a vector in the kernel's flush instead of walking a 32-key tile step
+  // (xattn_fused.hpp, XAttnArgs::one_j): it gets no segments.  (With the key masked the reference's softmax is NaN: that stays a segment.)
+  p.xa_one = -1;
+  if (c->one_key && c->hoist_memside && p.tmode == 0) {
+    for (int j = CFD_NMEM - 1; j >= 0 && p.xa_one < 0; --j) {
+      if (p.S[j] != 1) continue;
+      bool alive = true;
+      if (mem[j].key_padding_mask) {
+        std::vector<uint8_t> mk(p.U[j]);
+        HIPCHK(hipMemcpy(mk.data(), mem[j].key_padding_mask, (size_t)p.U[j], hipMemcpyDeviceToHost));
+        for (uint8_t v : mk) alive = alive && v == 0;
+      }
+      if (alive) p.xa_one = j;
+    }
+  }
   std::vector<XaRow> rows(p.Be);
   for (int b = 0; b < p.Be; ++b) {
-    rows[b].xrow = b; rows[b].aux = -1;
+    rows[b].xrow = b; rows[b].aux = -1; rows[b].one = p.xa_one >= 0 ? hm[p.xa_one][b] : -1;
     for (int j = 0; j < CFD_NMEM; ++j) rows[b].inst[j] = hm[j][b];
   }
+  const int all_mems = ((1 << CFD_NMEM) - 1) & ~(p.xa_one >= 0 ? 1 << p.xa_one : 0);
   std::vector<XaWg> wgs;
   std::vector<XaSeg> segs;
   size_t n_active = 0;
-  make_xattn_worklist(p, rows, (1 << CFD_NMEM) - 1, wgs, segs, n_active);
+  make_xattn_worklist(p, rows, all_mems, wgs, segs, n_active);
   if (wgs.empty() || segs.empty()) return CFD_OK;
   // A handful of workgroups cannot hide their serial walk over the key tiles (3 barriers and a fill round trip per 32 keys
   // with nothing else on the chip).  Round-2 measurements at the product shape, 1000 steps, since the memory-side projections
@@ -783,7 +805,7 @@ static int build_xattn_layer0_lists(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
       if (idx < 0) {
         idx = (int)ra.size();
         XaRow r;
-        r.xrow = row; r.aux = idx;
+        r.xrow = row; r.aux = idx; r.one = -1;
         for (int j = 0; j < CFD_NMEM; ++j) r.inst[j] = hm[j][row];
         ra.push_back(r);
         seen.emplace_back(u, idx);
@@ -793,14 +815,14 @@ static int build_xattn_layer0_lists(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
   }
   if (ra.size() * 2 > (size_t)p.Be) return CFD_OK;   // too little repetition
   for (int b = 0; b < p.Be; ++b) {
-    rb[b].xrow = b; rb[b].aux = aux_of[b];
+    rb[b].xrow = b; rb[b].aux = aux_of[b]; rb[b].one = p.xa_one >= 0 ? hm[p.xa_one][b] : -1;
     for (int j = 0; j < CFD_NMEM; ++j) rb[b].inst[j] = hm[j][b];
   }
   std::vector<XaWg> wa, wb;
   std::vector<XaSeg> sa, sb;
   size_t na = 0, nb = 0;
   make_xattn_worklist(p, ra, 1 << jg, wa, sa, na);
-  make_xattn_worklist(p, rb, ((1 << CFD_NMEM) - 1) & ~(1 << jg), wb, sb, nb);
+  make_xattn_worklist(p, rb, ((1 << CFD_NMEM) - 1) & ~(1 << jg) & ~(p.xa_one >= 0 ? 1 << p.xa_one : 0), wb, sb, nb);
   if (wa.empty() || wb.empty()) return CFD_OK;
   CHK(upload_worklist(c->w->xa0_wgs_a, c->w->xa0_segs_a, wa, sa));
   CHK(upload_worklist(c->w->xa0_wgs_b, c->w->xa0_segs_b, wb, sb));
@@ -984,6 +1006,19 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
     HIPCHK(hipMemsetAsync(c->w->zeros512.p, 0, CFD_D * 4, st));
   }
   if (dynamic_mask) p.rt = false;   // (a memory rewritten between iterations keeps its per-step projections: tile-kernel path)
+  if (p.xa_one >= 0 && ((dynamic_mask >> p.xa_one) & 1)) {   // the one-key memory is rewritten between iterations: it needs its segments back
+    cfd_memory mem[CFD_NMEM];
+    memset(mem, 0, sizeof(mem));
+    for (int j = 0; j < CFD_NMEM; ++j) {
+      mem[j].data = p.mem[j]; mem[j].U = p.U[j]; mem[j].S = p.S[j]; mem[j].row_map = p.map[j];
+      mem[j].key_padding_mask = p.has_mask[j] ? p.mask[j] : nullptr;
+    }
+    const int keep = c->one_key;
+    c->one_key = 0;
+    const int r = build_xattn_worklist(c, mem);
+    c->one_key = keep;
+    CHK(r);
+  }
   const bool fused = p.rt || (c->fused_xattn && p.xa_nwg > 0 && !want_att && !g_cfd_naive_gemm);
   if (!fused || !c->hoist_memside || p.tmode != 0) return CFD_OK;
   const int T = p.T;
@@ -1038,6 +1073,12 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }
     p.static_mask |= 1 << j;
+  }
+  if (p.xa_one >= 0 && !p.rt) {   // the one-key memory's value rows as float32 vectors (xattn_fused.hpp, XAttnArgs::one_va)
+    const int j = p.xa_one;
+    const long long n = (long long)nl * p.U[j] * CFD_D;
+    CHK(c->w->xa_one_va.ensure((size_t)n * 4));
+    LAUNCH(CFD_PROF_ROWS, one_key_va_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), st, c->w->vt_all[j].as<char>(), n, p.Sp[j], c->w->xa_one_va.as<float>());
   }
   if (p.rt) {   // per-key scale and key bias of every step of the run (the tile-kernel path makes one step's per iteration: mem_scale_all_kernel)
     for (int j = 0; j < CFD_NMEM; ++j) {
@@ -1428,6 +1469,14 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
         a.vb_stride[j] = stat ? nl * CFD_D : 0;
       }
       a.d_step = dstep;
+      a.one_j = -1;
+      if (p.xa_one >= 0) {   // (the work lists hold no segments for it: build_xattn_worklist)
+        const int j = p.xa_one;
+        const size_t rows = (size_t)p.U[j] * p.Sp[j];
+        a.one_j = j; a.one_sp = p.Sp[j];
+        a.one_va = c->w->xa_one_va.as<float>() + (size_t)l * p.U[j] * CFD_D;
+        a.one_rs = c->w->cb[j].as<float>() + (size_t)nl * rows;
+      }
       a.wgs = c->w->xa_wgs.as<XaWg>(); a.segs = c->w->xa_segs.as<XaSeg>();
 #if XA_STAMP
       CHK(c->w->xa_stamps.ensure((size_t)p.xa_nwg * XA_WAVES * XA_NSTAMP * 8));
@@ -1437,10 +1486,12 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       if (l == 0 && share && p.xa0_nwg_a > 0) {   // layer-0 de-duplication (build_xattn_layer0_lists): the longest memory once per distinct (utterance, instance) ...
         XAttnArgs a0 = a;
         a0.wgs = c->w->xa0_wgs_a.as<XaWg>(); a0.segs = c->w->xa0_segs_a.as<XaSeg>(); a0.dd_out = c->w->xa_dedup.as<float>(); a0.stamps = nullptr;
+        a0.one_j = -1;   // (the one-key memory belongs to the second launch)
         hipLaunchKernelGGL(xattn_fused_kernel, dim3(p.xa0_nwg_a), dim3(XA_WAVES * 64), XA_LDS, st, a0);
         HIPCHK(hipGetLastError());
         // ... then the other memories for every row, which also adds the stored results
         a0.wgs = c->w->xa0_wgs_b.as<XaWg>(); a0.segs = c->w->xa0_segs_b.as<XaSeg>(); a0.dd_out = nullptr; a0.dd_in = c->w->xa_dedup.as<float>();
+        a0.one_j = a.one_j;
         hipLaunchKernelGGL(xattn_fused_kernel, dim3(p.xa0_nwg_b), dim3(XA_WAVES * 64), XA_LDS, st, a0);
         HIPCHK(hipGetLastError());
         if (c->prof) c->prof_n[CFD_PROF_XATTN] += 1;   // (two launches under one bracket)

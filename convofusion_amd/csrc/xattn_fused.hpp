@@ -87,6 +87,7 @@ struct XaWg {
   int row[XA_TILES];   // effective-batch row of query tile t, or -1 (idle)
   int q0[XA_TILES];    // first query (token index inside the row) of tile t
   int aux[XA_TILES];   // layer-0 de-duplication: row of XAttnArgs::dd_out this tile's result is stored to / of dd_in it adds (-1: none)
+  int one[XA_TILES];   // one-key memory (XAttnArgs::one_j): its instance for this tile's row (-1: none)
   int seg0, nseg;
   int pf_slot, pf_n;   // L2 prefetch share (used by the archived role-split kernel, tools/experiments/r03_variants/xattn_role.hpp): this workgroup is number pf_slot of pf_n that stream the same instance of the
                        // longest memory on one XCD at about the same time (0, 0: no prefetch)
@@ -113,8 +114,25 @@ struct XAttnArgs {
   // terms, no bias) are STORED to dd_out[aux][query][512] and x is left alone.  dd_in: x += ... + dd_in[aux][query][512].
   float* dd_out;
   const float* dd_in;
+  // A memory with ONE key (lsnemb) has no softmax to speak of: its probability is 1, so its contribution to a row is the vector
+  //   rs_u (VA_u + VV b_t)      (u: the row's instance, rs_u: the key's scale at this step)
+  // and the 32-key tile step that used to produce it (a K and a V^T fill of 64 KB each for one live key, three barriers) is replaced by one
+  // 2 KB read in the flush.  one_j < 0: no such memory (or its key can be masked: then it stays a segment).  Such a memory has no segments
+  // in the work lists (cfd_api.hip, build_xattn_worklist).
+  int one_j;                  // memory index, or -1
+  int one_sp;                 // its padded length (row pitch of one_rs)
+  const float* one_va;        // fp32 [U][512]: VA of its key, this layer
+  const float* one_rs;        // fp32 [U * one_sp]: the scale plane of this step (key 0 of instance u at u * one_sp)
   long long* stamps;          // XA_STAMP builds only (tools/xa_stamps.py): per wave, cycles per section of the kernel
 };
+
+// float32 copy of the value row of a one-key memory: out[(l * U + u) * 512 + f] = VA_l,u[f] (key 0 of V^T [nl][U][512][Sp], hi + lo)
+__global__ void __launch_bounds__(256) one_key_va_kernel(const char* vt, long long n, int Sp, float* out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const char* p = vt + i * ((long long)Sp * 4);
+  out[i] = (float)*reinterpret_cast<const sp_t*>(p) + (float)*reinterpret_cast<const sp_t*>(p + 64);
+}
 
 template <class T>
 __device__ __forceinline__ T xa_sel(const T (&arr)[CFD_NMEM], int j) {
@@ -170,6 +188,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   const int my_row = wgp->row[tile];
   const int my_q0 = wgp->q0[tile];
   const int my_aux = wgp->aux[tile];
+  const int my_one = wgp->one[tile];
   const int seg0 = wgp->seg0, nseg = wgp->nseg;
   const bool active = my_row >= 0;                     // wave-uniform
   const long long tok0 = active ? (long long)my_row * a.L + my_q0 : 0;
@@ -255,6 +274,8 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       acc = xlane_sum(acc);
       if (q4 == 0) { cq_mine[l15 * 5 + j] = acc; wq_mine[l15 * 5 + j] = 0.f; }
     }
+    // the one-key memory: sum_s P'_s = rs_u for every query of the tile (its rank-one term is added with the others in the final flush)
+    if (a.one_j >= 0 && my_one >= 0 && q4 == 0) wq_mine[l15 * 5 + a.one_j] = a.one_rs[(long long)my_one * a.one_sp];
   }
   f32x4 o[16];   // O^T tiles of features 256 half + 16 f .. +15
 #pragma unroll
@@ -349,6 +370,12 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
         vbv[j] = *reinterpret_cast<const float4*>(ka->vb[j] + (long long)trow * ka->vb_stride[j] + half * 256 + lane * 4);
     }
     float* xp = ka->x + tok0 * CFD_D + half * 256 + lane * 4;
+    float4 one_v = make_float4(0.f, 0.f, 0.f, 0.f);   // rs_u VA_u of the one-key memory for this lane's 4 features
+    if (add_bias && ka->one_j >= 0 && my_one >= 0) {
+      const float rs1 = ka->one_rs[(long long)my_one * ka->one_sp];
+      const float4 va = *reinterpret_cast<const float4*>(ka->one_va + (long long)my_one * CFD_D + half * 256 + lane * 4);
+      one_v = make_float4(rs1 * va.x, rs1 * va.y, rs1 * va.z, rs1 * va.w);
+    }
     float* const dd_out = ka->dd_out;
     const float* const dd_in = ka->dd_in;
     const bool store_only = add_bias && dd_out != nullptr;                      // (wave-uniform)
@@ -375,6 +402,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
             const float wj = wq_mine[r * 5 + j];
             c.x += wj * vbv[j].x; c.y += wj * vbv[j].y; c.z += wj * vbv[j].z; c.w += wj * vbv[j].w;
           }
+          c.x += one_v.x; c.y += one_v.y; c.z += one_v.z; c.w += one_v.w;
         }
         if (store_only) {
           *reinterpret_cast<float4*>(dd_out + dd_off + (long long)r * CFD_D) = c;
