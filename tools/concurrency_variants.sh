@@ -1,5 +1,6 @@
 #!/bin/bash
-# Two-queue investigation.  BUILD (container, no GPU):  tools/concurrency_variants.sh build
+# Two-queue investigation.  HISTORICAL: the CFD_EXP variants and the CFD_EAGER_STEPS knob it drives left the product
+# sources in round 4 (tools/experiments/r03_variants/removed_from_product.patch restores them on the round-3 tree).  BUILD (container, no GPU):  tools/concurrency_variants.sh build
 #   -> tools/experiments/lib_exp<k>.so, k = CFD_EXP variant (gemm_sp.hpp / rows.hpp):
 #      1 s_waitcnt vmcnt(0) at the end of every gemm_sp_kernel wave      2 (1) + eps stored with sc1 (write-through)
 #      3 (1) + eps stored sc0 sc1                                         4 agent-scope release fence at the end of every gemm wave
