@@ -213,10 +213,17 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     const char* kp = reinterpret_cast<const char*>(xa_sel(a.kb, wid) + (long long)trow * xa_sel(a.kb_stride, wid)) + lane * 16;
     __builtin_amdgcn_global_load_lds((gptr_t)kp, (lptr_t)(smem + KBOFF + wid * 2048), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gptr_t)(kp + 1024), (lptr_t)(smem + KBOFF + wid * 2048 + 1024), 16, 0, 0);
+  } else if (wid < CFD_NMEM + 2) {
+    // norm2's weight (wave 5) and bias (wave 6) the same way, behind A b: read as 32 float4 per lane straight from memory they were
+    // 32 loads that the registers (the 16 rows are live) only let go out four at a time -- a chain of waits in front of the first fill
+    const char* gp = reinterpret_cast<const char*>(wid == CFD_NMEM ? a.ln_g : a.ln_b) + lane * 16;
+    __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(smem + KBOFF + wid * 2048), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(gp + 1024), (lptr_t)(smem + KBOFF + wid * 2048 + 1024), 16, 0, 0);
   }
+  float4 r[32];
+  float rstd;
   {
     const float* xr = a.x + (tok0 + min(l15, max(nq - 1, 0))) * CFD_D + q4 * 8;
-    float4 r[32];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       r[2 * c] = *reinterpret_cast<const float4*>(xr + 32 * c);
@@ -232,13 +239,19 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       r[i].x -= mean; r[i].y -= mean; r[i].z -= mean; r[i].w -= mean;
       ss += (r[i].x * r[i].x + r[i].y * r[i].y) + (r[i].z * r[i].z + r[i].w * r[i].w);
     }
-    const float rstd = 1.0f / sqrtf(xlane_sum(ss) * (1.0f / CFD_D) + 1e-5f);
+    rstd = 1.0f / sqrtf(xlane_sum(ss) * (1.0f / CFD_D) + 1e-5f);
+  }
+  XA_WAIT_VM_LGKM0(0);            // row loads consumed; A b, norm2's parameters landed
+  __builtin_amdgcn_s_barrier();   // ... and visible, with the segment list
+  {
+    const float* lng = reinterpret_cast<const float*>(smem + KBOFF + CFD_NMEM * 2048);
+    const float* lnb = reinterpret_cast<const float*>(smem + KBOFF + (CFD_NMEM + 1) * 2048);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const int c = 8 * half + ks;          // (half is wave-uniform: the two candidates are selected, not indexed)
       const float4 v0 = half ? r[2 * (8 + ks)] : r[2 * ks], v1 = half ? r[2 * (8 + ks) + 1] : r[2 * ks + 1];
-      const float* gp = a.ln_g + 32 * c + q4 * 8;
-      const float* bp = a.ln_b + 32 * c + q4 * 8;
+      const float* gp = lng + 32 * c + q4 * 8;
+      const float* bp = lnb + 32 * c + q4 * 8;
       const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
       const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
       const float y[8] = {v0.x * rstd * g0.x + b0.x, v0.y * rstd * g0.y + b0.y, v0.z * rstd * g0.z + b0.z, v0.w * rstd * g0.w + b0.w,
@@ -252,8 +265,6 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       }
     }
   }
-  XA_WAIT_VM_LGKM0(0);            // row loads consumed, A b landed
-  __builtin_amdgcn_s_barrier();   // A b and the segment list visible
   // this wave's half of c_q = q . (A b) for every memory, from the fragments (q = hi + lo); kept in LDS, read back by this wave only
   {
     float qf[8][8];
