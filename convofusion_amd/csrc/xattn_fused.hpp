@@ -660,7 +660,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
 #if XA_STAMP
   {
     const long long t_ = __builtin_amdgcn_s_memtime();
-    acc_[0] += t_ - tprev_;   // epilogue goes with the prologue
+    acc_[6] += t_ - tprev_;   // the final flush
     if (a.stamps && lane == 0)
       for (int k = 0; k < XA_NSTAMP; ++k) a.stamps[((long long)blockIdx.x * XA_WAVES + wid) * XA_NSTAMP + k] = acc_[k];
   }

@@ -24,7 +24,7 @@ nwg, W, NS = 744, 8, 12
 buf = torch.zeros(nwg * W * NS * 2, dtype=torch.float32, device=dev)
 _lib.check(_lib.load().cfd_debug_read(model._handle, b"xa_stamps", C.c_void_p(buf.data_ptr()), buf.numel()))
 st = buf.cpu().numpy().view(np.int64).reshape(nwg, W, NS).astype(np.float64)
-names = ["prologue+epilogue", "A0a compute", "wait+barrier mid-A0", "A0b+A1 compute", "wait+barrier end-A1", "B0a compute", "(unused)",
+names = ["prologue + pipeline priming", "A0a compute", "wait+barrier mid-A0", "A0b+A1 compute", "wait+barrier end-A1", "B0a compute", "final flush",
          "B0b + B1a compute", "wait+barrier mid-B1", "B1b + loop tail", "fills + softmax", "segment setup"]
 tot = st.sum(-1)
 print("xattn class ms:", prof["xattn"], " per-wave total cycles: mean %.0f  min %.0f  max %.0f" % (tot.mean(), tot.min(), tot.max()))
