@@ -81,7 +81,7 @@ __device__ __forceinline__ void rt_ln_bwd_row(float (&dy)[4][4], float (&xv)[4][
       float d = dy[i][e];
       if constexpr (TB) {                                 // through SiLU and the modulation: h = LN(x) (1 + scale) + shift
         const float h = (xv[i][e] * gam[i][e] + bet[i][e]) * s1[i][e] + sh[i][e];
-        const float sg = 1.0f / (1.0f + expf(-h));
+        const float sg = rt_rcp(1.0f + __expf(-h));   // (the forward's rt_silu: one Newton step on v_rcp, v_exp)
         d *= (sg * (1.0f + h * (1.0f - sg))) * s1[i][e];
       }
       d *= gam[i][e];
@@ -624,7 +624,7 @@ __global__ void __launch_bounds__(256) rt_selfattn_bwd_kernel(const RtSelfBwdArg
     float* dr = dS + min(q, L - 1) * (RT_MAX_L + 1);
     const float s0 = ok0 ? pr[k0] : -INFINITY, s1 = ok1 ? pr[k1] : -INFINITY;
     const float mx = rt_row_max<16>(fmaxf(s0, s1));
-    const float e0 = ok0 ? expf(s0 - mx) : 0.f, e1 = ok1 ? expf(s1 - mx) : 0.f;
+    const float e0 = ok0 ? __expf(s0 - mx) : 0.f, e1 = ok1 ? __expf(s1 - mx) : 0.f;   // (as rt_selfattn_kernel)
     const float sum = rt_row_sum<16>(e0 + e1);
     const float p0 = e0 / sum, p1 = e1 / sum;
     const float d0 = ok0 ? dr[k0] : 0.f, d1 = ok1 ? dr[k1] : 0.f;
