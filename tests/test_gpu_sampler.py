@@ -627,6 +627,36 @@ def test_row_tile_path_agrees_with_the_tile_kernels_on_random_shapes():
     print("worst", worst)
 
 
+def test_tile_kernel_forms_agree_on_random_shapes():
+    """Random shapes beyond the row-tile path (more than 800 token rows or L > 32) through the two forms of the tile-kernel forward --
+    fused cross-attention (with layer-0 de-duplication off: a plain forward has no guidance structure; the one-key memory as a vector)
+    and the three-launch cross-attention (CFD_FUSED_XATTN=0) -- including odd tile counts, ragged last tiles, memories of 1 .. 1600 keys
+    with padded tails and batches whose rows share memory instances through a row map."""
+    import torch
+    from tests.gpu_helpers import hip_denoiser, to_dev
+    rng = np.random.Generator(np.random.PCG64(4242))
+    m_fused = _handle_with_env({})                       # (handles of their own: return_attention is switched off below --
+    m_three = _handle_with_env({"CFD_FUSED_XATTN": "0"})  #  with attention maps wanted every forward takes the three-launch form)
+    m_fused.return_attention = m_three.return_attention = False
+    for case in range(8):
+        L = int(rng.choice([34, 48, 64, 100, 130, 196]))
+        lo = max(1, 820 // L + 1)                         # (past the row-tile path's 800 token rows, or L > 32 anyway)
+        Be = int(rng.integers(lo, lo + 10))
+        S = (int(rng.integers(1, 40)), int(rng.integers(33, 1600)), int(rng.integers(1, 40)), int(rng.integers(1, 12)), 1)
+        pad = tuple(int(rng.integers(0, max(1, s // 3))) if rng.random() < 0.5 else 0 for s in S[:4]) + (0,)
+        t = int(rng.integers(0, 1000))
+        inp = inputs.make_plain_batch(seed=300 + case, Be=Be, L=L, S=S, pad_tail=pad, scale=float(rng.choice([0.5, 1.0, 2.0])))
+        mems = [to_dev(x) for x in inp["memories"]]
+        masks = {k: to_dev(v) for k, v in inp["masks"].items()}
+        x = to_dev(inp["sample"])
+        with torch.no_grad():
+            a, _ = m_fused(x, torch.tensor(t), mems, mem_mask_dict=masks)
+            b, _ = m_three(x, torch.tensor(t), mems, mem_mask_dict=masks)
+        e = float((a - b).norm() / b.norm())
+        print(f"case {case}: Be={Be} L={L} S={S} pad={pad} t={t}: fused vs three-launch {e:.2e}")
+        assert torch.isfinite(a).all() and e < 1e-4
+
+
 def test_static_and_dynamic_memory_declarations_agree_and_mean_what_they_say():
     """cfd_sample_args.dynamic_memory_mask.  Memories are constants of a reference sampling run (convofusion.py:391-549), so by
     default the library projects the timestep-independent part of every memory once at cfd_sample_begin and never reads the
