@@ -17,12 +17,21 @@ __global__ void __launch_bounds__(256) rate_kernel(float* out, long long* cyc, i
   for (int e = 0; e < 8; ++e) { a8[e] = (_Float16)(0.001f * (threadIdx.x + e)); b8[e] = (_Float16)(0.002f * (threadIdx.x - e)); }
   for (int e = 0; e < 4; ++e) { a4[e] = a8[e]; b4[e] = b8[e]; }
   const long long t0 = __builtin_amdgcn_s_memtime();
+  // (inline assembly on fixed accumulators: written with the builtin, hipcc rotates the eight accumulators through the AGPR file between
+  //  iterations -- ~50 v_accvgpr moves per 8 MFMAs -- and the loop measures those)
   for (int i = 0; i < iters; ++i) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (KIND == 0) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, acc[k], 0, 0, 0);
-      else acc[k] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc[k], 0, 0, 0);
-    }
+    if (KIND == 0)
+      asm volatile("v_mfma_f32_16x16x32_f16 %0, %8, %9, %0\n v_mfma_f32_16x16x32_f16 %1, %8, %9, %1\n v_mfma_f32_16x16x32_f16 %2, %8, %9, %2\n"
+                   "v_mfma_f32_16x16x32_f16 %3, %8, %9, %3\n v_mfma_f32_16x16x32_f16 %4, %8, %9, %4\n v_mfma_f32_16x16x32_f16 %5, %8, %9, %5\n"
+                   "v_mfma_f32_16x16x32_f16 %6, %8, %9, %6\n v_mfma_f32_16x16x32_f16 %7, %8, %9, %7\n"
+                   : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                   : "v"(a8), "v"(b8));
+    else
+      asm volatile("v_mfma_f32_16x16x16_f16 %0, %8, %9, %0\n v_mfma_f32_16x16x16_f16 %1, %8, %9, %1\n v_mfma_f32_16x16x16_f16 %2, %8, %9, %2\n"
+                   "v_mfma_f32_16x16x16_f16 %3, %8, %9, %3\n v_mfma_f32_16x16x16_f16 %4, %8, %9, %4\n v_mfma_f32_16x16x16_f16 %5, %8, %9, %5\n"
+                   "v_mfma_f32_16x16x16_f16 %6, %8, %9, %6\n v_mfma_f32_16x16x16_f16 %7, %8, %9, %7\n"
+                   : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+                   : "v"(a4), "v"(b4));
   }
   asm volatile("s_nop 15\ns_nop 15" ::: "memory");
   const long long t1 = __builtin_amdgcn_s_memtime();
