@@ -1719,7 +1719,7 @@ static int enqueue_loop_iteration(Ctx* c, hipStream_t st) {
   ca.noise = s.step_noise; ca.seed = s.seed; ca.utt0 = s.first_utterance;
   const long long n4 = (long long)s.B * s.L * CFD_LAT / 4;
   ca.advance = c->w->d_step.as<int>();   // the last workgroup of cfg_step_kernel advances the loop index
-  LAUNCH(CFD_PROF_OTHER, cfg_step_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), st, ca);
+  LAUNCH(CFD_PROF_OTHER, cfg_step_kernel, dim3((unsigned)std::min<long long>((n4 + 255) / 256, 256)), dim3(256), st, ca);
   return CFD_OK;
 }
 

@@ -608,19 +608,20 @@ struct CfgStepArgs {
 };
 
 __global__ void cfg_step_kernel(const CfgStepArgs a) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one thread = 4 elements
   const int per_utt = a.L * CFD_LAT;
   const long long n4 = (long long)a.B * per_utt / 4;
   const int i = *a.d_step;
-  if (idx < n4) {
+  // grid-stride over groups of 4 elements: the launch has at most one workgroup per CU, because every workgroup ends with a fence and
+  // a ticket (one workgroup per 256 groups was 784 of them at the benchmark shape: most of the kernel's 28 us)
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long long)gridDim.x * blockDim.x) {
   const StepCoef c = a.coef[i];
   const long long e0 = idx * 4;
   const long long chunk = (long long)a.B * per_utt;
-  // every chunk's prediction is requested before the first is used (chunks past G re-read the last one and are ignored): in a loop
+  // every chunk's prediction is requested before the first is used (chunks past G re-read chunk 0 and are ignored): in a loop
   // of run-time length each load sat next to its use and the G round trips ran one after the other -- 28 us at the benchmark shape
   float4 e4[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) e4[k] = *reinterpret_cast<const float4*>(a.eps + a.pos[min(k, a.G - 1)] * chunk + e0);
+  for (int k = 0; k < 8; ++k) e4[k] = *reinterpret_cast<const float4*>(a.eps + (k < a.G ? a.pos[k] : a.pos[0]) * chunk + e0);   // (a select of two argument fields: indexed, pos[] is a dependent scalar load per chunk)
   float4 x4 = *reinterpret_cast<const float4*>(a.latents + e0);
   const float u[4] = {e4[0].x, e4[0].y, e4[0].z, e4[0].w};
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
