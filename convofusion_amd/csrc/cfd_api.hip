@@ -168,6 +168,12 @@ struct cfd_handle_s {
   // row-tile WEG evaluation, which runs between two replays of an open run and must not disturb it; `w` is the one in use
   Work wk[2];
   Work* w = &wk[0];
+  // saturation census of THIS handle (cfd_common.hpp): sat[CFD_SAT_MEM] weights / memories / their projections, sat[CFD_SAT_IN] the
+  // sample / latents handed to an entry point.  Zeroed at the entry of the calls that count, read at their end.
+  DBuf sat;
+  bool memside_in_forward = false;   // the last enqueue_denoise ran memory-side projections itself (not hoisted): census still open
+  unsigned int* sat_mem() const { return sat.as<unsigned int>() + CFD_SAT_MEM; }
+  unsigned int* sat_in() const { return sat.as<unsigned int>() + CFD_SAT_IN; }
   bool hoist_memside = true;
   bool use_runs = true;   // CFD_RUNS=0 disables the shared-memory run optimisation of the three-launch attention path
   // The cross-attention block is one fused kernel (xattn_fused.hpp) unless the caller wants att_mats, which only the
@@ -232,14 +238,22 @@ struct cfd_handle_s {
 };
 typedef cfd_handle_s Ctx;
 
-// Saturation census (cfd_common.hpp): reads and clears the device counter.  Called where the stream is waited for anyway.
-static int check_saturation(const char* what) {
-  unsigned int n = 0, zero = 0;
-  HIPCHK(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_cfd_sat), sizeof(n)));
-  if (n == 0) return CFD_OK;
-  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_cfd_sat), &zero, sizeof(zero)));
-  return fail(CFD_E_RANGE, "%s: %u groups of values exceed +-65504, the range of the fp16 split-pair operands (weights, centred memories and their "
-                           "folded key / value projections must stay inside it); rescale the conditioning input", what, n);
+// Saturation census (cfd_common.hpp) of this handle.  sat_begin zeroes the two counters in stream order at the entry of a call that
+// counts; check_saturation reads them (the caller has waited for the stream) and clears them, so an error is reported by the call
+// whose launches counted it and never leaks into the next call or another handle.
+static int sat_begin(Ctx* c, hipStream_t st) {
+  HIPCHK(hipMemsetAsync(c->sat.p, 0, 8, st));
+  return CFD_OK;
+}
+static int check_saturation(Ctx* c, const char* what) {
+  unsigned int n[2] = {0, 0};
+  HIPCHK(hipMemcpy(n, c->sat.p, 8, hipMemcpyDeviceToHost));
+  if (n[0] == 0 && n[1] == 0) return CFD_OK;
+  HIPCHK(hipMemset(c->sat.p, 0, 8));
+  if (n[CFD_SAT_MEM])
+    return fail(CFD_E_RANGE, "%s: %u groups of values exceed +-65504, the range of the fp16 split-pair operands (weights, centred memories and their "
+                             "folded key / value projections must stay inside it); rescale the conditioning input", what, n[CFD_SAT_MEM]);
+  return fail(CFD_E_RANGE, "%s: %u groups of values of the sample / latents exceed +-65504, the range of the fp16 split-pair operands", what, n[CFD_SAT_IN]);
 }
 
 static const float* rawp(Ctx* c, const std::string& name) {
@@ -350,6 +364,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
     if (wk.d_step.ensure(16) != CFD_OK) { delete c; return CFD_E_HIP; }
     if (hipMemset(wk.d_step.p, 0, 16) != hipSuccess) { delete c; return fail(CFD_E_HIP, "memset"); }
   }
+  if (c->sat.ensure(8) != CFD_OK) { delete c; return CFD_E_HIP; }
+  if (hipMemset(c->sat.p, 0, 8) != hipSuccess) { delete c; return fail(CFD_E_HIP, "memset"); }
   (void)hipEventCreate(&c->pev[0]);
   (void)hipEventCreate(&c->pev[1]);
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(CFD_E_HIP, "stream create"); }
@@ -370,6 +386,7 @@ extern "C" void cfd_destroy(cfd_handle c) {
   if (c->weg_ev) (void)hipEventDestroy(c->weg_ev);
   c->weg_io.release();
   c->weg_rt_ws.release();
+  c->sat.release();
   for (auto& kv : c->raw) kv.second.release();
   DBuf* all[] = {&c->we_sp, &c->wp_sp, &c->we_all, &c->be_all, &c->tsin, &c->weg_ws, &c->weg_tok, &c->latents, &c->coef, &c->inoise};
   for (DBuf* b : all) b->release();
@@ -416,7 +433,7 @@ static int to_sp(Ctx* c, const float* src, long long R, int K, DBuf& dst, long l
   if (dst_rows > R) HIPCHK(hipMemset(dst.p, 0, (size_t)dst_rows * K * 4));
   const long long n = R * (K / 8);
   hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, src, dst.as<char>(), R, K,
-                     (long long)K, (long long)K * 4);
+                     (long long)K, (long long)K * 4, c->sat_mem());
   HIPCHK(hipGetLastError());
   return CFD_OK;
 }
@@ -448,6 +465,7 @@ extern "C" int cfd_finalize_weights(cfd_handle c) {
   HIPCHK(hipSetDevice(c->cfg.device));
   const int D = CFD_D, nl = c->nl;
   const float *t0, *t1;
+  CHK(sat_begin(c, 0));
   // embed / projection / tables
   CHK(need(c, "latent_embd.weight", (size_t)D * CFD_LAT, &t0));
   CHK(to_sp(c, t0, D, CFD_LAT, c->we_sp));
@@ -579,7 +597,7 @@ extern "C" int cfd_finalize_weights(cfd_handle c) {
     CHK(to_sp(c, wv_f[j].as<float>(), kfeat, D, c->wv_all_sp[j]));
   }
   HIPCHK(hipDeviceSynchronize());
-  CHK(check_saturation("cfd_finalize_weights (a weight or a folded weight product)"));
+  CHK(check_saturation(c, "cfd_finalize_weights (a weight or a folded weight product)"));
   for (int j = 0; j < CFD_NMEM; ++j) { wk_f[j].release(); wv_f[j].release(); }
   tmpf.release(); tmpd1.release(); tmpd2.release(); vd1.release(); vd2.release(); accd.release();
   c->finalized = true;
@@ -1036,14 +1054,14 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
     CHK(c->w->kbtab[j].ensure((size_t)T * NK * 4));
     CHK(c->w->vbtab[j].ensure((size_t)T * nl * CFD_D * 4));
     MemCenterArgs ma{p.mem[j], p.U[j], p.S[j], p.Sp[j], rawp(c, "condition_embedding.weight") + (size_t)j * CFD_D, rawp(c, "mem_pos.pe"),
-                     c->w->n_sp[j].as<char>(), c->w->asq[j].as<float>()};
+                     c->w->n_sp[j].as<char>(), c->w->asq[j].as<float>(), c->sat_mem()};
     LAUNCH(CFD_PROF_ROWS, mem_center_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), st, ma);
     {  // KA = A a_s for all layers, ca = c_l . a_s (-inf on dead keys)
       GemmArgs a = gemm_args();
       a.X[0] = c->wk_all_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = NK; a.Iclamp[0] = NK; a.kt[0] = CFD_D / 32;
       a.Y = c->w->n_sp[j].as<char>(); a.ldy = ROWB; a.J = rows; a.Jclamp = rows;
       a.super_i = 8; a.super_j = 8;
-      EpiMemK e{c->w->kall_sp[j].as<char>(), (long long)rows, c->w->ca[j].as<float>(), nl * CFD_D, nl, p.mask[j], p.S[j], p.Sp[j]};
+      EpiMemK e{c->w->kall_sp[j].as<char>(), (long long)rows, c->w->ca[j].as<float>(), nl * CFD_D, nl, p.mask[j], p.S[j], p.Sp[j], c->sat_mem()};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }
     {  // VA^T
@@ -1051,7 +1069,7 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
       a.X[0] = c->w->n_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = rows; a.Iclamp[0] = rows; a.kt[0] = CFD_D / 32;
       a.Y = c->wv_all_sp[j].as<char>(); a.ldy = ROWB; a.J = nl * CFD_D; a.Jclamp = nl * CFD_D;
       a.super_i = 8; a.super_j = 8;
-      EpiMemV e{c->w->vt_all[j].as<char>(), p.Sp[j], p.U[j]};
+      EpiMemV e{c->w->vt_all[j].as<char>(), p.Sp[j], p.U[j], c->sat_mem()};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }
     {  // kbtab[t][:] = [A_l b_t for all l | c_l . b_t]
@@ -1135,12 +1153,13 @@ static int enqueue_memside(Ctx* c, hipStream_t st) {
   for (int j = 0; j < CFD_NMEM; ++j) {
     if ((p.static_mask >> j) & 1) continue;
     const int rows = p.U[j] * p.Sp[j];
+    c->memside_in_forward = true;   // these epilogues count into the handle's census: whoever waits for this stream next reads it
     {
       GemmArgs a = gemm_args();
       a.X[0] = c->wk_all_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = nl * CFD_D + 32; a.Iclamp[0] = nl * CFD_D + 32; a.kt[0] = CFD_D / 32;
       a.Y = c->w->n_sp[j].as<char>(); a.ldy = ROWB; a.J = rows; a.Jclamp = rows;
       a.super_i = 8; a.super_j = 8;
-      EpiMemK e{c->w->kall_sp[j].as<char>(), (long long)rows, c->w->cb[j].as<float>(), nl * CFD_D, nl, p.mask[j], p.S[j], p.Sp[j]};
+      EpiMemK e{c->w->kall_sp[j].as<char>(), (long long)rows, c->w->cb[j].as<float>(), nl * CFD_D, nl, p.mask[j], p.S[j], p.Sp[j], c->sat_mem()};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }
     {
@@ -1148,7 +1167,7 @@ static int enqueue_memside(Ctx* c, hipStream_t st) {
       a.X[0] = c->w->n_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = rows; a.Iclamp[0] = rows; a.kt[0] = CFD_D / 32;
       a.Y = c->wv_all_sp[j].as<char>(); a.ldy = ROWB; a.J = nl * CFD_D; a.Jclamp = nl * CFD_D;
       a.super_i = 8; a.super_j = 8;
-      EpiMemV e{c->w->vt_all[j].as<char>(), p.Sp[j], p.U[j]};
+      EpiMemV e{c->w->vt_all[j].as<char>(), p.Sp[j], p.U[j], c->sat_mem()};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }
   }
@@ -1633,23 +1652,34 @@ extern "C" int cfd_forward(cfd_handle c, const float* sample, int Be, int L, con
   hipStream_t st = (hipStream_t)stream;
   const int tmode = (n_t == 1) ? 0 : 1;
   CHK(setup_problem(c, Be, L, mem, att, tmode, n_t));
+  CHK(sat_begin(c, st));
   // tmode 0 reads table row d_step[0] which must be 0 outside a sampling run
   HIPCHK(hipMemsetAsync(c->w->d_step.p, 0, 16, st));
   CHK(build_time_tables(c, timesteps, n_t, st));
+  // (the sample is split in front of the once-per-call projections, so that ONE wait reads the census of both)
+  const long long n = c->w->pb.M * (CFD_LAT / 8);
+  LAUNCH(CFD_PROF_OTHER, to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), st, sample, c->w->sample_sp.as<char>(), c->w->pb.M,
+         CFD_LAT, (long long)CFD_LAT, (long long)CFD_LAT * 4, c->sat_in());
   {
     bool want_att = false;
     for (int j = 0; j < CFD_NMEM; ++j) want_att = want_att || (att && att[j]);
     CHK(prepare_static_memside(c, st, 0, want_att));
     if (c->w->pb.static_mask) {   // once-per-call projections of the caller's memories: the census is read before they are used
       HIPCHK(hipStreamSynchronize(st));
-      CHK(check_saturation("cfd_forward (memories / their projections)"));
+      CHK(check_saturation(c, "cfd_forward (sample, memories / their projections)"));
     }
   }
-  const long long n = c->w->pb.M * (CFD_LAT / 8);
-  LAUNCH(CFD_PROF_OTHER, to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), st, sample, c->w->sample_sp.as<char>(), c->w->pb.M,
-         CFD_LAT, (long long)CFD_LAT, (long long)CFD_LAT * 4);
+  c->memside_in_forward = false;
   CHK(enqueue_denoise(c, st));
   HIPCHK(hipMemcpyAsync(out, c->w->eps.p, (size_t)c->w->pb.M * CFD_LAT * 4, hipMemcpyDeviceToDevice, st));
+  if (c->memside_in_forward || !c->w->pb.static_mask) {
+    // Paths whose memory-side projections run INSIDE the forward (per-row timesteps, att_mats on the tile kernels, CFD_HOIST_MEMSIDE=0,
+    // the three-launch cross-attention): their census -- and the sample's, which no earlier wait has read on these paths -- is read here,
+    // so that a clamped projection fails THIS call instead of the next one (on these paths the call therefore returns with `out` complete).
+    HIPCHK(hipStreamSynchronize(st));
+    c->memside_in_forward = false;
+    CHK(check_saturation(c, "cfd_forward (sample, memories / their per-call projections)"));
+  }
   return CFD_OK;
 }
 
@@ -1814,7 +1844,7 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
   CHK(build_time_tables(c, ts.data(), N, st));
   CHK(prepare_static_memside(c, st, s.dynamic_memory_mask, false));
   HIPCHK(hipStreamSynchronize(st));  // ts / coef host vectors go out of scope
-  CHK(check_saturation("cfd_sample_begin (memories / their once-per-run projections)"));
+  CHK(check_saturation(c, "cfd_sample_begin (memories / their once-per-run projections)"));
   const size_t lat_bytes = (size_t)s.B * s.L * CFD_LAT * 4;
   CHK(c->latents.ensure(lat_bytes));
   if (s.init_latents) {
@@ -1936,8 +1966,10 @@ extern "C" int cfd_sample_read(cfd_handle c, float* out, int close) {
   const size_t lat_bytes = (size_t)c->sargs.B * c->sargs.L * CFD_LAT * 4;
   HIPCHK(hipMemcpyAsync(out, c->latents.p, lat_bytes, hipMemcpyDeviceToDevice, c->run_stream));
   HIPCHK(hipStreamSynchronize(c->run_stream));
+  // the census of everything the run's iterations counted (per-step projections of a dynamic memory, CFD_HOIST_MEMSIDE=0): read on
+  // every read, BEFORE the run is closed -- a run that fails here stays open and can be inspected or closed by the caller
+  CHK(check_saturation(c, "sampling run (the per-step projections of a memory)"));
   if (close) c->run_open = false;
-  if (c->sargs.dynamic_memory_mask) CHK(check_saturation("sampling run (the per-step projections of a dynamic memory)"));
   return CFD_OK;
 }
 
@@ -2181,6 +2213,7 @@ extern "C" int cfd_weg_eval(cfd_handle c, const cfd_weg_args* a, float* losses, 
   for (int j = 0; j < CFD_NMEM; ++j) {
     sig.push_back(a->mem[j].S);
     sig.push_back((long long)(size_t)a->mem[j].data);
+    sig.push_back((long long)(size_t)a->mem[j].key_padding_mask);   // (wegrt::prepare rebuilds the problem when a mask pointer changes: no reuse then)
   }
   weg::Ctx x{c, st, true, reinterpret_cast<char*>(256), 0, B, L, D, D, CFD_OK, std::string(), 0};
   // small problems (the product shape) run on the row-tile kernels, everything else on the float32 launch sequence of weg_eval.hpp
@@ -2269,6 +2302,7 @@ extern "C" int cfd_weg_eval(cfd_handle c, const cfd_weg_args* a, float* losses, 
     std::vector<float> l(B);
     HIPCHK(hipMemcpyAsync(l.data(), io + o_loss, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    CHK(check_saturation(c, "cfd_weg_eval (latents, memories / their projections)"));   // (without loss_host: read by the next call that waits on this handle)
     float sum = 0.f;
     for (int b = 0; b < B; ++b) sum += l[b];
     *loss_host = sum / (float)B;
@@ -2314,10 +2348,10 @@ extern "C" int cfd_debug_read(cfd_handle c, const char* what, float* dst_dev, si
   if (!c || !what || !dst_dev) return fail(CFD_E_ARG, "null argument");
   HIPCHK(hipSetDevice(c->cfg.device));
   if (!strcmp(what, "sat")) {   // the saturation census as one float (not cleared)
-    unsigned int n = 0;
+    unsigned int n[2] = {0, 0};
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_cfd_sat), sizeof(n)));
-    const float f = (float)n;
+    HIPCHK(hipMemcpy(n, c->sat.p, 8, hipMemcpyDeviceToHost));
+    const float f = (float)n[0] + (float)n[1];
     HIPCHK(hipMemcpy(dst_dev, &f, 4, hipMemcpyHostToDevice));
     return CFD_OK;
   }
@@ -2355,10 +2389,10 @@ extern "C" int cfd_test_gemm(cfd_handle c, const float* X, const float* Y, float
   CHK(ys.ensure((size_t)J * K * 4));
   long long n = (long long)I * (K / 8);
   hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, xs.as<char>(), (long long)I, K, (long long)K,
-                     (long long)K * 4);
+                     (long long)K * 4, (unsigned int*)nullptr);
   n = (long long)J * (K / 8);
   hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Y, ys.as<char>(), (long long)J, K, (long long)K,
-                     (long long)K * 4);
+                     (long long)K * 4, (unsigned int*)nullptr);
   GemmArgs a = gemm_args();
   a.X[0] = xs.as<char>(); a.ldx[0] = (long long)K * 4; a.I[0] = I; a.Iclamp[0] = I; a.kt[0] = K / 32;
   a.Y = ys.as<char>(); a.ldy = (long long)K * 4; a.J = J; a.Jclamp = J;
@@ -2394,9 +2428,9 @@ extern "C" int cfd_bench_gemm(cfd_handle c, int I, int J, int K, int tile_cfg, i
     HIPCHK(hipMemset(yf.p, 0, (size_t)J * K * 4));
   }
   n = (long long)I * (K / 8);
-  hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, xf.as<float>(), xs.as<char>(), (long long)I, K, (long long)K, (long long)K * 4);
+  hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, xf.as<float>(), xs.as<char>(), (long long)I, K, (long long)K, (long long)K * 4, (unsigned int*)nullptr);
   n = (long long)J * (K / 8);
-  hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, yf.as<float>(), ys.as<char>(), (long long)J, K, (long long)K, (long long)K * 4);
+  hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, yf.as<float>(), ys.as<char>(), (long long)J, K, (long long)K, (long long)K * 4, (unsigned int*)nullptr);
   GemmArgs a = gemm_args();
   a.X[0] = xs.as<char>(); a.ldx[0] = (long long)K * 4; a.I[0] = I; a.Iclamp[0] = I; a.kt[0] = K / 32;
   a.Y = ys.as<char>(); a.ldy = (long long)K * 4; a.J = J; a.Jclamp = J;

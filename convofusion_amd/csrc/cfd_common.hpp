@@ -51,16 +51,19 @@ __device__ __forceinline__ void split_f32(float v, sp_t& hi, sp_t& lo) {
 
 // Saturation census.  split_f32 clamps to +-65504 without telling anybody.  Operands made inside the network (LayerNorm outputs,
 // probabilities, GELU / SiLU outputs) are bounded by construction; operands whose magnitude follows the CALLER's data -- the
-// weights, the centred memories a_s and the folded projections KA = A a_s, VA = VV a_s of them -- are
-// counted here when one of them leaves the range, and the entry points refuse to go on (cfd_api.hip: check_saturation):
-// a clamped key or value is a silently wrong attention.  One compare per element; the atomic only fires on a fault.
-__device__ unsigned int g_cfd_sat;
+// weights, the centred memories a_s and the folded projections KA = A a_s, VA = VV a_s of them, and the
+// sample / latents handed to an entry point -- are counted when one of them leaves the range, and the entry points refuse to go
+// on (cfd_api.hip: check_saturation): a clamped key or value is a silently wrong attention.  The counters belong to the HANDLE
+// (cfd_handle_s::sat, two words: [CFD_SAT_MEM] weights / memories / their projections, [CFD_SAT_IN] sample / latents) and reach
+// the kernels through their arguments: a call reads what ITS launches counted, never another handle's or an earlier call's.
+// One compare per element; the atomic only fires on a fault.  sat == nullptr: not counted (micro-benchmarks).
+enum { CFD_SAT_MEM = 0, CFD_SAT_IN = 1 };
 template <int N>
-__device__ __forceinline__ void sat_note(const float* v) {
+__device__ __forceinline__ void sat_note(unsigned int* sat, const float* v) {
   bool s = false;
 #pragma unroll
   for (int e = 0; e < N; ++e) s = s || !(fabsf(v[e]) <= 65504.0f);   // (NaN counts)
-  if (s) atomicAdd(&g_cfd_sat, 1u);
+  if (s && sat) atomicAdd(sat, 1u);
 }
 
 // store 4 consecutive-column values (col % 4 == 0) of one row into an SP matrix

@@ -221,13 +221,14 @@ struct EpiMemK {  // i < nfeat: K_layer[i/512][j][i%512] = split(v)  (one contig
   // then needs no mask loads, and the three-launch path's softmax masks them (again) anyway
   const uint8_t* mask;   // [U][S] (1 = padded key); never null
   int S, Sp;
+  unsigned int* sat;     // the handle's saturation census (cfd_common.hpp), or null
   static constexpr bool kPrefetch = false;
   static constexpr bool kStore8 = true;
   __device__ __forceinline__ void store8(int g, int b, int z, int i, int j, f32x4 v0, f32x4 v1) const {
     if (i + 8 <= nfeat) {   // (nfeat is a multiple of 512: 8 consecutive features never straddle a layer)
       const int layer = i >> 9, o = i & (CFD_D - 1);
       const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      sat_note<8>(v);
+      sat_note<8>(sat, v);
       sp_store8(kall + ((long long)layer * rows + j) * (CFD_D * 4), o, v);
     } else {
       (*this)(g, b, z, i, j, v0);
@@ -238,7 +239,7 @@ struct EpiMemK {  // i < nfeat: K_layer[i/512][j][i%512] = split(v)  (one contig
     if (i < nfeat) {
       const int layer = i >> 9, o = i & (CFD_D - 1);
       const float vv[4] = {v[0], v[1], v[2], v[3]};
-      sat_note<4>(vv);
+      sat_note<4>(sat, vv);
       sp_store4(kall + ((long long)layer * rows + j) * (CFD_D * 4), o, v[0], v[1], v[2], v[3]);
     } else {
       const int u = j / Sp, sk = j - u * Sp;
@@ -253,20 +254,21 @@ struct EpiMemK {  // i < nfeat: K_layer[i/512][j][i%512] = split(v)  (one contig
 struct EpiMemV {  // V^T_layer_u[j/512][i/Sp][j%512][i%Sp] = split(v): one contiguous [512][Sp] SP block per (layer, memory)
   char* vt;
   int Sp, U;
+  unsigned int* sat;     // the handle's saturation census, or null
   static constexpr bool kPrefetch = false;
   static constexpr bool kStore8 = true;
   __device__ __forceinline__ void store8(int g, int b, int z, int i, int j, f32x4 v0, f32x4 v1) const {
     const int layer = j >> 9, f = j & (CFD_D - 1);
     const int u = i / Sp, s = i - u * Sp;   // (Sp is a multiple of 32: 8 consecutive rows belong to one memory)
     const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-    sat_note<8>(v);
+    sat_note<8>(sat, v);
     sp_store8(vt + (((long long)layer * U + u) * CFD_D + f) * ((long long)Sp * 4), s, v);
   }
   __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
     const int layer = j >> 9, f = j & (CFD_D - 1);
     const int u = i / Sp, s = i - u * Sp;
     const float vv[4] = {v[0], v[1], v[2], v[3]};
-    sat_note<4>(vv);
+    sat_note<4>(sat, vv);
     sp_store4(vt + (((long long)layer * U + u) * CFD_D + f) * ((long long)Sp * 4), s, v[0], v[1], v[2], v[3]);
   }
 };

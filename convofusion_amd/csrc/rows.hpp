@@ -126,6 +126,7 @@ struct MemCenterArgs {
   const float* pe;    // [>=S][512]
   char* a_sp;         // SP [U*Sp][512]
   float* asq;         // [U*Sp]
+  unsigned int* sat;  // the handle's saturation census (cfd_common.hpp), or null
 };
 
 __global__ void __launch_bounds__(256) mem_center_kernel(const MemCenterArgs a) {
@@ -153,7 +154,7 @@ __global__ void __launch_bounds__(256) mem_center_kernel(const MemCenterArgs a) 
     for (int e = 0; e < 8; ++e) { v[e] -= mean; ss += v[e] * v[e]; }
     ss = wave_sum(ss);
   }
-  sat_note<8>(v);
+  sat_note<8>(a.sat, v);
   sp_store8(a.a_sp + row * (CFD_D * 4), lane * 8, v);
   if (lane == 0) a.asq[row] = ss;
 }
@@ -415,7 +416,7 @@ __global__ void attn_alpha_kernel(const float2* stats, float* alpha, long long r
 // ------------------------------------------------------------------------------------------------
 // fp32 [R][K] -> SP [R][K]   (K % 8 == 0); used for weights at load time
 // ------------------------------------------------------------------------------------------------
-__global__ void to_split_kernel(const float* in, char* out, long long R, int K, long long ld_in, long long ld_out_bytes) {
+__global__ void to_split_kernel(const float* in, char* out, long long R, int K, long long ld_in, long long ld_out_bytes, unsigned int* sat) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int kc = K / 8;
   if (idx >= R * kc) return;
@@ -424,7 +425,7 @@ __global__ void to_split_kernel(const float* in, char* out, long long R, int K, 
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = in[r * ld_in + c + e];
-  sat_note<8>(v);
+  sat_note<8>(sat, v);
   sp_store8(out + r * ld_out_bytes, c, v);
 }
 

@@ -119,7 +119,7 @@ static int enqueue(Ctx* c, hipStream_t st, bool full, const EvalArgs& e) {
   {
     const long long n = M * (CFD_LAT / 8);
     hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, e.latents, w->sample_sp.as<char>(), M, CFD_LAT,
-                       (long long)CFD_LAT, (long long)CFD_LAT * 4);
+                       (long long)CFD_LAT, (long long)CFD_LAT * 4, c->sat_in());
     HIPCHK(hipGetLastError());
   }
   CHK(enqueue_rows_rt(c, st, &s.sv));

@@ -233,3 +233,29 @@ def test_out_of_range_memories_are_refused_not_clamped():
     with torch.no_grad():   # the handle is usable afterwards
         out2, _ = m(x, torch.tensor(t), mems, mem_mask_dict=masks)
     assert torch.equal(out, out2)
+    # Paths whose memory-side projections run INSIDE the forward (per-row timesteps; attention maps wanted) count after the
+    # once-per-call check: the census belongs to the handle and is read at the end of the SAME call -- the call that clamped
+    # fails, the next call (this handle or another) does not inherit the count.
+    Be = inp["sample"].shape[0]
+    with pytest.raises(CfdError) as ei:
+        m(x, torch.full((Be,), t), hm, mem_mask_dict=masks)
+    assert ei.value.code == -5 and "memories" in str(ei.value)
+    keep = m.return_attention
+    try:
+        m.return_attention = True
+        with pytest.raises(CfdError) as ei:
+            m(x, torch.tensor(t), hm, mem_mask_dict=masks)
+        assert ei.value.code == -5
+    finally:
+        m.return_attention = keep
+    with torch.no_grad():
+        out3, _ = m(x, torch.full((Be,), t), mems, mem_mask_dict=masks)                  # same handle, per-row path: clean
+        out4, _ = m(x, torch.tensor(t), mems, mem_mask_dict=masks, side_engine=True)      # the other handle: clean
+    assert rel_l2(out3.cpu().numpy(), want) < FWD_TOL and rel_l2(out4.cpu().numpy(), want) < FWD_TOL
+    # a sample outside the range is named as such
+    with pytest.raises(CfdError) as ei:
+        m(x * 1e6, torch.tensor(t), mems, mem_mask_dict=masks)
+    assert ei.value.code == -5 and "sample" in str(ei.value)
+    with torch.no_grad():
+        out5, _ = m(x, torch.tensor(t), mems, mem_mask_dict=masks)
+    assert torch.equal(out, out5)

@@ -7,7 +7,7 @@ B=${1:-1}
 TAG=${2:-c1prof}
 mkdir -p gpurun_out
 rm -rf gpurun_out/$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG -o run -- python tools/c1_time.py $B 1 > gpurun_out/$TAG.log 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG -o run -- python tools/c1_time.py $B 1 > gpurun_out/$TAG.log 2>&1 || { rc=$?; echo "rocprofv3 run failed (rc $rc); log tail:" >&2; tail -20 gpurun_out/$TAG.log >&2; exit $rc; }
 tail -3 gpurun_out/$TAG.log
 python - "$TAG" <<'PY'
 import csv,glob,sys

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 TAG=${1:-wegprof}
 mkdir -p gpurun_out
 rm -rf gpurun_out/$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG -o run -- python tools/weg_time.py > gpurun_out/$TAG.log 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG -o run -- python tools/weg_time.py > gpurun_out/$TAG.log 2>&1 || { rc=$?; echo "rocprofv3 run failed (rc $rc); log tail:" >&2; tail -20 gpurun_out/$TAG.log >&2; exit $rc; }
 tail -2 gpurun_out/$TAG.log
 python - "$TAG" <<'PY'
 import csv,glob,sys,shutil
