@@ -38,11 +38,14 @@ def canonical_flops_per_step(Be, Lq, Ss, nl=NL):
     return 2.0 * macs_row * Be
 
 
-def executed_gemm_flops(Be, Lq, Ss, U, nl=NL, shared_rows=None):
+def executed_gemm_flops(Be, Lq, Ss, U, nl=NL, shared_rows=None, l0_pairs=None, one_key=True):
     """Algorithmic (single-product) FLOPs of the GEMMs the HIP pipeline actually launches, per class.
     Every product is issued as 3 f16 MFMAs, so MFMA-issued FLOPs are 3x these.  ``shared_rows``: rows that run the
     replica-independent head of the network (embedding, layer 0's self-attention and first time block) when the
-    batch is G replicas of them (cfd_api.hip Problem::share_B); the other rows do not launch those products."""
+    batch is G replicas of them (cfd_api.hip Problem::share_B); the other rows do not launch those products.
+    ``l0_pairs``: layer 0's attention against the audio memory is evaluated once per distinct (utterance, instance) pair
+    (cfd_api.hip build_xattn_layer0_lists; None: for every row).  ``one_key``: the one-key memory (lsnemb) has no tile
+    step in the fused kernel (XAttnArgs::one_j): its 32 padded keys are not multiplied at all."""
     M = Be * Lq
     M0 = (shared_rows if shared_rows else Be) * Lq
     B0 = shared_rows if shared_rows else Be
@@ -55,6 +58,10 @@ def executed_gemm_flops(Be, Lq, Ss, U, nl=NL, shared_rows=None):
     att = nl * 2.0 * Be * 4 * Lq * Lp * 128 * 2                           # self-attention (fused kernel), padded key axis
     att -= 2.0 * (Be - B0) * 4 * Lq * Lp * 128 * 2                        # layer 0's self-attention on the shared rows only
     xat = nl * sum(2.0 * Be * Lq * sp * 512 * 2 for sp in Sp)             # cross-attention: scores + P.V over the padded keys
+    if l0_pairs is not None:
+        xat -= 2.0 * (Be - l0_pairs) * Lq * Sp[1] * 512 * 2               # layer 0, audio memory: distinct pairs only
+    if one_key:
+        xat -= nl * sum(2.0 * Be * Lq * sp * 512 * 2 for s_, sp in zip(Ss, Sp) if s_ == 1)
     return {"gemm_token": tok, "gemm_mem": mem, "gemm_attn": att, "xattn": xat}
 
 
@@ -269,10 +276,13 @@ def secondary_configs(model, device):
         out["c1_single_utterance"] = {"s_per_1000": dt, "steps_per_s": 1000 / dt, "launches_per_step": c1_launches,
                                       "gpu_us_per_step": t_gpu / 900 * 1e6, "host_enqueue_us_per_step": t_enq / 900 * 1e6,
                                       "workload": f"B=1 (denoiser batch {G}), L={L}, S={S}, 1000-step DDPM end to end through sample()",
-                                      "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                                                   "algorithmic_bytes_per_step": alg_bytes, "traffic": None,
-                                                   "note": "latency-bound: ~86 dependent launches of ~5 us per step (rowtile.hpp); "
-                                                           "algorithmic bytes = SURVEY.md 8d (float32 weights + memories x 9 layers + latents)"}}
+                                      "roofline": {"bound": "latency", "launches_per_step": c1_launches, "us_per_launch": t_gpu / 900 * 1e6 / max(c1_launches, 1),
+                                                   "algorithmic_bytes_per_step": alg_bytes, "algorithmic_bytes_rate_GBps": ach,
+                                                   "algorithmic_bytes_rate_over_hbm_peak": ach / 8000.0, "traffic": None,
+                                                   "note": "latency-bound: ~86 dependent launches per step (rowtile.hpp), each a kernel boundary + one memory "
+                                                           "round trip; algorithmic bytes = SURVEY.md 8d's figure for the REFERENCE formulation (float32 weights + "
+                                                           "memories x 9 layers + latents) -- a rate of that figure, NOT measured traffic of this engine (the folded, "
+                                                           "hoisted row-tile path moves fewer bytes, mostly L2-resident split-pair weights), hence no `frac`"}}
         # ---- WEG at the product shape
         gw = torch.Generator().manual_seed(9)
         enc_w = [torch.randn(1, s, 512, generator=gw).to(device) for s in S]
@@ -346,16 +356,32 @@ def selftest_cpu(args, world, rank):
     single JSON line -- with NO denoiser work and no throughput value, so it cannot be mistaken for a measurement."""
     import torch.distributed as dist
     from convofusion_amd.distributed import gather_latents
-    seen = 1
+    from convofusion_amd.distributed import sample_sharded
+    seen, shard_ok = 1, True
+
+    def stand_in(enc, masks, B, first_utterance):
+        # what the sharding contract promises about a sampler: utterance u's result depends on its GLOBAL id and its own
+        # conditioning only (SamplingRun keys Philox by first_utterance + local index) -- a closed form with that property
+        ids = first_utterance + torch.arange(B, dtype=torch.float32)
+        own = enc[0].reshape(7, B, -1)[3].sum(-1)                       # chunk 3 carries the utterance's own spkemb (make_inputs)
+        return (ids * 1000.0 + own)[:, None, None].expand(B, 4, 128).contiguous()
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
         local = torch.full((2, 4, 128), float(rank))
         total = gather_latents(local, 2 * world)
         seen = int(total[:, 0, 0].unique().numel())
+        # rank r's latents == rows of the single-rank run of the whole batch (here: the stand-in sampler through sample_sharded)
+        Bt = 3 * world + 1                                              # ragged on purpose
+        g = torch.Generator().manual_seed(5)
+        enc = [torch.randn(7 * Bt, 2, 8, generator=g)]
+        whole = stand_in(enc, {}, Bt, 0)
+        got = sample_sharded(stand_in, enc, {}, Bt)
+        shard_ok = bool(torch.equal(got, whole))
         dist.barrier()
     if rank == 0:
-        print(json.dumps({"selftest": True, "metric": None, "value": None, "n_gpus": world, "ranks_seen": seen,
+        print(json.dumps({"selftest": True, "metric": None, "value": None, "n_gpus": world, "ranks_seen": seen, "shards_reproduce_single_rank": shard_ok,
                           "steps": args.steps, "warmup": args.warmup}))
+    assert shard_ok
     if world > 1:
         dist.destroy_process_group()
 
@@ -369,8 +395,12 @@ def main():
     ap.add_argument("--shape", default="C2", choices=["C2", "R"])
     ap.add_argument("--no-full-loop", action="store_true", help="skip the secondary whole-1000-step-run wall time")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configurations (R, C1, WEG, C4, C5) appended to the line")
+    ap.add_argument("--headline-only", action="store_true", help="only the headline workload's launches (profiling passes): no zero-weight-chunk run, "
+                    "no whole-run wall time, no other configurations, no CPU baseline")
     ap.add_argument("--selftest-cpu", action="store_true", help="exercise only the N-rank launch path on CPU (gloo); no measurement")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_cpu_baseline = args.no_full_loop = args.no_secondary = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)          # does not return
@@ -425,19 +455,26 @@ def main():
     t0 = time.perf_counter()
     run.steps(args.steps)
     local = run.read()                         # syncs the run's stream
+    t_steps = time.perf_counter() - t0         # this rank's K iterations alone (no collective, no barrier)
     total = gather_latents(local, world * B_PER_GPU) if world > 1 else local
     torch.cuda.synchronize()
+    t_gather = time.perf_counter() - t0 - t_steps
     barrier()
     dt = time.perf_counter() - t0
     rank_ms = [1000.0 * dt / args.steps]
+    rank_steps_ms, rank_gather_ms = [1000.0 * t_steps / args.steps], [1000.0 * t_gather]
     if world > 1:
         import torch.distributed as dist
-        tall = [torch.zeros(1, device=device) for _ in range(world)]
-        dist.all_gather(tall, torch.tensor([dt], device=device))      # a real RCCL collective: one entry per rank that answered
+        tall = [torch.zeros(3, device=device) for _ in range(world)]
+        dist.all_gather(tall, torch.tensor([dt, t_steps, t_gather], device=device))      # a real RCCL collective: one entry per rank that answered
         ranks_seen = len(tall)
         assert ranks_seen == dist.get_world_size() == args.gpus
-        rank_ms = [1000.0 * float(t.item()) / args.steps for t in tall]
-        dt = max(float(t.item()) for t in tall)
+        rank_ms = [1000.0 * float(t[0].item()) / args.steps for t in tall]
+        rank_steps_ms = [1000.0 * float(t[1].item()) / args.steps for t in tall]
+        rank_gather_ms = [1000.0 * float(t[2].item()) for t in tall]
+        dt = max(float(t[0].item()) for t in tall)
+        # the collated tensor holds every rank's shard at ITS rows: rank r's local latents are rows 32 r .. 32 r + 31 on every rank
+        assert torch.equal(total[rank * B_PER_GPU:(rank + 1) * B_PER_GPU], local)
     assert torch.isfinite(total).all()
     assert total.shape[0] == world * B_PER_GPU
 
@@ -449,16 +486,18 @@ def main():
 
     # secondary measurement (NOT the headline value): same job without evaluating the full-conditioning chunk,
     # whose guidance weight is 7.5 * 0 in the reference (convofusion.py:538) -- identical latents, 6/7 of the work
-    run2 = open_run(skip_zero_weight_chunks=True)
-    run2.steps(args.warmup)
-    run2.read()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    run2.steps(args.steps)
-    run2.read()
-    torch.cuda.synchronize()
-    dt_skip = time.perf_counter() - t1
-    run2.close()
+    dt_skip = None
+    if not args.headline_only:
+        run2 = open_run(skip_zero_weight_chunks=True)
+        run2.steps(args.warmup)
+        run2.read()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run2.steps(args.steps)
+        run2.read()
+        torch.cuda.synchronize()
+        dt_skip = time.perf_counter() - t1
+        run2.close()
 
     # secondary measurement: the ENTIRE 1000-step run of the same job (set-up, capture, 1000 replays, read), wall clock;
     # puts the sustained clock on record next to the short timed window above
@@ -479,7 +518,11 @@ def main():
         Be = G * B_PER_GPU
         U = [B_PER_GPU + 1] * 5
         canon = canonical_flops_per_step(Be, L, S)
-        ex = executed_gemm_flops(Be, L, S, U, shared_rows=B_PER_GPU if os.environ.get("CFD_SHARE0", "1") != "0" else None)
+        share0 = os.environ.get("CFD_SHARE0", "1") != "0"
+        # distinct (utterance, audio instance) pairs of the 7-chunk pattern of make_inputs: the unconditional tensor + the utterance's own
+        l0_pairs = 2 * B_PER_GPU if (share0 and os.environ.get("CFD_L0_DEDUP", "1") != "0" and os.environ.get("CFD_FUSED_XATTN", "1") != "0") else None
+        ex = executed_gemm_flops(Be, L, S, U, shared_rows=B_PER_GPU if share0 else None, l0_pairs=l0_pairs,
+                                 one_key=os.environ.get("CFD_ONE_KEY", "1") != "0" and os.environ.get("CFD_FUSED_XATTN", "1") != "0")
         classes = {k: {"ms": round(v[0], 4), "launches": v[1]} for k, v in prof.items()}
         once_per_run = {k: round(ex[k] / 1e12, 4) for k in ex if prof[k][1] == 0 and ex[k] > 0}
         for k in once_per_run:      # not launched inside an iteration (memory-side projections: made once at cfd_sample_begin)
@@ -497,30 +540,50 @@ def main():
             traffic, xa_traffic = tj.get("bytes_per_launch_mean"), tj.get("xattn_bytes_per_launch")
         for k in ex:
             classes[k]["algorithmic_tflop"] = round(ex[k] / 1e12, 4)
-            classes[k]["tflops"] = round(ex[k] / (prof[k][0] * 1e-3) / 1e12, 1) if prof[k][0] > 0 else None
-            classes[k]["frac_of_peak"] = round(classes[k]["tflops"] / PEAK_BF16_TFLOPS, 4) if classes[k]["tflops"] else None
+            classes[k]["tflops_eager"] = round(ex[k] / (prof[k][0] * 1e-3) / 1e12, 1) if prof[k][0] > 0 else None
         xa_ms, xa_n = prof["xattn"]
         xa_ach = ex["xattn"] / (xa_ms * 1e-3) / 1e12 if xa_ms > 0 else 0.0
+        # The fractions are quoted on the REPLAYED graph's clock: a class's share of the eager, event-bracketed forward times
+        # ms_per_step (the timed region).  The brackets and eager launch gaps inflate the class times by a few per cent; the
+        # shares are what the committed rocprofv3 kernel stats of the same command agree with (profiles/rNN_roofline.json,
+        # tools/profile_post.py).  The eager figures stay as achieved_eager / frac_eager.
+        class_sum = sum(v[0] for v in prof.values())
+        ms_step = 1000.0 * dt / args.steps
+        scale = ms_step / class_sum if class_sum > 0 else 1.0
+        achieved_eager, xa_eager = achieved, xa_ach
+        achieved, xa_ach = achieved_eager / scale, xa_eager / scale
+        for k in classes:
+            classes[k]["ms_eager"] = classes[k].pop("ms")
+            classes[k]["ms"] = round(prof[k][0] * scale, 4)          # share of the timed region (replayed graph)
+        for k in ex:
+            classes[k]["tflops"] = round(ex[k] / (prof[k][0] * scale * 1e-3) / 1e12, 1) if prof[k][0] > 0 else None
+            classes[k]["frac_of_peak"] = round(classes[k]["tflops"] / PEAK_BF16_TFLOPS, 4) if classes[k]["tflops"] else None
         xattn_roofline = {"bound": "mfma", "kernel": "xattn_fused_kernel (the largest single symbol of the trace: LayerNorm2, scores, softmax, "
                                                      "P.V and residual update of a layer's five cross-attentions in one launch)",
                           "achieved": xa_ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": xa_ach / PEAK_BF16_TFLOPS,
                           "frac_issued": 3.0 * xa_ach / PEAK_BF16_TFLOPS, "frac_of_issued_peak_div3": xa_ach / (PEAK_BF16_TFLOPS / 3.0),
-                          "launches_per_step": xa_n, "avg_launch_ms": xa_ms / max(xa_n, 1), "traffic": xa_traffic}
-        # the same fractions on the REPLAYED graph's clock: the classes' shares of the eager, event-bracketed forward scaled to
-        # ms_per_step (the brackets and eager launch gaps inflate the class times; the shares are what rocprofv3 agrees with)
-        class_sum = sum(v[0] for v in prof.values())
-        scale = (1000.0 * dt / args.steps) / class_sum if class_sum > 0 else 1.0
-        achieved_replay, xa_replay = achieved / scale, xa_ach / scale
-        xattn_roofline.update({"achieved_replay": xa_replay, "frac_replay": xa_replay / PEAK_BF16_TFLOPS, "traffic_source": "profiles/hbm_traffic_gemm.json"
-                               if xa_traffic else None})
-        mfma_ms = sum(prof[k][0] for k in ex)
+                          "achieved_eager": xa_eager, "frac_eager": xa_eager / PEAK_BF16_TFLOPS,
+                          "algorithmic_tflop_per_step": ex["xattn"] / 1e12,
+                          "launches_per_step": xa_n, "avg_launch_ms": xa_ms * scale / max(xa_n, 1), "avg_launch_ms_eager": xa_ms / max(xa_n, 1),
+                          "traffic": xa_traffic, "traffic_source": "profiles/hbm_traffic_gemm.json" if xa_traffic else None}
+        mfma_ms = sum(prof[k][0] for k in ex) * scale
         all_mfma = sum(ex.values()) / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
+        executed = sum(ex.values())
+        step_roofline = {"bound": "mfma", "executed_tflop_per_step": executed / 1e12, "executed_tflops": executed / (ms_step * 1e-3) / 1e12,
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": executed / (ms_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                         "frac_issued": 3.0 * executed / (ms_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                         "canonical_tflop_per_step": canon / 1e12, "canonical_tflops": canon / (ms_step * 1e-3) / 1e12,
+                         "note": "whole step on the timed region's clock: executed = algorithmic FLOPs of every product launched inside an iteration "
+                                 "(after de-duplication: shared layer-0 head, layer-0 audio attention per distinct pair, no one-key tile step); "
+                                 "canonical = the reference formulation's FLOPs for the same step (SURVEY.md 8d)"}
         out = {
             "metric": ("denoise-steps/sec (B=32 per GPU, 196-token latent, 1500 audio tokens, 1000-step DDPM schedule)" if args.shape == "C2" else
                        f"denoise-steps/sec at the product shape (NOT the BASELINE metric: B=32 per GPU, L={L}, S={S}, 1000-step DDPM schedule)"),
             "value": world * args.steps / dt,
             "unit": "denoise-steps/s (32-utterance batches, summed over GPUs)",
             "n_gpus": world, "ranks_seen": ranks_seen, "rank_ms_per_step": [round(x, 4) for x in rank_ms],
+            "rank_ms_per_step_iterations_only": [round(x, 4) for x in rank_steps_ms],
+            "rank_all_gather_ms": [round(x, 4) for x in rank_gather_ms],      # once per timed region (one all_gather of [B, L, 128] fp32 per rank), incl. the wait for the slowest rank
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -531,7 +594,7 @@ def main():
                        "shape": args.shape,
                        "parallelism": f"batch-shard x{world}, one all_gather of latents"},
             "utterance_steps_per_s": world * B_PER_GPU * args.steps / dt,
-            "value_without_zero_weight_chunk": args.steps / dt_skip,
+            "value_without_zero_weight_chunk": (args.steps / dt_skip) if dt_skip else None,
             "full_loop_s": full_loop_s,
             "full_loop_steps_per_s": (n_sched / full_loop_s) if full_loop_s else None,
             "canonical_tflop_per_step": canon / 1e12,
@@ -541,21 +604,24 @@ def main():
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
                          "frac_issued": 3.0 * achieved / PEAK_BF16_TFLOPS,
                          "peak_div3": PEAK_BF16_TFLOPS / 3.0, "frac_of_issued_peak_div3": achieved / (PEAK_BF16_TFLOPS / 3.0),
-                         "achieved_replay": achieved_replay, "frac_replay": achieved_replay / PEAK_BF16_TFLOPS,
+                         "achieved_eager": achieved_eager, "frac_eager": achieved_eager / PEAK_BF16_TFLOPS,
                          "eager_to_replay_scale": scale,
+                         "algorithmic_tflop_per_step": sum(ex[k] for k in gk) / 1e12,
                          "traffic": traffic,
                          "traffic_source": "profiles/hbm_traffic_gemm.json (a committed rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE profile of this "
                                            "command, not a quantity of this run)" if traffic else None,
-                         "launches_per_step": dom_n, "avg_launch_ms": dom_ms / max(dom_n, 1),
+                         "launches_per_step": dom_n, "avg_launch_ms": dom_ms * scale / max(dom_n, 1), "avg_launch_ms_eager": dom_ms / max(dom_n, 1),
                          "all_mfma_kernels_achieved": all_mfma, "all_mfma_kernels_frac": all_mfma / PEAK_BF16_TFLOPS,
-                         "note": "achieved / frac = algorithmic (single-product) FLOPs of the launched GEMMs / their HIP-event time, taken "
-                                 "from ONE EAGER forward with every launch bracketed by an event pair (the class times sum to more "
-                                 "than ms_per_step, which is the replayed hipGraph: the brackets cost that); achieved_replay / frac_replay = "
-                                 "the same FLOPs over the class's share of ms_per_step (what the committed rocprofv3 kernel stats give); "
+                         "note": "achieved / frac = algorithmic (single-product) FLOPs of the launched GEMMs / the class's share of ms_per_step "
+                                 "(the timed region of replayed hipGraph iterations); the shares come from ONE EAGER forward with every launch "
+                                 "bracketed by a HIP-event pair on the launch stream (cfd_profile_forward) -- its class times sum to more than "
+                                 "ms_per_step (the brackets cost that: achieved_eager / frac_eager are the un-scaled figures), the shares are what "
+                                 "the committed rocprofv3 kernel stats of this command give (profiles/rNN_roofline.json); "
                                  "each product is issued as 3 f16 MFMAs, so the MFMA pipe sees 3x this and the ceiling of the "
                                  "f16x3 instruction mix is peak / 3 = 833 TFLOP/s (frac_of_issued_peak_div3); traffic = mean HBM bytes "
                                  "per launch from rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE (profiles/)"},
             "roofline_xattn": xattn_roofline,
+            "roofline_step": step_roofline,
             "kernel_classes": classes,
             "tflop_once_per_run_not_per_step": once_per_run,
         }

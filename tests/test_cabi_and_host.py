@@ -203,7 +203,7 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["selftest"] is True and d["value"] is None
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["selftest"] is True and d["value"] is None and d["shards_reproduce_single_rank"] is True
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--selftest-cpu"], capture_output=True, text=True,
                          timeout=120, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
     assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)

@@ -13,10 +13,10 @@ export TMPDIR=/tmp
 python bench.py --steps 20 --warmup 3 > $out/${tag}_bench_c2.json 2> $out/${tag}_bench_c2.err
 python bench.py --steps 50 --warmup 5 --shape R --no-cpu-baseline --no-secondary > $out/${tag}_bench_realshape.json 2>> $out/${tag}_bench_c2.err
 rm -rf $out/${tag}_stats $out/${tag}_pmc_fetch $out/${tag}_pmc_write $out/${tag}_pmc_mfma
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o run -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-full-loop --no-secondary > $out/${tag}_rocprof_stdout.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -o run -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-full-loop --no-secondary > $out/${tag}_pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmc_write -o run -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-full-loop --no-secondary > $out/${tag}_pmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/${tag}_pmc_mfma -o run -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-full-loop --no-secondary > $out/${tag}_pmc_mfma.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o run -- python bench.py --steps 20 --warmup 3 --headline-only > $out/${tag}_rocprof_stdout.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -o run -- python bench.py --steps 3 --warmup 1 --headline-only > $out/${tag}_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmc_write -o run -- python bench.py --steps 3 --warmup 1 --headline-only > $out/${tag}_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/${tag}_pmc_mfma -o run -- python bench.py --steps 3 --warmup 1 --headline-only > $out/${tag}_pmc_mfma.log 2>&1
 # one utterance at the product shape (C1) and WEG evaluations: kernel stats of the row-tile path
 bash tools/c1prof.sh 1 ${tag}_c1 > $out/${tag}_c1.txt 2>&1
 bash tools/wegprof.sh ${tag}_weg > $out/${tag}_weg.txt 2>&1
