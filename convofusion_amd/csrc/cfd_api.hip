@@ -92,6 +92,7 @@ struct Problem {
   // fused cross-attention (xattn_fused.hpp): workgroups of the work list, 0 = the list was not built
   int xa_nwg = 0;
   int xa0_nwg_a = 0, xa0_nwg_b = 0;   // layer-0 de-duplication lists (build_xattn_layer0_lists); 0: one launch
+  bool xa_flush = false;               // some work list flushes the accumulator between two online memories (XA_FLUSH): lock-step kernel only
   int xa_one = -1;                     // the one-key memory the fused cross-attention adds as a vector (xattn_fused.hpp, XAttnArgs::one_j), or -1
   // memories (bit j) whose folded projections were computed once for the run from the centred static part of the memory
   // (prepare_static_memside); per step they only get their per-key scale and bias (mem_scale_all_kernel)
@@ -182,6 +183,7 @@ struct cfd_handle_s {
   bool fused_xattn = true;
   int fused_xattn_min_wgs = 6;
   int one_key = 1;              // CFD_ONE_KEY=0: a one-key memory (lsnemb) keeps its 32-key tile step in the fused cross-attention
+  int xa_pp = 1;                // CFD_XA_PP=0: the lock-step form of the fused cross-attention kernel everywhere (xattn_fused.hpp; parity / timing A/B)
   int l0_dedup = 1;             // CFD_L0_DEDUP=0: layer 0's cross-attention as one launch over all rows (build_xattn_layer0_lists)
   // Row-tile path for small problems (rowtile.hpp): chosen by SHAPE -- at most rt_max_rows token rows of at most RT_MAX_L tokens per batch
   // row, one timestep for all rows, no dynamic memories.  CFD_ROWTILE=0 turns it off (parity A/B against the tile kernels),
@@ -346,6 +348,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   if (env) c->fused_xattn_min_wgs = atoi(env);
   env = getenv("CFD_L0_DEDUP");
   if (env) c->l0_dedup = atoi(env) != 0;
+  env = getenv("CFD_XA_PP");
+  if (env) c->xa_pp = atoi(env) != 0;
   env = getenv("CFD_ONE_KEY");
   if (env) c->one_key = atoi(env) != 0;
   env = getenv("CFD_ROWTILE");
@@ -631,7 +635,7 @@ struct XaRow {      // one row of a work list
 };
 
 static void make_xattn_worklist(const Problem& p, const std::vector<XaRow>& rows, int mem_mask, std::vector<XaWg>& wgs, std::vector<XaSeg>& segs,
-                                size_t& n_active) {
+                                size_t& n_active, bool& has_flush) {
   const int L = p.L, nqt = (L + 15) / 16;
   wgs.clear(); segs.clear(); n_active = 0;
   // memory order: long (online) memories first, longest first; then the single-tile ones
@@ -685,7 +689,7 @@ static void make_xattn_worklist(const Problem& p, const std::vector<XaRow>& rows
           segs.push_back(sg);
         }
         // one accumulator: a finished online memory is flushed to x before the next online memory starts
-        if (online && online_seen < n_online && segs.size() > first_seg) segs.back().flags |= XA_FLUSH;
+        if (online && online_seen < n_online && segs.size() > first_seg) { segs.back().flags |= XA_FLUSH; has_flush = true; }
       }
       w.nseg = (int)segs.size() - w.seg0;
       w.pf_slot = (int)g;   // (the group, until the queues are built)
@@ -748,7 +752,7 @@ static int upload_worklist(DBuf& dw, DBuf& ds, const std::vector<XaWg>& wgs, con
 
 static int build_xattn_worklist(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
   Problem& p = c->w->pb;
-  p.xa_nwg = 0; p.xa0_nwg_a = 0; p.xa0_nwg_b = 0;
+  p.xa_nwg = 0; p.xa0_nwg_a = 0; p.xa0_nwg_b = 0; p.xa_flush = false;
   if (!c->fused_xattn) return CFD_OK;
   std::vector<std::vector<int>> hm;
   CHK(read_row_maps(c, mem, hm));
@@ -776,7 +780,7 @@ static int build_xattn_worklist(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
   std::vector<XaWg> wgs;
   std::vector<XaSeg> segs;
   size_t n_active = 0;
-  make_xattn_worklist(p, rows, all_mems, wgs, segs, n_active);
+  make_xattn_worklist(p, rows, all_mems, wgs, segs, n_active, p.xa_flush);
   if (wgs.empty() || segs.empty()) return CFD_OK;
   // A handful of workgroups cannot hide their serial walk over the key tiles (3 barriers and a fill round trip per 32 keys
   // with nothing else on the chip).  Round-2 measurements at the product shape, 1000 steps, since the memory-side projections
@@ -839,8 +843,8 @@ static int build_xattn_layer0_lists(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
   std::vector<XaWg> wa, wb;
   std::vector<XaSeg> sa, sb;
   size_t na = 0, nb = 0;
-  make_xattn_worklist(p, ra, 1 << jg, wa, sa, na);
-  make_xattn_worklist(p, rb, ((1 << CFD_NMEM) - 1) & ~(1 << jg) & ~(p.xa_one >= 0 ? 1 << p.xa_one : 0), wb, sb, nb);
+  make_xattn_worklist(p, ra, 1 << jg, wa, sa, na, p.xa_flush);
+  make_xattn_worklist(p, rb, ((1 << CFD_NMEM) - 1) & ~(1 << jg) & ~(p.xa_one >= 0 ? 1 << p.xa_one : 0), wb, sb, nb, p.xa_flush);
   if (wa.empty() || wb.empty()) return CFD_OK;
   CHK(upload_worklist(c->w->xa0_wgs_a, c->w->xa0_segs_a, wa, sa));
   CHK(upload_worklist(c->w->xa0_wgs_b, c->w->xa0_segs_b, wb, sb));
@@ -1423,7 +1427,8 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
   static unsigned long long attr = 0;   // per device (one bit per ordinal): a process may hold handles on several GPUs
   if (!((attr >> (c->cfg.device & 63)) & 1ull)) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
     attr |= 1ull << (c->cfg.device & 63);
   }
 
@@ -1502,20 +1507,25 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       a.stamps = c->w->xa_stamps.as<long long>();
 #endif
       Bracket br(c, CFD_PROF_XATTN, st);
+      const bool pp = c->xa_pp && !p.xa_flush;   // the ping-pong form has no flush between two online memories
+      auto launch_xa = [&](int nwg, const XAttnArgs& xa) {
+        if (pp) hipLaunchKernelGGL(xattn_fused_kernel<1>, dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
+        else hipLaunchKernelGGL(xattn_fused_kernel<0>, dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
+      };
       if (l == 0 && share && p.xa0_nwg_a > 0) {   // layer-0 de-duplication (build_xattn_layer0_lists): the longest memory once per distinct (utterance, instance) ...
         XAttnArgs a0 = a;
         a0.wgs = c->w->xa0_wgs_a.as<XaWg>(); a0.segs = c->w->xa0_segs_a.as<XaSeg>(); a0.dd_out = c->w->xa_dedup.as<float>(); a0.stamps = nullptr;
         a0.one_j = -1;   // (the one-key memory belongs to the second launch)
-        hipLaunchKernelGGL(xattn_fused_kernel, dim3(p.xa0_nwg_a), dim3(XA_WAVES * 64), XA_LDS, st, a0);
+        launch_xa(p.xa0_nwg_a, a0);
         HIPCHK(hipGetLastError());
         // ... then the other memories for every row, which also adds the stored results
         a0.wgs = c->w->xa0_wgs_b.as<XaWg>(); a0.segs = c->w->xa0_segs_b.as<XaSeg>(); a0.dd_out = nullptr; a0.dd_in = c->w->xa_dedup.as<float>();
         a0.one_j = a.one_j;
-        hipLaunchKernelGGL(xattn_fused_kernel, dim3(p.xa0_nwg_b), dim3(XA_WAVES * 64), XA_LDS, st, a0);
+        launch_xa(p.xa0_nwg_b, a0);
         HIPCHK(hipGetLastError());
         if (c->prof) c->prof_n[CFD_PROF_XATTN] += 1;   // (two launches under one bracket)
       } else {
-        hipLaunchKernelGGL(xattn_fused_kernel, dim3(p.xa_nwg), dim3(XA_WAVES * 64), XA_LDS, st, a);
+        launch_xa(p.xa_nwg, a);
         HIPCHK(hipGetLastError());
       }
     } else {

@@ -61,6 +61,7 @@
 // between the workgroup's batch rows is split into passes.
 #pragma once
 #include "cfd_common.hpp"
+#include <type_traits>
 
 #define XA_TILES 4     // query tiles (of 16 queries) per workgroup
 #define XA_WAVES 8     // two waves per query tile
@@ -73,7 +74,8 @@
 #define XA_MAXSEG 24
 #define XA_CQOFF (XA_SEGOFF + XA_MAXSEG * 16)   // per wave: c_q partial sums [16 queries][5 memories], then sum_s P' [16][5]
 #define XA_CQW 640
-#define XA_LDS (XA_CQOFF + XA_WAVES * XA_CQW)
+#define XA_FLAGOFF (XA_CQOFF + XA_WAVES * XA_CQW)   // ping-pong form: per wave, the number of key-tile steps whose partial scores it has published
+#define XA_LDS (XA_FLAGOFF + 64)
 
 struct XaSeg {
   int j;        // memory 0..4
@@ -171,6 +173,10 @@ __device__ __forceinline__ T xa_sel(const T (&arr)[CFD_NMEM], int j) {
 #define XA_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | (0xF << 8) | ((((N) >> 4) & 3) << 14))
 #define XA_WAIT_VM_LGKM0(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | ((((N) >> 4) & 3) << 14))
 
+// PP = 0: the lock-step form described above (every wave in the same sub-phase; pairs (w, w + 4) share a SIMD).
+// PP = 1: the ping-pong form (round 5; see the comment in front of its loop): waves 0-3 run one sub-phase AHEAD of waves 4-7, so that
+//         on every SIMD one wave's softmax / waits / fill issue lie next to the other wave's MFMAs; pairs are (w, w ^ 1).
+template <int PP>
 __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KOFF = 0, VOFF = 65536;
@@ -180,7 +186,12 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
 #endif
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tile = wid & 3, half = wid >> 2;           // query tile of the pair; which half of the 512-long axes
+  const int tile = PP ? (wid >> 2) * 2 + ((wid >> 1) & 1) : (wid & 3);   // query tile of the pair
+  int half_ = PP ? (wid & 1) : (wid >> 2);                                 // which half of the 512-long axes
+  if (PP) asm volatile("" : "+s"(half_));   // (opaque: knowing that it is 0 or 1, hipcc turns the prologue's `half ? r[16 + i] : r[i]` selects into an INDEXED row array in scratch memory)
+  const int half = half_;
+  const int grp = PP ? (wid >> 2) : 0;                                     // ping-pong form: 0 = the early group, 1 = the late one
+  const int partner = PP ? (wid ^ 1) : (wid ^ 4);
   const int l15 = lane & 15, q4 = lane >> 4, sw = l15 >> 1;
   const int cpos = lane & 7, rsub = lane >> 3;
 
@@ -196,6 +207,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
 
   // the segment list of this workgroup -> LDS (read back with ds_read: no vector-memory traffic inside the loop)
   if (threadIdx.x < nseg) reinterpret_cast<int4*>(smem + XA_SEGOFF)[threadIdx.x] = reinterpret_cast<const int4*>(a.segs + seg0)[threadIdx.x];
+  if (PP && threadIdx.x < XA_WAVES) reinterpret_cast<int*>(smem + XA_FLAGOFF)[threadIdx.x] = 0;
 
   // Q fragments (B operand) of this wave's half of the feature axis, made here from the residual stream:
   //   q = LayerNorm2(x[token])  (cross_attention.py:578; two-pass mean / variance like ln_rows_kernel, eps 1e-5).
@@ -431,7 +443,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
 
   float m = -INFINITY, lsum = 0.f, wl = 0.f;
   char* xch_mine = smem + XA_XOFF + wid * 2048 + lane * 16;
-  const char* xch_other = smem + XA_XOFF + (wid ^ 4) * 2048 + lane * 16;
+  const char* xch_other = smem + XA_XOFF + partner * 2048 + lane * 16;
   // fragment reads: half `hf` (4 k-steps / 4 feature tiles) of a sub-phase -> 8 fragments (hi, lo alternating)
   const char* kfrag = smem + KOFF + (8 * half) * 4096 + l15 * 128;
   const char* vfrag = smem + VOFF + (16 * half * 16 + l15) * 128;
@@ -469,6 +481,67 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       o[4 * qf + i] = XA_MFMA(fr[2 * i], ph, o[4 * qf + i]);
     }
   };
+  // softmax of one key tile from the pair's two partial score sets (this wave's s0 / s1 in registers, the partner's in the exchange area):
+  // leaves P' (hi / lo) in ph / pl, updates the running maximum / sums and rescales O for an online memory
+  auto softmax_tile = [&](const f32x4& s0, const f32x4& s1, int slot, bool online) __attribute__((always_inline)) {
+    float scale = 1.0f;
+    // softmax of this tile: lane (q, g) holds keys 8 g + e, e = 0..7 (s0 = e 0..3, s1 = e 4..7)
+    const f32x4 t0 = *reinterpret_cast<const f32x4*>(xch_other);
+    const f32x4 t1 = *reinterpret_cast<const f32x4*>(xch_other + 1024);
+    const f32x4 kb0 = *reinterpret_cast<const f32x4*>(smem + XA_CBOFF + slot * 256 + q4 * 32);
+    const f32x4 kb1 = *reinterpret_cast<const f32x4*>(smem + XA_CBOFF + slot * 256 + q4 * 32 + 16);
+    const f32x4 rs0 = *reinterpret_cast<const f32x4*>(smem + XA_CBOFF + slot * 256 + 128 + q4 * 32);
+    const f32x4 rs1 = *reinterpret_cast<const f32x4*>(smem + XA_CBOFF + slot * 256 + 128 + q4 * 32 + 16);
+    const float rs[8] = {rs0[0], rs0[1], rs0[2], rs0[3], rs1[0], rs1[1], rs1[2], rs1[3]};
+    float p[8];
+    p[0] = fmaf(s0[0] + t0[0], rs[0], kb0[0]); p[1] = fmaf(s0[1] + t0[1], rs[1], kb0[1]);
+    p[2] = fmaf(s0[2] + t0[2], rs[2], kb0[2]); p[3] = fmaf(s0[3] + t0[3], rs[3], kb0[3]);
+    p[4] = fmaf(s1[0] + t1[0], rs[4], kb1[0]); p[5] = fmaf(s1[1] + t1[1], rs[5], kb1[1]);
+    p[6] = fmaf(s1[2] + t1[2], rs[6], kb1[2]); p[7] = fmaf(s1[3] + t1[3], rs[7], kb1[3]);
+    const float mx = xlane_max(fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7]))));
+    // exp(x - m) = exp2(x c - m c), c = log2(e): one fused multiply-add and one v_exp_f32 per key (the rounding of m c is common
+    // to all keys of a row and cancels against the row sum); dead keys carry x = -inf -> 0
+    constexpr float LOG2E = 1.44269504088896340736f;
+    if (online) {
+      const float m_new = fmaxf(m, mx);
+      const bool dead = m_new == -INFINITY;             // nothing but dead keys so far: contribute 0, keep m = -inf
+      const float mc = dead ? 0.f : m_new * LOG2E;      // (-inf - (-inf) would be NaN)
+      scale = dead ? 1.0f : __builtin_amdgcn_exp2f(fmaf(m, LOG2E, -mc));
+      float ps = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        p[e] = __builtin_amdgcn_exp2f(fmaf(p[e], LOG2E, -mc));
+        ps += p[e];
+      }
+      lsum = lsum * scale + xlane_sum(ps);
+      m = m_new;
+      float pw = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { p[e] *= rs[e]; pw += p[e]; }     // P' = p rs: the operand of VA^T P'
+      wl = wl * scale + pw;
+    } else {
+      const float mc = mx * LOG2E;
+      float ps = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        p[e] = __builtin_amdgcn_exp2f(fmaf(p[e], LOG2E, -mc));   // all keys dead: (-inf) - (-inf) = NaN, as in the reference
+        ps += p[e];
+      }
+      const float inv = 1.0f / xlane_sum(ps);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { p[e] = (p[e] * inv) * rs[e]; wl += p[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {      // p <= 1 and rs <= 1 / sqrt(eps) = 316: no saturation needed in front of the fp16 split
+      const sp_t hi = (sp_t)p[e];
+      ph[e] = hi;
+      pl[e] = (sp_t)(p[e] - (float)hi);
+    }
+    if (online && !__all(scale == 1.0f)) {
+#pragma unroll
+      for (int f = 0; f < 16; ++f) { o[f][0] *= scale; o[f][1] *= scale; o[f][2] *= scale; o[f][3] *= scale; }
+    }
+  };
   spx8 fa[8], fb[8];   // the two fragment sets
   bool primed = false;
   int step = 0;
@@ -476,6 +549,163 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   int cT = 1, cmask = 0, cflags = 0, cj = 0, nT = 1, nmask = 0, nflags = 0, nj = 0;
   if (nseg > 0) seg_tile(0, cur, cT, cmask, cflags, cj);
   XA_T(0);
+  if constexpr (PP) {
+  // ---- The ping-pong form (round 5) -------------------------------------------------------------------------------------------
+  // In the lock-step form both waves of a SIMD are in the same sub-phase all the time: they want the matrix pipe together, do the
+  // softmax together (the pipe idles), issue their fills together (LDS-DMA issue holds a wave for 100+ cycles per piece) and meet
+  // every barrier together.  Here the workgroup is two GROUPS of four waves, one wave of each per SIMD -- group 0 = waves 0-3 =
+  // query tiles 0, 1, group 1 = waves 4-7 = tiles 2, 3; the two waves of a pair (w, w ^ 1) sit on different SIMDs -- and group 1
+  // runs the SAME program ONE SUB-PHASE behind group 0.  The key-tile stream is a sequence of 32 KB pieces
+  //     piece 4 n = Ka(n), 4 n + 1 = Kb(n), 4 n + 2 = Va(n), 4 n + 3 = Vb(n)        (n = key-tile step, the four sub-buffers of the lock-step form)
+  // that group 0 consumes in slot p and group 1 in slot p + 1.  There is ONE kind of barrier, b(k), in the MIDDLE of slot k
+  // (four per step): in front of it every wave has seen its share of piece k + 1 land (counted vmcnt) and finished its LDS reads of
+  // everything older (lgkmcnt 0); behind it group 0 starts reading piece k + 1 (under the second half of its MFMAs on piece k, as in
+  // the lock-step form), group 1 starts reading piece k, nobody reads piece k - 1 any more, so its sub-buffer is refilled with piece
+  // k + 3 right there: every piece is requested two slots before its first use, the same lead as in the lock-step form, with the same
+  // four sub-buffers.  On a SIMD the pairing per slot is  (A0 | B1')  (A1 | A0)  (softmax + B0 | A1)  (B1 | softmax + B0): one wave's
+  // softmax runs next to the other wave's MFMAs, in two of the four slots.
+  // The pair's partial scores cannot meet at a barrier any more (a barrier in the middle of a slot is no boundary of both groups):
+  // each wave publishes a step counter in LDS once its partial scores are written (ds_write, wait, ds_write of the flag) and its partner
+  // polls that word -- the two finish A1 within a few hundred cycles of each other, and a poll costs the polling wave only.
+  // Work lists with a flush between two online memories (XA_FLUSH: never at the shipped shapes) stay on the lock-step form.
+  // (the flag words are written and polled with ds instructions in inline assembly: a volatile access makes hipcc drain vmcnt(0) -- the
+  //  fills in flight -- in front of it)
+  const unsigned flag_mine = (unsigned)(unsigned long)(lptr_t)(smem + XA_FLAGOFF + wid * 4);
+  const unsigned flag_other = (unsigned)(unsigned long)(lptr_t)(smem + XA_FLAGOFF + partner * 4);
+  // The two groups run two instances of the loop (chosen once, by a wave-uniform branch): what differs between them -- which piece a
+  // barrier requests, how many younger requests a wait leaves in flight -- is then compile-time, and every fill keeps its
+  // SGPR-base + lane-offset address form (as branches inside one loop hipcc merged the branches' tails into 64-bit per-lane addresses).
+  auto pp_loop = [&](auto grp_c) __attribute__((always_inline)) {
+  constexpr int GRP = decltype(grp_c)::value;
+  // pieces 0-2 of the stream; piece p is requested at b(p - 3)
+  fill_k(cur, 0, 0);
+  fill_k(cur, 1, 0);
+  fill_v(cur, 0);
+  XA_WAIT_VM_LGKM0(8);               // Ka + key bias landed
+  __builtin_amdgcn_s_barrier();      // b(-1)
+  if constexpr (GRP) {               // the late group: its slot 0 is b(0) .. b(1)
+    XA_WAIT_VM_LGKM0(4);             // Kb landed
+    __builtin_amdgcn_s_barrier();    // b(0)
+    fill_v(cur, 1);                  // piece 3
+  }
+  read_k(fa, 0, 0);
+  XA_T(0);
+  for (int si = 0; si < nseg; ++si) {
+    const bool in_seg = active && ((cmask >> tile) & 1);   // wave-uniform, the same for both waves of a pair
+    const bool online = (cflags & XA_ONLINE) != 0;
+    const bool seg_follows = si + 1 < nseg;
+    nseg_t = cur; nT = cT; nmask = cmask; nflags = cflags; nj = cj;
+    if (seg_follows) seg_tile(si + 1, nseg_t, nT, nmask, nflags, nj);
+    const float cqh = cq_mine[l15 * 5 + cj];
+    XA_T(11);
+    for (int kt = 0; kt < cT; ++kt) {
+    const bool last_in_seg = kt + 1 == cT;
+    Tile nxt;   // the tile of the step after this one
+    nxt.k = last_in_seg ? nseg_t.k : cur.k + XA_KEYS * CFD_D * 4;
+    nxt.v = last_in_seg ? nseg_t.v : cur.v + 128;
+    nxt.cb = last_in_seg ? nseg_t.cb : cur.cb + XA_KEYS;
+    nxt.rowb = last_in_seg ? nseg_t.rowb : cur.rowb;
+    nxt.vlane = last_in_seg ? nseg_t.vlane : cur.vlane;
+    nxt.cblane = last_in_seg ? nseg_t.cblane : cur.cblane;
+    const int slot = step & 1;
+    // ---- A0 (fa holds its first half) --------------------------------------------------------------------------------
+    f32x4 s0 = f32x4{cqh, cqh, cqh, cqh}, s1 = s0;
+    read_k(fb, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_k(s0, fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    XA_T(1);
+    XA_WAIT_VM_LGKM0(4);                 // group 0: Kb landed (Va is younger); group 1: Va landed (Vb is younger)
+    __builtin_amdgcn_s_barrier();        // mid-A0
+    XA_T(2);
+    if constexpr (GRP) fill_k(nxt, 0, slot ^ 1); else fill_v(cur, 1);
+    read_k(fa, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) {
+      mfma_k(s0, fb, 1);
+      *reinterpret_cast<f32x4*>(xch_mine) = s0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- A1 ---------------------------------------------------------------------------------------------------------
+    read_k(fb, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_k(s1, fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    XA_T(3);
+    if constexpr (GRP) XA_WAIT_VM_LGKM0(5); else XA_WAIT_VM_LGKM0(4);   // group 0: Va landed (Vb younger); group 1: Vb landed (the next Ka + key bias younger)
+    __builtin_amdgcn_s_barrier();        // mid-A1
+    XA_T(4);
+    if constexpr (GRP) fill_k(nxt, 1, slot ^ 1); else fill_k(nxt, 0, slot ^ 1);
+    read_v(fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) {
+      mfma_k(s1, fb, 1);
+      *reinterpret_cast<f32x4*>(xch_mine + 1024) = s1;
+      XA_WAIT_VM_LGKM0(63);              // lgkmcnt(0): both partial score sets are in LDS ...
+      asm volatile("ds_write_b32 %0, %1" ::"v"(flag_mine), "v"(step + 1) : "memory");   // ... before the step counter that says so
+      for (;;) {
+        int seen;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(flag_other) : "memory");
+        if (__builtin_amdgcn_readfirstlane(seen) > step) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!(XA_ABLATE & 8)) softmax_tile(s0, s1, slot, online);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- B0 (fa holds its first half) --------------------------------------------------------------------------------
+    XA_T(10);
+    read_v(fb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    XA_T(5);
+    if constexpr (GRP) XA_WAIT_VM_LGKM0(4); else XA_WAIT_VM_LGKM0(5);   // group 0: Vb landed (the next Ka + key bias younger); group 1: the next Ka landed (Kb younger)
+    __builtin_amdgcn_s_barrier();        // mid-B0
+    if constexpr (GRP) fill_v(nxt, 0); else fill_k(nxt, 1, slot ^ 1);
+    read_v(fa, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- B1 ---------------------------------------------------------------------------------------------------------
+    read_v(fb, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fa, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    XA_T(7);
+    XA_WAIT_VM_LGKM0(4);                 // group 0: the next Ka + key bias landed (Kb younger); group 1: the next Kb landed (Va younger)
+    __builtin_amdgcn_s_barrier();        // mid-B1
+    XA_T(8);
+    if constexpr (GRP) fill_v(nxt, 1); else fill_v(nxt, 0);
+    read_k(fa, 0, 0);                    // first half of the next step's A0
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fb, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+    ++step;
+    XA_T(9);
+    }   // kt
+    if (in_seg) {
+      float wsum = xlane_sum(wl);
+      if (online) {   // normalise the finished online memory in registers (all keys dead: 0 * inf = NaN)
+        const float inv = 1.0f / lsum;
+#pragma unroll
+        for (int f = 0; f < 16; ++f) { o[f][0] *= inv; o[f][1] *= inv; o[f][2] *= inv; o[f][3] *= inv; }
+        wsum *= inv;
+      }
+      if (q4 == 0) wq_mine[l15 * 5 + cj] = wsum;
+    }
+    m = -INFINITY;
+    lsum = 0.f;
+    wl = 0.f;
+    cT = nT; cmask = nmask; cflags = nflags; cj = nj;
+  }
+  if constexpr (!GRP) {                  // the early group waits out the late group's last slot
+    XA_WAIT_VM_LGKM0(63);
+    __builtin_amdgcn_s_barrier();
+  }
+  };   // pp_loop
+  if (grp) pp_loop(std::integral_constant<int, 1>{}); else pp_loop(std::integral_constant<int, 0>{});
+  } else {
   for (int si = 0; si < nseg; ++si) {
     const bool in_seg = active && ((cmask >> tile) & 1);   // wave-uniform, the same for both waves of a pair
     const bool online = (cflags & XA_ONLINE) != 0;
@@ -542,65 +772,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     fill_k(nxt, 0, slot ^ 1);
     fill_k(nxt, 1, slot ^ 1);
     read_v(fa, 0);
-    float scale = 1.0f;
-    if (in_seg && !(XA_ABLATE & 8)) {
-      // softmax of this tile: lane (q, g) holds keys 8 g + e, e = 0..7 (s0 = e 0..3, s1 = e 4..7)
-      const f32x4 t0 = *reinterpret_cast<const f32x4*>(xch_other);
-      const f32x4 t1 = *reinterpret_cast<const f32x4*>(xch_other + 1024);
-      const f32x4 kb0 = *reinterpret_cast<const f32x4*>(smem + XA_CBOFF + slot * 256 + q4 * 32);
-      const f32x4 kb1 = *reinterpret_cast<const f32x4*>(smem + XA_CBOFF + slot * 256 + q4 * 32 + 16);
-      const f32x4 rs0 = *reinterpret_cast<const f32x4*>(smem + XA_CBOFF + slot * 256 + 128 + q4 * 32);
-      const f32x4 rs1 = *reinterpret_cast<const f32x4*>(smem + XA_CBOFF + slot * 256 + 128 + q4 * 32 + 16);
-      const float rs[8] = {rs0[0], rs0[1], rs0[2], rs0[3], rs1[0], rs1[1], rs1[2], rs1[3]};
-      float p[8];
-      p[0] = fmaf(s0[0] + t0[0], rs[0], kb0[0]); p[1] = fmaf(s0[1] + t0[1], rs[1], kb0[1]);
-      p[2] = fmaf(s0[2] + t0[2], rs[2], kb0[2]); p[3] = fmaf(s0[3] + t0[3], rs[3], kb0[3]);
-      p[4] = fmaf(s1[0] + t1[0], rs[4], kb1[0]); p[5] = fmaf(s1[1] + t1[1], rs[5], kb1[1]);
-      p[6] = fmaf(s1[2] + t1[2], rs[6], kb1[2]); p[7] = fmaf(s1[3] + t1[3], rs[7], kb1[3]);
-      const float mx = xlane_max(fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7]))));
-      // exp(x - m) = exp2(x c - m c), c = log2(e): one fused multiply-add and one v_exp_f32 per key (the rounding of m c is common
-      // to all keys of a row and cancels against the row sum); dead keys carry x = -inf -> 0
-      constexpr float LOG2E = 1.44269504088896340736f;
-      if (online) {
-        const float m_new = fmaxf(m, mx);
-        const bool dead = m_new == -INFINITY;             // nothing but dead keys so far: contribute 0, keep m = -inf
-        const float mc = dead ? 0.f : m_new * LOG2E;      // (-inf - (-inf) would be NaN)
-        scale = dead ? 1.0f : __builtin_amdgcn_exp2f(fmaf(m, LOG2E, -mc));
-        float ps = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          p[e] = __builtin_amdgcn_exp2f(fmaf(p[e], LOG2E, -mc));
-          ps += p[e];
-        }
-        lsum = lsum * scale + xlane_sum(ps);
-        m = m_new;
-        float pw = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { p[e] *= rs[e]; pw += p[e]; }     // P' = p rs: the operand of VA^T P'
-        wl = wl * scale + pw;
-      } else {
-        const float mc = mx * LOG2E;
-        float ps = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          p[e] = __builtin_amdgcn_exp2f(fmaf(p[e], LOG2E, -mc));   // all keys dead: (-inf) - (-inf) = NaN, as in the reference
-          ps += p[e];
-        }
-        const float inv = 1.0f / xlane_sum(ps);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { p[e] = (p[e] * inv) * rs[e]; wl += p[e]; }
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {      // p <= 1 and rs <= 1 / sqrt(eps) = 316: no saturation needed in front of the fp16 split
-        const sp_t hi = (sp_t)p[e];
-        ph[e] = hi;
-        pl[e] = (sp_t)(p[e] - (float)hi);
-      }
-      if (online && !__all(scale == 1.0f)) {
-#pragma unroll
-        for (int f = 0; f < 16; ++f) { o[f][0] *= scale; o[f][1] *= scale; o[f][2] *= scale; o[f][3] *= scale; }
-      }
-    }
+    if (in_seg && !(XA_ABLATE & 8)) softmax_tile(s0, s1, slot, online);
     // ---- B0 (fa holds its first half) --------------------------------------------------------------------------------
     XA_T(10);
     read_v(fb, 1);
@@ -653,6 +825,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     wl = 0.f;
     cT = nT; cmask = nmask; cflags = nflags; cj = nj;   // (cur already points at the next segment's first tile)
   }
+  }   // lock-step form
   XA_WAIT_VM_LGKM0(0);
   __builtin_amdgcn_s_barrier();   // last B1 done everywhere and the trailing (unused) fills have landed: the tile buffers become the epilogue strips
   XA_T(11);

@@ -233,25 +233,31 @@ def test_out_of_range_memories_are_refused_not_clamped():
     with torch.no_grad():   # the handle is usable afterwards
         out2, _ = m(x, torch.tensor(t), mems, mem_mask_dict=masks)
     assert torch.equal(out, out2)
-    # Paths whose memory-side projections run INSIDE the forward (per-row timesteps; attention maps wanted) count after the
-    # once-per-call check: the census belongs to the handle and is read at the end of the SAME call -- the call that clamped
-    # fails, the next call (this handle or another) does not inherit the count.
+    # Paths whose memory-side projections run INSIDE the forward (per-row timesteps; attention maps wanted) project the NORMALISED
+    # memories (the memory LayerNorm comes first there), so the caller's scale cannot reach the split pairs: the same huge memories are
+    # served, match the oracle, and leave the census -- which belongs to the handle and is read at the end of the SAME call -- clean.
     Be = inp["sample"].shape[0]
-    with pytest.raises(CfdError) as ei:
-        m(x, torch.full((Be,), t), hm, mem_mask_dict=masks)
-    assert ei.value.code == -5 and "memories" in str(ei.value)
+    want_huge, _ = denoiser_ref.denoiser_forward(sd, inp["sample"], t, huge, inp["masks"])
+    with torch.no_grad():
+        out3, _ = m(x, torch.full((Be,), t), hm, mem_mask_dict=masks)
+    assert rel_l2(out3.cpu().numpy(), want_huge) < 10 * FWD_TOL and float(read_debug(m, "sat", (1,))[0]) == 0
     keep = m.return_attention
     try:
         m.return_attention = True
-        with pytest.raises(CfdError) as ei:
-            m(x, torch.tensor(t), hm, mem_mask_dict=masks)
-        assert ei.value.code == -5
+        try:       # served from normalised memories (tile kernels) or refused (small problems keep the once-per-call projections): never clamped
+            with torch.no_grad():
+                out4, _ = m(x, torch.tensor(t), hm, mem_mask_dict=masks)
+            assert rel_l2(out4.cpu().numpy(), want_huge) < 10 * FWD_TOL
+        except CfdError as e:
+            assert e.code == -5
     finally:
         m.return_attention = keep
+    # a failed call on one handle leaves the other handle (and the next call on this one) alone
+    with pytest.raises(CfdError):
+        m(x, torch.tensor(t), hm, mem_mask_dict=masks)
     with torch.no_grad():
-        out3, _ = m(x, torch.full((Be,), t), mems, mem_mask_dict=masks)                  # same handle, per-row path: clean
-        out4, _ = m(x, torch.tensor(t), mems, mem_mask_dict=masks, side_engine=True)      # the other handle: clean
-    assert rel_l2(out3.cpu().numpy(), want) < FWD_TOL and rel_l2(out4.cpu().numpy(), want) < FWD_TOL
+        out6, _ = m(x, torch.tensor(t), mems, mem_mask_dict=masks, side_engine=True)
+    assert rel_l2(out6.cpu().numpy(), want) < FWD_TOL
     # a sample outside the range is named as such
     with pytest.raises(CfdError) as ei:
         m(x * 1e6, torch.tensor(t), mems, mem_mask_dict=masks)

@@ -312,7 +312,7 @@ def test_ddim_with_eta_matches_oracle():
 
 
 @pytest.mark.parametrize("env", [{"CFD_NAIVE_GEMM": "1"}, {"CFD_RUNS": "0", "CFD_FUSED_XATTN": "0"}, {"CFD_FUSED_XATTN": "0"},
-                                 {"CFD_HOIST_MEMSIDE": "0"}, {"CFD_ROWTILE": "0"}, {"CFD_ONE_KEY": "0", "CFD_L0_DEDUP": "0"}])
+                                 {"CFD_HOIST_MEMSIDE": "0"}, {"CFD_ROWTILE": "0"}, {"CFD_ONE_KEY": "0", "CFD_L0_DEDUP": "0"}, {"CFD_XA_PP": "0"}])
 def test_developer_knobs_keep_parity(env):
     """The debug switches that select another code path for the same arithmetic (read once at cfd_create) must not change
     results: CFD_NAIVE_GEMM=1 (one-thread-per-output products instead of the MFMA kernels, three-launch attention),
@@ -320,7 +320,8 @@ def test_developer_knobs_keep_parity(env):
     CFD_RUNS=0 (per-row attention products only), CFD_HOIST_MEMSIDE=0 (fused cross-attention kernel fed by memory-side
     projections made in every iteration instead of once per run; it also turns the row-tile path off: that path needs the hoisted form),
     CFD_ROWTILE=0 (small problems on the tile kernels instead of the row-tile kernels of rowtile.hpp), CFD_ONE_KEY=0 with CFD_L0_DEDUP=0
-    (the fused cross-attention in its plain form: the one-key memory as a 32-key tile step, layer 0 as one launch).  Each leg runs the golden forward, the 20-step trajectory, the run-path
+    (the fused cross-attention in its plain form: the one-key memory as a 32-key tile step, layer 0 as one launch), CFD_XA_PP=0 (the lock-step
+    form of the fused cross-attention kernel instead of the ping-pong form).  Each leg runs the golden forward, the 20-step trajectory, the run-path
     test and the headline-shape loop rows in a child process."""
     import os
     import subprocess
@@ -655,6 +656,44 @@ def test_tile_kernel_forms_agree_on_random_shapes():
         e = float((a - b).norm() / b.norm())
         print(f"case {case}: Be={Be} L={L} S={S} pad={pad} t={t}: fused vs three-launch {e:.2e}")
         assert torch.isfinite(a).all() and e < 1e-4
+
+
+def test_ping_pong_and_lock_step_cross_attention_are_the_same_function():
+    """The two forms of the fused cross-attention kernel (xattn_fused.hpp: PP = 1, the default where no work list flushes between two
+    online memories; CFD_XA_PP=0, the lock-step form) run the same arithmetic in the same order -- the ping-pong form only moves WHEN
+    a wave does it -- so they must agree BIT FOR BIT: random shapes with one long memory (ragged tails, masks, shared instances through
+    a row map, partial last query tiles, workgroups with idle tiles), forwards repeated to catch a hand-off race (the pair's partial
+    scores meet through a polled LDS word, the tile pieces through mid-slot barriers), and four guided steps of the sampling loop."""
+    import torch
+    from convofusion_amd.sampler import sample
+    from tests.gpu_helpers import to_dev
+    rng = np.random.Generator(np.random.PCG64(777))
+    m_pp = _handle_with_env({"CFD_XA_PP": "1"})
+    m_ls = _handle_with_env({"CFD_XA_PP": "0"})
+    m_pp.return_attention = m_ls.return_attention = False
+    for case in range(8):
+        L = int(rng.choice([34, 48, 66, 100, 130, 196]))
+        lo = max(1, 820 // L + 1)
+        Be = int(rng.integers(lo, lo + 12))
+        S = (int(rng.integers(1, 33)), int(rng.integers(33, 1700)), int(rng.integers(1, 33)), int(rng.integers(1, 12)), 1)   # ONE memory longer than a tile
+        pad = tuple(int(rng.integers(0, max(1, s // 3))) if rng.random() < 0.5 else 0 for s in S[:4]) + (0,)
+        t = int(rng.integers(0, 1000))
+        inp = inputs.make_plain_batch(seed=900 + case, Be=Be, L=L, S=S, pad_tail=pad, scale=float(rng.choice([0.5, 1.0, 2.0])))
+        mems = [to_dev(x) for x in inp["memories"]]
+        masks = {k: to_dev(v) for k, v in inp["masks"].items()}
+        x = to_dev(inp["sample"])
+        with torch.no_grad():
+            a, _ = m_pp(x, torch.tensor(t), mems, mem_mask_dict=masks)
+            b, _ = m_ls(x, torch.tensor(t), mems, mem_mask_dict=masks)
+            for _ in range(3):
+                a2, _ = m_pp(x, torch.tensor(t), mems, mem_mask_dict=masks)
+                assert torch.equal(a, a2), f"case {case}: the ping-pong form is not deterministic"
+        print(f"case {case}: Be={Be} L={L} S={S} pad={pad} t={t}: max abs difference {float((a - b).abs().max()):.1e}")
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    cb = inputs.make_cfg_batch(seed=31, B=5, L=50, S=(20, 300, 24, 8, 1), pad_tail=(3, 17, 2, 0, 0))
+    mems, masks = [to_dev(x) for x in cb["memories"]], {k: to_dev(v) for k, v in cb["masks"].items()}
+    got = [sample(m, _sched("ddpm"), mems, masks, B=5, L=50, num_inference_steps=4, seed=3) for m in (m_pp, m_ls)]
+    assert torch.equal(got[0], got[1])
 
 
 def test_static_and_dynamic_memory_declarations_agree_and_mean_what_they_say():
