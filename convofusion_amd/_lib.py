@@ -134,7 +134,7 @@ def load():
     lib.cfd_sample_position.argtypes = [C.c_void_p]
     lib.cfd_sample_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.cfd_scheduler_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                       C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+                                       C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     lib.cfd_add_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_size_t, C.c_void_p]
     lib.cfd_philox_normal.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint32,

@@ -1984,12 +1984,13 @@ extern "C" int cfd_sample_read(cfd_handle c, float* out, int close) {
 }
 
 // ---- stand-alone scheduler ops ----------------------------------------------------------------------------
-__global__ void sched_step_kernel(const float* eps, const float* noise, float* x, size_t n, StepCoef c, int kind, int clip) {
+__global__ void sched_step_kernel(const float* eps, const float* noise, float* x, size_t n, StepCoef c, int kind, int clip, float* x0_out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float e = eps[i], xv = x[i];
   float x0 = (xv - c.sb * e) / c.sa;
   if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+  if (x0_out) x0_out[i] = x0;
   float prev = (kind == 0) ? c.c0 * x0 + c.cx * xv : c.c0 * x0 + c.cx * e;
   if (c.use_noise != 0.f) prev = prev + c.sigma * noise[i];
   x[i] = prev;
@@ -2001,7 +2002,7 @@ __global__ void add_noise_kernel(const float* x0, const float* noise, float* out
 
 extern "C" int cfd_scheduler_step(cfd_handle c, int scheduler, const float* ac, int T, int n_inf, int t, int clip, float eta,
                                   int set_alpha_to_one, const float* model_output, const float* noise, float* sample_inout,
-                                  size_t numel, void* stream) {
+                                  size_t numel, float* pred_original_sample, void* stream) {
   if (!c || !ac || !model_output || !sample_inout || t < 0 || t >= T || n_inf < 1) return fail(CFD_E_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->cfg.device));
   StepCoef k;
@@ -2009,7 +2010,7 @@ extern "C" int cfd_scheduler_step(cfd_handle c, int scheduler, const float* ac, 
   else ddim_coef(ac, T, n_inf, t, eta, set_alpha_to_one, &k);
   if (k.use_noise != 0.f && !noise) return fail(CFD_E_ARG, "this step adds noise: pass the N(0,1) draw");
   hipLaunchKernelGGL(sched_step_kernel, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, (hipStream_t)stream, model_output, noise,
-                     sample_inout, numel, k, scheduler, clip);
+                     sample_inout, numel, k, scheduler, clip, pred_original_sample);
   HIPCHK(hipGetLastError());
   return CFD_OK;
 }

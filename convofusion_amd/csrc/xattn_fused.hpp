@@ -704,7 +704,9 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     __builtin_amdgcn_s_barrier();
   }
   };   // pp_loop
-  if (grp) pp_loop(std::integral_constant<int, 1>{}); else pp_loop(std::integral_constant<int, 0>{});
+  if (nseg > 0) {   // (the idle workgroups that pad the list have no tile to request; the branch is uniform over the workgroup)
+    if (grp) pp_loop(std::integral_constant<int, 1>{}); else pp_loop(std::integral_constant<int, 0>{});
+  }
   } else {
   for (int si = 0; si < nseg; ++si) {
     const bool in_seg = active && ((cmask >> tile) & 1);   // wave-uniform, the same for both waves of a pair

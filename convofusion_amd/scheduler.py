@@ -98,14 +98,15 @@ class _SchedulerBase:
         if needs_noise and noise is None:
             noise = torch.randn(eps.shape, generator=generator, device=eps.device, dtype=eps.dtype)
         acp, acp_p = self._acp_host()
+        x0 = torch.empty_like(x)     # the x0 estimate the step forms on the way (diffusers: SchedulerOutput.pred_original_sample)
         lib = _lib.load()
         with torch.cuda.device(x.device):
             _lib.check(lib.cfd_scheduler_step(
                 _ops_handle(x.device), self.KIND, acp_p, self.config.num_train_timesteps, n_inf, t,
                 1 if self.config.clip_sample else 0, float(eta), 1 if self.config.get("set_alpha_to_one", True) else 0,
                 C.c_void_p(eps.data_ptr()), C.c_void_p(noise.data_ptr()) if noise is not None else None,
-                C.c_void_p(x.data_ptr()), x.numel(), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
-        return x
+                C.c_void_p(x.data_ptr()), x.numel(), C.c_void_p(x0.data_ptr()), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        return x, x0
 
 
 class DDPMScheduler(_SchedulerBase):
@@ -152,8 +153,8 @@ class DDPMScheduler(_SchedulerBase):
         self.timesteps = torch.from_numpy(timesteps).to(device)
 
     def step(self, model_output, timestep, sample, generator=None, return_dict=True, variance_noise=None):
-        prev = self._step(model_output, timestep, sample, 0.0, variance_noise, generator)
-        return SchedulerOutput(prev_sample=prev) if return_dict else (prev,)
+        prev, x0 = self._step(model_output, timestep, sample, 0.0, variance_noise, generator)
+        return SchedulerOutput(prev_sample=prev, pred_original_sample=x0) if return_dict else (prev,)
 
 
 class DDIMScheduler(_SchedulerBase):
@@ -187,5 +188,5 @@ class DDIMScheduler(_SchedulerBase):
             raise NotImplementedError("use_clipped_model_output")
         if self.num_inference_steps is None:
             raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
-        prev = self._step(model_output, timestep, sample, eta, variance_noise, generator)
-        return SchedulerOutput(prev_sample=prev) if return_dict else (prev,)
+        prev, x0 = self._step(model_output, timestep, sample, eta, variance_noise, generator)
+        return SchedulerOutput(prev_sample=prev, pred_original_sample=x0) if return_dict else (prev,)

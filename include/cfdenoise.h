@@ -173,6 +173,8 @@ int cfd_sample_read(cfd_handle h, float* out, int close);
 int cfd_scheduler_step(cfd_handle h, int scheduler, const float* alphas_cumprod, int num_train_timesteps,
                        int num_inference_steps, int t, int clip_sample, float eta, int set_alpha_to_one,
                        const float* model_output, const float* noise, float* sample_inout, size_t numel,
+                       float* pred_original_sample /* dev [numel] or NULL: the (clipped) x0 estimate the step forms,
+                       SchedulerOutput.pred_original_sample (read at convofusion.py:619) */,
                        void* stream);
 int cfd_add_noise(cfd_handle h, const float* alphas_cumprod_host, int t, const float* original,
                   const float* noise, float* out, size_t numel, void* stream);

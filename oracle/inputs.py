@@ -74,3 +74,27 @@ def make_plain_batch(seed, Be, L, S, pad_tail=(0, 0, 0, 0, 0), scale=1.0):
         else:
             masks[MEM_NAMES[j]] = None
     return dict(sample=sample, memories=mems, masks=masks)
+
+
+def add_outlier_tokens(mem, seed, frac=0.03, factor=30.0):
+    """A copy of ``mem`` [rows, S, 512] in which ``frac`` of the tokens (at least one per tensor) are ``factor`` times larger and a
+    handful of single features are 100 times larger: what encoder outputs look like next to Gaussian test memories."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = mem.copy()
+    rows, S, D = out.shape
+    n = max(1, int(frac * rows * S))
+    r, s = rng.integers(0, rows, n), rng.integers(0, S, n)
+    out[r, s] *= F32(factor)
+    k = max(1, n // 2)
+    out[rng.integers(0, rows, k), rng.integers(0, S, k), rng.integers(0, D, k)] *= F32(100.0)
+    return out
+
+
+def make_outlier_batch(seed, Be, L, S, pad_tail=(0, 0, 0, 0, 0)):
+    """``make_plain_batch`` with outlier tokens / features in every memory and a few large latent entries."""
+    inp = make_plain_batch(seed, Be, L, S, pad_tail)
+    inp["memories"] = [add_outlier_tokens(m, seed + 10 + j) for j, m in enumerate(inp["memories"])]
+    rng = np.random.Generator(np.random.PCG64(seed + 99))
+    k = max(1, Be * L // 50)
+    inp["sample"][rng.integers(0, Be, k), rng.integers(0, L, k)] *= F32(8.0)
+    return inp

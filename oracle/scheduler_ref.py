@@ -110,6 +110,7 @@ class DDPMSchedulerRef(_Tables):
         prev = (c0 * x0 + cx * sample).astype(F32)
         if int(t) > 0:
             prev = (prev + sigma * noise).astype(F32)
+        self.pred_original_sample = x0      # diffusers: SchedulerOutput.pred_original_sample (read by convofusion.py:619)
         return prev
 
 
@@ -146,4 +147,5 @@ class DDIMSchedulerRef(_Tables):
         prev = (sp * x0 + dirc * model_output).astype(F32)
         if eta > 0:
             prev = (prev + std * noise).astype(F32)
+        self.pred_original_sample = x0
         return prev

@@ -52,3 +52,29 @@ def rel_l2(a, b):
 
 def max_abs(a, b):
     return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())
+
+
+@functools.lru_cache(maxsize=2)
+def heavy_state_dict(gain=20.0):
+    """gain 20: the single forwards; gain 8: the guided 50-step loop (at 20 it is chaotic: oracle/weights.py)."""
+    return weights.make_state_dict_heavy(seed=777, gain=gain)
+
+
+def heavy_case(name):
+    """(inputs dict, t, expected output, expected listener-text maps) of tests/golden/heavy.npz (made by make_golden_heavy.py from the
+    imported reference on oracle.weights.make_state_dict_heavy)."""
+    g = load_golden("heavy")
+    meta = [int(x) for x in g[name + "_meta"]]
+    Be, L, S, pad, t = meta[0], meta[1], tuple(meta[2:7]), tuple(meta[7:12]), meta[12]
+    inp = inputs.make_outlier_batch(seed=50 + len(name), Be=Be, L=L, S=S, pad_tail=pad)
+    return inp, t, g[name], g[name + "_att2"]
+
+
+def heavy_traj_case():
+    """(guidance batch with outlier tokens, B, L, steps, seed, golden npz) of the 50-step DDIM trajectory in heavy.npz."""
+    g = load_golden("heavy")
+    meta = [int(x) for x in g["traj_meta"]]
+    B, L, S, pad, n, seed = meta[0], meta[1], tuple(meta[2:7]), tuple(meta[7:12]), meta[12], meta[13]
+    cb = inputs.make_cfg_batch(seed=seed, B=B, L=L, S=S, pad_tail=pad)
+    cb["memories"] = [inputs.add_outlier_tokens(u, seed + j)[rm] for j, (u, rm) in enumerate(zip(cb["unique"], cb["row_map"]))]
+    return cb, B, L, n, seed, g

@@ -265,3 +265,31 @@ def test_out_of_range_memories_are_refused_not_clamped():
     with torch.no_grad():
         out5, _ = m(x, torch.tensor(t), mems, mem_mask_dict=masks)
     assert torch.equal(out, out5)
+
+
+def test_heavy_tailed_weights_stress_case():
+    """Stand-in for the trained checkpoint that cannot be loaded here (README.md:52-57): weights with outlier LayerNorm gains, outlier and
+    near-zero (fp16-subnormal ``hi``) rows in the FFN / in-projection matrices, memories with outlier tokens and features
+    (oracle.weights.make_state_dict_heavy, oracle.inputs.make_outlier_batch).  Goldens from the imported reference
+    (tests/golden/make_golden_heavy.py): one forward on the row-tile path, one on the tile kernels (fused cross-attention), within the
+    tolerance of the uniform-weight goldens; the listener-text attention maps; the saturation census must stay clean (or the call must
+    fail with CFD_E_RANGE -- never a silently clamped operand)."""
+    import torch
+    from convofusion_amd.denoiser import Denoiser
+    from tests.gpu_helpers import ABL, DENOISER_KW, dev_inputs, read_debug, to_dev
+    from tests.helpers import heavy_case, heavy_state_dict
+    m = Denoiser(ablation=ABL, **DENOISER_KW)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in heavy_state_dict().items()}, strict=True)
+    m = m.cuda().eval()
+    for name in ("fwd_small", "fwd_tile"):
+        inp, t, want, want_att = heavy_case(name)
+        mems, masks = dev_inputs(inp)
+        for ra in (False, True):
+            m.return_attention = ra
+            with torch.no_grad():
+                out, att = m(to_dev(inp["sample"]), torch.tensor(t), mems, mem_mask_dict=masks)
+            e = rel_l2(out.cpu().numpy(), want)
+            ea = max_abs(att[2].cpu().numpy(), want_att) if ra else 0.0
+            print(f"{name} (attention maps {'on' if ra else 'off'}): rel {e:.2e}, listener-text maps max abs {ea:.2e}, census {float(read_debug(m, 'sat', (1,))[0])}")
+            # (maps: the outlier gains make the logits large -- the numpy oracle and the torch reference, both float32, differ by 3e-3 there)
+            assert e < FWD_TOL and ea < 1e-2 and float(read_debug(m, "sat", (1,))[0]) == 0

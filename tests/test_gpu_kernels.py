@@ -92,12 +92,15 @@ def test_scheduler_step_and_add_noise(kind):
         np.testing.assert_array_equal(s.timesteps.numpy(), r.timesteps)
         for t in (int(r.timesteps[0]), int(r.timesteps[n // 2]), int(r.timesteps[-1])):
             if kind == "ddpm":
-                got = s.step(torch.from_numpy(eps).cuda(), t, torch.from_numpy(x).cuda(), variance_noise=torch.from_numpy(z).cuda()).prev_sample
+                out = s.step(torch.from_numpy(eps).cuda(), t, torch.from_numpy(x).cuda(), variance_noise=torch.from_numpy(z).cuda())
                 want = r.step(eps, t, x, noise=z)
             else:
-                got = s.step(torch.from_numpy(eps).cuda(), t, torch.from_numpy(x).cuda(), eta=0.0).prev_sample
+                out = s.step(torch.from_numpy(eps).cuda(), t, torch.from_numpy(x).cuda(), eta=0.0)
                 want = r.step(eps, t, x)
-            np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(out.prev_sample.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+            # the x0 estimate the step forms on the way (the reference's training path reads it: convofusion.py:619)
+            np.testing.assert_allclose(out.pred_original_sample.cpu().numpy(), r.pred_original_sample, rtol=2e-5, atol=2e-5)
+            assert float(out.pred_original_sample.abs().max()) <= 1.0      # clip_sample
     got = s.add_noise(torch.from_numpy(x).cuda(), torch.from_numpy(z).cuda(), torch.tensor([321]))
     np.testing.assert_allclose(got.cpu().numpy(), r.add_noise(x, z, np.array([321])), rtol=1e-6, atol=1e-6)
 

@@ -774,3 +774,29 @@ def test_utterance_shards_equal_the_single_run(kind):
                 part.steps(n)
                 got.append(part.read(close=True))
         assert torch.equal(torch.cat(got), want), sorted(kw)
+
+
+def test_heavy_tailed_weights_ddim50_trajectory():
+    """50 guided DDIM steps (eta = 0: nothing damps a perturbation, the hardest case for the split-pair arithmetic) on the heavy-tailed
+    stress weights with outlier-token memories, against the trajectory the restated loop produced driving the REFERENCE denoiser
+    (tests/golden/heavy.npz, make_golden_heavy.py): the 1e-3 budget must hold with outliers in weights and conditioning too."""
+    import torch
+    from convofusion_amd.denoiser import Denoiser
+    from convofusion_amd.sampler import SamplingRun
+    from tests.gpu_helpers import ABL, DENOISER_KW, to_dev
+    from tests.helpers import heavy_state_dict, heavy_traj_case
+    cb, B, L, n, seed, g = heavy_traj_case()
+    m = Denoiser(ablation=ABL, **DENOISER_KW)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in heavy_state_dict(8.0).items()}, strict=True)   # (outlier factor 8: at 20 the loop is chaotic, oracle/weights.py)
+    m = m.cuda().eval()
+    init = philox_ref.normal_tensor(seed, 0, range(B), 1, L)
+    run = SamplingRun(m, _sched("ddim"), [to_dev(x) for x in cb["memories"]], {k: to_dev(v) for k, v in cb["masks"].items()}, B, L, n,
+                      guidance_scale=7.5, init_latents=to_dev(init), eta=0.0)
+    errs = {}
+    for k in (1, 10, 50):
+        run.steps(k - run.position)
+        errs[k] = rel_l2(run.read().cpu().numpy(), g[f"traj_step{k}"])
+    lat = run.read(close=True).permute(1, 0, 2).cpu().numpy()
+    errs["final"] = rel_l2(lat, g["traj"])
+    print("heavy-tailed ddim50:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert np.isfinite(lat).all() and all(v < TRAJ_TOL for v in errs.values()), errs

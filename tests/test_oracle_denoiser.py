@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import denoiser_ref, weights
-from tests.helpers import forward_case, max_abs, rel_l2, state_dict
+from tests.helpers import forward_case, heavy_case, heavy_state_dict, heavy_traj_case, max_abs, rel_l2, state_dict
 
 
 def test_state_dict_layout():
@@ -72,3 +72,24 @@ def test_torch_restatement_matches_reference_golden(name):
     for j in range(5):
         ref = g[f"att{j}"]
         assert max_abs(att[j].numpy()[: ref.shape[0]], ref) < 2e-4
+
+
+def test_heavy_tailed_weights_against_the_reference():
+    """The oracle on the heavy-tailed stress weights (outlier LayerNorm gains, outlier / near-zero FFN and in-projection rows, memories
+    with outlier tokens: the stand-in for the trained checkpoint that cannot be loaded here) against the imported reference's outputs
+    (tests/golden/heavy.npz), and the first 10 steps of the guided 50-step DDIM loop."""
+    from oracle import philox_ref, sampler_ref, scheduler_ref
+    sd = heavy_state_dict()
+    for name in ("fwd_small", "fwd_tile"):
+        inp, t, want, want_att = heavy_case(name)
+        out, att = denoiser_ref.denoiser_forward(sd, inp["sample"], t, inp["memories"], inp["masks"])
+        # (the outlier gains make the logits large, so two float32 evaluations of one softmax already differ by ~3e-3 in a probability:
+        #  numpy oracle vs torch reference here; the OUTPUT budget is unchanged)
+        assert rel_l2(out, want) < 1e-4 and max_abs(att[2], want_att) < 1e-2
+    cb, B, L, n, seed, g = heavy_traj_case()
+    sd8 = heavy_state_dict(8.0)
+    _, snaps, _ = sampler_ref.diffusion_reverse(
+        lambda x, t, e, mk: denoiser_ref.denoiser_forward(sd8, x, t, e, mk), scheduler_ref.DDIMSchedulerRef(), cb["memories"], cb["masks"],
+        philox_ref.normal_tensor(seed, 0, range(B), 1, L), lambda i, t: philox_ref.normal_tensor(seed, i, range(B), 0, L),
+        guidance_scale=7.5, num_inference_steps=n, eta=0.0, keep_steps=(1, 10), stop_after=10)
+    assert rel_l2(snaps[1], g["traj_step1"]) < 1e-4 and rel_l2(snaps[10], g["traj_step10"]) < 1e-3
