@@ -94,6 +94,23 @@ __device__ __forceinline__ void sp_store8(char* row_base, int col, const float* 
   *reinterpret_cast<spx8*>(p + 64) = l;
 }
 
+// sp_store8 for values that may legitimately be NaN (LayerNorm outputs and probabilities of a row whose softmax had nothing but masked
+// keys: the reference returns NaN for such a row, from the attention on through every later LayerNorm to the output).  split_f32's clamp
+// (v_med3_f32 returns the minimum of the other two operands for a NaN) would store -65504, a finite and wrong operand; here the NaN is kept.
+__device__ __forceinline__ void sp_store8_keep_nan(char* row_base, int col, const float* v) {
+  spx8 h, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sp_t a, b;
+    split_f32(v[e], a, b);
+    h[e] = (v[e] != v[e]) ? (sp_t)v[e] : a;
+    l[e] = b;
+  }
+  char* p = row_base + (size_t)(col >> 5) * 128 + (col & 31) * 2;
+  *reinterpret_cast<spx8*>(p) = h;
+  *reinterpret_cast<spx8*>(p + 64) = l;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

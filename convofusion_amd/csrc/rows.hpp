@@ -59,7 +59,9 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const LnArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e] * scv[e] + shv[e]);
   }
-  sp_store8(a.out + row * (CFD_D * 4), lane * 8, v);
+  // (a NaN anywhere in the row -- a token whose cross-attention had nothing but masked keys -- makes the whole row NaN, as in the
+  //  reference's LayerNorm; the store keeps it a NaN so that it reaches the output: cfd_common.hpp)
+  sp_store8_keep_nan(a.out + row * (CFD_D * 4), lane * 8, v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -275,7 +277,7 @@ struct SoftmaxArgs {
 // segment, so a row costs one load->reduce->store round for all of them instead of one serialised round each.
 __device__ __forceinline__ void softmax_store(const SoftmaxArgs& a, int g, int b, int l, char* prow, int c0, float* v) {
   const int S = a.S[g];
-  sp_store8(prow, a.off[g] + c0, v);
+  sp_store8_keep_nan(prow, a.off[g] + c0, v);   // (an all-masked row's probabilities are NaN, like the reference's)
   if (a.att[g]) {
     float* att = a.att[g] + (((long long)b * a.nl + a.layer) * a.rows_per_b + l) * S;
 #pragma unroll

@@ -137,7 +137,12 @@ __device__ __forceinline__ float rt_rcp(float x) {
   const float r = __builtin_amdgcn_rcpf(x);
   return fmaf(fmaf(-x, r, 1.0f), r, r);
 }
-__device__ __forceinline__ float rt_silu(float x) { return x * rt_rcp(1.0f + __expf(-x)); }
+// sigmoid(x) = 1 / (1 + exp(-x)).  The exponent is clamped at 80: for x < -88.7 exp(-x) is +inf in float32 and the Newton step of rt_rcp
+// turns 1 / inf into inf * 0 = NaN -- which split_f32's v_med3 then "clamps" to -65504 (found by the heavy-tailed stress weights:
+// tests/golden/make_golden_heavy.py; AdaLN inputs below -89 do not occur with the uniform test weights).  exp(80) = 5.5e34 keeps every
+// intermediate a normal number; the result differs from the exact one by less than 2e-35 |x|.
+__device__ __forceinline__ float rt_sigmoid(float x) { return rt_rcp(1.0f + __expf(fminf(-x, 80.0f))); }
+__device__ __forceinline__ float rt_silu(float x) { return x * rt_sigmoid(x); }
 
 // store 4 consecutive columns (c0 % 4 == 0) of row r into the image
 __device__ __forceinline__ void rt_lstore4(char* img, int r, int c0, const float* v) {
@@ -146,7 +151,7 @@ __device__ __forceinline__ void rt_lstore4(char* img, int r, int c0, const float
   for (int e = 0; e < 4; ++e) {
     sp_t a, b;
     split_f32(v[e], a, b);
-    h[e] = a;
+    h[e] = (v[e] != v[e]) ? (sp_t)v[e] : a;   // a NaN stays a NaN (split_f32's v_med3 clamp would make it -65504): see ln_rows_kernel
     l[e] = b;
   }
   const int sw = (r >> 1) & 7, ch = (c0 & 31) >> 3, half = ((c0 & 31) >> 2) & 1;

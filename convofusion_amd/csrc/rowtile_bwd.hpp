@@ -81,7 +81,7 @@ __device__ __forceinline__ void rt_ln_bwd_row(float (&dy)[4][4], float (&xv)[4][
       float d = dy[i][e];
       if constexpr (TB) {                                 // through SiLU and the modulation: h = LN(x) (1 + scale) + shift
         const float h = (xv[i][e] * gam[i][e] + bet[i][e]) * s1[i][e] + sh[i][e];
-        const float sg = rt_rcp(1.0f + __expf(-h));   // (the forward's rt_silu: one Newton step on v_rcp, v_exp)
+        const float sg = rt_sigmoid(h);               // (the forward's rt_silu: one Newton step on v_rcp, v_exp, exponent clamped)
         d *= (sg * (1.0f + h * (1.0f - sg))) * s1[i][e];
       }
       d *= gam[i][e];

@@ -293,3 +293,33 @@ def test_heavy_tailed_weights_stress_case():
             print(f"{name} (attention maps {'on' if ra else 'off'}): rel {e:.2e}, listener-text maps max abs {ea:.2e}, census {float(read_debug(m, 'sat', (1,))[0])}")
             # (maps: the outlier gains make the logits large -- the numpy oracle and the torch reference, both float32, differ by 3e-3 there)
             assert e < FWD_TOL and ea < 1e-2 and float(read_debug(m, "sat", (1,))[0]) == 0
+
+
+@pytest.mark.parametrize("shape", ["row_tile", "tile_kernels"])
+def test_a_row_with_a_fully_masked_memory_is_nan_like_the_reference(shape):
+    """A batch row whose key-padding mask covers EVERY key of a memory has a softmax over nothing: the reference's MultiheadAttention
+    returns NaN there, the residual stream of that row becomes NaN and stays NaN through every later LayerNorm, so the row's whole output
+    is NaN while the other rows are untouched.  The HIP path must do the same -- in particular the split-pair stores must not turn the
+    NaN into a clamped, finite operand (split_f32's v_med3 maps NaN to -65504)."""
+    import torch
+    from oracle import denoiser_ref
+    from tests.gpu_helpers import dev_inputs, hip_denoiser, to_dev
+    Be, L, S = (5, 16, (6, 20, 6, 8, 1)) if shape == "row_tile" else (9, 100, (20, 70, 24, 8, 1))
+    inp = inputs.make_plain_batch(seed=606, Be=Be, L=L, S=S, pad_tail=(2, 0, 3, 0, 0))
+    inp["masks"]["tlsn"][1, :] = True
+    sd = state_dict()
+    want, _ = denoiser_ref.denoiser_forward(sd, inp["sample"], 300, inp["memories"], inp["masks"])
+    assert np.isnan(want[1]).all() and np.isfinite(np.delete(want, 1, axis=0)).all()      # what the reference's arithmetic gives
+    m = hip_denoiser(1234, 1.0)
+    mems, masks = dev_inputs(inp)
+    keep = m.return_attention
+    try:
+        for ra in (False, True):
+            m.return_attention = ra
+            with torch.no_grad():
+                out, _ = m(to_dev(inp["sample"]), torch.tensor(300), mems, mem_mask_dict=masks)
+            out = out.cpu().numpy()
+            assert np.isnan(out[1]).all(), f"{shape}, attention maps {ra}: the masked row came out finite"
+            assert rel_l2(np.delete(out, 1, axis=0), np.delete(want, 1, axis=0)) < FWD_TOL
+    finally:
+        m.return_attention = keep
