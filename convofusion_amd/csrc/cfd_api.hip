@@ -183,7 +183,8 @@ struct cfd_handle_s {
   bool fused_xattn = true;
   int fused_xattn_min_wgs = 6;
   int one_key = 1;              // CFD_ONE_KEY=0: a one-key memory (lsnemb) keeps its 32-key tile step in the fused cross-attention
-  int xa_pp = 1;                // CFD_XA_PP=0: the lock-step form of the fused cross-attention kernel everywhere (xattn_fused.hpp; parity / timing A/B)
+  int xa_pp = 0;                // form of the fused cross-attention kernel (xattn_fused.hpp): CFD_XA_PP=0 lock-step, every wave requests its share of every
+                                // sub-buffer (rounds 2-4); 1 ping-pong (two wave groups one sub-phase apart); 2 lock-step, requests divided between the groups
   int l0_dedup = 1;             // CFD_L0_DEDUP=0: layer 0's cross-attention as one launch over all rows (build_xattn_layer0_lists)
   // Row-tile path for small problems (rowtile.hpp): chosen by SHAPE -- at most rt_max_rows token rows of at most RT_MAX_L tokens per batch
   // row, one timestep for all rows, no dynamic memories.  CFD_ROWTILE=0 turns it off (parity A/B against the tile kernels),
@@ -349,7 +350,7 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   env = getenv("CFD_L0_DEDUP");
   if (env) c->l0_dedup = atoi(env) != 0;
   env = getenv("CFD_XA_PP");
-  if (env) c->xa_pp = atoi(env) != 0;
+  if (env) c->xa_pp = atoi(env);
   env = getenv("CFD_ONE_KEY");
   if (env) c->one_key = atoi(env) != 0;
   env = getenv("CFD_ROWTILE");
@@ -654,17 +655,24 @@ static void make_xattn_worklist(const Problem& p, const std::vector<XaRow>& rows
     if (g < 0) { g = (int)groups.size(); groups.emplace_back(); }
     groups[g].push_back((int)r);
   }
+  // Query tiles per workgroup.  A workgroup has room for XA_TILES = 4 (its K / V^T tiles then serve 64 queries), but a short list must
+  // first of all FILL THE CHIP: at the product shape (L = 16: one tile per batch row) 32 utterances are 224 tiles = 56 workgroups for 256
+  // CUs, each walking 14 segment steps because its four rows use different instances of the short memories (a pass per instance).  With
+  // one tile per workgroup (six of the eight waves only request tile pieces) that is 224 workgroups of 9 steps: half the launch time.
+  // Halve while the list stays at or below 128 workgroups.
+  int tpw = XA_TILES;
+  while (tpw > 1 && (rows.size() * (size_t)nqt + tpw - 1) / tpw <= 128) tpw /= 2;
   std::vector<std::vector<XaWg>> group_wgs(groups.size());
   for (size_t g = 0; g < groups.size(); ++g) {
     std::vector<std::pair<int, int>> tiles;   // (row of `rows`, first query)
     for (int r : groups[g])
       for (int t = 0; t < nqt; ++t) tiles.emplace_back(r, t * 16);
-    for (size_t t0 = 0; t0 < tiles.size(); t0 += XA_TILES) {
+    for (size_t t0 = 0; t0 < tiles.size(); t0 += tpw) {
       XaWg w;
       memset(&w, 0, sizeof(w));
       int vr[XA_TILES];
       for (int k = 0; k < XA_TILES; ++k) {
-        const bool on = t0 + k < tiles.size();
+        const bool on = k < tpw && t0 + k < tiles.size();
         vr[k] = on ? tiles[t0 + k].first : -1;
         w.row[k] = on ? rows[vr[k]].xrow : -1;
         w.aux[k] = on ? rows[vr[k]].aux : -1;
@@ -788,7 +796,9 @@ static int build_xattn_worklist(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
   // 1.318 s three-launch, four utterances (7 workgroups) 1.370 against 1.404, 16 (28 workgroups, one shard of the product-shape
   // benchmark) 470 against 465 steps/s.  Below 6 workgroups the three-launch path stays (CFD_FUSED_XATTN_MIN_WGS overrides;
   // the test suite sets 0 and runs its small cases through the fused kernel).
-  if ((int)n_active < c->fused_xattn_min_wgs) return CFD_OK;
+  // (counted in workgroups of four query tiles, as measured -- the list itself may deal fewer tiles per workgroup: make_xattn_worklist)
+  if ((int)(((size_t)p.Be * ((p.L + 15) / 16) + XA_TILES - 1) / XA_TILES) < c->fused_xattn_min_wgs) return CFD_OK;
+  (void)n_active;
   CHK(upload_worklist(c->w->xa_wgs, c->w->xa_segs, wgs, segs));
   p.xa_nwg = (int)wgs.size();
   return CFD_OK;
@@ -1429,6 +1439,7 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
     attr |= 1ull << (c->cfg.device & 63);
   }
 
@@ -1507,9 +1518,10 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       a.stamps = c->w->xa_stamps.as<long long>();
 #endif
       Bracket br(c, CFD_PROF_XATTN, st);
-      const bool pp = c->xa_pp && !p.xa_flush;   // the ping-pong form has no flush between two online memories
+      const int form = (c->xa_pp == 1 && p.xa_flush) ? 2 : c->xa_pp;   // the ping-pong form has no flush between two online memories
       auto launch_xa = [&](int nwg, const XAttnArgs& xa) {
-        if (pp) hipLaunchKernelGGL(xattn_fused_kernel<1>, dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
+        if (form == 1) hipLaunchKernelGGL(xattn_fused_kernel<1>, dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
+        else if (form == 2) hipLaunchKernelGGL(xattn_fused_kernel<2>, dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
         else hipLaunchKernelGGL(xattn_fused_kernel<0>, dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
       };
       if (l == 0 && share && p.xa0_nwg_a > 0) {   // layer-0 de-duplication (build_xattn_layer0_lists): the longest memory once per distinct (utterance, instance) ...

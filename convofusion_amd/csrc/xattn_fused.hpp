@@ -176,6 +176,10 @@ __device__ __forceinline__ T xa_sel(const T (&arr)[CFD_NMEM], int j) {
 // PP = 0: the lock-step form described above (every wave in the same sub-phase; pairs (w, w + 4) share a SIMD).
 // PP = 1: the ping-pong form (round 5; see the comment in front of its loop): waves 0-3 run one sub-phase AHEAD of waves 4-7, so that
 //         on every SIMD one wave's softmax / waits / fill issue lie next to the other wave's MFMAs; pairs are (w, w ^ 1).
+// PP = 2: the lock-step form with the REQUESTS divided between the wave groups instead of among all waves (round 5): waves 0-3 request
+//         the K sub-buffers, waves 4-7 the V^T ones, eight pieces per wave (fill_k8 / fill_v8).  With every wave requesting, both waves
+//         of a SIMD sit in the LDS-DMA issue together (100+ cycles per piece: the CU's one texture path takes the pieces one after the
+//         other) and the matrix pipe idles; a requesting wave beside a computing one costs the computing wave nothing.
 template <int PP>
 __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -186,12 +190,12 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
 #endif
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tile = PP ? (wid >> 2) * 2 + ((wid >> 1) & 1) : (wid & 3);   // query tile of the pair
-  int half_ = PP ? (wid & 1) : (wid >> 2);                                 // which half of the 512-long axes
-  if (PP) asm volatile("" : "+s"(half_));   // (opaque: knowing that it is 0 or 1, hipcc turns the prologue's `half ? r[16 + i] : r[i]` selects into an INDEXED row array in scratch memory)
+  const int tile = PP == 1 ? (wid >> 2) * 2 + ((wid >> 1) & 1) : (wid & 3);   // query tile of the pair
+  int half_ = PP == 1 ? (wid & 1) : (wid >> 2);                                 // which half of the 512-long axes
+  if (PP == 1) asm volatile("" : "+s"(half_));   // (opaque: knowing that it is 0 or 1, hipcc turns the prologue's `half ? r[16 + i] : r[i]` selects into an INDEXED row array in scratch memory)
   const int half = half_;
-  const int grp = PP ? (wid >> 2) : 0;                                     // ping-pong form: 0 = the early group, 1 = the late one
-  const int partner = PP ? (wid ^ 1) : (wid ^ 4);
+  const int grp = PP ? (wid >> 2) : 0;                                     // ping-pong form: 0 = the early group, 1 = the late one; PP = 2: who requests what
+  const int partner = PP == 1 ? (wid ^ 1) : (wid ^ 4);
   const int l15 = lane & 15, q4 = lane >> 4, sw = l15 >> 1;
   const int cpos = lane & 7, rsub = lane >> 3;
 
@@ -207,7 +211,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
 
   // the segment list of this workgroup -> LDS (read back with ds_read: no vector-memory traffic inside the loop)
   if (threadIdx.x < nseg) reinterpret_cast<int4*>(smem + XA_SEGOFF)[threadIdx.x] = reinterpret_cast<const int4*>(a.segs + seg0)[threadIdx.x];
-  if (PP && threadIdx.x < XA_WAVES) reinterpret_cast<int*>(smem + XA_FLAGOFF)[threadIdx.x] = 0;
+  if (PP == 1 && threadIdx.x < XA_WAVES) reinterpret_cast<int*>(smem + XA_FLAGOFF)[threadIdx.x] = 0;
 
   // Q fragments (B operand) of this wave's half of the feature axis, made here from the residual stream:
   //   q = LayerNorm2(x[token])  (cross_attention.py:578; two-pass mean / variance like ln_rows_kernel, eps 1e-5).
@@ -317,6 +321,12 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   //      V^T tile LDS image: [feature 512][128 B]; Va = features [0,128) + [256,384), Vb = the rest.  Piece n of wave `wid`:
   //      8-row group g = wid + 8 (n&1) + 32 (n>>1) (+16 for Vb); swizzle ((f>>1)&7) = ((wid&1)<<2) | (rsub>>1)
   const int vsw = (cpos ^ (((wid & 1) << 2) | (rsub >> 1))) << 4;
+  //      ping-pong form (fill_k8 / fill_v8 below: eight pieces per wave of ONE group): the same images cut over w4 = the wave's index in its group
+  const int w4 = wid & 3;
+  const int kr8 = (w4 & 1) * 8 + rsub;
+  const int ksrc8_lane = (8 * (kr8 >> 2) + (kr8 & 3)) * (CFD_D * 4) + (w4 >> 1) * 128 + ((cpos ^ ((kr8 >> 1) & 7)) << 4);
+  const int kdst8_wave = KOFF + (w4 >> 1) * 4096 + (w4 & 1) * 1024;
+  const int vsw8 = (cpos ^ (((w4 & 1) << 2) | (rsub >> 1))) << 4;
 
   // A tile = 32 keys of one memory instance: its K rows, its V^T column block, its key bias; rowb = bytes per V^T feature
   // row of that memory; vlane = this lane's byte offset inside a V^T piece (depends on rowb).  All but vlane are wave-uniform.
@@ -334,7 +344,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     t.v = xa_sel(a.VT, j) + (long long)u * CFD_D * Sp * 4;
     t.cb = xa_sel(a.cb, j) + (long long)u * Sp;
     t.rowb = (long long)Sp * 4;
-    t.vlane = (unsigned)((wid * 8 + rsub) * Sp * 4 + vsw);    // (512 rows x Sp x 4 B < 4 GiB)
+    t.vlane = PP ? (unsigned)((w4 * 8 + rsub) * Sp * 4 + vsw8) : (unsigned)((wid * 8 + rsub) * Sp * 4 + vsw);    // (512 rows x Sp x 4 B < 4 GiB)
     t.cblane = (unsigned)((lane & 31) * 4) + (lane >= 32 ? xa_sel(a.rs_off, j) : 0u);   // lanes 0-31: key bias, lanes 32-63: key scale
   };
   // fills: K half `hb` (0: Ka, 1: Kb) of tile `t`; with Ka travels the key bias and key scale of the tile (1 piece: 64 x 4 B:
@@ -365,6 +375,38 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       const char* b = t.v + (long long)g * 8 * t.rowb;
       asm volatile("" : "+v"(vl), "+s"(b));
       __builtin_amdgcn_global_load_lds((gptr_t)(b + vl), (lptr_t)(smem + VOFF + (wid + g) * 1024), 16, 0, 0);
+    }
+  };
+
+  // Ping-pong form: a sub-buffer is requested by ONE group (four waves, one per SIMD), eight pieces per wave, while the other group
+  // computes: with all eight waves issuing together both waves of every SIMD are held by the LDS-DMA issue at the same time (100+ cycles
+  // per piece, the CU's one texture path takes them one after the other) and the matrix pipe idles; a filling wave beside a computing
+  // wave costs the computing wave nothing.  w4 = the wave's index in its group.  K half hb: piece n = rows (w4 & 1) * 8 .. + 7 of
+  // k-step (w4 >> 1) + 2 n; V^T half hb: 8-row groups w4 + 4 (n & 3) + 32 (n >> 2) + 16 hb (swizzle parity = w4 & 1 as above).
+  auto fill_k8 = [&](const Tile& t, int hb, int slot) __attribute__((always_inline)) {
+    if (XA_ABLATE & 1) return;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      unsigned kl = (unsigned)ksrc8_lane;
+      const char* b = t.k + hb * (4 * CFD_D * 4) + n * 256;
+      asm volatile("" : "+v"(kl), "+s"(b));
+      __builtin_amdgcn_global_load_lds((gptr_t)(b + kl), (lptr_t)(smem + kdst8_wave + hb * 2048 + n * 8192), 16, 0, 0);
+    }
+    if (hb == 0) {
+      unsigned cl = t.cblane;
+      asm volatile("" : "+v"(cl));
+      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(t.cb) + cl), (lptr_t)(smem + XA_CBOFF + slot * 256), 4, 0, 0);
+    }
+  };
+  auto fill_v8 = [&](const Tile& t, int hb) __attribute__((always_inline)) {
+    if (XA_ABLATE & 1) return;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      unsigned vl = t.vlane;
+      const int g = 4 * (n & 3) + 32 * (n >> 2) + 16 * hb;
+      const char* b = t.v + (long long)g * 8 * t.rowb;
+      asm volatile("" : "+v"(vl), "+s"(b));
+      __builtin_amdgcn_global_load_lds((gptr_t)(b + vl), (lptr_t)(smem + VOFF + (w4 + g) * 1024), 16, 0, 0);
     }
   };
 
@@ -549,7 +591,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   int cT = 1, cmask = 0, cflags = 0, cj = 0, nT = 1, nmask = 0, nflags = 0, nj = 0;
   if (nseg > 0) seg_tile(0, cur, cT, cmask, cflags, cj);
   XA_T(0);
-  if constexpr (PP) {
+  if constexpr (PP == 1) {
   // ---- The ping-pong form (round 5) -------------------------------------------------------------------------------------------
   // In the lock-step form both waves of a SIMD are in the same sub-phase all the time: they want the matrix pipe together, do the
   // softmax together (the pipe idles), issue their fills together (LDS-DMA issue holds a wave for 100+ cycles per piece) and meet
@@ -577,16 +619,16 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   // SGPR-base + lane-offset address form (as branches inside one loop hipcc merged the branches' tails into 64-bit per-lane addresses).
   auto pp_loop = [&](auto grp_c) __attribute__((always_inline)) {
   constexpr int GRP = decltype(grp_c)::value;
-  // pieces 0-2 of the stream; piece p is requested at b(p - 3)
-  fill_k(cur, 0, 0);
-  fill_k(cur, 1, 0);
-  fill_v(cur, 0);
-  XA_WAIT_VM_LGKM0(8);               // Ka + key bias landed
+  // Piece p is requested at b(p - 3) by ONE group, alternately: Ka (+ key bias) and Va by the late group, Kb and Vb by the early one --
+  // at every barrier the requesting group is the one whose SIMD partner is busiest (Ka goes out while the early group does its softmax,
+  // Kb while the late group does).  A wave therefore has at most one request (8 - 9 pieces) in flight, and "my share of piece k + 1 has
+  // landed" is vmcnt(0) at every second barrier and nothing at the others.  Pieces 0 - 2 of the stream:
+  if constexpr (GRP) { fill_k8(cur, 0, 0); fill_v8(cur, 0); } else { fill_k8(cur, 1, 0); }
+  if constexpr (GRP) XA_WAIT_VM_LGKM0(8); else XA_WAIT_VM_LGKM0(63);   // Ka + key bias landed (Va is younger)
   __builtin_amdgcn_s_barrier();      // b(-1)
   if constexpr (GRP) {               // the late group: its slot 0 is b(0) .. b(1)
-    XA_WAIT_VM_LGKM0(4);             // Kb landed
-    __builtin_amdgcn_s_barrier();    // b(0)
-    fill_v(cur, 1);                  // piece 3
+    XA_WAIT_VM_LGKM0(63);
+    __builtin_amdgcn_s_barrier();    // b(0)  (the early group requests Vb behind it)
   }
   read_k(fa, 0, 0);
   XA_T(0);
@@ -615,10 +657,10 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     if (in_seg) mfma_k(s0, fa, 0);
     __builtin_amdgcn_sched_barrier(0);
     XA_T(1);
-    XA_WAIT_VM_LGKM0(4);                 // group 0: Kb landed (Va is younger); group 1: Va landed (Vb is younger)
+    XA_WAIT_VM_LGKM0(0);                 // group 0: its Kb has landed; group 1: its Va has landed
     __builtin_amdgcn_s_barrier();        // mid-A0
     XA_T(2);
-    if constexpr (GRP) fill_k(nxt, 0, slot ^ 1); else fill_v(cur, 1);
+    if constexpr (GRP) fill_k8(nxt, 0, slot ^ 1); else fill_v8(cur, 1);
     read_k(fa, 1, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (in_seg) {
@@ -632,10 +674,9 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     if (in_seg) mfma_k(s1, fa, 0);
     __builtin_amdgcn_sched_barrier(0);
     XA_T(3);
-    if constexpr (GRP) XA_WAIT_VM_LGKM0(5); else XA_WAIT_VM_LGKM0(4);   // group 0: Va landed (Vb younger); group 1: Vb landed (the next Ka + key bias younger)
+    XA_WAIT_VM_LGKM0(63);                // (the piece this barrier publishes belongs to the other group; this group's request stays in flight)
     __builtin_amdgcn_s_barrier();        // mid-A1
     XA_T(4);
-    if constexpr (GRP) fill_k(nxt, 1, slot ^ 1); else fill_k(nxt, 0, slot ^ 1);
     read_v(fa, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (in_seg) {
@@ -659,9 +700,9 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     if (in_seg) mfma_v(fa, 0);
     __builtin_amdgcn_sched_barrier(0);
     XA_T(5);
-    if constexpr (GRP) XA_WAIT_VM_LGKM0(4); else XA_WAIT_VM_LGKM0(5);   // group 0: Vb landed (the next Ka + key bias younger); group 1: the next Ka landed (Kb younger)
+    XA_WAIT_VM_LGKM0(0);                 // group 0: its Vb has landed; group 1: its next Ka + key bias
     __builtin_amdgcn_s_barrier();        // mid-B0
-    if constexpr (GRP) fill_v(nxt, 0); else fill_k(nxt, 1, slot ^ 1);
+    if constexpr (GRP) fill_v8(nxt, 0); else fill_k8(nxt, 1, slot ^ 1);
     read_v(fa, 2);
     __builtin_amdgcn_sched_barrier(0);
     if (in_seg) mfma_v(fb, 1);
@@ -672,10 +713,9 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     if (in_seg) mfma_v(fa, 2);
     __builtin_amdgcn_sched_barrier(0);
     XA_T(7);
-    XA_WAIT_VM_LGKM0(4);                 // group 0: the next Ka + key bias landed (Kb younger); group 1: the next Kb landed (Va younger)
+    XA_WAIT_VM_LGKM0(63);
     __builtin_amdgcn_s_barrier();        // mid-B1
     XA_T(8);
-    if constexpr (GRP) fill_v(nxt, 1); else fill_v(nxt, 0);
     read_k(fa, 0, 0);                    // first half of the next step's A0
     __builtin_amdgcn_sched_barrier(0);
     if (in_seg) mfma_v(fb, 3);
@@ -708,6 +748,10 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     if (grp) pp_loop(std::integral_constant<int, 1>{}); else pp_loop(std::integral_constant<int, 0>{});
   }
   } else {
+  // (PP = 2: one instance of the loop per group, chosen once: which group requests what is then compile-time and the fills keep their
+  //  SGPR-base + lane-offset form -- see the ping-pong form)
+  auto ls_loop = [&](auto grp_c) __attribute__((always_inline)) {
+  constexpr int GRP = decltype(grp_c)::value;     // PP = 0: always 0
   for (int si = 0; si < nseg; ++si) {
     const bool in_seg = active && ((cmask >> tile) & 1);   // wave-uniform, the same for both waves of a pair
     const bool online = (cflags & XA_ONLINE) != 0;
@@ -731,10 +775,14 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     nxt.cblane = last_in_seg ? nseg_t.cblane : cur.cblane;
     const int slot = step & 1;
     if (!primed) {   // (re)start of the pipeline: Ka (+ key bias), Kb, Va of this step; Vb follows behind mid-A0
+      if constexpr (PP == 2) {
+        if constexpr (GRP) { fill_v8(cur, 0); XA_WAIT_VM_LGKM0(63); } else { fill_k8(cur, 0, slot); fill_k8(cur, 1, slot); XA_WAIT_VM_LGKM0(8); }
+      } else {
       fill_k(cur, 0, slot);
       fill_k(cur, 1, slot);
       fill_v(cur, 0);
       XA_WAIT_VM_LGKM0(8);               // Ka + key bias landed
+      }
       __builtin_amdgcn_s_barrier();
       read_k(fa, 0, 0);
       primed = true;
@@ -747,10 +795,11 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     if (in_seg) mfma_k(s0, fa, 0);
     __builtin_amdgcn_sched_barrier(0);
     XA_T(1);
-    XA_WAIT_VM_LGKM0(4);                 // Kb landed (one fill of 4 pieces is younger); this wave's reads of Ka's first half are done
+    if constexpr (PP == 2) { if constexpr (GRP) XA_WAIT_VM_LGKM0(63); else XA_WAIT_VM_LGKM0(0); }   // the K group's Kb has landed
+    else XA_WAIT_VM_LGKM0(4);            // Kb landed (one fill of 4 pieces is younger); this wave's reads of Ka's first half are done
     __builtin_amdgcn_s_barrier();        // mid-A0: Kb ready; every wave is done with Vb
     XA_T(2);
-    fill_v(cur, 1);
+    if constexpr (PP == 2) { if constexpr (GRP) fill_v8(cur, 1); } else fill_v(cur, 1);
     read_k(fa, 1, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (in_seg) {
@@ -771,8 +820,11 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     XA_WAIT_VM_LGKM0(0);                 // Va and Vb landed (nothing younger is in flight); partial scores written
     __builtin_amdgcn_s_barrier();        // end of A1: the whole V^T tile ready, partial scores visible, every wave is done with Ka and Kb
     XA_T(4);
+    if constexpr (PP == 2) { if constexpr (!GRP) { fill_k8(nxt, 0, slot ^ 1); fill_k8(nxt, 1, slot ^ 1); } }
+    else {
     fill_k(nxt, 0, slot ^ 1);
     fill_k(nxt, 1, slot ^ 1);
+    }
     read_v(fa, 0);
     if (in_seg && !(XA_ABLATE & 8)) softmax_tile(s0, s1, slot, online);
     // ---- B0 (fa holds its first half) --------------------------------------------------------------------------------
@@ -792,10 +844,11 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     if (in_seg) mfma_v(fa, 2);
     __builtin_amdgcn_sched_barrier(0);
     XA_T(7);
-    XA_WAIT_VM_LGKM0(4);                 // next Ka + key bias landed (the next Kb, 4 pieces, is younger)
+    if constexpr (PP == 2) { if constexpr (GRP) XA_WAIT_VM_LGKM0(63); else XA_WAIT_VM_LGKM0(8); }   // the K group's next Ka + key bias (its Kb, 8 pieces, is younger)
+    else XA_WAIT_VM_LGKM0(4);            // next Ka + key bias landed (the next Kb, 4 pieces, is younger)
     __builtin_amdgcn_s_barrier();        // mid-B1: next Ka ready; every wave is done with Va
     XA_T(8);
-    fill_v(nxt, 0);
+    if constexpr (PP == 2) { if constexpr (GRP) fill_v8(nxt, 0); } else fill_v(nxt, 0);
     read_k(fa, 0, 0);                    // first half of the next step's A0
     __builtin_amdgcn_sched_barrier(0);
     if (in_seg) mfma_v(fb, 3);
@@ -827,6 +880,9 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     wl = 0.f;
     cT = nT; cmask = nmask; cflags = nflags; cj = nj;   // (cur already points at the next segment's first tile)
   }
+  };   // ls_loop
+  if constexpr (PP == 2) { if (grp) ls_loop(std::integral_constant<int, 1>{}); else ls_loop(std::integral_constant<int, 0>{}); }
+  else ls_loop(std::integral_constant<int, 0>{});
   }   // lock-step form
   XA_WAIT_VM_LGKM0(0);
   __builtin_amdgcn_s_barrier();   // last B1 done everywhere and the trailing (unused) fills have landed: the tile buffers become the epilogue strips

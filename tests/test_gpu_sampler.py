@@ -312,7 +312,7 @@ def test_ddim_with_eta_matches_oracle():
 
 
 @pytest.mark.parametrize("env", [{"CFD_NAIVE_GEMM": "1"}, {"CFD_RUNS": "0", "CFD_FUSED_XATTN": "0"}, {"CFD_FUSED_XATTN": "0"},
-                                 {"CFD_HOIST_MEMSIDE": "0"}, {"CFD_ROWTILE": "0"}, {"CFD_ONE_KEY": "0", "CFD_L0_DEDUP": "0"}, {"CFD_XA_PP": "0"}])
+                                 {"CFD_HOIST_MEMSIDE": "0"}, {"CFD_ROWTILE": "0"}, {"CFD_ONE_KEY": "0", "CFD_L0_DEDUP": "0"}, {"CFD_XA_PP": "0"}, {"CFD_XA_PP": "1"}])
 def test_developer_knobs_keep_parity(env):
     """The debug switches that select another code path for the same arithmetic (read once at cfd_create) must not change
     results: CFD_NAIVE_GEMM=1 (one-thread-per-output products instead of the MFMA kernels, three-launch attention),
@@ -320,8 +320,8 @@ def test_developer_knobs_keep_parity(env):
     CFD_RUNS=0 (per-row attention products only), CFD_HOIST_MEMSIDE=0 (fused cross-attention kernel fed by memory-side
     projections made in every iteration instead of once per run; it also turns the row-tile path off: that path needs the hoisted form),
     CFD_ROWTILE=0 (small problems on the tile kernels instead of the row-tile kernels of rowtile.hpp), CFD_ONE_KEY=0 with CFD_L0_DEDUP=0
-    (the fused cross-attention in its plain form: the one-key memory as a 32-key tile step, layer 0 as one launch), CFD_XA_PP=0 (the lock-step
-    form of the fused cross-attention kernel instead of the ping-pong form).  Each leg runs the golden forward, the 20-step trajectory, the run-path
+    (the fused cross-attention in its plain form: the one-key memory as a 32-key tile step, layer 0 as one launch), CFD_XA_PP=0 / 1 (the other
+    two forms of the fused cross-attention kernel: every wave requesting its share of every tile piece; ping-pong).  Each leg runs the golden forward, the 20-step trajectory, the run-path
     test and the headline-shape loop rows in a child process."""
     import os
     import subprocess
@@ -658,24 +658,25 @@ def test_tile_kernel_forms_agree_on_random_shapes():
         assert torch.isfinite(a).all() and e < 1e-4
 
 
-def test_ping_pong_and_lock_step_cross_attention_are_the_same_function():
-    """The two forms of the fused cross-attention kernel (xattn_fused.hpp: PP = 1, the default where no work list flushes between two
-    online memories; CFD_XA_PP=0, the lock-step form) run the same arithmetic in the same order -- the ping-pong form only moves WHEN
-    a wave does it -- so they must agree BIT FOR BIT: random shapes with one long memory (ragged tails, masks, shared instances through
-    a row map, partial last query tiles, workgroups with idle tiles), forwards repeated to catch a hand-off race (the pair's partial
-    scores meet through a polled LDS word, the tile pieces through mid-slot barriers), and four guided steps of the sampling loop."""
+def test_the_three_forms_of_the_fused_cross_attention_are_the_same_function():
+    """The three forms of the fused cross-attention kernel (xattn_fused.hpp: CFD_XA_PP=0 lock-step with every wave requesting its share of
+    every sub-buffer; 1 ping-pong, two wave groups one sub-phase apart; 2 -- the default -- lock-step with the requests divided between
+    the wave groups) run the same arithmetic in the same order -- they only move WHEN a wave does it and WHO requests a tile piece -- so
+    they must agree BIT FOR BIT: random shapes with one or two long memories (two: the accumulator flush, which form 1 hands to form 2),
+    ragged tails, masks, partial last query tiles, workgroups with idle tiles; forwards repeated to catch a hand-off race (the ping-pong
+    pair's partial scores meet through a polled LDS word, the tile pieces through mid-slot barriers); four guided steps of the loop."""
     import torch
     from convofusion_amd.sampler import sample
     from tests.gpu_helpers import to_dev
     rng = np.random.Generator(np.random.PCG64(777))
-    m_pp = _handle_with_env({"CFD_XA_PP": "1"})
-    m_ls = _handle_with_env({"CFD_XA_PP": "0"})
-    m_pp.return_attention = m_ls.return_attention = False
-    for case in range(8):
+    ms = [_handle_with_env({"CFD_XA_PP": str(f)}) for f in (0, 1, 2)]
+    for m in ms:
+        m.return_attention = False
+    for case in range(10):
         L = int(rng.choice([34, 48, 66, 100, 130, 196]))
         lo = max(1, 820 // L + 1)
         Be = int(rng.integers(lo, lo + 12))
-        S = (int(rng.integers(1, 33)), int(rng.integers(33, 1700)), int(rng.integers(1, 33)), int(rng.integers(1, 12)), 1)   # ONE memory longer than a tile
+        S = (int(rng.integers(1, 33)) if case % 4 else int(rng.integers(33, 90)), int(rng.integers(33, 1700)), int(rng.integers(1, 33)), int(rng.integers(1, 12)), 1)
         pad = tuple(int(rng.integers(0, max(1, s // 3))) if rng.random() < 0.5 else 0 for s in S[:4]) + (0,)
         t = int(rng.integers(0, 1000))
         inp = inputs.make_plain_batch(seed=900 + case, Be=Be, L=L, S=S, pad_tail=pad, scale=float(rng.choice([0.5, 1.0, 2.0])))
@@ -683,17 +684,17 @@ def test_ping_pong_and_lock_step_cross_attention_are_the_same_function():
         masks = {k: to_dev(v) for k, v in inp["masks"].items()}
         x = to_dev(inp["sample"])
         with torch.no_grad():
-            a, _ = m_pp(x, torch.tensor(t), mems, mem_mask_dict=masks)
-            b, _ = m_ls(x, torch.tensor(t), mems, mem_mask_dict=masks)
-            for _ in range(3):
-                a2, _ = m_pp(x, torch.tensor(t), mems, mem_mask_dict=masks)
-                assert torch.equal(a, a2), f"case {case}: the ping-pong form is not deterministic"
-        print(f"case {case}: Be={Be} L={L} S={S} pad={pad} t={t}: max abs difference {float((a - b).abs().max()):.1e}")
-        assert torch.isfinite(a).all() and torch.equal(a, b)
+            outs = [m(x, torch.tensor(t), mems, mem_mask_dict=masks)[0] for m in ms]
+            for f, m in enumerate(ms):
+                for _ in range(2):
+                    again, _ = m(x, torch.tensor(t), mems, mem_mask_dict=masks)
+                    assert torch.equal(outs[f], again), f"case {case}: form {f} is not deterministic"
+        print(f"case {case}: Be={Be} L={L} S={S} pad={pad} t={t}: max abs difference to form 0: {[float((o - outs[0]).abs().max()) for o in outs[1:]]}")
+        assert torch.isfinite(outs[0]).all() and torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0])
     cb = inputs.make_cfg_batch(seed=31, B=5, L=50, S=(20, 300, 24, 8, 1), pad_tail=(3, 17, 2, 0, 0))
     mems, masks = [to_dev(x) for x in cb["memories"]], {k: to_dev(v) for k, v in cb["masks"].items()}
-    got = [sample(m, _sched("ddpm"), mems, masks, B=5, L=50, num_inference_steps=4, seed=3) for m in (m_pp, m_ls)]
-    assert torch.equal(got[0], got[1])
+    got = [sample(m, _sched("ddpm"), mems, masks, B=5, L=50, num_inference_steps=4, seed=3) for m in ms]
+    assert torch.equal(got[1], got[0]) and torch.equal(got[2], got[0])
 
 
 def test_static_and_dynamic_memory_declarations_agree_and_mean_what_they_say():
