@@ -268,6 +268,28 @@ def secondary_configs(model, device):
         sample(model, ddpm, mems, masks, B=1, L=L, num_inference_steps=1000, seed=0)
         sync()
         dt = time.perf_counter() - t0
+        # every iteration's attention maps kept (the reference's default dict, convofusion.py:517-523): the captured iteration stores them
+        sample(model, ddpm, mems, masks, B=1, L=L, num_inference_steps=4, seed=0, return_attention="all")
+        sync()
+        t0 = time.perf_counter()
+        _, atts_all = sample(model, ddpm, mems, masks, B=1, L=L, num_inference_steps=1000, seed=0, return_attention="all")
+        sync()
+        dt_all = time.perf_counter() - t0
+        assert len(atts_all) == 1000
+        del atts_all
+        # set-up of a run (cfd_sample_begin): with the timestep-only tables built for another timestep list / served from the handle's cache
+        SamplingRun(model, ddpm, mems, masks, 1, L, 500, guidance_scale=7.5, seed=0).close()
+        sync()
+        t0 = time.perf_counter()
+        r_ = SamplingRun(model, ddpm, mems, masks, 1, L, 1000, guidance_scale=7.5, seed=0)
+        sync()
+        setup_first = time.perf_counter() - t0
+        r_.close()
+        t0 = time.perf_counter()
+        r_ = SamplingRun(model, ddpm, mems, masks, 1, L, 1000, guidance_scale=7.5, seed=0)
+        sync()
+        setup_repeat = time.perf_counter() - t0
+        r_.close()
         # SURVEY.md section 8d, B = 1 at the product shape: float32 weights once per step + the memories read by each of the 9
         # layers + the latents (in, 7 replicas of eps out)
         n_w = sum(p.numel() for p in model.parameters()) * 4
@@ -275,6 +297,8 @@ def secondary_configs(model, device):
         ach = alg_bytes / (dt / 1000) / 1e9
         out["c1_single_utterance"] = {"s_per_1000": dt, "steps_per_s": 1000 / dt, "launches_per_step": c1_launches,
                                       "gpu_us_per_step": t_gpu / 900 * 1e6, "host_enqueue_us_per_step": t_enq / 900 * 1e6,
+                                      "all_attention_maps_s_per_1000": dt_all, "all_attention_maps_over_last": dt_all / dt,
+                                      "setup_ms_first": setup_first * 1e3, "setup_ms_repeat": setup_repeat * 1e3,
                                       "workload": f"B=1 (denoiser batch {G}), L={L}, S={S}, 1000-step DDPM end to end through sample()",
                                       "roofline": {"bound": "latency", "launches_per_step": c1_launches, "us_per_launch": t_gpu / 900 * 1e6 / max(c1_launches, 1),
                                                    "algorithmic_bytes_per_step": alg_bytes, "algorithmic_bytes_rate_GBps": ach,

@@ -60,7 +60,7 @@ class SampleArgs(C.Structure):
                 ("step_noise", C.c_void_p), ("seed", C.c_uint64), ("first_utterance", C.c_uint32),
                 ("preseq", C.c_void_p), ("preseq_len", C.c_int), ("mem", Memory * NUM_MEM),
                 ("skip_zero_weight_chunks", C.c_int), ("dynamic_memory_mask", C.c_int),
-                ("timesteps", C.c_void_p), ("num_timesteps", C.c_int)]
+                ("timesteps", C.c_void_p), ("num_timesteps", C.c_int), ("att_ring", C.c_void_p * NUM_MEM)]
 
 
 class WegArgs(C.Structure):

@@ -77,6 +77,10 @@ struct Problem {
   const uint8_t* mask[CFD_NMEM];
   int has_mask[CFD_NMEM];
   float* att[CFD_NMEM];
+  // attention ring of a sampling run (cfd_sample_args::att_ring): only the batch rows [att_b0, att_b0 + att_nb) write their maps, into
+  // slot *d_step of att[j] (att_slot[j] floats per slot), as rows 0 .. att_nb - 1 of that slot.  att_nb == 0: att[j] is one [Be][nl][L][S_j] block.
+  int att_b0 = 0, att_nb = 0;
+  long long att_slot[CFD_NMEM] = {0, 0, 0, 0, 0};
   int tmode = 0;  // 0: all rows share the timestep of table row *d_step ; 1: row b uses table row b
   // Sampling loop only: the effective batch is G replicas (chunk-major) of the same B latent rows, so everything
   // before the first cross-attention -- embedding, layer 0's self-attention and first time block -- is identical
@@ -135,6 +139,12 @@ struct Work {
   DBuf d_step;  // [0] = loop index, [1] = constant 0, [2] = "this iteration's in-painting overwrite is done" (cfd_sample_inpaint)
   DBuf rt_vt, rt_cbt[CFD_NMEM];   // row-tile path: V^T of the self-attention, per-step key tables
   DBuf rt_cur;                    // row-tile path, sampling run: this step's rows of every per-step table (rt_step_rows_kernel)
+  // What the timestep-only tables of this workspace were built from: the table rows' timesteps and the weights' generation.  temb / AdaLN
+  // rows (20 launches) and, per memory, A_l b_t / VV_l b_t (kbtab / vbtab: two products each) depend on nothing else, so a run that
+  // finds them built for its own timestep list skips them (the rollout opens eleven 1000-step runs per sample, unbounded_synthesis.py:285-468).
+  std::vector<int32_t> tt_key;
+  long long tt_wver = -1;
+  int tt_mem_mask = 0;            // bit j: kbtab[j] / vbtab[j] (and b_tab / b_sp / bsq) hold the products for tt_key
   // row-tile path: where the launches of the current problem find this step's AdaLN rows and A b / VV b vectors (the tables themselves
   // when they have one row, rt_cur otherwise); set by enqueue_rows_rt, read by the WEG reverse sweep (weg_rt.hpp)
   const float* now_ss = nullptr;
@@ -169,6 +179,8 @@ struct cfd_handle_s {
   // row-tile WEG evaluation, which runs between two replays of an open run and must not disturb it; `w` is the one in use
   Work wk[2];
   Work* w = &wk[0];
+  long long wver = 0;     // generation of the prepared weights (cfd_finalize_weights)
+  int setup_launches = 0; // launches the last cfd_sample_begin spent on timestep-only tables (0: served from the cache); test / bench read-out
   // saturation census of THIS handle (cfd_common.hpp): sat[CFD_SAT_MEM] weights / memories / their projections, sat[CFD_SAT_IN] the
   // sample / latents handed to an entry point.  Zeroed at the entry of the calls that count, read at their end.
   DBuf sat;
@@ -606,6 +618,7 @@ extern "C" int cfd_finalize_weights(cfd_handle c) {
   for (int j = 0; j < CFD_NMEM; ++j) { wk_f[j].release(); wv_f[j].release(); }
   tmpf.release(); tmpd1.release(); tmpd2.release(); vd1.release(); vd2.release(); accd.release();
   c->finalized = true;
+  ++c->wver;
   return CFD_OK;
 }
 
@@ -893,6 +906,8 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
     if (p.Sp[j] > SM_MAX_CHUNKS * 512) return fail(CFD_E_SHAPE, "memory %s: %d keys exceed the in-register softmax limit", MEM_NAMES[j], m.S);
     p.mem[j] = m.data; p.map[j] = m.row_map ? m.row_map : c->w->iota.as<int>(); p.mask[j] = m.key_padding_mask;
     p.att[j] = att ? att[j] : nullptr;
+    p.att_slot[j] = 0;
+    p.att_b0 = p.att_nb = 0;      // (a sampling run with an attention ring sets them after this call)
   }
   p.Sp_tot = off;
   {  // memories without a key-padding mask get an all-zero one, so the softmax kernel needs no null test
@@ -975,6 +990,10 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
     CHK(c->w->cb[j].ensure(rows * (nl + 1) * 4));   // + one plane: the per-key scale of the fused cross-attention kernel
     CHK(c->w->vt_all[j].ensure(rows * nl * CFD_D * 4));
   }
+  if (c->w->temb_tab.bytes < (size_t)T * CFD_D * 4 || c->w->ss_tab.bytes < (size_t)T * nl * 2 * 2 * CFD_D * 4) {
+    c->w->tt_key.clear();          // (a table that is reallocated is an empty one: the timestep-only tables are rebuilt)
+    c->w->tt_mem_mask = 0;
+  }
   CHK(c->w->temb_tab.ensure((size_t)T * CFD_D * 4));
   CHK(c->w->h1_tab.ensure((size_t)T * CFD_D * 4));
   CHK(c->w->ss_tab.ensure((size_t)T * nl * 2 * 2 * CFD_D * 4));
@@ -990,6 +1009,13 @@ static int build_time_tables(Ctx* c, const int32_t* trows_host, int T, hipStream
     if (trows_host[i] < 0 || trows_host[i] >= c->tsin_rows)
       return fail(CFD_E_ARG, "timestep %d outside the sinusoid table (0..%d)", trows_host[i], c->tsin_rows - 1);
   HIPCHK(hipMemcpyAsync(c->w->trows.p, trows_host, (size_t)T * 4, hipMemcpyHostToDevice, st));
+  Work* w = c->w;
+  const bool same = w->tt_wver == c->wver && (int)w->tt_key.size() == T && std::equal(w->tt_key.begin(), w->tt_key.end(), trows_host);
+  if (same) return CFD_OK;          // temb_tab / ss_tab already hold these rows (and kbtab / vbtab may: tt_mem_mask)
+  w->tt_key.assign(trows_host, trows_host + T);
+  w->tt_wver = c->wver;
+  w->tt_mem_mask = 0;
+  c->setup_launches += 2 + 2 * c->nl;
   return enqueue_time_tables(c, T, st);
 }
 
@@ -1054,19 +1080,27 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
   const bool fused = p.rt || (c->fused_xattn && p.xa_nwg > 0 && !want_att && !g_cfd_naive_gemm);
   if (!fused || !c->hoist_memside || p.tmode != 0) return CFD_OK;
   const int T = p.T;
+  if (c->w->b_tab.bytes < (size_t)T * CFD_D * 4 || c->w->b_sp.bytes < (size_t)T * CFD_D * 4 || c->w->bsq.bytes < (size_t)T * 4)
+    c->w->tt_mem_mask = 0;       // (a table that is reallocated is an empty one)
   CHK(c->w->b_tab.ensure((size_t)T * CFD_D * 4));
   CHK(c->w->b_sp.ensure((size_t)T * CFD_D * 4));
   CHK(c->w->bsq.ensure((size_t)T * 4));
-  LAUNCH(CFD_PROF_OTHER, temb_center_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), st, c->w->temb_tab.as<float>(), T, c->w->b_tab.as<float>(),
-         c->w->b_sp.as<char>(), c->w->bsq.as<float>());
+  if (c->w->tt_mem_mask == 0) {
+    c->w->tt_mem_mask = 0;
+    LAUNCH(CFD_PROF_OTHER, temb_center_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), st, c->w->temb_tab.as<float>(), T, c->w->b_tab.as<float>(),
+           c->w->b_sp.as<char>(), c->w->bsq.as<float>());
+    c->setup_launches += 1;
+  }
   for (int j = 0; j < CFD_NMEM; ++j) {
     if ((dynamic_mask >> j) & 1) continue;
     const int rows = p.U[j] * p.Sp[j];
     const int NK = nl * CFD_D + 32;
     CHK(c->w->ca[j].ensure((size_t)rows * nl * 4));
     CHK(c->w->asq[j].ensure((size_t)rows * 4));
+    if (c->w->kbtab[j].bytes < (size_t)T * NK * 4 || c->w->vbtab[j].bytes < (size_t)T * nl * CFD_D * 4) c->w->tt_mem_mask &= ~(1 << j);
     CHK(c->w->kbtab[j].ensure((size_t)T * NK * 4));
     CHK(c->w->vbtab[j].ensure((size_t)T * nl * CFD_D * 4));
+    const bool have_tb = (c->w->tt_mem_mask >> j) & 1;   // A_l b_t / VV_l b_t of this memory are already there for this timestep list
     MemCenterArgs ma{p.mem[j], p.U[j], p.S[j], p.Sp[j], rawp(c, "condition_embedding.weight") + (size_t)j * CFD_D, rawp(c, "mem_pos.pe"),
                      c->w->n_sp[j].as<char>(), c->w->asq[j].as<float>(), c->sat_mem()};
     LAUNCH(CFD_PROF_ROWS, mem_center_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), st, ma);
@@ -1086,7 +1120,7 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
       EpiMemV e{c->w->vt_all[j].as<char>(), p.Sp[j], p.U[j], c->sat_mem()};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }
-    {  // kbtab[t][:] = [A_l b_t for all l | c_l . b_t]
+    if (!have_tb) {  // kbtab[t][:] = [A_l b_t for all l | c_l . b_t]
       GemmArgs a = gemm_args();
       a.X[0] = c->wk_all_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = NK; a.Iclamp[0] = NK; a.kt[0] = CFD_D / 32;
       a.Y = c->w->b_sp.as<char>(); a.ldy = ROWB; a.J = T; a.Jclamp = T;
@@ -1095,7 +1129,7 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
       e.out = c->w->kbtab[j].as<float>(); e.ldo = NK;
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }
-    {  // vbtab[t][:] = VV_l b_t for all l
+    if (!have_tb) {  // vbtab[t][:] = VV_l b_t for all l
       GemmArgs a = gemm_args();
       a.X[0] = c->wv_all_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = nl * CFD_D; a.Iclamp[0] = nl * CFD_D; a.kt[0] = CFD_D / 32;
       a.Y = c->w->b_sp.as<char>(); a.ldy = ROWB; a.J = T; a.Jclamp = T;
@@ -1103,6 +1137,8 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
       memset(&e, 0, sizeof(e));
       e.out = c->w->vbtab[j].as<float>(); e.ldo = nl * CFD_D;
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
+      c->w->tt_mem_mask |= 1 << j;
+      c->setup_launches += 2;
     }
     p.static_mask |= 1 << j;
   }
@@ -1288,11 +1324,14 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
   int nkb = 0;
   for (int j = 0; j < CFD_NMEM; ++j) {
     xa.map[j] = p.map[j]; xa.rows[j] = p.U[j] * p.Sp[j]; xa.S[j] = p.S[j]; xa.Sp[j] = p.Sp[j]; xa.off[j] = p.off[j];
-    xa.cbt[j] = cbt_now[j]; xa.att[j] = p.att[j];
+    xa.cbt[j] = cbt_now[j]; xa.att[j] = p.att[j]; xa.att_slot[j] = p.att_slot[j];
     memcpy(xa.inst[j], p.rt_inst[j], RT_ARG_ROWS);
     xa.blk0[j] = nkb; nkb += p.Sp[j] / 16;
   }
   xa.blk0[CFD_NMEM] = nkb;
+  xa.att_b0 = p.att_nb > 0 ? p.att_b0 : 0;
+  xa.att_nb = p.att_nb > 0 ? p.att_nb : p.Be;
+  xa.att_step = p.att_nb > 0 ? c->w->d_step.as<int>() : nullptr;
   for (int l = 0; l < nl; ++l) {
     const LayerW& w = c->lw[l];
     char* qk = sv ? sv->qk[l] : c->w->qk_sp.as<char>();
@@ -1793,6 +1832,12 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
   hipStream_t st = (hipStream_t)stream;
   c->sargs = s;
   c->run_stream = st;
+  c->setup_launches = 0;
+  int n_ring = 0;
+  for (int j = 0; j < CFD_NMEM; ++j) n_ring += s.att_ring[j] != nullptr;
+  if (n_ring != 0 && n_ring != CFD_NMEM) return fail(CFD_E_ARG, "att_ring: give all five buffers or none");
+  if (n_ring && s.skip_zero_weight_chunks && s.G > 1 && s.guidance_weight[s.G - 1] == 0.0f)
+    return fail(CFD_E_ARG, "att_ring keeps the maps of the LAST guidance chunk: it must be evaluated (skip_zero_weight_chunks = 0)");
   if (s.skip_zero_weight_chunks)   // chunk-major batch: dropping trailing chunks = using the first G' * B rows
     while (c->sargs.G > 1 && s.guidance_weight[c->sargs.G - 1] == 0.0f) c->sargs.G -= 1;
   // N = loop iterations (the length of scheduler.timesteps); n_inf = the count given to set_timesteps, which fixes the
@@ -1848,6 +1893,23 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
   }
   CHK(setup_problem(c, Be, s.L, mem_in, nullptr, 0, N));
   if (c->share0 && c->sargs.G > 1) c->w->pb.share_B = s.B;   // begin_step_kernel writes G identical copies of the B rows
+  c->w->pb.att_nb = 0;
+  if (n_ring) {
+    // The reference keeps att_mats of the full-conditioning chunk of EVERY iteration (convofusion.py:517-523).  On the row-tile path the
+    // second cross-attention launch has the probabilities in registers anyway: the rows of the last chunk store them into slot *d_step
+    // of the caller's ring, inside the captured iteration -- no second forward, no host round trip.
+    Problem& pb = c->w->pb;
+    if (!pb.rt || s.dynamic_memory_mask)
+      return fail(CFD_E_SHAPE, "att_ring needs the row-tile path (one timestep per step, L <= %d, at most %lld token rows, at most %d padded keys, no "
+                               "dynamic memory): this run has L = %d, %lld token rows; take the maps with one forward per iteration instead",
+                  RT_MAX_L, c->rt_max_rows, RT_MAX_KEYS, s.L, (long long)Be * s.L);
+    pb.att_b0 = c->chunk_pos[c->sargs.G - 1] * s.B;
+    pb.att_nb = s.B;
+    for (int j = 0; j < CFD_NMEM; ++j) {
+      pb.att[j] = s.att_ring[j];
+      pb.att_slot[j] = (long long)s.B * c->nl * s.L * pb.S[j];
+    }
+  }
   CHK(build_xattn_layer0_lists(c, mem_in));
   // timesteps: (arange(N) * (T // N)).round()[::-1] (+ steps_offset for DDIM)
   std::vector<int32_t> ts(N);
@@ -2370,6 +2432,11 @@ extern "C" int cfd_debug_stop_stage(cfd_handle c, int stage) {
 extern "C" int cfd_debug_read(cfd_handle c, const char* what, float* dst_dev, size_t numel) {
   if (!c || !what || !dst_dev) return fail(CFD_E_ARG, "null argument");
   HIPCHK(hipSetDevice(c->cfg.device));
+  if (!strcmp(what, "setup_launches")) {   // launches the last cfd_sample_begin spent on timestep-only tables (0: all served from the cache)
+    const float f = (float)c->setup_launches;
+    HIPCHK(hipMemcpy(dst_dev, &f, 4, hipMemcpyHostToDevice));
+    return CFD_OK;
+  }
   if (!strcmp(what, "sat")) {   // the saturation census as one float (not cleared)
     unsigned int n[2] = {0, 0};
     HIPCHK(hipDeviceSynchronize());

@@ -565,7 +565,10 @@ struct RtXArgs {
   float* sc;                    // fp32 [M][Sp_tot]: e_s = exp(score_s - its cell's maximum)
   float* cst;                   // float4 [M][Sp_tot / 32]: per (token, cell) maximum, sum e_s, sum e_s rs_s
   float* rsp;                   // fp32 [M][Sp_tot]: rs of every key, repeated per token by the score launch
-  float* att[CFD_NMEM];         // optional att_mats [Be][nl][L][S_j]
+  float* att[CFD_NMEM];         // optional att_mats [Be][nl][L][S_j]; with att_step: a ring of such blocks for the rows [att_b0, att_b0 + att_nb)
+  int att_b0, att_nb;           // batch rows that write their maps (as rows 0 .. att_nb - 1 of the block)
+  const int* att_step;          // ring slot = *att_step (the sampling run's iteration counter), or null: one block
+  long long att_slot[CFD_NMEM]; // floats per slot
 };
 
 // The softmax of a memory is assembled from CELLS of 32 keys: the score launch leaves e_s = exp(score_s - m_c) and, per (token, cell),
@@ -811,11 +814,12 @@ __global__ void __launch_bounds__(512) rt_xpv_kernel(const RtXArgs a) {
       const float f = __expf(crow[c0 >> 5].x - sg.x) * sg.y;
 #pragma unroll
       for (int e = 0; e < 4; ++e) s[n][e] *= f;
-      if (any_att && fb == 0 && pr < nq) {
+      if (any_att && fb == 0 && pr < nq && b >= a.att_b0 && b < a.att_b0 + a.att_nb) {
         float* att = rt_sel(a.att, j);
         if (att) {
           const int S = rt_pick5(j, sz0, sz1, sz2, sz3, sz4);
-          float* ap = att + (((long long)b * a.nl + a.layer) * a.L + q0 + pr) * S;
+          if (a.att_step) att += (long long)(*a.att_step) * rt_sel(a.att_slot, j);
+          float* ap = att + (((long long)(b - a.att_b0) * a.nl + a.layer) * a.L + q0 + pr) * S;
           const int k0 = c0 - rt_pick5(j, 0, o1, o2, o3, o4);
 #pragma unroll
           for (int e = 0; e < 4; ++e)

@@ -111,6 +111,8 @@ static int enqueue(Ctx* c, hipStream_t st, bool full, const EvalArgs& e) {
   const int nl = c->nl, B = p.Be, L = p.L, tpr = (L + 15) / 16, ntile = B * tpr, St = p.S[2];
   const long long M = p.M;
   if (full) {
+    w->tt_key.clear();     // (this workspace's timestep-only tables are rebuilt from w->trows, whatever they held: cfd_api.hip, build_time_tables)
+    w->tt_mem_mask = 0;
     CHK(enqueue_time_tables(c, p.T, st));      // one row: the timestep index is in w->trows (copied in front of the launch sequence); full tables: row t = timestep t
     CHK(prepare_static_memside(c, st, 0, true));
     if (!p.rt) return fail(CFD_E_STATE, "row-tile WEG evaluation lost its path");

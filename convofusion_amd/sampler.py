@@ -113,8 +113,12 @@ class SamplingRun:
     def __init__(self, denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
                  guidance_scale=7.5, guidance_chunks=CFG_CHUNKS, eta=0.0, init_latents=None, step_noise=None,
                  seed=0, first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False, row_maps=None,
-                 dynamic_memories=(), side_engine=False):
-        """side_engine: open the run on the denoiser's second library handle (its own weights copy, workspace and stream), so that
+                 dynamic_memories=(), side_engine=False, attention_ring=False):
+        """attention_ring: keep the attention maps of the full-conditioning chunk of EVERY iteration (the reference's per-iteration dict,
+        convofusion.py:517-523): the captured iteration stores them into ``self.att_ring`` -- five tensors [iterations, B, layers, L, S_j]
+        -- with no extra forward and no host round trip (cfd_sample_args.att_ring; small problems only: the library answers CFD_E_SHAPE
+        otherwise and ``sample`` then takes the maps with one forward per iteration).  ``attention_dict()`` turns the ring into the dict.
+        side_engine: open the run on the denoiser's second library handle (its own weights copy, workspace and stream), so that
         two runs on one module can be open at once (the attention forward of ``last_step_attention`` uses it for a plain forward).
         dynamic_memories: indices j of memories whose CONTENTS the caller rewrites between iterations (DyadicRun's partner
         projection).  All others are constants of the run, as in the reference loop, and the library computes the
@@ -190,6 +194,14 @@ class SamplingRun:
         ts = (C.c_int32 * self.N)(*self.timesteps)
         self._keep.append(ts)
         a.timesteps, a.num_timesteps = C.cast(ts, C.c_void_p), self.N
+        self.att_ring = None
+        if attention_ring:
+            if skip_zero_weight_chunks:
+                raise ValueError("attention_ring keeps the last guidance chunk's maps: that chunk must be evaluated (skip_zero_weight_chunks=False)")
+            nl = int(denoiser.num_layers)
+            # memory lengths as the CALLER sees them (the maps' key axis); torch.empty: every element is written by the iteration that owns the slot
+            self.att_ring = [torch.empty((self.N, B, nl, L, int(m.shape[1])), dtype=torch.float32, device=dev) for m in mems]
+            a.att_ring = (C.c_void_p * _lib.NUM_MEM)(*[t.data_ptr() for t in self.att_ring])
         self._args = a
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
@@ -200,6 +212,14 @@ class SamplingRun:
     def steps(self, n):
         with torch.cuda.device(self.device):
             _lib.check(self.lib.cfd_sample_steps(self.handle, int(n)))
+
+    def attention_dict(self, upto=None):
+        """{timestep: [5 tensors [B, layers, L, S_j]]} of the iterations executed so far (views into the ring; read the latents first --
+        ``read`` waits for the run's stream)."""
+        if self.att_ring is None:
+            raise RuntimeError("the run was opened without attention_ring=True")
+        n = self.position if upto is None else int(upto)
+        return {int(t): [r[i] for r in self.att_ring] for i, t in enumerate(self.timesteps[:n])}
 
     @property
     def position(self):
@@ -284,20 +304,42 @@ def last_step_attention(run, denoiser, timestep, encoder_hidden_states, cond_mas
     return att
 
 
+def _open_run(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps, want_ring, **kw):
+    """SamplingRun with the attention ring when every iteration's maps are wanted and the problem is one the library keeps them for (the
+    row-tile path: the product's single utterances and small batches); otherwise -- CFD_E_SHAPE from cfd_sample_begin -- a plain run,
+    and the caller takes the maps with one forward per iteration (``last_step_attention``)."""
+    if want_ring:
+        try:
+            return SamplingRun(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
+                               **dict(kw, attention_ring=True, skip_zero_weight_chunks=False))
+        except _lib.CfdError as e:
+            if e.code != -2:      # CFD_E_SHAPE: not a row-tile problem
+                raise
+    return SamplingRun(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps, **kw)
+
+
 def sample(denoiser, scheduler, encoder_hidden_states, cond_masks=None, *, B, L=16, num_inference_steps=1000,
            guidance_scale=7.5, guidance_chunks=CFG_CHUNKS, eta=0.0, init_latents=None, step_noise=None, seed=0,
            first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False, row_maps=None, return_attention=False):
     """Run the whole loop; returns latents [B, L, 128] (batch-first); with ``return_attention=True`` also the last
     iteration's attention maps (``last_step_attention``), with ``return_attention="all"`` a dict {timestep: maps} over every
-    iteration like the reference's (the loop then leaves the device once per step)."""
-    run = SamplingRun(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
-                      guidance_scale, guidance_chunks, eta, init_latents, step_noise, seed, first_utterance, preseq, dedup,
-                      skip_zero_weight_chunks, row_maps)
+    iteration like the reference's: kept by the captured iteration itself for small problems (``SamplingRun(attention_ring=True)``),
+    otherwise taken with one extra forward and one host round trip per step."""
+    run = _open_run(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps, return_attention == "all",
+                    guidance_scale=guidance_scale, guidance_chunks=guidance_chunks, eta=eta, init_latents=init_latents, step_noise=step_noise,
+                    seed=seed, first_utterance=first_utterance, preseq=preseq, dedup=dedup, skip_zero_weight_chunks=skip_zero_weight_chunks,
+                    row_maps=row_maps)
     try:
         if not return_attention:
             run.steps(run.N)
             return run.read(close=True)
         scheduler.set_timesteps(num_inference_steps)
+        if return_attention == "all" and run.att_ring is not None:   # the captured iteration kept them (SamplingRun(attention_ring=True))
+            run.steps(run.N)
+            lat = run.read()
+            atts = run.attention_dict()
+            run.close()
+            return lat, atts
         if return_attention == "all":   # the reference's full dict: one entry per iteration (convofusion.py:523); one extra forward + sync per step
             atts = {}
             for t in run.timesteps:
@@ -363,8 +405,8 @@ def sample_with_weg(denoiser, scheduler, encoder_hidden_states, cond_masks, focu
     from . import weg
     G = guidance_chunks
     scheduler.set_timesteps(num_inference_steps)
-    run = SamplingRun(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
-                      guidance_chunks=G, **kw)
+    run = _open_run(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps, return_attention == "all",
+                    guidance_chunks=G, **kw)
     try:
         rm = kw.get("row_maps")
         if rm is not None:       # distinct memories + row maps (build_guidance_batch): gather the text-only chunk's rows
@@ -379,7 +421,8 @@ def sample_with_weg(denoiser, scheduler, encoder_hidden_states, cond_masks, focu
         timesteps = run.timesteps
         carry = [weg_parameters["scale_range"][0], weg_parameters["scale_range"][1]] if carry_scale_range else None   # :395
         guided = 0                            # evaluations of the objective so far (their conditioning never changes inside the loop)
-        every = return_attention == "all"     # the reference's dict: one entry per iteration (convofusion.py:517-523)
+        ring = run.att_ring is not None       # every iteration's maps are kept by the captured iteration itself
+        every = return_attention == "all" and not ring     # the reference's dict: one entry per iteration (convofusion.py:517-523)
         att = {} if every else None
 
         def maps(t):
@@ -404,11 +447,16 @@ def sample_with_weg(denoiser, scheduler, encoder_hidden_states, cond_masks, focu
             elif last and return_attention:
                 att = maps(t)
             run.steps(1)
-        if return_attention and att is None:
+        if return_attention and att is None and not ring:
             run.steps(run.N - 1 - run.position)
             att = maps(timesteps[-1])
         run.steps(run.N - run.position)
-        lat = run.read(close=True)
+        if ring:
+            lat = run.read()
+            att = run.attention_dict()
+            run.close()
+        else:
+            lat = run.read(close=True)
     finally:
         run.close()     # an exception (bad focus index, CfdError ...) must not leave the run open on the denoiser's handle
     return (lat, att) if return_attention else lat

@@ -133,6 +133,13 @@ typedef struct {
                                  diffusers 0.14.0's table arange(0, T, T // N)[::-1] has MORE than N entries (unpinned, see
                                  convofusion_amd/scheduler.py); the run then has num_timesteps iterations. */
   int num_timesteps;
+  float* att_ring[CFD_NUM_MEM];/* all NULL, or five dev buffers [iterations][B][num_layers][L][S_j] float32: the captured iteration
+                                 stores the attention probabilities of the LAST guidance chunk (full conditioning) of iteration i into
+                                 slot i -- the reference's per-iteration dict attention_matrices[t] = att_mats of the last chunk
+                                 (convofusion.py:517-523, dumped as att_<t>.npy by base.py:243-259).  Needs the row-tile path (small
+                                 problems: L <= 32, at most 800 token rows, at most 1024 padded keys, no dynamic memory; otherwise
+                                 cfd_sample_begin fails with CFD_E_SHAPE and the caller takes the maps with one cfd_forward per
+                                 iteration) and skip_zero_weight_chunks == 0. */
 } cfd_sample_args;
 
 /* Opens a sampling run: builds the per-step coefficient and timestep-embedding tables, draws / copies

@@ -424,6 +424,49 @@ def test_attention_of_every_iteration_leaves_the_latents_alone():
     assert all(torch.equal(a, b) for a, b in zip(atts[t7], want))
 
 
+def test_every_iterations_attention_maps_match_the_oracle():
+    """The reference fills ``attention_matrices[t]`` with the full-conditioning chunk's att_mats of EVERY iteration (convofusion.py:517-523;
+    base.py:243-259 writes them out).  For small problems the captured iteration keeps them itself (cfd_sample_args.att_ring: the row-tile
+    path's second cross-attention launch stores the last chunk's probabilities into slot *d_step): every entry of a 12-step run against the
+    restated loop driving the numpy oracle, the latents untouched by the extra chunk, and -- for a batch beyond the row-tile path -- the
+    fall-back (one forward per iteration) giving the same dict."""
+    import torch
+    from convofusion_amd.sampler import SamplingRun, sample
+    from tests.gpu_helpers import hip_denoiser, to_dev
+    B, L, S, n, seed = 2, 16, (6, 20, 6, 8, 1), 12, 5
+    cb = inputs.make_cfg_batch(seed=seed, B=B, L=L, S=S, pad_tail=(2, 0, 1, 0, 0))
+    sd = state_dict()
+    init = philox_ref.normal_tensor(seed, 0, range(B), 1, L)
+    want_lat, _, want = sampler_ref.diffusion_reverse(
+        lambda x, t, e, mk: denoiser_ref.denoiser_forward(sd, x, t, e, mk), scheduler_ref.DDPMSchedulerRef(), cb["memories"], cb["masks"],
+        init, lambda i, t: philox_ref.normal_tensor(seed, i, range(B), 0, L), num_inference_steps=n, return_att=True)
+    m = hip_denoiser(1234, 1.0)
+    mems, masks = [to_dev(x) for x in cb["memories"]], {k: to_dev(v) for k, v in cb["masks"].items()}
+    with SamplingRun(m, _sched("ddpm"), mems, masks, B, L, n, seed=seed, attention_ring=True) as run:     # (this shape is served by the ring)
+        assert run.att_ring is not None and tuple(run.att_ring[1].shape) == (n, B, 9, L, S[1])
+    lat, atts = sample(m, _sched("ddpm"), mems, masks, B=B, L=L, num_inference_steps=n, seed=seed, return_attention="all")
+    plain = sample(m, _sched("ddpm"), mems, masks, B=B, L=L, num_inference_steps=n, seed=seed)
+    assert torch.equal(lat, plain)
+    assert rel_l2(lat.permute(1, 0, 2).cpu().numpy(), want_lat) < TRAJ_TOL
+    assert sorted(atts) == sorted(want)
+    worst = 0.0
+    for t in want:
+        for j in range(5):
+            got = atts[t][j].cpu().numpy()
+            assert got.shape == want[t][j].shape
+            worst = max(worst, max_abs(got, want[t][j]))
+    print("worst attention-map difference over", n, "iterations x 5 memories:", worst)
+    assert worst < 1e-4
+    # beyond the row-tile path (more than 800 token rows): the dict comes from one forward per iteration, same contract
+    B2 = 8
+    cb2 = inputs.make_cfg_batch(seed=seed + 1, B=B2, L=L, S=S, pad_tail=(2, 0, 1, 0, 0))
+    mems2, masks2 = [to_dev(x) for x in cb2["memories"]], {k: to_dev(v) for k, v in cb2["masks"].items()}
+    with pytest.raises(Exception):
+        SamplingRun(m, _sched("ddpm"), mems2, masks2, B2, L, 4, seed=seed, attention_ring=True)
+    lat2, atts2 = sample(m, _sched("ddpm"), mems2, masks2, B=B2, L=L, num_inference_steps=4, seed=seed, return_attention="all")
+    assert len(atts2) == 4 and torch.equal(lat2, sample(m, _sched("ddpm"), mems2, masks2, B=B2, L=L, num_inference_steps=4, seed=seed))
+
+
 def test_ddpm_step_count_that_does_not_divide_the_schedule():
     """DDPM with N = 300 of 1000 (opt-in, unpinned: scheduler.DDPMScheduler(allow_unpinned_timesteps=True)): the loop runs over the
     334 entries of diffusers 0.14.0's table arange(0, 1000, 3)[::-1] with prev_t = t - 3, like the oracle's restated loop; the

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import denoiser_ref, inputs, philox_ref, sampler_ref, scheduler_ref, weg_ref
-from tests.helpers import load_golden, rel_l2, state_dict
+from tests.helpers import max_abs, load_golden, rel_l2, state_dict
 from tests.test_oracle_weg import CASES, weg_case
 
 pytestmark = pytest.mark.gpu
@@ -197,9 +197,10 @@ def test_loop_with_weg_matches_oracle(rollout):
         log.append(loss)
         return new
 
-    ref, _, _ = sampler_ref.diffusion_reverse(
+    ref, _, ref_atts = sampler_ref.diffusion_reverse(
         lambda x, t, enc, masks: denoiser_ref.denoiser_forward(sd, x, t, enc, masks), scheduler_ref.DDPMSchedulerRef(), cb["memories"],
-        cb["masks"], init, lambda i, t: noise[i], guidance_scale=7.5, num_inference_steps=n_steps, pre_step=pre_step, preseq=preseq)
+        cb["masks"], init, lambda i, t: noise[i], guidance_scale=7.5, num_inference_steps=n_steps, pre_step=pre_step, preseq=preseq,
+        return_att=True)
     plain, _, _ = sampler_ref.diffusion_reverse(
         lambda x, t, enc, masks: denoiser_ref.denoiser_forward(sd, x, t, enc, masks), scheduler_ref.DDPMSchedulerRef(), cb["memories"],
         cb["masks"], init, lambda i, t: noise[i], guidance_scale=7.5, num_inference_steps=n_steps, preseq=preseq)
@@ -239,6 +240,11 @@ def test_loop_with_weg_matches_oracle(rollout):
         assert sorted(att_all) == [0, 200, 400, 600, 800] and all(len(v) == 5 for v in att_all.values())
         assert all(torch.equal(a, b) for a, b in zip(att_all[0], att_last))
         assert all(tuple(a.shape) == (B, 9, L, s) for a, s in zip(att_all[800], S))
+        # ... and every entry is the oracle's: the maps of the full-conditioning chunk of the GUIDED loop's iteration t (kept by the captured
+        # iteration itself at this size: cfd_sample_args.att_ring)
+        worst = max(max_abs(att_all[t][j].cpu().numpy(), ref_atts[t][j]) for t in ref_atts for j in range(5))
+        print("guided loop, every iteration's maps vs the oracle: worst", worst)
+        assert sorted(ref_atts) == sorted(att_all) and worst < 1e-4
 
 
 def test_gradient_at_the_synthetic_shape_matches_oracle():
