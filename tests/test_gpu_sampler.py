@@ -427,13 +427,13 @@ def test_attention_of_every_iteration_leaves_the_latents_alone():
 def test_every_iterations_attention_maps_match_the_oracle():
     """The reference fills ``attention_matrices[t]`` with the full-conditioning chunk's att_mats of EVERY iteration (convofusion.py:517-523;
     base.py:243-259 writes them out).  For small problems the captured iteration keeps them itself (cfd_sample_args.att_ring: the row-tile
-    path's second cross-attention launch stores the last chunk's probabilities into slot *d_step): every entry of a 12-step run against the
+    path's second cross-attention launch stores the last chunk's probabilities into slot *d_step): every entry of a 10-step run against the
     restated loop driving the numpy oracle, the latents untouched by the extra chunk, and -- for a batch beyond the row-tile path -- the
     fall-back (one forward per iteration) giving the same dict."""
     import torch
     from convofusion_amd.sampler import SamplingRun, sample
     from tests.gpu_helpers import hip_denoiser, to_dev
-    B, L, S, n, seed = 2, 16, (6, 20, 6, 8, 1), 12, 5
+    B, L, S, n, seed = 2, 16, (6, 20, 6, 8, 1), 10, 5
     cb = inputs.make_cfg_batch(seed=seed, B=B, L=L, S=S, pad_tail=(2, 0, 1, 0, 0))
     sd = state_dict()
     init = philox_ref.normal_tensor(seed, 0, range(B), 1, L)
