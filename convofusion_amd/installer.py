@@ -38,7 +38,7 @@ def _diffusion_reverse(self, encoder_hidden_states, lengths=None, cond_masks=dic
     the attention-matrix dict -- see ``convofusion_amd.sampler.diffusion_reverse`` for which entries it holds)."""
     from .sampler import diffusion_reverse
     return diffusion_reverse(self, encoder_hidden_states, lengths, cond_masks, focus_indices,
-                             attention_steps=getattr(self, "_cfd_attention_steps", "last"))
+                             attention_steps=getattr(self, "_cfd_attention_steps", "auto"))
 
 
 def diffusion_reverse_forecast(model, encoder_hidden_states, lengths=None, preseq=None, cond_masks=dict(), focus_indices=[]):
@@ -47,17 +47,20 @@ def diffusion_reverse_forecast(model, encoder_hidden_states, lengths=None, prese
     return impl(model, encoder_hidden_states, lengths, preseq, cond_masks, focus_indices)
 
 
-def install(model, attention_steps="last"):
+def install(model, attention_steps="auto"):
     """Bind the fused loop as ``model._diffusion_reverse``.  Returns the model.  ``uninstall`` removes the binding.
 
     ``attention_steps``: which entries the returned attention-matrix dict holds.  The reference keeps the full-conditioning
     chunk's maps of EVERY iteration (convofusion.py:517-523) and its result writer dumps one ``att_<t>.npy`` per entry and
-    memory (convofusion/models/modeltype/base.py:252-259).  "last" (default) returns the final iteration's entry only -- the
-    loop then never leaves the device; "all" reproduces the reference's dict (one extra forward of the B full-conditioning
-    rows and one host round trip per iteration), so an unchanged ``test.py`` writes the same files."""
+    memory (convofusion/models/modeltype/base.py:252-259).  "all" reproduces the reference's dict, so that an unchanged ``test.py``
+    writes the same files: for small problems (single utterances, small batches: what WEG and the rollout run) the captured iteration
+    stores the maps itself (+5 % run time), for larger batches it costs one extra forward of the B full-conditioning rows and one
+    host round trip per iteration.  "last" returns the final iteration's entry only -- the loop then never leaves the device and does
+    not evaluate the zero-weight full-conditioning chunk.  "auto" (default): "all" where the captured iteration keeps the maps,
+    "last" elsewhere."""
     _check_model(model)
-    if attention_steps not in ("last", "all"):
-        raise ValueError("attention_steps must be 'last' or 'all'")
+    if attention_steps not in ("auto", "last", "all"):
+        raise ValueError("attention_steps must be 'auto', 'last' or 'all'")
     model._cfd_attention_steps = attention_steps
     model._diffusion_reverse = types.MethodType(_diffusion_reverse, model)
     return model

@@ -324,8 +324,9 @@ def sample(denoiser, scheduler, encoder_hidden_states, cond_masks=None, *, B, L=
     """Run the whole loop; returns latents [B, L, 128] (batch-first); with ``return_attention=True`` also the last
     iteration's attention maps (``last_step_attention``), with ``return_attention="all"`` a dict {timestep: maps} over every
     iteration like the reference's: kept by the captured iteration itself for small problems (``SamplingRun(attention_ring=True)``),
-    otherwise taken with one extra forward and one host round trip per step."""
-    run = _open_run(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps, return_attention == "all",
+    otherwise taken with one extra forward and one host round trip per step; ``return_attention="auto"`` always returns a dict: every
+    iteration's entries where the captured iteration keeps them itself, the last iteration's entry otherwise."""
+    run = _open_run(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps, return_attention in ("all", "auto"),
                     guidance_scale=guidance_scale, guidance_chunks=guidance_chunks, eta=eta, init_latents=init_latents, step_noise=step_noise,
                     seed=seed, first_utterance=first_utterance, preseq=preseq, dedup=dedup, skip_zero_weight_chunks=skip_zero_weight_chunks,
                     row_maps=row_maps)
@@ -334,7 +335,7 @@ def sample(denoiser, scheduler, encoder_hidden_states, cond_masks=None, *, B, L=
             run.steps(run.N)
             return run.read(close=True)
         scheduler.set_timesteps(num_inference_steps)
-        if return_attention == "all" and run.att_ring is not None:   # the captured iteration kept them (SamplingRun(attention_ring=True))
+        if return_attention in ("all", "auto") and run.att_ring is not None:   # the captured iteration kept them (SamplingRun(attention_ring=True))
             run.steps(run.N)
             lat = run.read()
             atts = run.attention_dict()
@@ -349,7 +350,8 @@ def sample(denoiser, scheduler, encoder_hidden_states, cond_masks=None, *, B, L=
         run.steps(run.N - 1)
         att = last_step_attention(run, denoiser, run.timesteps[-1], encoder_hidden_states, cond_masks, guidance_chunks, row_maps)
         run.steps(1)
-        return run.read(close=True), att
+        lat = run.read(close=True)
+        return (lat, {int(run.timesteps[-1]): att}) if return_attention == "auto" else (lat, att)
     finally:
         run.close()     # an exception must not leave the run open on the denoiser's handle
 
@@ -405,7 +407,7 @@ def sample_with_weg(denoiser, scheduler, encoder_hidden_states, cond_masks, focu
     from . import weg
     G = guidance_chunks
     scheduler.set_timesteps(num_inference_steps)
-    run = _open_run(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps, return_attention == "all",
+    run = _open_run(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps, return_attention in ("all", "auto"),
                     guidance_chunks=G, **kw)
     try:
         rm = kw.get("row_maps")
@@ -457,6 +459,8 @@ def sample_with_weg(denoiser, scheduler, encoder_hidden_states, cond_masks, focu
             run.close()
         else:
             lat = run.read(close=True)
+            if return_attention == "auto":      # no ring at this size: the last iteration's entry, as a dict
+                att = {int(timesteps[-1]): att}
     finally:
         run.close()     # an exception (bad focus index, CfdError ...) must not leave the run open on the denoiser's handle
     return (lat, att) if return_attention else lat
@@ -469,14 +473,15 @@ def diffusion_reverse(model, encoder_hidden_states, lengths=None, cond_masks=dic
     clf_guidance_drops / latent_dim / do_classifier_free_guidance exactly like the reference).
     Returns (latents [L, B, 128], attention_matrices dict).  The reference fills the dict with the full-conditioning
     chunk's ``att_mats`` of EVERY iteration (1000 x 5 tensors kept alive, written out as att_<t>.npy by base.py:252-259);
-    by default the fused loop keeps the last iteration's entry only: {t_last: att_mats} (``last_step_attention``);
-    ``attention_steps="all"`` fills the whole dict like the reference at the price of one extra forward of the B
-    full-conditioning rows and one host round trip per iteration (``convofusion_amd.install(model, attention_steps="all")``
-    makes the binding do that, so that base.py's per-timestep dump comes out complete)."""
-    if attention_steps not in ("last", "all"):
-        raise ValueError("attention_steps must be 'last' or 'all'")
-    if attention_steps == "all":
-        lat, atts = _loop_from_model(model, encoder_hidden_states, cond_masks, None, focus_indices, init_latents, seed, attention="all")
+    ``attention_steps="last"`` keeps the last iteration's entry only: {t_last: att_mats} (``last_step_attention``);
+    ``"all"`` fills the whole dict like the reference -- for small problems (the product's single utterances and small batches: the
+    row-tile path) the captured iteration stores the maps itself (cfd_sample_args.att_ring: +5 % run time), otherwise at the price of one
+    extra forward of the B full-conditioning rows and one host round trip per iteration; ``"auto"`` (what ``convofusion_amd.install``
+    binds by default) is "all" where the captured iteration keeps the maps and "last" elsewhere."""
+    if attention_steps not in ("last", "all", "auto"):
+        raise ValueError("attention_steps must be 'auto', 'last' or 'all'")
+    if attention_steps in ("all", "auto"):
+        lat, atts = _loop_from_model(model, encoder_hidden_states, cond_masks, None, focus_indices, init_latents, seed, attention=attention_steps)
         return lat.permute(1, 0, 2), atts
     lat, att = _loop_from_model(model, encoder_hidden_states, cond_masks, None, focus_indices, init_latents, seed)
     return lat.permute(1, 0, 2), {int(model.scheduler.timesteps[-1]): att}                        # :523,548-549

@@ -521,7 +521,7 @@ def test_no_edit_installer_runs_the_fused_loop():
     model.denoiser, model.scheduler, model.guidance_scale, model.clf_guidance_drops = hip_denoiser(1234, 1.0), _sched("ddpm"), 7.5, 6
     model.latent_dim, model.do_classifier_free_guidance = [1, 128], True
     model.cfg = SimpleNamespace(model=SimpleNamespace(scheduler=SimpleNamespace(num_inference_timesteps=4, eta=0.0)))
-    convofusion_amd.install(model)
+    convofusion_amd.install(model, attention_steps="last")
     enc = [to_dev(x) for x in cb["memories"]]
     masks = {k: to_dev(v) for k, v in cb["masks"].items()}
     torch.manual_seed(7)
@@ -529,9 +529,14 @@ def test_no_edit_installer_runs_the_fused_loop():
     torch.manual_seed(7)
     z2, _ = diffusion_reverse(model, enc, None, masks, [])
     assert tuple(z.shape) == (L, B, 128) and torch.equal(z, z2) and len(att) == 1
+    # the DEFAULT binding ("auto"): at this size the captured iteration keeps every iteration's maps itself, so the dict is the reference's
+    convofusion_amd.install(model)
+    torch.manual_seed(7)
+    z_auto, att_auto = model._diffusion_reverse(enc, None, cond_masks=masks, focus_indices=[])
+    assert torch.equal(z_auto, z) and sorted(att_auto) == [0, 250, 500, 750]
     # the reference's dict holds the full-conditioning chunk's maps of EVERY iteration (convofusion.py:517-523; base.py:252-259 dumps
     # one file per entry): install(model, attention_steps="all") reproduces it -- same latents, one entry per timestep, and the last
-    # entry equals the default binding's only entry
+    # entry equals the "last" binding's only entry
     convofusion_amd.install(model, attention_steps="all")
     torch.manual_seed(7)
     z3, att_all = model._diffusion_reverse(enc, None, cond_masks=masks, focus_indices=[])
