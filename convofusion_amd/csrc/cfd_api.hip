@@ -202,7 +202,8 @@ struct cfd_handle_s {
   // row, one timestep for all rows, no dynamic memories.  CFD_ROWTILE=0 turns it off (parity A/B against the tile kernels),
   // CFD_ROWTILE_MAX_ROWS moves the threshold.
   bool rt_on = true;
-  long long rt_max_rows = 800;    // measured crossover at the product shape (L = 16): 6 utterances 1.20 s vs 1.42 s per 1000 steps on the tile kernels, 8 utterances 1.40 vs 1.41
+  long long rt_max_rows = 700;    // measured crossover at the product shape (L = 16), seconds per 1000 steps, row-tile vs tile kernels (profiles/r05_rowtile_crossover.log:
+                                  // the short cross-attention work lists of round 5 made the tile kernels faster): 5 utterances 1.04 / 1.22, 6: 1.18 / 1.24, 7: 1.34 / 1.23
   bool share0 = true;       // CFD_SHARE0=0: evaluate the pre-cross-attention part of layer 0 for every guidance replica
   DBuf weg_ws, weg_tok;   // cfd_weg_eval: activation arena, focus-token tables
   // cfd_weg_eval replays its ~400 launches as a hipGraph.  A graph holds its kernels' arguments BY VALUE, so everything the

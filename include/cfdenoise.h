@@ -137,7 +137,7 @@ typedef struct {
                                  stores the attention probabilities of the LAST guidance chunk (full conditioning) of iteration i into
                                  slot i -- the reference's per-iteration dict attention_matrices[t] = att_mats of the last chunk
                                  (convofusion.py:517-523, dumped as att_<t>.npy by base.py:243-259).  Needs the row-tile path (small
-                                 problems: L <= 32, at most 800 token rows, at most 1024 padded keys, no dynamic memory; otherwise
+                                 problems: L <= 32, at most 700 token rows, at most 1024 padded keys, no dynamic memory; otherwise
                                  cfd_sample_begin fails with CFD_E_SHAPE and the caller takes the maps with one cfd_forward per
                                  iteration) and skip_zero_weight_chunks == 0. */
 } cfd_sample_args;

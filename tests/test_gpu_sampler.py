@@ -457,7 +457,7 @@ def test_every_iterations_attention_maps_match_the_oracle():
             worst = max(worst, max_abs(got, want[t][j]))
     print("worst attention-map difference over", n, "iterations x 5 memories:", worst)
     assert worst < 1e-4
-    # beyond the row-tile path (more than 800 token rows): the dict comes from one forward per iteration, same contract
+    # beyond the row-tile path (more than 700 token rows): the dict comes from one forward per iteration, same contract
     B2 = 8
     cb2 = inputs.make_cfg_batch(seed=seed + 1, B=B2, L=L, S=S, pad_tail=(2, 0, 1, 0, 0))
     mems2, masks2 = [to_dev(x) for x in cb2["memories"]], {k: to_dev(v) for k, v in cb2["masks"].items()}
@@ -622,11 +622,11 @@ def test_row_tile_path_is_race_free_and_shape_general():
     from tests.gpu_helpers import hip_denoiser, to_dev
     m = hip_denoiser(1234, 1.0)
     sd = state_dict(1234, 1.0)
-    # ... and the edges of the path's eligibility: 800 token rows exactly, 1024 padded keys exactly (the 1024-key instantiation of
+    # ... and the edges of the path's eligibility: 700 token rows exactly, 1024 padded keys exactly (the 1024-key instantiation of
     # the second cross-attention launch), both with padded tails in the key masks
     shapes = ((7, 16, (24, 161, 24, 8, 1), None), (35, 16, (6, 20, 6, 8, 1), None), (3, 20, (5, 40, 3, 8, 1), None),
               (2, 32, (33, 70, 12, 8, 1), None), (1, 2, (1, 1, 1, 1, 1), None),
-              (25, 32, (32, 700, 32, 8, 1), (3, 100, 5, 0, 0)), (2, 16, (32, 890, 32, 8, 1), (0, 37, 31, 0, 0)))
+              (25, 28, (32, 700, 32, 8, 1), (3, 100, 5, 0, 0)), (2, 16, (32, 890, 32, 8, 1), (0, 37, 31, 0, 0)))
     for Be, L, S, pad in shapes:
         inp = inputs.make_plain_batch(seed=50 + Be, Be=Be, L=L, S=S, pad_tail=pad or (0, 0, 0, 0, 0), scale=1.0)
         mems = [to_dev(x) for x in inp["memories"]]
@@ -677,7 +677,7 @@ def test_row_tile_path_agrees_with_the_tile_kernels_on_random_shapes():
 
 
 def test_tile_kernel_forms_agree_on_random_shapes():
-    """Random shapes beyond the row-tile path (more than 800 token rows or L > 32) through the two forms of the tile-kernel forward --
+    """Random shapes beyond the row-tile path (more than 700 token rows or L > 32) through the two forms of the tile-kernel forward --
     fused cross-attention (with layer-0 de-duplication off: a plain forward has no guidance structure; the one-key memory as a vector)
     and the three-launch cross-attention (CFD_FUSED_XATTN=0) -- including odd tile counts, ragged last tiles, memories of 1 .. 1600 keys
     with padded tails and batches whose rows share memory instances through a row map."""
@@ -689,7 +689,7 @@ def test_tile_kernel_forms_agree_on_random_shapes():
     m_fused.return_attention = m_three.return_attention = False
     for case in range(8):
         L = int(rng.choice([34, 48, 64, 100, 130, 196]))
-        lo = max(1, 820 // L + 1)                         # (past the row-tile path's 800 token rows, or L > 32 anyway)
+        lo = max(1, 820 // L + 1)                         # (past the row-tile path's 700 token rows, or L > 32 anyway)
         Be = int(rng.integers(lo, lo + 10))
         S = (int(rng.integers(1, 40)), int(rng.integers(33, 1600)), int(rng.integers(1, 40)), int(rng.integers(1, 12)), 1)
         pad = tuple(int(rng.integers(0, max(1, s // 3))) if rng.random() < 0.5 else 0 for s in S[:4]) + (0,)
