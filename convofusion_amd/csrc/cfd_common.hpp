@@ -94,6 +94,31 @@ __device__ __forceinline__ void sp_store8(char* row_base, int col, const float* 
   *reinterpret_cast<spx8*>(p + 64) = l;
 }
 
+// Developer experiment (-DCFD_SPLIT_SC1=1, round 5): the split-pair OUTPUT of a product stored write-through (`sc1`: the line leaves the
+// XCD's L2 instead of staying in it), to see whether the 2.17 x over-fetch of the N = 1024 products' operand panels is their own output
+// evicting them.  Off in the product.
+#ifndef CFD_SPLIT_SC1
+#define CFD_SPLIT_SC1 0
+#endif
+__device__ __forceinline__ void sp_store8_out(char* row_base, int col, const float* v) {
+#if CFD_SPLIT_SC1
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  spx8 h, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sp_t a, b;
+    split_f32(v[e], a, b);
+    h[e] = a;
+    l[e] = b;
+  }
+  char* p = row_base + (size_t)(col >> 5) * 128 + (col & 31) * 2;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(__builtin_bit_cast(u32x4_t, h)) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off offset:64 sc1" ::"v"(p), "v"(__builtin_bit_cast(u32x4_t, l)) : "memory");
+#else
+  sp_store8(row_base, col, v);
+#endif
+}
+
 // sp_store8 for values that may legitimately be NaN (LayerNorm outputs and probabilities of a row whose softmax had nothing but masked
 // keys: the reference returns NaN for such a row, from the attention on through every later LayerNorm to the output).  split_f32's clamp
 // (v_med3_f32 returns the minimum of the other two operands for a NaN) would store -65504, a finite and wrong operand; here the NaN is kept.

@@ -142,7 +142,7 @@ struct EpiSplit {  // out_sp[j][coloff + i] = split(act(v + bias[i]))
       sp_store4(row, c0, v[0], v[1], v[2], v[3]);
       sp_store4(row, c1, v[4], v[5], v[6], v[7]);
     } else {
-      sp_store8(row, i, v);
+      sp_store8_out(row, i, v);
     }
   }
 };

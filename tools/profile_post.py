@@ -103,7 +103,7 @@ def publish():
                 n += k
         xt, xn = 0.0, 0
         for r in csv.DictReader(open(t)):    # the full-batch launches of the fused cross-attention kernel (the largest grid in the trace)
-            if r["kernel"].startswith("xattn_fused_kernel") or r["kernel"].startswith("xattn_role_kernel"):
+            if "xattn_fused_kernel" in r["kernel"] or r["kernel"].startswith("xattn_role_kernel"):
                 xt, xn = max((xt, xn), ((float(r["read_MB_per_launch_(2xFETCH)"]) + float(r["write_MB_per_launch_(WRITE_SIZE)"])) * 1e6, int(r["launches_in_trace"])))
         json.dump({"bytes_per_launch_mean": tot / max(n, 1), "launches_in_trace": n,
                    "xattn_bytes_per_launch": xt or None, "xattn_launches_in_trace": xn,
@@ -143,9 +143,9 @@ def roofline():
     def cls(name):
         if "gemm_sp_kernel" in name:
             return "gemm_mem" if ("EpiMemK" in name or "EpiMemV" in name) else "gemm_token"
-        if name.startswith("xattn_fused_kernel") or name.startswith("xattn_pp_kernel"):
+        if "xattn_fused_kernel" in name:
             return "xattn"
-        if name.startswith("self_attn_fused_kernel"):
+        if "self_attn_fused_kernel" in name:
             return "gemm_attn"
         if name.startswith(("ln_rows_kernel", "mem_scale", "replicate_rows", "begin_step", "cfg_step")):
             return "rows"
