@@ -29,11 +29,17 @@ CASES = {
     "b1": (1234, None, 1, 16, (6, 20, 12, 8, 1), (2, 0, 3, 0, 0), 981, [[2, 5]], True),
     "b1_sharp": (4321, 4.0, 1, 16, (24, 161, 24, 8, 1), (5, 0, 7, 0, 0), 400, [[3, 9, 14]], True),
     "b3": (1234, None, 3, 8, (5, 33, 10, 8, 1), (1, 0, 2, 0, 0), 37, [[1, 4], [], [6]], False),
+    # the heavy-tailed stress weights (outlier factor 8) and memories with outlier tokens at the product shape (round 5)
+    "b1_heavy": (777, "heavy8", 1, 16, (24, 161, 24, 8, 1), (5, 0, 7, 0, 0), 600, [[3, 9, 14]], True),
 }
 
 
 def case_inputs(name):
     wseed, sharp, B, L, S, pad, t, focus, neot = CASES[name]
+    if sharp == "heavy8":
+        sd = weights.make_state_dict_heavy(seed=wseed, gain=8.0)
+        inp = inputs.make_outlier_batch(seed=500 + len(name), Be=B, L=L, S=S, pad_tail=pad)
+        return sd, inp, t, focus, neot
     sd = weights.make_state_dict(seed=wseed) if sharp is None else weights.make_state_dict(seed=wseed, sharp=sharp)
     inp = inputs.make_plain_batch(seed=500 + len(name), Be=B, L=L, S=S, pad_tail=pad)
     return sd, inp, t, focus, neot

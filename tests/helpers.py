@@ -19,6 +19,9 @@ FORWARD_CASES = {
 
 @functools.lru_cache(maxsize=4)
 def state_dict(seed=1234, sharp=1.0, mem_len=1024):
+    if isinstance(sharp, str) and sharp.startswith("heavy"):     # "heavy8": the heavy-tailed stress weights at outlier factor 8 (oracle/weights.py)
+        sd = weights.make_state_dict_heavy(seed=seed, gain=float(sharp[5:]))
+        return weights.extend_pe(sd, mem_len) if mem_len > 1024 else sd
     sd = weights.make_state_dict(seed=seed, sharp=sharp)
     return weights.extend_pe(sd, mem_len) if mem_len > 1024 else sd
 

@@ -166,7 +166,7 @@ def test_gradient_matches_oracle_and_reference_autograd(name):
     assert abs(float(l3) - float(loss)) < 2e-6 and rel_l2(g3.cpu().numpy(), grad) < 1e-4
     # attention maps of the saved-activation forward against the reference's
     att, _ = weg.forward_saved(m, to_dev(inp["sample"]), t, mems, masks)
-    assert np.abs(att.cpu().numpy() - g[name + ".att_tlsn"]).max() < (2e-4 if "sharp" in name else 1e-5)   # sharp: logits of +-40
+    assert np.abs(att.cpu().numpy() - g[name + ".att_tlsn"]).max() < (2e-4 if ("sharp" in name or "heavy" in name) else 1e-5)   # sharp / heavy-tailed: large logits
 
 
 @pytest.mark.parametrize("rollout", [False, True])
