@@ -629,6 +629,7 @@ extern "C" int cfd_set_timestep_table(cfd_handle c, const float* rows, int n_row
   CHK(c->tsin.ensure((size_t)n_rows * CFD_D * 4));
   HIPCHK(hipMemcpy(c->tsin.p, rows, (size_t)n_rows * CFD_D * 4, hipMemcpyHostToDevice));
   c->tsin_rows = n_rows;
+  ++c->wver;              // (the timestep-only tables cached in the workspaces were built from the previous sinusoid rows: build_time_tables)
   return CFD_OK;
 }
 

@@ -904,3 +904,48 @@ def test_heavy_tailed_weights_at_the_headline_shape():
     # (at this shape the guided loop is ill-conditioned even at factor 8: the numpy oracle and the torch reference, both float32, are
     #  9e-6 / 8e-5 / 8.5e-4 apart after 1 / 3 / 5 steps -- make_golden_heavy_c2.py prints it -- so the later steps say less and less)
     assert errs[1] < 1e-4 and errs[3] < 5e-4 and errs[5] < 3e-3, errs
+
+
+def test_cached_time_tables_never_serve_another_timestep_list():
+    """cfd_sample_begin keeps the timestep-only tables (temb, AdaLN rows, A b_t / VV b_t of every memory) on the handle, keyed by the
+    timestep list and the weights' generation, and skips their 31 launches when the key matches (the rollout opens eleven runs per sample
+    with the same list).  Runs with list A, list B of the same length, a longer list, A again, a plain forward in between and new weights
+    must each equal the result of a handle that has never seen another list -- bit for bit -- and the skip must really happen."""
+    import torch
+    from convofusion_amd.denoiser import Denoiser
+    from convofusion_amd.sampler import SamplingRun, sample
+    from tests.gpu_helpers import ABL, DENOISER_KW, hip_denoiser, read_debug, to_dev
+    B, L, S = 2, 16, (6, 20, 6, 8, 1)
+    cb = inputs.make_cfg_batch(seed=9, B=B, L=L, S=S, pad_tail=(2, 0, 1, 0, 0))
+    mems, masks = [to_dev(x) for x in cb["memories"]], {k: to_dev(v) for k, v in cb["masks"].items()}
+
+    def fresh_model(src):
+        m = Denoiser(ablation=ABL, **DENOISER_KW)
+        m.load_state_dict(src.state_dict(), strict=True)
+        return m.cuda().eval()
+
+    def run(m, kind, n):
+        return sample(m, _sched(kind), mems, masks, B=B, L=L, num_inference_steps=n, seed=4)
+    base = hip_denoiser(1234, 1.0)
+    m = fresh_model(base)
+    plan = [("ddpm", 10), ("ddim", 10), ("ddpm", 20), ("ddpm", 10), ("ddim", 50), ("ddpm", 10)]
+    got = []
+    for k, (kind, n) in enumerate(plan):
+        if k == 3:       # a plain forward rebuilds the tables for its single timestep
+            with torch.no_grad():
+                m(to_dev(np.concatenate([cb["init"]] * 7)), torch.tensor(77), mems, mem_mask_dict=masks)
+        got.append(run(m, kind, n))
+    for (kind, n), g_ in zip(plan, got):
+        assert torch.equal(g_, run(fresh_model(base), kind, n)), (kind, n)
+    # the skip happens: same list twice in a row (DDPM-10 and DDIM-10 walk the same timesteps) -> no table launches the second time
+    SamplingRun(m, _sched("ddpm"), mems, masks, B, L, 10, seed=4).close()
+    r = SamplingRun(m, _sched("ddim"), mems, masks, B, L, 10, seed=4)
+    assert float(read_debug(m, "setup_launches", (1,))[0]) == 0
+    r.close()
+    r = SamplingRun(m, _sched("ddpm"), mems, masks, B, L, 20, seed=4)
+    assert float(read_debug(m, "setup_launches", (1,))[0]) > 0
+    r.close()
+    # new weights on the same module: the tables are rebuilt (the engine re-uploads and the generation changes)
+    sharp = hip_denoiser(4321, 4.0)
+    m.load_state_dict(sharp.state_dict(), strict=True)
+    assert torch.equal(run(m, "ddpm", 20), run(fresh_model(sharp), "ddpm", 20))
