@@ -212,13 +212,14 @@ class SamplingRun:
     def steps(self, n):
         with torch.cuda.device(self.device):
             _lib.check(self.lib.cfd_sample_steps(self.handle, int(n)))
+        self._done = getattr(self, "_done", 0) + int(n)
 
     def attention_dict(self, upto=None):
         """{timestep: [5 tensors [B, layers, L, S_j]]} of the iterations executed so far (views into the ring; read the latents first --
         ``read`` waits for the run's stream)."""
         if self.att_ring is None:
             raise RuntimeError("the run was opened without attention_ring=True")
-        n = self.position if upto is None else int(upto)
+        n = getattr(self, "_done", 0) if upto is None else int(upto)     # (also valid after the run has been closed)
         return {int(t): [r[i] for r in self.att_ring] for i, t in enumerate(self.timesteps[:n])}
 
     @property
