@@ -9,7 +9,7 @@ i=0
 for g in "${groups[@]}"; do
   d=$out/${tag}_pmc_$i
   rm -rf $d
-  rocprofv3 --kernel-trace --pmc $g --kernel-include-regex "$re" --output-format csv -d $d -o run -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-full-loop > $out/${tag}_pmc_$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $g --kernel-include-regex "$re" --output-format csv -d $d -o run -- python bench.py --steps 2 --warmup 1 --headline-only > $out/${tag}_pmc_$i.log 2>&1
   i=$((i+1))
 done
 python tools/pmc_post.py $tag

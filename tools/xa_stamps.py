@@ -12,6 +12,8 @@ import bench  # noqa: E402
 from convofusion_amd import _lib, scheduler  # noqa: E402
 from convofusion_amd.sampler import SamplingRun  # noqa: E402
 
+if os.environ.get("SHAPE") == "R":          # the product shape with 32 utterances instead of the headline shape
+    bench.L, bench.S = 16, (24, 161, 24, 8, 1)
 dev = torch.device("cuda", 0)
 model = bench.make_model(dev)
 mems, masks = bench.make_inputs(32, dev, seed=1234)
@@ -20,7 +22,7 @@ sch = scheduler.DDPMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta
 run = SamplingRun(model, sch, mems, masks, 32, bench.L, 1000, guidance_scale=7.5, seed=0)
 run.steps(3)
 prof = run.profile()
-nwg, W, NS = 744, 8, 12
+nwg, W, NS = int(os.environ.get("NWG", "744")), 8, 12       # workgroups of the full-size launch (744 at the headline shape, 224 at SHAPE=R)
 buf = torch.zeros(nwg * W * NS * 2, dtype=torch.float32, device=dev)
 _lib.check(_lib.load().cfd_debug_read(model._handle, b"xa_stamps", C.c_void_p(buf.data_ptr()), buf.numel()))
 st = buf.cpu().numpy().view(np.int64).reshape(nwg, W, NS).astype(np.float64)
@@ -29,4 +31,4 @@ names = ["prologue + pipeline priming", "A0a compute", "wait+barrier mid-A0", "A
 tot = st.sum(-1)
 print("xattn class ms:", prof["xattn"], " per-wave total cycles: mean %.0f  min %.0f  max %.0f" % (tot.mean(), tot.min(), tot.max()))
 for k, n in enumerate(names):
-    print(f"  {n:24s} {st[:, :, k].mean():10.0f} cycles  {100 * st[:, :, k].mean() / tot.mean():5.1f} %   (per step {st[:, :, k].mean() / 51:7.1f})")
+    print(f"  {n:24s} {st[:, :, k].mean():10.0f} cycles  {100 * st[:, :, k].mean() / tot.mean():5.1f} %   (per step {st[:, :, k].mean() / float(os.environ.get('NSTEP', '51')):7.1f})")
