@@ -185,6 +185,7 @@ struct cfd_handle_s {
   // sample / latents handed to an entry point.  Zeroed at the entry of the calls that count, read at their end.
   DBuf sat;
   bool memside_in_forward = false;   // the last enqueue_denoise ran memory-side projections itself (not hoisted): census still open
+  bool run_counts = false;           // the open run's captured iteration contains launches that count into the census (per-step projections)
   unsigned int* sat_mem() const { return sat.as<unsigned int>() + CFD_SAT_MEM; }
   unsigned int* sat_in() const { return sat.as<unsigned int>() + CFD_SAT_IN; }
   bool hoist_memside = true;
@@ -1971,8 +1972,11 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
   // set-up work above was enqueued on the caller's stream and has been waited for.
   hipStream_t cap = c->own_stream;
   c->run_stream = cap;
+  c->memside_in_forward = false;
   HIPCHK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
   int r = enqueue_loop_iteration(c, cap);
+  c->run_counts = c->memside_in_forward;   // (the hoisted / row-tile iteration has no counting launch: cfd_sample_read then skips the census read)
+  c->memside_in_forward = false;
   hipGraph_t g = nullptr;
   hipError_t e = hipStreamEndCapture(cap, &g);
   if (r != CFD_OK) { if (g) (void)hipGraphDestroy(g); return r; }
@@ -2053,8 +2057,9 @@ extern "C" int cfd_sample_read(cfd_handle c, float* out, int close) {
   HIPCHK(hipMemcpyAsync(out, c->latents.p, lat_bytes, hipMemcpyDeviceToDevice, c->run_stream));
   HIPCHK(hipStreamSynchronize(c->run_stream));
   // the census of everything the run's iterations counted (per-step projections of a dynamic memory, CFD_HOIST_MEMSIDE=0): read on
-  // every read, BEFORE the run is closed -- a run that fails here stays open and can be inspected or closed by the caller
-  CHK(check_saturation(c, "sampling run (the per-step projections of a memory)"));
+  // every read of a run whose captured iteration has such launches, BEFORE the run is closed -- a run that fails here stays open and can be
+  // inspected or closed by the caller
+  if (c->run_counts) CHK(check_saturation(c, "sampling run (the per-step projections of a memory)"));
   if (close) c->run_open = false;
   return CFD_OK;
 }
