@@ -743,6 +743,17 @@ def test_the_three_forms_of_the_fused_cross_attention_are_the_same_function():
     mems, masks = [to_dev(x) for x in cb["memories"]], {k: to_dev(v) for k, v in cb["masks"].items()}
     got = [sample(m, _sched("ddpm"), mems, masks, B=5, L=50, num_inference_steps=4, seed=3) for m in ms]
     assert torch.equal(got[1], got[0]) and torch.equal(got[2], got[0])
+    # ... and at the headline size with every CU busy (744 workgroups, three per CU one after the other): ten forwards per form, one result
+    cb = inputs.make_cfg_batch(seed=1234, B=32, L=196, S=(32, 1500, 32, 8, 1), pad_tail=(8, 0, 8, 0, 0), uncond_pad_tail=(8, 0, 8, 0, 0))
+    mems, masks = [to_dev(x) for x in cb["memories"]], {k: to_dev(v) for k, v in cb["masks"].items()}
+    x = to_dev(np.concatenate([cb["init"]] * 7))
+    first = None
+    with torch.no_grad():
+        for f, m in enumerate(ms):
+            for rep in range(10):
+                out, _ = m(x, torch.tensor(417), mems, mem_mask_dict=masks)
+                first = out if first is None else first
+                assert torch.equal(out, first), f"headline size: form {f}, repetition {rep} differs"
 
 
 def test_static_and_dynamic_memory_declarations_agree_and_mean_what_they_say():
