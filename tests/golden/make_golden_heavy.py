@@ -9,6 +9,7 @@ with memories that carry outlier tokens:
   traj        the restated guided loop (oracle.sampler_ref + restated DDIM scheduler) driving the reference denoiser for 50 DDIM steps
               (eta = 0: no noise to damp a perturbation -- the hardest case for the split-pair arithmetic), at
               outlier factor 8 (at 20 the loop is chaotic: see main())
+  ddpm1000    the full-length loop: 1000 DDPM steps, one utterance, outlier factor 8 (snapshots after 1 / 10 / 100 / 500 steps)
 
 Usage:  python tests/golden/make_golden_heavy.py"""
 import os
@@ -62,6 +63,19 @@ def main():
     out["traj"] = lat
     out.update({f"traj_step{k}": v for k, v in snaps.items()})
     out["traj_meta"] = np.array([B, L, *S, *pad, n, seed], dtype=np.int64)
+    # the full-length DDPM loop (1000 steps, one utterance) at outlier factor 8: well conditioned -- the clipped x0 estimate contracts it: the
+    # numpy oracle ends 1.4e-6 from the reference (measured once: 6 CPU-minutes, not repeated here)
+    seed1, B1 = 4242, 1
+    cb1 = inputs.make_cfg_batch(seed=seed1, B=B1, L=L, S=S, pad_tail=pad)
+    cb1["memories"] = [inputs.add_outlier_tokens(u, seed1 + j)[rm] for j, (u, rm) in enumerate(zip(cb1["unique"], cb1["row_map"]))]
+    lat1, snaps1, _ = sampler_ref.diffusion_reverse(
+        lambda x, t, e, mk: ref_forward(ref8, x, t, e, mk), scheduler_ref.DDPMSchedulerRef(), cb1["memories"], cb1["masks"],
+        philox_ref.normal_tensor(seed1, 0, range(B1), 1, L), lambda i, t: philox_ref.normal_tensor(seed1, i, range(B1), 0, L),
+        guidance_scale=7.5, num_inference_steps=1000, keep_steps=(1, 10, 100, 500, 1000))
+    out["ddpm1000"] = lat1
+    out.update({f"ddpm1000_step{k}": v for k, v in snaps1.items()})
+    out["ddpm1000_meta"] = np.array([B1, L, *S, *pad, 1000, seed1], dtype=np.int64)
+    print(f"ddpm1000: |lat| {np.abs(lat1).mean():.3f}")
     np.savez_compressed(os.path.join(HERE, "heavy.npz"), **out)
     print("wrote heavy.npz")
 

@@ -73,10 +73,11 @@ def heavy_case(name):
     return inp, t, g[name], g[name + "_att2"]
 
 
-def heavy_traj_case():
-    """(guidance batch with outlier tokens, B, L, steps, seed, golden npz) of the 50-step DDIM trajectory in heavy.npz."""
+def heavy_traj_case(key="traj"):
+    """(guidance batch with outlier tokens, B, L, steps, seed, golden npz) of a trajectory in heavy.npz: "traj" = the 50-step DDIM loop,
+    "ddpm1000" = the full-length DDPM loop."""
     g = load_golden("heavy")
-    meta = [int(x) for x in g["traj_meta"]]
+    meta = [int(x) for x in g[key + "_meta"]]
     B, L, S, pad, n, seed = meta[0], meta[1], tuple(meta[2:7]), tuple(meta[7:12]), meta[12], meta[13]
     cb = inputs.make_cfg_batch(seed=seed, B=B, L=L, S=S, pad_tail=pad)
     cb["memories"] = [inputs.add_outlier_tokens(u, seed + j)[rm] for j, (u, rm) in enumerate(zip(cb["unique"], cb["row_map"]))]

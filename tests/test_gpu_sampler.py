@@ -862,6 +862,33 @@ def test_heavy_tailed_weights_ddim50_trajectory():
     assert np.isfinite(lat).all() and all(v < TRAJ_TOL for v in errs.values()), errs
 
 
+def test_heavy_tailed_weights_ddpm1000_trajectory():
+    """The full-length loop -- 1000 guided DDPM steps, one utterance, the row-tile path -- on the heavy-tailed stress weights (outlier factor 8)
+    with outlier-token memories, against the restated loop driving the REFERENCE denoiser (tests/golden/heavy.npz).  This loop is well
+    conditioned (the clipped x0 estimate contracts it: the numpy oracle ends 1.4e-6 from the reference), so it holds the whole budget."""
+    import torch
+    from convofusion_amd.denoiser import Denoiser
+    from convofusion_amd.sampler import SamplingRun
+    from tests.gpu_helpers import ABL, DENOISER_KW, to_dev
+    from tests.helpers import heavy_state_dict, heavy_traj_case
+    cb, B, L, n, seed, g = heavy_traj_case("ddpm1000")
+    m = Denoiser(ablation=ABL, **DENOISER_KW)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in heavy_state_dict(8.0).items()}, strict=True)
+    m = m.cuda().eval()
+    init = philox_ref.normal_tensor(seed, 0, range(B), 1, L)
+    noise = np.stack([philox_ref.normal_tensor(seed, i, range(B), 0, L) for i in range(n)])
+    run = SamplingRun(m, _sched("ddpm"), [to_dev(x) for x in cb["memories"]], {k: to_dev(v) for k, v in cb["masks"].items()}, B, L, n,
+                      guidance_scale=7.5, init_latents=to_dev(init), step_noise=to_dev(noise))
+    errs = {}
+    for k in (1, 10, 100, 500, 1000):
+        run.steps(k - run.position)
+        errs[k] = rel_l2(run.read().cpu().numpy(), g[f"ddpm1000_step{k}"])
+    lat = run.read(close=True).permute(1, 0, 2).cpu().numpy()
+    errs["final"] = rel_l2(lat, g["ddpm1000"])
+    print("heavy-tailed ddpm1000:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert np.isfinite(lat).all() and all(v < TRAJ_TOL for v in errs.values()), errs
+
+
 def test_heavy_tailed_weights_at_the_headline_shape():
     """BASELINE configs[1] at full size (B = 32, L = 196, 1500 audio tokens) on the heavy-tailed stress weights with outlier-token memories
     (tests/golden/heavy_c2.npz, make_golden_heavy_c2.py: the imported reference on the 7 guidance rows of utterance 5): one forward of the
