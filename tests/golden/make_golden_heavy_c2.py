@@ -4,9 +4,8 @@ from the REFERENCE itself (build container only): tests/golden/heavy_c2.npz.
 
   out5        reference ``Denoiser.forward`` (oracle.weights.make_state_dict_heavy, outlier factor 20; extended memory PE) on the 7 guidance
               rows of utterance 5 of the seeded batch whose DISTINCT memories carry outlier tokens (oracle.inputs.add_outlier_tokens), t = 333
-  out5_f64    the same forward with the reference module in float64: the input is ill-conditioned for one guidance chunk (the listener-id
-              memory's single key carries an outlier feature x 100, so its LayerNorm output is one feature), where the float32 reference
-              itself is 3e-4 from the float64 result
+  out5_f64    the same forward with the reference module in float64: the input is ill-conditioned for one guidance chunk (one query token
+              meets a softmax with very large logits at layer 4), where the float32 reference itself is 3e-4 from the float64 result
   traj_*      5 guided DDIM steps (eta = 0) of the restated loop driving the reference denoiser for utterance 5 alone, outlier factor 8
               (at 20 the guided loop is chaotic: oracle/weights.py)
 

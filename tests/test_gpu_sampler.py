@@ -920,9 +920,10 @@ def test_heavy_tailed_weights_at_the_headline_shape():
     idx = np.array([c * B + u for c in range(7)])
     got = out.cpu().numpy()[idx]
     # Per guidance chunk, against the reference module run in FLOAT64 (out5_f64): what the float32 reference itself is worth on this input,
-    # and what the split-pair path is.  Six chunks are well conditioned (float32 1e-5 from the exact result); in the listener-id chunk the
-    # memory's single key carries an outlier feature x 100, its LayerNorm output is essentially one feature, and float32 itself is 3e-4 off.
-    # The engine's operands carry 22 significant bits against float32's 24, so it may be a small multiple of float32's own error further out.
+    # and what the split-pair path is.  Six chunks are well conditioned (float32 1e-5 from the exact result); in the listener-id chunk one
+    # query token meets a softmax with very large logits at layer 4 (tools/heavy_c2_debug.py: all of the error sits there) and float32 itself
+    # is 3e-4 off.  The engine's operands carry 22 significant bits against float32's 24, so it may be a small multiple of float32's own
+    # error further out.
     e32 = [rel_l2(g["out5"][c], g["out5_f64"][c]) for c in range(7)]
     ehip = [rel_l2(got[c], g["out5_f64"][c]) for c in range(7)]
     e = rel_l2(got, g["out5"])

@@ -36,3 +36,48 @@ out = out.cpu().numpy()
 got = out if rows_only else out[idx]
 per_row = [rel_l2(got[c], g["out5"][c]) for c in range(7)]
 print({k: os.environ.get(k) for k in ("CFD_HOIST_MEMSIDE", "CFD_FUSED_XATTN", "ATT", "ROWS_ONLY", "CFD_L0_DEDUP", "CFD_ONE_KEY")}, f"rel {rel_l2(got, g['out5']):.2e}", "per chunk", [f"{e:.1e}" for e in per_row])
+
+if os.environ.get("TAPS"):
+    # residual stream of the listener-id chunk's row (chunk 5) after every sub-block against the numpy oracle's taps (needs ROWS_ONLY=1)
+    from convofusion_amd import _lib
+    from oracle import denoiser_ref, weights
+    from tests.gpu_helpers import read_debug
+    assert rows_only
+    sd = weights.extend_pe(heavy_state_dict(float(os.environ.get("GAIN", "20"))), 1536)
+    taps = {}
+    denoiser_ref.denoiser_forward(sd, x_np, t, mems_np, masks_np, taps=taps)
+    lib = _lib.load()
+    stages = [(1, "x0")]
+    for l in range(9):
+        stages += [(2 + 4 * l, f"l{l}.after_self"), (3 + 4 * l, f"l{l}.after_tb1"), (4 + 4 * l, f"l{l}.after_cross"), (5 + 4 * l, f"l{l}.out")]
+    for stage, key in stages:
+        _lib.check(lib.cfd_debug_stop_stage(m._handle, stage))
+        with torch.no_grad():
+            m(to_dev(x_np), torch.tensor(t), [to_dev(v) for v in mems_np], mem_mask_dict={k: to_dev(v) for k, v in masks_np.items()})
+        got = read_debug(m, "x", (7, L, 512))
+        w = taps[key].transpose(1, 0, 2)
+        print(f"  {key:16s} per chunk rel:", [f"{rel_l2(got[c], w[c]):.1e}" for c in range(7)], flush=True)
+    _lib.check(lib.cfd_debug_stop_stage(m._handle, 0))
+
+if os.environ.get("DIAG"):
+    # structure of the error of chunk 5 behind layer DIAG's cross-attention: the same vector for every token (a per-row constant: the one-key
+    # memory's contribution, a bias) or different per token (scores / softmax / P.V)?
+    l = int(os.environ["DIAG"])
+    for stage, key in ((3 + 4 * l, f"l{l}.after_tb1"), (4 + 4 * l, f"l{l}.after_cross")):
+        _lib.check(lib.cfd_debug_stop_stage(m._handle, stage))
+        with torch.no_grad():
+            m(to_dev(x_np), torch.tensor(t), [to_dev(v) for v in mems_np], mem_mask_dict={k: to_dev(v) for k, v in masks_np.items()})
+        got = read_debug(m, "x", (7, L, 512))[5].astype(np.float64)
+        w = taps[key].transpose(1, 0, 2)[5].astype(np.float64)
+        if key.endswith("tb1"):
+            g0, w0 = got, w
+        else:
+            dg, dw = got - g0, w - w0                        # what the cross-attention block added (HIP / oracle)
+            e = dg - dw
+            tok = np.linalg.norm(e, axis=1)
+            mean_e = e.mean(0)
+            print(f"layer {l} cross-attention update of chunk 5: |update| {np.linalg.norm(dw):.3e}, |error| {np.linalg.norm(e):.3e}, "
+                  f"error explained by ONE vector common to all tokens: {1 - np.linalg.norm(e - mean_e) ** 2 / np.linalg.norm(e) ** 2:.3f}; "
+                  f"per-token |error| min/max {tok.min():.2e}/{tok.max():.2e}; largest features of the common vector {np.argsort(-np.abs(mean_e))[:5]} "
+                  f"values {mean_e[np.argsort(-np.abs(mean_e))[:5]]}", flush=True)
+    _lib.check(lib.cfd_debug_stop_stage(m._handle, 0))
