@@ -323,3 +323,47 @@ def test_a_row_with_a_fully_masked_memory_is_nan_like_the_reference(shape):
             assert rel_l2(np.delete(out, 1, axis=0), np.delete(want, 1, axis=0)) < FWD_TOL
     finally:
         m.return_attention = keep
+
+
+@pytest.mark.parametrize("shape", ["row_tile", "tile_kernels"])
+def test_key_padding_masks_with_holes(shape):
+    """nn.MultiheadAttention's key_padding_mask is any boolean pattern, not only a padded tail (every other fixture masks tails): masks
+    with holes -- the first key, isolated keys, whole 32-key tiles, different patterns per batch row -- on all five memories, against the
+    numpy oracle, with and without attention maps (the fused kernel's -inf key bias, the three-launch softmax's mask loads, the row-tile
+    path's per-step tables); masked columns must come out exactly zero and the rows must sum to one."""
+    import torch
+    from oracle import denoiser_ref
+    from tests.gpu_helpers import dev_inputs, hip_denoiser, to_dev
+    Be, L, S = (6, 16, (24, 161, 24, 8, 2)) if shape == "row_tile" else (10, 100, (40, 300, 33, 8, 3))
+    inp = inputs.make_plain_batch(seed=808, Be=Be, L=L, S=S)
+    rng = np.random.Generator(np.random.PCG64(12))
+    names = ("spkemb", "alsn", "tlsn", "apb", "lsnemb")
+    for j, name in enumerate(names):
+        mk = rng.random((Be, S[j])) < 0.3
+        mk[0, 0] = True                                   # the first key
+        if S[j] > 64:
+            mk[1, 32:64] = True                           # a whole 32-key tile
+            mk[2, :] = False                              # a row without any masked key next to masked ones
+        mk[:, S[j] - 1] = False                           # (never everything: that case is test_a_row_with_a_fully_masked_memory_...)
+        inp["masks"][name] = mk
+    sd = state_dict()
+    want, watt = denoiser_ref.denoiser_forward(sd, inp["sample"], 123, inp["memories"], inp["masks"])
+    m = hip_denoiser(1234, 1.0)
+    mems, masks = dev_inputs(inp)
+    keep = m.return_attention
+    try:
+        for ra in (False, True):
+            m.return_attention = ra
+            with torch.no_grad():
+                out, att = m(to_dev(inp["sample"]), torch.tensor(123), mems, mem_mask_dict=masks)
+            e = rel_l2(out.cpu().numpy(), want)
+            print(f"{shape}, attention maps {ra}: rel {e:.2e}")
+            assert e < FWD_TOL
+            if ra:
+                for j, name in enumerate(names):
+                    a = att[j].cpu().numpy()
+                    assert max_abs(a, watt[j]) < 1e-4
+                    assert np.all(a[np.broadcast_to(inp["masks"][name][:, None, None, :], a.shape)] == 0)
+                    np.testing.assert_allclose(a.sum(-1), 1.0, atol=1e-5)
+    finally:
+        m.return_attention = keep
