@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     XA_WAIT_VM(0);                                       // the counted waits of the loop assume an empty queue
   };
 
-  float m = -INFINITY, lsum = 0.f, wl = 0.f;
+  float m = -INFINITY, lsum = 0.f, wl = 0.f, mc_run = -INFINITY;   // online softmax: maximum, sums, and the exponent reference the sums are relative to
   char* xch_mine = smem + XA_XOFF + wid * 2048 + lane * 16;
   const char* xch_other = smem + XA_XOFF + partner * 2048 + lane * 16;
   // fragment reads: half `hf` (4 k-steps / 4 feature tiles) of a sub-phase -> 8 fragments (hi, lo alternating)
@@ -548,7 +548,11 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       const float m_new = fmaxf(m, mx);
       const bool dead = m_new == -INFINITY;             // nothing but dead keys so far: contribute 0, keep m = -inf
       const float mc = dead ? 0.f : m_new * LOG2E;      // (-inf - (-inf) would be NaN)
-      scale = dead ? 1.0f : __builtin_amdgcn_exp2f(fmaf(m, LOG2E, -mc));
+      // The running sums are relative to the ROUNDED reference mc of the tile that wrote them (mc_run): the factor to this tile's reference is
+      // exp2(mc_run - mc), exactly 1 while the maximum stands.  (Until round 5: exp2(fma(m, c, -mc)), the exact m c against the rounded one --
+      // 2^(rounding error of m c) per tile instead of 1, compounding over the 47 tiles of the audio memory; attn_fused.hpp has the figures.)
+      scale = dead ? 1.0f : __builtin_amdgcn_exp2f(mc_run - mc);     // (first live tile: mc_run = -inf -> 0, times sums that are still 0)
+      mc_run = dead ? -INFINITY : mc;
       float ps = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -735,6 +739,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       if (q4 == 0) wq_mine[l15 * 5 + cj] = wsum;
     }
     m = -INFINITY;
+    mc_run = -INFINITY;
     lsum = 0.f;
     wl = 0.f;
     cT = nT; cmask = nmask; cflags = nflags; cj = nj;
@@ -876,6 +881,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       primed = false;
     }
     m = -INFINITY;
+    mc_run = -INFINITY;
     lsum = 0.f;
     wl = 0.f;
     cT = nT; cmask = nmask; cflags = nflags; cj = nj;   // (cur already points at the next segment's first tile)
