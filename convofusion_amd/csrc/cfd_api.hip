@@ -198,6 +198,7 @@ struct cfd_handle_s {
   int one_key = 1;              // CFD_ONE_KEY=0: a one-key memory (lsnemb) keeps its 32-key tile step in the fused cross-attention
   int xa_pp = 0;                // form of the fused cross-attention kernel (xattn_fused.hpp): CFD_XA_PP=0 lock-step, every wave requests its share of every
                                 // sub-buffer (rounds 2-4); 1 ping-pong (two wave groups one sub-phase apart); 2 lock-step, requests divided between the groups
+  int qkv_fused = 1;            // CFD_QKV_FUSED=0: batch rows of 16 tokens keep the separate v^T product (EpiQkvT, gemm_sp.hpp)
   int l0_dedup = 1;             // CFD_L0_DEDUP=0: layer 0's cross-attention as one launch over all rows (build_xattn_layer0_lists)
   // Row-tile path for small problems (rowtile.hpp): chosen by SHAPE -- at most rt_max_rows token rows of at most RT_MAX_L tokens per batch
   // row, one timestep for all rows, no dynamic memories.  CFD_ROWTILE=0 turns it off (parity A/B against the tile kernels),
@@ -367,6 +368,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   if (env) c->xa_pp = atoi(env);
   env = getenv("CFD_ONE_KEY");
   if (env) c->one_key = atoi(env) != 0;
+  env = getenv("CFD_QKV_FUSED");
+  if (env) c->qkv_fused = atoi(env) != 0;
   env = getenv("CFD_ROWTILE");
   c->rt_on = !(env && atoi(env) == 0);
   env = getenv("CFD_WEG_ROWTILE");
@@ -1507,8 +1510,17 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       av.X[0] = c->w->h_sp.as<char>(); av.ldx[0] = ROWB; av.xbs[0] = (long long)L * ROWB; av.I[0] = Lv; av.Iclamp[0] = L; av.kt[0] = CFD_D / 32;
       av.Y = w.wv_sp.as<char>(); av.ldy = ROWB; av.J = CFD_D; av.Jclamp = CFD_D;
       EpiSplit ev{c->w->vts_sp.as<char>(), (long long)Lv * 4, (long long)CFD_D * Lv * 4, 0, nullptr, 0, 1};
+      if (L == 16 && c->qkv_fused && !g_cfd_naive_gemm) {
+        // batch rows of exactly 16 tokens: both in ONE grouped launch, the value projection stored transposed by the epilogue (EpiQkvT)
+        GemmArgs ag = a;
+        ag.nslot = 2;
+        ag.X[1] = w.wv_sp.as<char>(); ag.ldx[1] = ROWB; ag.I[1] = CFD_D; ag.Iclamp[1] = CFD_D; ag.kt[1] = CFD_D / 32;
+        EpiQkvT eg{c->w->qk_sp.as<char>(), 2 * ROWB, w.bqk.as<float>(), c->w->vts_sp.as<char>()};
+        CHK((run_gemm<MODE_GROUPED>(c, CFD_PROF_GEMM_TOKEN, ag, eg, 1, 1, st)));
+      } else {
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, av, ev, Ba, 1, st)));
+      }
     }
     {
       SelfAttnArgs a{c->w->qk_sp.as<char>(), c->w->vts_sp.as<char>(), c->w->o_sp.as<char>(), L, Lv};
@@ -2507,7 +2519,7 @@ extern "C" int cfd_test_gemm(cfd_handle c, const float* X, const float* Y, float
 // Micro-benchmark hook: `iters` launches of the MFMA GEMM (EpiResid epilogue: x[j][i] += D + bias) on device-resident
 // SP operands filled from a float32 pattern; returns the average milliseconds per launch (HIP events).
 extern "C" int cfd_bench_gemm(cfd_handle c, int I, int J, int K, int tile_cfg, int iters, float* ms_out) {
-  if (!c || !ms_out || K % 32 || I != CFD_D || J < 1 || iters < 1) return fail(CFD_E_ARG, "bad argument (I must be 512)");
+  if (!c || !ms_out || K % 32 || I % CFD_D || I < CFD_D || J < 1 || iters < 1) return fail(CFD_E_ARG, "bad argument (I must be a multiple of 512)");
   HIPCHK(hipSetDevice(c->cfg.device));
   DBuf xf, yf, xs, ys, out;
   CHK(xf.ensure((size_t)I * K * 4));
@@ -2537,10 +2549,15 @@ extern "C" int cfd_bench_gemm(cfd_handle c, int I, int J, int K, int tile_cfg, i
   memset(&ef, 0, sizeof(ef));
   ef.out = out.as<float>(); ef.ldo = I;
   const char* ev = getenv("CFD_BENCH_EPI");
-  const int epi_kind = ev ? atoi(ev) : 0;   // 0 residual RMW, 1 no stores, 2 plain fp32 store
+  const int epi_kind = ev ? atoi(ev) : 0;   // 0 residual RMW, 1 no stores, 2 plain fp32 store, 3 split-pair store
+  EpiSplit es;
+  memset(&es, 0, sizeof(es));
+  es.out = out.as<char>(); es.ldo = (long long)I * 4;
+  if (epi_kind == 0 && I != CFD_D) return fail(CFD_E_ARG, "the residual epilogue has rows of 512");
   auto go = [&]() -> hipError_t {
     if (epi_kind == 1) return launch_gemm<MODE_PLAIN, EpiNull>(a, en, 1, 1, nullptr, tile_cfg);
     if (epi_kind == 2) return launch_gemm<MODE_PLAIN, EpiF32>(a, ef, 1, 1, nullptr, tile_cfg);
+    if (epi_kind == 3) return launch_gemm<MODE_PLAIN, EpiSplit>(a, es, 1, 1, nullptr, tile_cfg);
     return launch_gemm<MODE_PLAIN, EpiResid>(a, e, 1, 1, nullptr, tile_cfg);
   };
   hipError_t err = go();   // warm-up

@@ -147,6 +147,55 @@ struct EpiSplit {  // out_sp[j][coloff + i] = split(act(v + bias[i]))
   }
 };
 
+// q | k and v^T of the self-attention in ONE grouped launch for batch rows of exactly 16 tokens (the product shape; round 5).
+// Group 0 (X = [Wq; Wk], 1024 features): out_qk[j][i] = split(v + bias[i]), as EpiSplit.  Group 1 (X = Wv, 512 features): the value
+// projection stored TRANSPOSED, vts[j / 16][i][perm32(j % 16)] -- what the separate batched product with swapped operand roles
+// (X = the row's tokens, Y = Wv, EpiSplit::perm32) wrote, but that launch works on half-empty 32-token tiles (20.7 us beside the
+// q | k product's 21 at 32 utterances).  The wide epilogue has a wave's band of 16 tokens x 16 TI features in its LDS strip anyway:
+// read by columns, a lane gets 8 consecutive tokens of one feature.  Token t = 4 q + r of a 16-token row sits at key position
+// 8 q + r of the 32-key block (attn_fused.hpp), so tokens 8 h .. 8 h + 7 fill positions [16 h, 16 h + 4) and [16 h + 8, 16 h + 12);
+// the gaps are the padding keys 16 .. 31, stored as zeros (the kernel masks their scores; their values only have to be finite).
+struct EpiQkvT {
+  char* out_qk;          // SP [M][1024]
+  long long ldo;         // bytes per q | k row
+  const float* bias;     // [1024] (the value bias is folded into the out-projection's)
+  char* vts;             // SP [Be][512][32]
+  static constexpr bool kPrefetch = false;
+  static constexpr bool kStore8 = true;
+  static constexpr bool kBias8 = true;
+  static constexpr bool kStoreT = true;   // group 1 is stored by store_t
+  __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {
+    const float4 t = *reinterpret_cast<const float4*>(bias + i);
+    sp_store4(out_qk + (long long)j * ldo, i, v[0] + t.x, v[1] + t.y, v[2] + t.z, v[3] + t.w);
+  }
+  __device__ __forceinline__ void tile_bias8(int i, float4& t0, float4& t1) const {   // (group 1 reads it too and ignores it: i < 512 there)
+    t0 = *reinterpret_cast<const float4*>(bias + i);
+    t1 = *reinterpret_cast<const float4*>(bias + i + 4);
+  }
+  __device__ __forceinline__ void store8(int g, int b, int z, int i, int j, f32x4 v0, f32x4 v1, float4 t0, float4 t1) const {
+    const float v[8] = {v0[0] + t0.x, v0[1] + t0.y, v0[2] + t0.z, v0[3] + t0.w, v1[0] + t1.x, v1[1] + t1.y, v1[2] + t1.z, v1[3] + t1.w};
+    sp_store8_out(out_qk + (long long)j * ldo, i, v);
+  }
+  // feature i of the value projection, tokens jb + 8 h .. + 7 (jb % 16 == 0): 16 key positions = 32 bytes of the hi plane and of the lo plane
+  __device__ __forceinline__ void store_t(int i, int jb, int h, const float* v) const {
+    spx8 hi0, lo0, hi1, lo1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sp_t a, c;
+      split_f32(v[e], a, c);
+      hi0[e] = a; lo0[e] = c;
+      split_f32(v[4 + e], a, c);
+      hi1[e] = a; lo1[e] = c;
+      hi0[4 + e] = (sp_t)0.f; lo0[4 + e] = (sp_t)0.f; hi1[4 + e] = (sp_t)0.f; lo1[4 + e] = (sp_t)0.f;
+    }
+    char* p = vts + ((long long)(jb >> 4) * CFD_D + i) * 128 + h * 32;
+    *reinterpret_cast<spx8*>(p) = hi0;
+    *reinterpret_cast<spx8*>(p + 16) = hi1;
+    *reinterpret_cast<spx8*>(p + 64) = lo0;
+    *reinterpret_cast<spx8*>(p + 80) = lo1;
+  }
+};
+
 struct EpiResid {  // x[(b*rows_per_b + j)][i] += v + bias[i]   (row length CFD_D floats)
   float* x;
   long long obs;  // floats per batch
@@ -279,6 +328,8 @@ template <class E, class = void> struct EpiHasBand { static constexpr bool value
 template <class E> struct EpiHasBand<E, typename std::enable_if<E::kBand>::type> { static constexpr bool value = true; };
 template <class E, class = void> struct EpiHasStore8 { static constexpr bool value = false; };
 template <class E> struct EpiHasStore8<E, typename std::enable_if<E::kStore8>::type> { static constexpr bool value = true; };
+template <class E, class = void> struct EpiHasStoreT { static constexpr bool value = false; };
+template <class E> struct EpiHasStoreT<E, typename std::enable_if<E::kStoreT>::type> { static constexpr bool value = true; };
 template <class E, bool P = E::kPrefetch> struct EpiPre { struct type {}; };
 template <class E> struct EpiPre<E, true> { typedef typename E::Pre type; };
 
@@ -593,6 +644,22 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
       for (int ti = 0; ti < TI; ++ti)
         *reinterpret_cast<f32x4*>(strip + l15 * RS + (ti * 16 + q4 * 4) * 4) = acc[ti][tj];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private strip: no barrier needed
+      if constexpr (EpiHasStoreT<Epi>::value) {
+        if (MODE == MODE_GROUPED && g == 1) {   // (workgroup-uniform) the band read by columns: lane = (feature, token half), see EpiQkvT
+          static_assert(TI % 2 == 0, "32 features x 2 token halves per wave instruction");
+#pragma unroll
+          for (int it = 0; it < TI / 2; ++it) {
+            const int il = (lane & 31) + 32 * it, hf = lane >> 5;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const float*>(strip + (8 * hf + e) * RS + il * 4);
+            const int i = i0 + wi * TI * 16 + il, jb = j0 + (wj * TJ + tj) * 16;
+            if (i < Ig && jb < a.J) epi.store_t(i, jb, hf, v);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next band overwrites the strip
+          continue;
+        }
+      }
       if constexpr (EpiHasStore8<Epi>::value) {
         // split-pair outputs: LPR8 lanes per row, 8 consecutive i per lane
         constexpr int LPR8 = TI * 2, RPI8 = 64 / LPR8, NIT8 = 16 / RPI8;
@@ -749,6 +816,7 @@ static hipError_t launch_cfg(GemmArgs a, const Epi& epi, int nb, int nz, hipStre
 //   6 = 128 x 112 (4 waves of 32 x 112, 2-stage)               J in (128, 224]: per-row attention products of 196 tokens
 //  19 = 64 x 64   (2 x 2 waves of 32 x 32, 3-stage counted-vmcnt loop)   small problems: few workgroups per CU, latency-bound
 //  20 = 32 x 128  (1 x 4 waves of 32 x 32, 3-stage)            memories of <= 64 keys
+//  24 = 128 x 64  (2 x 2 waves of 64 x 32, 3-stage)            small problems with more than 768 tiles of 64 x 64
 // The variants measured and rejected in round 1 (3-stage / software-pipelined / deep-prefetch / single-buffer loops,
 // 128 x 256, 256 x 128, 128 x 176 and 256 x 176 tiles, the tile-softmax epilogues) live in tools/experiments/gemm_sp_r01_variants.hpp.
 template <int MODE, class Epi>
@@ -776,12 +844,20 @@ static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStr
     else if (a.J > 128 && a.J <= 224 && big_tiles * 2 >= 256) cfg = 6;
     else if (big_tiles * 2 >= 384 && a.J >= 96) cfg = 1;
     else cfg = 19;
+    // more 64 x 64 tiles than the chip holds at once (3 per CU) but too few for the 128 x 128 class: 128 x 64 tiles, one round of two per CU
+    // (the q | k and FFN1 products of 32 utterances at the product shape: 896 tiles -> 448; 21 -> 19 us in the captured step, round 5)
+    if (cfg == 19 && nb * nz == 1) {
+      long long t64 = 0;
+      for (int g = 0; g < ng; ++g) t64 += (long long)((a.I[g] + 63) / 64) * ((a.J + 63) / 64);
+      if (t64 > 768 && imax >= 128) cfg = 24;
+    }
   }
   switch (cfg) {
     case 1: return launch_cfg<2, 2, 4, 4, 2, MODE, Epi>(a, epi, nb, nz, st);
     case 6: return launch_cfg<4, 1, 2, 7, 2, MODE, Epi>(a, epi, nb, nz, st);
     case 19: return launch_cfg<2, 2, 2, 2, 3, MODE, Epi>(a, epi, nb, nz, st);
     case 20: return launch_cfg<1, 4, 2, 2, 3, MODE, Epi>(a, epi, nb, nz, st);
+    case 24: return launch_cfg<2, 2, 4, 2, 3, MODE, Epi>(a, epi, nb, nz, st);
     default: return launch_cfg<4, 1, 2, 1, 2, MODE, Epi>(a, epi, nb, nz, st);
   }
 }

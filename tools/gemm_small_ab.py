@@ -10,13 +10,14 @@ from convofusion_amd import _lib  # noqa: E402
 lib = _lib.load()
 h = _lib.create_handle(0)
 cfgs = [int(x) for x in sys.argv[1:]] or [1, 6, 19, 20, 30]
-for (J, K) in [(3584, 512), (3584, 1024), (112, 512), (896, 512)]:
-    for epi in (0, 1):
+I = int(os.environ.get("GEMM_I", "512"))
+for (J, K) in [(3584, 512), (3584, 1024), (1792, 512), (896, 512), (112, 512)]:
+    for epi in ((0, 1) if I == 512 else (3, 1)):
         os.environ["CFD_BENCH_EPI"] = str(epi)
         best = {c: 1e9 for c in cfgs}
         for rep in range(3):
             for cfg in cfgs:
                 ms = C.c_float()
-                _lib.check(lib.cfd_bench_gemm(h, 512, J, K, cfg, 50, C.byref(ms)))
+                _lib.check(lib.cfd_bench_gemm(h, I, J, K, cfg, 50, C.byref(ms)))
                 best[cfg] = min(best[cfg], ms.value)
-        print(f"J={J} K={K} epi={epi}: " + "  ".join(f"cfg {c}: {best[c] * 1e3:6.1f} us" for c in cfgs), flush=True)
+        print(f"I={I} J={J} K={K} epi={epi}: " + "  ".join(f"cfg {c}: {best[c] * 1e3:6.1f} us" for c in cfgs), flush=True)
