@@ -80,6 +80,7 @@ struct Problem {
   // attention ring of a sampling run (cfd_sample_args::att_ring): only the batch rows [att_b0, att_b0 + att_nb) write their maps, into
   // slot *d_step of att[j] (att_slot[j] floats per slot), as rows 0 .. att_nb - 1 of that slot.  att_nb == 0: att[j] is one [Be][nl][L][S_j] block.
   int att_b0 = 0, att_nb = 0;
+  bool att_fused = false;       // the ring is written by the fused cross-attention kernel's ATT instance + att_fixup_kernel (tile kernels)
   long long att_slot[CFD_NMEM] = {0, 0, 0, 0, 0};
   int tmode = 0;  // 0: all rows share the timestep of table row *d_step ; 1: row b uses table row b
   // Sampling loop only: the effective batch is G replicas (chunk-major) of the same B latent rows, so everything
@@ -135,7 +136,7 @@ struct Work {
   // timestep-independent memory-side projections (rows.hpp mem_center_kernel): per memory the dot products c_l . a_s (ca), |a_s|^2 (asq)
   // and, per table row t, A_l b_t / c_l . b_t (kbtab) and VV_l b_t (vbtab); b_t = centred timestep embedding.  CFD_HOIST_MEMSIDE=0: off.
   DBuf ca[CFD_NMEM], asq[CFD_NMEM], kbtab[CFD_NMEM], vbtab[CFD_NMEM], b_tab, b_sp, bsq, zeros512;
-  DBuf xa_wgs, xa_segs, xa_stamps, xa0_wgs_a, xa0_segs_a, xa0_wgs_b, xa0_segs_b, xa_dedup, xa_one_va;
+  DBuf xa_wgs, xa_segs, xa_stamps, xa0_wgs_a, xa0_segs_a, xa0_wgs_b, xa0_segs_b, xa_dedup, xa_one_va, xa_att_raw, xa_att_mc, xa_att_fin, xa_att_desc;
   DBuf d_step;  // [0] = loop index, [1] = constant 0, [2] = "this iteration's in-painting overwrite is done" (cfd_sample_inpaint)
   DBuf rt_vt, rt_cbt[CFD_NMEM];   // row-tile path: V^T of the self-attention, per-step key tables
   DBuf rt_cur;                    // row-tile path, sampling run: this step's rows of every per-step table (rt_step_rows_kernel)
@@ -152,7 +153,7 @@ struct Work {
   const float* now_vb[CFD_NMEM] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   void release() {
     DBuf* all[] = {&x, &h_sp, &qk_sp, &vts_sp, &ssc, &sp_sp, &o_sp, &u_sp, &sc, &p_sp, &eps, &sample_sp, &temb_tab, &h1_tab, &ss_tab, &trows, &iota,
-                   &long_rows, &short_rows, &zero_mask, &b_tab, &b_sp, &bsq, &zeros512, &xa_wgs, &xa_segs, &xa_stamps, &xa0_wgs_a, &xa0_segs_a, &xa0_wgs_b, &xa0_segs_b, &xa_dedup, &xa_one_va, &d_step, &rt_vt, &rt_cur};
+                   &long_rows, &short_rows, &zero_mask, &b_tab, &b_sp, &bsq, &zeros512, &xa_wgs, &xa_segs, &xa_stamps, &xa0_wgs_a, &xa0_segs_a, &xa0_wgs_b, &xa0_segs_b, &xa_dedup, &xa_one_va, &xa_att_raw, &xa_att_mc, &xa_att_fin, &xa_att_desc, &d_step, &rt_vt, &rt_cur};
     for (DBuf* b : all) b->release();
     for (int j = 0; j < CFD_NMEM; ++j) {
       n_sp[j].release(); kall_sp[j].release(); cb[j].release(); vt_all[j].release(); ca[j].release(); asq[j].release(); kbtab[j].release();
@@ -652,6 +653,7 @@ struct XaRow {      // one row of a work list
   int inst[CFD_NMEM]; // memory instance per memory
   int aux;            // row of xa_dedup this row's tiles store to / add (-1: none)
   int one;            // instance of the one-key memory (Problem::xa_one), or -1
+  int att;            // row of the attention-map blocks this row's tiles store to (Problem::att_fused), or -1
 };
 
 static void make_xattn_worklist(const Problem& p, const std::vector<XaRow>& rows, int mem_mask, std::vector<XaWg>& wgs, std::vector<XaSeg>& segs,
@@ -696,6 +698,7 @@ static void make_xattn_worklist(const Problem& p, const std::vector<XaRow>& rows
         w.row[k] = on ? rows[vr[k]].xrow : -1;
         w.aux[k] = on ? rows[vr[k]].aux : -1;
         w.one[k] = on ? rows[vr[k]].one : -1;
+        w.att[k] = on ? rows[vr[k]].att : -1;
         w.q0[k] = on ? tiles[t0 + k].second : 0;
       }
       w.seg0 = (int)segs.size();
@@ -749,7 +752,7 @@ static void make_xattn_worklist(const Problem& p, const std::vector<XaRow>& rows
   for (int x = 0; x < 8; ++x) qlen = std::max(qlen, queue[x].size());
   XaWg idle;
   memset(&idle, 0, sizeof(idle));
-  for (int k = 0; k < XA_TILES; ++k) { idle.row[k] = -1; idle.aux[k] = -1; idle.one[k] = -1; }
+  for (int k = 0; k < XA_TILES; ++k) { idle.row[k] = -1; idle.aux[k] = -1; idle.one[k] = -1; idle.att[k] = -1; }
   wgs.assign(qlen * 8, idle);
   for (int x = 0; x < 8; ++x) {
     for (size_t i = 0; i < queue[x].size(); ++i) wgs[i * 8 + x] = queue[x][i];
@@ -801,6 +804,7 @@ static int build_xattn_worklist(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
   std::vector<XaRow> rows(p.Be);
   for (int b = 0; b < p.Be; ++b) {
     rows[b].xrow = b; rows[b].aux = -1; rows[b].one = p.xa_one >= 0 ? hm[p.xa_one][b] : -1;
+    rows[b].att = (p.att_fused && b >= p.att_b0 && b < p.att_b0 + p.att_nb) ? b - p.att_b0 : -1;
     for (int j = 0; j < CFD_NMEM; ++j) rows[b].inst[j] = hm[j][b];
   }
   const int all_mems = ((1 << CFD_NMEM) - 1) & ~(p.xa_one >= 0 ? 1 << p.xa_one : 0);
@@ -857,6 +861,8 @@ static int build_xattn_layer0_lists(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
         idx = (int)ra.size();
         XaRow r;
         r.xrow = row; r.aux = idx; r.one = -1;
+        // (every chunk of the utterance enters layer 0 with the same state: the full-conditioning chunk's map against this instance is this row's)
+        r.att = (p.att_fused && p.att_b0 + b < p.Be && hm[jg][p.att_b0 + b] == u) ? b : -1;
         for (int j = 0; j < CFD_NMEM; ++j) r.inst[j] = hm[j][row];
         ra.push_back(r);
         seen.emplace_back(u, idx);
@@ -867,6 +873,7 @@ static int build_xattn_layer0_lists(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
   if (ra.size() * 2 > (size_t)p.Be) return CFD_OK;   // too little repetition
   for (int b = 0; b < p.Be; ++b) {
     rb[b].xrow = b; rb[b].aux = aux_of[b]; rb[b].one = p.xa_one >= 0 ? hm[p.xa_one][b] : -1;
+    rb[b].att = (p.att_fused && b >= p.att_b0 && b < p.att_b0 + p.att_nb) ? b - p.att_b0 : -1;
     for (int j = 0; j < CFD_NMEM; ++j) rb[b].inst[j] = hm[j][b];
   }
   std::vector<XaWg> wa, wb;
@@ -914,6 +921,7 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
     p.att[j] = att ? att[j] : nullptr;
     p.att_slot[j] = 0;
     p.att_b0 = p.att_nb = 0;      // (a sampling run with an attention ring sets them after this call)
+    p.att_fused = false;
   }
   p.Sp_tot = off;
   {  // memories without a key-padding mask get an all-zero one, so the softmax kernel needs no null test
@@ -1444,6 +1452,7 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     attj[j] = p.att[j] ? p.att[j] + (size_t)row0 * nl * L * p.S[j] : nullptr;
     want_att = want_att || p.att[j];
   }
+  if (p.att_fused) want_att = false;   // (the ring of a sampling run on the tile kernels: the fused kernel keeps the maps itself)
   // one fused kernel per layer for the cross-attention block, unless att_mats are wanted (or the naive debug GEMMs)
   const bool fused_x = c->fused_xattn && p.xa_nwg > 0 && !want_att && !g_cfd_naive_gemm && row0 == 0 && Be == p.Be;
 
@@ -1485,6 +1494,7 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
     attr |= 1ull << (c->cfg.device & 63);
   }
 
@@ -1573,8 +1583,10 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
 #endif
       Bracket br(c, CFD_PROF_XATTN, st);
       const int form = (c->xa_pp == 1 && p.xa_flush) ? 2 : c->xa_pp;   // the ping-pong form has no flush between two online memories
+      if (p.att_fused) a.att = c->w->xa_att_desc.as<XaAtt>() + l;
       auto launch_xa = [&](int nwg, const XAttnArgs& xa) {
-        if (form == 1) hipLaunchKernelGGL(xattn_fused_kernel<1>, dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
+        if (p.att_fused) hipLaunchKernelGGL((xattn_fused_kernel<0, true>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
+        else if (form == 1) hipLaunchKernelGGL(xattn_fused_kernel<1>, dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
         else if (form == 2) hipLaunchKernelGGL(xattn_fused_kernel<2>, dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
         else hipLaunchKernelGGL(xattn_fused_kernel<0>, dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
       };
@@ -1714,6 +1726,13 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     memset(&e, 0, sizeof(e));
     e.out = eps_out; e.ldo = CFD_LAT; e.bias = rawp(c, "latent_proj.bias");
     CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
+  }
+  if (p.att_fused && fused_x) {   // this step's maps: from what the nine cross-attention launches kept, into slot *d_step of the ring
+    XaFixArgs f;
+    memset(&f, 0, sizeof(f));
+    f.att = c->w->xa_att_desc.as<XaAtt>(); f.nl = nl; f.L = L; f.one_j = p.xa_one; f.d_step = c->w->d_step.as<int>();
+    for (int j = 0; j < CFD_NMEM; ++j) { f.S[j] = p.S[j]; f.ring[j] = p.att[j]; f.slot[j] = p.att_slot[j]; }
+    LAUNCH(CFD_PROF_ROWS, att_fixup_kernel, dim3((unsigned)(p.att_nb * L), nl), dim3(256), st, f);
   }
   return CFD_OK;
 }
@@ -1914,15 +1933,39 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
     // second cross-attention launch has the probabilities in registers anyway: the rows of the last chunk store them into slot *d_step
     // of the caller's ring, inside the captured iteration -- no second forward, no host round trip.
     Problem& pb = c->w->pb;
-    if (!pb.rt || s.dynamic_memory_mask)
-      return fail(CFD_E_SHAPE, "att_ring needs the row-tile path (one timestep per step, L <= %d, at most %lld token rows, at most %d padded keys, no "
-                               "dynamic memory): this run has L = %d, %lld token rows; take the maps with one forward per iteration instead",
-                  RT_MAX_L, c->rt_max_rows, RT_MAX_KEYS, s.L, (long long)Be * s.L);
+    // ... and on the tile kernels the fused cross-attention kernel has them in its softmax: its ATT instance keeps them, att_fixup_kernel
+    // normalises them once per step (xattn_fused.hpp, XaAtt).  What cannot keep them: a run without the fused kernel (memories made per
+    // step: dynamic memories; the developer switches that turn it off).
+    const bool fused_ok = c->fused_xattn && pb.xa_nwg > 0 && c->hoist_memside && !g_cfd_naive_gemm && c->xa_pp != 1;
+    if ((!pb.rt && !fused_ok) || s.dynamic_memory_mask)
+      return fail(CFD_E_SHAPE, "att_ring needs the row-tile path or the fused cross-attention kernel (one timestep per step, no dynamic memory): "
+                               "this run has L = %d, %lld token rows; take the maps with one forward per iteration instead", s.L, (long long)Be * s.L);
     pb.att_b0 = c->chunk_pos[c->sargs.G - 1] * s.B;
     pb.att_nb = s.B;
     for (int j = 0; j < CFD_NMEM; ++j) {
       pb.att[j] = s.att_ring[j];
       pb.att_slot[j] = (long long)s.B * c->nl * s.L * pb.S[j];
+    }
+    if (!pb.rt) {
+      pb.att_fused = true;
+      XaAtt d;
+      memset(&d, 0, sizeof(d));
+      d.nb = pb.att_nb;
+      for (int j = 0; j < CFD_NMEM; ++j) { d.off[j] = d.sp_tot; d.t0[j] = d.nt; d.sp_tot += pb.Sp[j]; d.nt += pb.Sp[j] / XA_KEYS; }
+      const size_t rows = (size_t)pb.att_nb * s.L;
+      CHK(c->w->xa_att_raw.ensure(c->nl * rows * d.sp_tot * 4));
+      CHK(c->w->xa_att_mc.ensure(c->nl * rows * d.nt * 4));
+      CHK(c->w->xa_att_fin.ensure(c->nl * rows * CFD_NMEM * 2 * 4));
+      CHK(c->w->xa_att_desc.ensure(c->nl * sizeof(XaAtt)));
+      std::vector<XaAtt> desc(c->nl, d);
+      for (int l = 0; l < c->nl; ++l) {
+        desc[l].raw = c->w->xa_att_raw.as<float>() + (size_t)l * rows * d.sp_tot;
+        desc[l].mc = c->w->xa_att_mc.as<float>() + (size_t)l * rows * d.nt;
+        desc[l].fin = c->w->xa_att_fin.as<float>() + (size_t)l * rows * CFD_NMEM * 2;
+      }
+      HIPCHK(hipMemcpy(c->w->xa_att_desc.p, desc.data(), c->nl * sizeof(XaAtt), hipMemcpyHostToDevice));
+      CHK(build_xattn_worklist(c, mem_in));   // (once more: the list now says which tiles keep their maps)
+      if (pb.xa_nwg <= 0) return fail(CFD_E_SHAPE, "att_ring: the fused cross-attention work list is empty");
     }
   }
   CHK(build_xattn_layer0_lists(c, mem_in));

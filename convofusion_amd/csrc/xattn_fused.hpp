@@ -90,9 +90,23 @@ struct XaWg {
   int q0[XA_TILES];    // first query (token index inside the row) of tile t
   int aux[XA_TILES];   // layer-0 de-duplication: row of XAttnArgs::dd_out this tile's result is stored to / of dd_in it adds (-1: none)
   int one[XA_TILES];   // one-key memory (XAttnArgs::one_j): its instance for this tile's row (-1: none)
+  int att[XA_TILES];   // the ATT instance: row of XaAtt's blocks this tile's attention maps go to (-1: the tile keeps none)
   int seg0, nseg;
   int pf_slot, pf_n;   // L2 prefetch share (used by the archived role-split kernel, tools/experiments/r03_variants/xattn_role.hpp): this workgroup is number pf_slot of pf_n that stream the same instance of the
                        // longest memory on one XCD at about the same time (0, 0: no prefetch)
+};
+
+// Attention maps kept by the kernel itself (the ATT instance; round 5): a sampling run that wants the reference's per-iteration attention
+// dict (convofusion.py:517-523) on the tile kernels.  The tiles the work list marks (XaWg::att: the full-conditioning chunk's rows) store
+// what the softmax has in registers anyway -- for an online memory the tile's probabilities RELATIVE to the tile's exponent reference,
+// that reference, and at the end of the memory the final reference and 1 / sum; for a single-tile memory the normalised probabilities --
+// and att_fixup_kernel turns them into the maps of ring slot *d_step once per step.  One descriptor per layer.
+struct XaAtt {
+  float* raw;          // [nb][L][sp_tot]: key column off[j] + s of memory j
+  float* mc;           // [nb][L][nt]: tile column t0[j] + s / 32
+  float* fin;          // [nb][L][CFD_NMEM][2]: final exponent reference, 1 / sum (single-tile memories: 0, 1)
+  int nb, sp_tot, nt;
+  int off[CFD_NMEM], t0[CFD_NMEM];
 };
 
 struct XAttnArgs {
@@ -126,6 +140,7 @@ struct XAttnArgs {
   const float* one_va;        // fp32 [U][512]: VA of its key, this layer
   const float* one_rs;        // fp32 [U * one_sp]: the scale plane of this step (key 0 of instance u at u * one_sp)
   long long* stamps;          // XA_STAMP builds only (tools/xa_stamps.py): per wave, cycles per section of the kernel
+  const XaAtt* att;           // the ATT instance: this layer's descriptor
 };
 
 // float32 copy of the value row of a one-key memory: out[(l * U + u) * 512 + f] = VA_l,u[f] (key 0 of V^T [nl][U][512][Sp], hi + lo)
@@ -180,8 +195,10 @@ __device__ __forceinline__ T xa_sel(const T (&arr)[CFD_NMEM], int j) {
 //         the K sub-buffers, waves 4-7 the V^T ones, eight pieces per wave (fill_k8 / fill_v8).  With every wave requesting, both waves
 //         of a SIMD sit in the LDS-DMA issue together (100+ cycles per piece: the CU's one texture path takes the pieces one after the
 //         other) and the matrix pipe idles; a requesting wave beside a computing one costs the computing wave nothing.
-template <int PP>
+// ATT: the rows of XaAtt also store their attention maps (lock-step form only).
+template <int PP, bool ATT = false>
 __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAttnArgs a) {
+  static_assert(!ATT || PP == 0, "attention maps: the lock-step form");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KOFF = 0, VOFF = 65536;
 #if XA_STAMP
@@ -208,6 +225,9 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   const bool active = my_row >= 0;                     // wave-uniform
   const long long tok0 = active ? (long long)my_row * a.L + my_q0 : 0;
   const int nq = active ? min(16, a.L - my_q0) : 0;    // valid queries of this wave's tile
+  bool att_on = false;                                 // (wave-uniform) this wave stores its tile's attention maps: one wave of the pair
+  int my_att = -1;
+  if constexpr (ATT) { my_att = wgp->att[tile]; att_on = active && (wid >> 2) == 0 && my_att >= 0; }
 
   // the segment list of this workgroup -> LDS (read back with ds_read: no vector-memory traffic inside the loop)
   if (threadIdx.x < nseg) reinterpret_cast<int4*>(smem + XA_SEGOFF)[threadIdx.x] = reinterpret_cast<const int4*>(a.segs + seg0)[threadIdx.x];
@@ -525,7 +545,29 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   };
   // softmax of one key tile from the pair's two partial score sets (this wave's s0 / s1 in registers, the partner's in the exchange area):
   // leaves P' (hi / lo) in ph / pl, updates the running maximum / sums and rescales O for an online memory
-  auto softmax_tile = [&](const f32x4& s0, const f32x4& s1, int slot, bool online) __attribute__((always_inline)) {
+  // ATT: where this lane's 8 probabilities of key tile kt of memory j go (queries beyond L store nothing)
+  auto att_store = [&](int j, int kt, const float* pv, float mc) __attribute__((always_inline)) {
+    const XAttnArgs* ka = reinterpret_cast<const XAttnArgs*>((unsigned long long)__builtin_amdgcn_kernarg_segment_ptr());   // (as in the flush: nothing kept in SGPRs across the loop)
+    asm volatile("" : "+s"(ka));
+    const XaAtt* ap = ka->att;
+    if (l15 < nq) {
+      const long long qi = (long long)my_att * ka->L + my_q0 + l15;
+      float* rp = ap->raw + qi * ap->sp_tot + ap->off[j] + kt * XA_KEYS + q4 * 8;
+      *reinterpret_cast<float4*>(rp) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      *reinterpret_cast<float4*>(rp + 4) = make_float4(pv[4], pv[5], pv[6], pv[7]);
+      if (q4 == 0) ap->mc[qi * ap->nt + ap->t0[j] + kt] = mc;
+    }
+  };
+  auto att_finish = [&](int j, float mc_fin, float inv_sum) __attribute__((always_inline)) {
+    const XAttnArgs* ka = reinterpret_cast<const XAttnArgs*>((unsigned long long)__builtin_amdgcn_kernarg_segment_ptr());
+    asm volatile("" : "+s"(ka));
+    const XaAtt* ap = ka->att;
+    if (l15 < nq && q4 == 0) {
+      float* fp = ap->fin + (((long long)my_att * ka->L + my_q0 + l15) * CFD_NMEM + j) * 2;
+      fp[0] = mc_fin; fp[1] = inv_sum;
+    }
+  };
+  auto softmax_tile = [&](const f32x4& s0, const f32x4& s1, int slot, bool online, int j, int kt) __attribute__((always_inline)) {
     float scale = 1.0f;
     // softmax of this tile: lane (q, g) holds keys 8 g + e, e = 0..7 (s0 = e 0..3, s1 = e 4..7)
     const f32x4 t0 = *reinterpret_cast<const f32x4*>(xch_other);
@@ -561,6 +603,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       }
       lsum = lsum * scale + xlane_sum(ps);
       m = m_new;
+      if constexpr (ATT) { if (att_on) att_store(j, kt, p, mc); }     // (a dead tile: p = 0 against the reference 0)
       float pw = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { p[e] *= rs[e]; pw += p[e]; }     // P' = p rs: the operand of VA^T P'
@@ -575,7 +618,10 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       }
       const float inv = 1.0f / xlane_sum(ps);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { p[e] = (p[e] * inv) * rs[e]; wl += p[e]; }
+      for (int e = 0; e < 8; ++e) p[e] = p[e] * inv;
+      if constexpr (ATT) { if (att_on) { att_store(j, kt, p, 0.f); att_finish(j, 0.f, 1.0f); } }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { p[e] = p[e] * rs[e]; wl += p[e]; }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {      // p <= 1 and rs <= 1 / sqrt(eps) = 316: no saturation needed in front of the fp16 split
@@ -694,7 +740,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
         if (__builtin_amdgcn_readfirstlane(seen) > step) break;
         __builtin_amdgcn_s_sleep(1);
       }
-      if (!(XA_ABLATE & 8)) softmax_tile(s0, s1, slot, online);
+      if (!(XA_ABLATE & 8)) softmax_tile(s0, s1, slot, online, cj, kt);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- B0 (fa holds its first half) --------------------------------------------------------------------------------
@@ -831,7 +877,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     fill_k(nxt, 1, slot ^ 1);
     }
     read_v(fa, 0);
-    if (in_seg && !(XA_ABLATE & 8)) softmax_tile(s0, s1, slot, online);
+    if (in_seg && !(XA_ABLATE & 8)) softmax_tile(s0, s1, slot, online, cj, kt);
     // ---- B0 (fa holds its first half) --------------------------------------------------------------------------------
     XA_T(10);
     read_v(fb, 1);
@@ -869,6 +915,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
 #pragma unroll
         for (int f = 0; f < 16; ++f) { o[f][0] *= inv; o[f][1] *= inv; o[f][2] *= inv; o[f][3] *= inv; }
         wsum *= inv;
+        if constexpr (ATT) { if (att_on) att_finish(cj, mc_run, inv); }
       }
       if (q4 == 0) wq_mine[l15 * 5 + cj] = wsum;
     }
@@ -902,4 +949,38 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       for (int k = 0; k < XA_NSTAMP; ++k) a.stamps[((long long)blockIdx.x * XA_WAVES + wid) * XA_NSTAMP + k] = acc_[k];
   }
 #endif
+}
+
+// The maps of one step from what the ATT instance stored (XaAtt), into slot *d_step of the caller's ring: block [nb][nl][L][S_j] per memory.
+//   p(s) = raw(s) 2^(mc_tile - mc_final) / sum        (raw = 0 stays 0 whatever the exponents: a dead tile in front of live ones;
+//                                                      every key dead: 0 x (1 / 0) = NaN like the reference's softmax)
+// A one-key memory that the work lists skip (XAttnArgs::one_j) has probability 1.
+struct XaFixArgs {
+  const XaAtt* att;            // [nl]
+  int nl, L, one_j;
+  int S[CFD_NMEM];
+  float* ring[CFD_NMEM];
+  long long slot[CFD_NMEM];    // floats per ring slot
+  const int* d_step;
+};
+__global__ void __launch_bounds__(256) att_fixup_kernel(const XaFixArgs a) {
+  const int l = blockIdx.y;
+  const XaAtt at = a.att[l];
+  const long long qi = blockIdx.x;                 // (row r, query q): r * L + q
+  const int r = (int)(qi / a.L), q = (int)(qi - (long long)r * a.L);
+  const int step = *a.d_step;
+#pragma unroll
+  for (int j = 0; j < CFD_NMEM; ++j) {
+    const int S = xa_sel(a.S, j);
+    float* out = xa_sel(a.ring, j);
+    if (!out) continue;
+    out += (long long)step * xa_sel(a.slot, j) + (((long long)r * a.nl + l) * a.L + q) * S;
+    if (j == a.one_j) { if (threadIdx.x == 0) out[0] = 1.0f; continue; }
+    const float mcf = at.fin[(qi * CFD_NMEM + j) * 2], inv = at.fin[(qi * CFD_NMEM + j) * 2 + 1];
+    for (int s = threadIdx.x; s < S; s += 256) {
+      const float raw = at.raw[qi * at.sp_tot + at.off[j] + s];
+      const float mct = at.mc[qi * at.nt + at.t0[j] + (s >> 5)];
+      out[s] = (raw == 0.f ? 0.f : raw * __builtin_amdgcn_exp2f(mct - mcf)) * inv;
+    }
+  }
 }

@@ -116,8 +116,11 @@ class SamplingRun:
                  dynamic_memories=(), side_engine=False, attention_ring=False):
         """attention_ring: keep the attention maps of the full-conditioning chunk of EVERY iteration (the reference's per-iteration dict,
         convofusion.py:517-523): the captured iteration stores them into ``self.att_ring`` -- five tensors [iterations, B, layers, L, S_j]
-        -- with no extra forward and no host round trip (cfd_sample_args.att_ring; small problems only: the library answers CFD_E_SHAPE
-        otherwise and ``sample`` then takes the maps with one forward per iteration).  ``attention_dict()`` turns the ring into the dict.
+        -- with no extra forward and no host round trip (cfd_sample_args.att_ring: the row-tile kernels store them from their second
+        cross-attention launch, the fused cross-attention kernel of the tile path from its softmax; a run that has neither -- dynamic
+        memories -- gets CFD_E_SHAPE and ``sample`` then takes the maps with one forward per iteration).  The ring is
+        iterations x B x layers x L x keys floats: ``sample`` / ``diffusion_reverse`` ask for it only up to ATT_RING_MAX_BYTES.
+        ``attention_dict()`` turns the ring into the dict.
         side_engine: open the run on the denoiser's second library handle (its own weights copy, workspace and stream), so that
         two runs on one module can be open at once (the attention forward of ``last_step_attention`` uses it for a plain forward).
         dynamic_memories: indices j of memories whose CONTENTS the caller rewrites between iterations (DyadicRun's partner
@@ -305,16 +308,25 @@ def last_step_attention(run, denoiser, timestep, encoder_hidden_states, cond_mas
     return att
 
 
+# Largest attention ring the loop drop-ins allocate by themselves (bytes): the product shape with 32 utterances and 1000 iterations is
+# 4.0 GB; the headline shape (196 tokens, 1500 audio keys) would be 356 MB PER ITERATION.  Beyond it "auto" keeps the last entry.
+ATT_RING_MAX_BYTES = 16 << 30
+
+
 def _open_run(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps, want_ring, **kw):
-    """SamplingRun with the attention ring when every iteration's maps are wanted and the problem is one the library keeps them for (the
-    row-tile path: the product's single utterances and small batches); otherwise -- CFD_E_SHAPE from cfd_sample_begin -- a plain run,
-    and the caller takes the maps with one forward per iteration (``last_step_attention``)."""
+    """SamplingRun with the attention ring when every iteration's maps are wanted, the ring fits ATT_RING_MAX_BYTES and the run is one
+    the library keeps them for (every run but those with dynamic memories or with the fused cross-attention switched off); otherwise --
+    CFD_E_SHAPE from cfd_sample_begin -- a plain run, and the caller takes the maps with one forward per iteration (``last_step_attention``)."""
+    if want_ring:
+        n_it = len(scheduler.timestep_table(num_inference_steps)[1])
+        keys = sum(int(m.shape[1]) for m in encoder_hidden_states)
+        want_ring = 4 * n_it * B * int(denoiser.num_layers) * L * keys <= ATT_RING_MAX_BYTES
     if want_ring:
         try:
             return SamplingRun(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
                                **dict(kw, attention_ring=True, skip_zero_weight_chunks=False))
         except _lib.CfdError as e:
-            if e.code != -2:      # CFD_E_SHAPE: not a row-tile problem
+            if e.code != -2:      # CFD_E_SHAPE: a run whose maps the captured iteration cannot keep
                 raise
     return SamplingRun(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps, **kw)
 

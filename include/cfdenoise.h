@@ -136,10 +136,12 @@ typedef struct {
   float* att_ring[CFD_NUM_MEM];/* all NULL, or five dev buffers [iterations][B][num_layers][L][S_j] float32: the captured iteration
                                  stores the attention probabilities of the LAST guidance chunk (full conditioning) of iteration i into
                                  slot i -- the reference's per-iteration dict attention_matrices[t] = att_mats of the last chunk
-                                 (convofusion.py:517-523, dumped as att_<t>.npy by base.py:243-259).  Needs the row-tile path (small
-                                 problems: L <= 32, at most 700 token rows, at most 1024 padded keys, no dynamic memory; otherwise
+                                 (convofusion.py:517-523, dumped as att_<t>.npy by base.py:243-259).  Small problems (the row-tile
+                                 path) store them from their second cross-attention launch, all others from the fused
+                                 cross-attention kernel's softmax (+ one small launch per iteration): 2 - 5 % of the run time.
+                                 Needs skip_zero_weight_chunks == 0 and no dynamic memory (such a run has no fused cross-attention:
                                  cfd_sample_begin fails with CFD_E_SHAPE and the caller takes the maps with one cfd_forward per
-                                 iteration) and skip_zero_weight_chunks == 0. */
+                                 iteration).  The ring's size is the caller's business: iterations x B x layers x L x keys. */
 } cfd_sample_args;
 
 /* Opens a sampling run: builds the per-step coefficient and timestep-embedding tables, draws / copies

@@ -429,10 +429,9 @@ def test_attention_of_every_iteration_leaves_the_latents_alone():
 
 def test_every_iterations_attention_maps_match_the_oracle():
     """The reference fills ``attention_matrices[t]`` with the full-conditioning chunk's att_mats of EVERY iteration (convofusion.py:517-523;
-    base.py:243-259 writes them out).  For small problems the captured iteration keeps them itself (cfd_sample_args.att_ring: the row-tile
-    path's second cross-attention launch stores the last chunk's probabilities into slot *d_step): every entry of a 10-step run against the
-    restated loop driving the numpy oracle, the latents untouched by the extra chunk, and -- for a batch beyond the row-tile path -- the
-    fall-back (one forward per iteration) giving the same dict."""
+    base.py:243-259 writes them out).  The captured iteration keeps them itself (cfd_sample_args.att_ring: the row-tile path's second
+    cross-attention launch stores the last chunk's probabilities into slot *d_step): every entry of a 10-step run against the restated
+    loop driving the numpy oracle, the latents untouched by the extra chunk -- and the same through the tile kernels."""
     import torch
     from convofusion_amd.sampler import SamplingRun, sample
     from tests.gpu_helpers import hip_denoiser, to_dev
@@ -460,14 +459,58 @@ def test_every_iterations_attention_maps_match_the_oracle():
             worst = max(worst, max_abs(got, want[t][j]))
     print("worst attention-map difference over", n, "iterations x 5 memories:", worst)
     assert worst < 1e-4
-    # beyond the row-tile path (more than 700 token rows): the dict comes from one forward per iteration, same contract
-    B2 = 8
-    cb2 = inputs.make_cfg_batch(seed=seed + 1, B=B2, L=L, S=S, pad_tail=(2, 0, 1, 0, 0))
-    mems2, masks2 = [to_dev(x) for x in cb2["memories"]], {k: to_dev(v) for k, v in cb2["masks"].items()}
-    with pytest.raises(Exception):
-        SamplingRun(m, _sched("ddpm"), mems2, masks2, B2, L, 4, seed=seed, attention_ring=True)
-    lat2, atts2 = sample(m, _sched("ddpm"), mems2, masks2, B=B2, L=L, num_inference_steps=4, seed=seed, return_attention="all")
-    assert len(atts2) == 4 and torch.equal(lat2, sample(m, _sched("ddpm"), mems2, masks2, B=B2, L=L, num_inference_steps=4, seed=seed))
+    # The same run on the TILE kernels (CFD_ROWTILE=0): there the fused cross-attention kernel keeps the maps (its ATT instance stores each
+    # key tile's probabilities relative to the tile's exponent reference, att_fixup_kernel normalises them once per step).
+    m_tile = _handle_with_env({"CFD_ROWTILE": "0"})
+    lat_t, atts_t = sample(m_tile, _sched("ddpm"), mems, masks, B=B, L=L, num_inference_steps=n, seed=seed, return_attention="all")
+    assert torch.equal(lat_t, sample(m_tile, _sched("ddpm"), mems, masks, B=B, L=L, num_inference_steps=n, seed=seed))
+    worst_t = max(max_abs(atts_t[t][j].cpu().numpy(), want[t][j]) for t in want for j in range(5))
+    print("tile kernels, the same run: worst attention-map difference", worst_t)
+    assert sorted(atts_t) == sorted(want) and worst_t < 1e-4
+
+
+def test_attention_maps_of_every_iteration_beyond_the_row_tile_path():
+    """Eight utterances (896 token rows: the tile kernels, with layer 0's de-duplicated cross-attention lists): the ring is filled by the fused
+    cross-attention kernel.  Every entry against the restated loop driving the numpy oracle (masked keys exactly 0, rows summing to 1), the
+    latents bit-identical to a run that keeps no maps, and the fall-back that an over-budget ring takes (one forward per iteration through the
+    three-launch attention) giving the same dict."""
+    import torch
+    from convofusion_amd import sampler
+    from convofusion_amd.sampler import SamplingRun, sample
+    from tests.gpu_helpers import hip_denoiser, to_dev
+    B, L, S, n, seed = 8, 16, (6, 40, 6, 8, 1), 4, 6
+    cb = inputs.make_cfg_batch(seed=seed, B=B, L=L, S=S, pad_tail=(2, 5, 1, 0, 0))
+    sd = state_dict()
+    init = philox_ref.normal_tensor(seed, 0, range(B), 1, L)
+    want_lat, _, want = sampler_ref.diffusion_reverse(
+        lambda x, t, e, mk: denoiser_ref.denoiser_forward(sd, x, t, e, mk), scheduler_ref.DDPMSchedulerRef(), cb["memories"], cb["masks"],
+        init, lambda i, t: philox_ref.normal_tensor(seed, i, range(B), 0, L), num_inference_steps=n, return_att=True)
+    m = hip_denoiser(1234, 1.0)
+    mems, masks = [to_dev(x) for x in cb["memories"]], {k: to_dev(v) for k, v in cb["masks"].items()}
+    with SamplingRun(m, _sched("ddpm"), mems, masks, B, L, n, seed=seed, attention_ring=True) as run:
+        assert run.att_ring is not None and tuple(run.att_ring[1].shape) == (n, B, 9, L, S[1])
+    lat, atts = sample(m, _sched("ddpm"), mems, masks, B=B, L=L, num_inference_steps=n, seed=seed, return_attention="all")
+    assert torch.equal(lat, sample(m, _sched("ddpm"), mems, masks, B=B, L=L, num_inference_steps=n, seed=seed))
+    assert rel_l2(lat.permute(1, 0, 2).cpu().numpy(), want_lat) < TRAJ_TOL
+    assert sorted(atts) == sorted(want)
+    worst = 0.0
+    for t in want:
+        for j in range(5):
+            got = atts[t][j].cpu().numpy()
+            assert got.shape == want[t][j].shape
+            worst = max(worst, max_abs(got, want[t][j]))
+            assert np.all(got[want[t][j] == 0] == 0)                       # masked keys: exactly 0
+            assert np.abs(got.sum(-1) - 1).max() < 1e-5
+    print("8 utterances, fused kernel's maps: worst difference over", n, "iterations x 5 memories:", worst)
+    assert worst < 1e-4
+    keep = sampler.ATT_RING_MAX_BYTES
+    try:
+        sampler.ATT_RING_MAX_BYTES = 0     # the ring "does not fit": one forward per iteration
+        lat2, atts2 = sample(m, _sched("ddpm"), mems, masks, B=B, L=L, num_inference_steps=n, seed=seed, return_attention="all")
+    finally:
+        sampler.ATT_RING_MAX_BYTES = keep
+    assert torch.equal(lat2, lat)
+    assert max(max_abs(atts2[t][j].cpu().numpy(), want[t][j]) for t in want for j in range(5)) < 1e-4
 
 
 def test_ddpm_step_count_that_does_not_divide_the_schedule():
