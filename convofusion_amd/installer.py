@@ -53,11 +53,11 @@ def install(model, attention_steps="auto"):
     ``attention_steps``: which entries the returned attention-matrix dict holds.  The reference keeps the full-conditioning
     chunk's maps of EVERY iteration (convofusion.py:517-523) and its result writer dumps one ``att_<t>.npy`` per entry and
     memory (convofusion/models/modeltype/base.py:252-259).  "all" reproduces the reference's dict, so that an unchanged ``test.py``
-    writes the same files: for small problems (single utterances, small batches: what WEG and the rollout run) the captured iteration
-    stores the maps itself (+5 % run time), for larger batches it costs one extra forward of the B full-conditioning rows and one
-    host round trip per iteration.  "last" returns the final iteration's entry only -- the loop then never leaves the device and does
-    not evaluate the zero-weight full-conditioning chunk.  "auto" (default): "all" where the captured iteration keeps the maps,
-    "last" elsewhere."""
+    writes the same files: the captured iteration stores the maps itself (+2 - 5 % run time; a ring of iterations x B x layers x L x keys
+    floats, 4 GB for 32 utterances x 1000 iterations at the product shape); beyond ``sampler.ATT_RING_MAX_BYTES`` it costs one extra
+    forward of the B full-conditioning rows and one host round trip per iteration.  "last" returns the final iteration's entry only --
+    the loop then does not evaluate the zero-weight full-conditioning chunk.  "auto" (default): "all" while the ring fits the budget,
+    "last" beyond it."""
     _check_model(model)
     if attention_steps not in ("auto", "last", "all"):
         raise ValueError("attention_steps must be 'auto', 'last' or 'all'")

@@ -336,9 +336,9 @@ def sample(denoiser, scheduler, encoder_hidden_states, cond_masks=None, *, B, L=
            first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False, row_maps=None, return_attention=False):
     """Run the whole loop; returns latents [B, L, 128] (batch-first); with ``return_attention=True`` also the last
     iteration's attention maps (``last_step_attention``), with ``return_attention="all"`` a dict {timestep: maps} over every
-    iteration like the reference's: kept by the captured iteration itself for small problems (``SamplingRun(attention_ring=True)``),
-    otherwise taken with one extra forward and one host round trip per step; ``return_attention="auto"`` always returns a dict: every
-    iteration's entries where the captured iteration keeps them itself, the last iteration's entry otherwise."""
+    iteration like the reference's: kept by the captured iteration itself (``SamplingRun(attention_ring=True)``) while the ring fits
+    ATT_RING_MAX_BYTES, otherwise taken with one extra forward and one host round trip per step; ``return_attention="auto"`` always
+    returns a dict: every iteration's entries where the captured iteration keeps them itself, the last iteration's entry otherwise."""
     run = _open_run(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps, return_attention in ("all", "auto"),
                     guidance_scale=guidance_scale, guidance_chunks=guidance_chunks, eta=eta, init_latents=init_latents, step_noise=step_noise,
                     seed=seed, first_utterance=first_utterance, preseq=preseq, dedup=dedup, skip_zero_weight_chunks=skip_zero_weight_chunks,
@@ -487,10 +487,10 @@ def diffusion_reverse(model, encoder_hidden_states, lengths=None, cond_masks=dic
     Returns (latents [L, B, 128], attention_matrices dict).  The reference fills the dict with the full-conditioning
     chunk's ``att_mats`` of EVERY iteration (1000 x 5 tensors kept alive, written out as att_<t>.npy by base.py:252-259);
     ``attention_steps="last"`` keeps the last iteration's entry only: {t_last: att_mats} (``last_step_attention``);
-    ``"all"`` fills the whole dict like the reference -- for small problems (the product's single utterances and small batches: the
-    row-tile path) the captured iteration stores the maps itself (cfd_sample_args.att_ring: +5 % run time), otherwise at the price of one
-    extra forward of the B full-conditioning rows and one host round trip per iteration; ``"auto"`` (what ``convofusion_amd.install``
-    binds by default) is "all" where the captured iteration keeps the maps and "last" elsewhere."""
+    ``"all"`` fills the whole dict like the reference -- the captured iteration stores the maps itself (cfd_sample_args.att_ring: +2 - 5 %
+    run time) while the ring fits ATT_RING_MAX_BYTES, otherwise at the price of one extra forward of the B full-conditioning rows and
+    one host round trip per iteration; ``"auto"`` (what ``convofusion_amd.install`` binds by default) is "all" where the captured
+    iteration keeps the maps and "last" elsewhere."""
     if attention_steps not in ("last", "all", "auto"):
         raise ValueError("attention_steps must be 'auto', 'last' or 'all'")
     if attention_steps in ("all", "auto"):

@@ -250,7 +250,7 @@ def test_no_edit_installer_binds_the_reference_entry_points():
     assert convofusion_amd.install(model) is model
     assert isinstance(model._diffusion_reverse, types.MethodType) and model._diffusion_reverse.__func__ is inst._diffusion_reverse
     assert RefLike()._diffusion_reverse(None) == "reference loop"           # other instances and the class are untouched
-    assert model._cfd_attention_steps == "auto"      # "all" where the captured iteration keeps the maps (small problems), "last" elsewhere
+    assert model._cfd_attention_steps == "auto"      # "all" while the ring of maps fits the budget, "last" beyond it
     convofusion_amd.install(model, attention_steps="all")                  # the reference's per-iteration attention dict (base.py:252-259)
     assert model._cfd_attention_steps == "all"
     with pytest.raises(ValueError):
