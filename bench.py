@@ -246,7 +246,18 @@ def secondary_configs(model, device):
         run.read()
         dt = time.perf_counter() - t0
         run.close()
-        out["r_product_shape_b32"] = {"steps_per_s": 50 / dt, "ms_per_step": 1000 * dt / 50, "workload": f"B={B_PER_GPU}, L={L}, S={S}"}
+        # ... and with every iteration's attention maps kept (the reference's default dict; here by the fused cross-attention kernel itself)
+        run = SamplingRun(model, ddpm, mems, masks, B_PER_GPU, L, 100, guidance_scale=7.5, seed=0, attention_ring=True)
+        run.steps(3)
+        run.read()
+        t0 = time.perf_counter()
+        run.steps(50)
+        run.read()
+        dt_ring = time.perf_counter() - t0
+        run.close()
+        del run
+        out["r_product_shape_b32"] = {"steps_per_s": 50 / dt, "ms_per_step": 1000 * dt / 50, "workload": f"B={B_PER_GPU}, L={L}, S={S}",
+                                      "all_attention_maps_ms_per_step": 1000 * dt_ring / 50, "all_attention_maps_over_none": dt_ring / dt}
         mems, masks = make_inputs(1, device, seed=1234)
         run = SamplingRun(model, ddpm, mems, masks, 1, L, 1000, guidance_scale=7.5, seed=0)
         run.steps(2)

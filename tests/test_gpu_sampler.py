@@ -1034,3 +1034,36 @@ def test_cached_time_tables_never_serve_another_timestep_list():
     sharp = hip_denoiser(4321, 4.0)
     m.load_state_dict(sharp.state_dict(), strict=True)
     assert torch.equal(run(m, "ddpm", 20), run(fresh_model(sharp), "ddpm", 20))
+
+
+def test_attention_maps_of_every_iteration_at_the_headline_row_shape():
+    """The fused kernel's maps where its online softmax really runs: one utterance of the headline shape (196 tokens: a last query tile of 4
+    rows; 1500 audio keys: 47 key tiles whose running maximum moves, with a masked tail; layer 0 through the de-duplicated lists), two
+    iterations against the restated loop driving the numpy oracle."""
+    import torch
+    from convofusion_amd.sampler import sample
+    from tests.gpu_helpers import hip_denoiser, to_dev
+    B, L, S, n, seed = 1, 196, (32, 1500, 32, 8, 1), 2, 11
+    pad = (5, 37, 7, 0, 0)
+    cb = inputs.make_cfg_batch(seed=seed, B=B, L=L, S=S, pad_tail=pad, uncond_pad_tail=pad)
+    sd = state_dict(1234, 1.0, 1500)     # (the memory PE buffer extended to 1500 rows, as the HIP Denoiser extends its own)
+    init = philox_ref.normal_tensor(seed, 0, range(B), 1, L)
+    want_lat, _, want = sampler_ref.diffusion_reverse(
+        lambda x, t, e, mk: denoiser_ref.denoiser_forward(sd, x, t, e, mk), scheduler_ref.DDIMSchedulerRef(), cb["memories"], cb["masks"],
+        init, lambda i, t: philox_ref.normal_tensor(seed, i, range(B), 0, L), num_inference_steps=n, return_att=True)
+    m = hip_denoiser(1234, 1.0)
+    mems, masks = [to_dev(x) for x in cb["memories"]], {k: to_dev(v) for k, v in cb["masks"].items()}
+    lat, atts = sample(m, _sched("ddim"), mems, masks, B=B, L=L, num_inference_steps=n, seed=seed, return_attention="all")
+    assert torch.equal(lat, sample(m, _sched("ddim"), mems, masks, B=B, L=L, num_inference_steps=n, seed=seed))
+    assert rel_l2(lat.permute(1, 0, 2).cpu().numpy(), want_lat) < TRAJ_TOL
+    assert sorted(atts) == sorted(want)
+    worst = 0.0
+    for t in want:
+        for j in range(5):
+            got = atts[t][j].cpu().numpy()
+            assert got.shape == want[t][j].shape == (B, 9, L, S[j])
+            worst = max(worst, max_abs(got, want[t][j]))
+            assert np.all(got[want[t][j] == 0] == 0)
+            assert np.abs(got.sum(-1) - 1).max() < 1e-5
+    print("headline row shape, fused kernel's maps: worst difference", worst)
+    assert worst < 1e-4
