@@ -18,7 +18,7 @@ PROF_CLASSES = ("gemm_token", "gemm_mem", "gemm_attn", "rows", "other", "xattn")
 
 SYMBOLS = [
     "cfd_create", "cfd_destroy", "cfd_last_error", "cfd_source_hash", "cfd_load_tensor", "cfd_finalize_weights",
-    "cfd_set_timestep_table", "cfd_forward", "cfd_sample_begin", "cfd_sample_steps", "cfd_sample_position",
+    "cfd_set_timestep_table", "cfd_forward", "cfd_forward_same_memories", "cfd_sample_begin", "cfd_sample_steps", "cfd_sample_position",
     "cfd_sample_read", "cfd_scheduler_step", "cfd_add_noise", "cfd_philox_normal", "cfd_profile_forward",
     "cfd_test_gemm", "cfd_debug_stop_stage", "cfd_debug_read", "cfd_bench_gemm", "cfd_linear_act",
     "cfd_layer_norm", "cfd_mha", "cfd_add", "cfd_zero_rows", "cfd_gemm_f32", "cfd_softmax", "cfd_softmax_bwd",
@@ -127,6 +127,7 @@ def load():
     lib.cfd_load_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int]
     lib.cfd_finalize_weights.argtypes = [C.c_void_p]
     lib.cfd_set_timestep_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.cfd_forward_same_memories.argtypes = [C.c_void_p]
     lib.cfd_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                 C.POINTER(Memory), C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]
     lib.cfd_sample_begin.argtypes = [C.c_void_p, C.POINTER(SampleArgs), C.c_void_p]

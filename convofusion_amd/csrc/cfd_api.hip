@@ -80,6 +80,7 @@ struct Problem {
   // attention ring of a sampling run (cfd_sample_args::att_ring): only the batch rows [att_b0, att_b0 + att_nb) write their maps, into
   // slot *d_step of att[j] (att_slot[j] floats per slot), as rows 0 .. att_nb - 1 of that slot.  att_nb == 0: att[j] is one [Be][nl][L][S_j] block.
   int att_b0 = 0, att_nb = 0;
+  bool prev_same = false;       // setup_problem: the workspace still holds the previous cfd_forward's projections of memories of these shapes
   bool att_fused = false;       // the ring is written by the fused cross-attention kernel's ATT instance + att_fixup_kernel (tile kernels)
   long long att_slot[CFD_NMEM] = {0, 0, 0, 0, 0};
   int tmode = 0;  // 0: all rows share the timestep of table row *d_step ; 1: row b uses table row b
@@ -138,6 +139,12 @@ struct Work {
   DBuf ca[CFD_NMEM], asq[CFD_NMEM], kbtab[CFD_NMEM], vbtab[CFD_NMEM], b_tab, b_sp, bsq, zeros512;
   DBuf xa_wgs, xa_segs, xa_stamps, xa0_wgs_a, xa0_segs_a, xa0_wgs_b, xa0_segs_b, xa_dedup, xa_one_va, xa_att_raw, xa_att_mc, xa_att_fin, xa_att_desc;
   DBuf d_step;  // [0] = loop index, [1] = constant 0, [2] = "this iteration's in-painting overwrite is done" (cfd_sample_inpaint)
+  // the timestep-independent memory-side projections the last cfd_forward left in this workspace (cfd_forward_same_memories): valid only
+  // from the end of a cfd_forward that made (or reused) all five until the next setup_problem on this workspace
+  bool fwd_mem_valid = false;
+  int fwd_U[CFD_NMEM] = {0, 0, 0, 0, 0}, fwd_S[CFD_NMEM] = {0, 0, 0, 0, 0}, fwd_Be = 0;
+  bool fwd_mask[CFD_NMEM] = {false, false, false, false, false}, fwd_map[CFD_NMEM] = {false, false, false, false, false};
+  unsigned long long fwd_wver = 0;
   DBuf rt_vt, rt_cbt[CFD_NMEM];   // row-tile path: V^T of the self-attention, per-step key tables
   DBuf rt_cur;                    // row-tile path, sampling run: this step's rows of every per-step table (rt_step_rows_kernel)
   // What the timestep-only tables of this workspace were built from: the table rows' timesteps and the weights' generation.  temb / AdaLN
@@ -199,6 +206,9 @@ struct cfd_handle_s {
   int one_key = 1;              // CFD_ONE_KEY=0: a one-key memory (lsnemb) keeps its 32-key tile step in the fused cross-attention
   int xa_pp = 0;                // form of the fused cross-attention kernel (xattn_fused.hpp): CFD_XA_PP=0 lock-step, every wave requests its share of every
                                 // sub-buffer (rounds 2-4); 1 ping-pong (two wave groups one sub-phase apart); 2 lock-step, requests divided between the groups
+  bool hint_same_mem = false;   // cfd_forward_same_memories: consumed by the next cfd_forward
+  int att_fused = 1;            // CFD_ATT_FUSED=0: a forward that returns att_mats takes the three-launch cross-attention on the tile kernels (the fused
+                                // kernel's ATT instance keeps the maps otherwise: xattn_fused.hpp, XaAtt)
   int qkv_fused = 1;            // CFD_QKV_FUSED=0: batch rows of 16 tokens keep the separate v^T product (EpiQkvT, gemm_sp.hpp)
   int l0_dedup = 1;             // CFD_L0_DEDUP=0: layer 0's cross-attention as one launch over all rows (build_xattn_layer0_lists)
   // Row-tile path for small problems (rowtile.hpp): chosen by SHAPE -- at most rt_max_rows token rows of at most RT_MAX_L tokens per batch
@@ -369,6 +379,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   if (env) c->xa_pp = atoi(env);
   env = getenv("CFD_ONE_KEY");
   if (env) c->one_key = atoi(env) != 0;
+  env = getenv("CFD_ATT_FUSED");
+  if (env) c->att_fused = atoi(env) != 0;
   env = getenv("CFD_QKV_FUSED");
   if (env) c->qkv_fused = atoi(env) != 0;
   env = getenv("CFD_ROWTILE");
@@ -890,6 +902,28 @@ static int build_xattn_layer0_lists(Ctx* c, const cfd_memory mem[CFD_NMEM]) {
   return CFD_OK;
 }
 
+// Buffers and per-layer descriptors of the attention maps the fused cross-attention kernel keeps (Problem::att_fused; rows att_nb, set by the caller)
+static int setup_att_fused(Ctx* c) {
+  Problem& pb = c->w->pb;
+  XaAtt d;
+  memset(&d, 0, sizeof(d));
+  d.nb = pb.att_nb;
+  for (int j = 0; j < CFD_NMEM; ++j) { d.off[j] = d.sp_tot; d.t0[j] = d.nt; d.sp_tot += pb.Sp[j]; d.nt += pb.Sp[j] / XA_KEYS; }
+  const size_t rows = (size_t)pb.att_nb * pb.L;
+  CHK(c->w->xa_att_raw.ensure(c->nl * rows * d.sp_tot * 4));
+  CHK(c->w->xa_att_mc.ensure(c->nl * rows * d.nt * 4));
+  CHK(c->w->xa_att_fin.ensure(c->nl * rows * CFD_NMEM * 2 * 4));
+  CHK(c->w->xa_att_desc.ensure(c->nl * sizeof(XaAtt)));
+  std::vector<XaAtt> desc(c->nl, d);
+  for (int l = 0; l < c->nl; ++l) {
+    desc[l].raw = c->w->xa_att_raw.as<float>() + (size_t)l * rows * d.sp_tot;
+    desc[l].mc = c->w->xa_att_mc.as<float>() + (size_t)l * rows * d.nt;
+    desc[l].fin = c->w->xa_att_fin.as<float>() + (size_t)l * rows * CFD_NMEM * 2;
+  }
+  HIPCHK(hipMemcpy(c->w->xa_att_desc.p, desc.data(), c->nl * sizeof(XaAtt), hipMemcpyHostToDevice));
+  return CFD_OK;
+}
+
 static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], float* const att[CFD_NMEM], int tmode, int T) {
   if (!c->finalized) return fail(CFD_E_STATE, "weights not finalized");
   if (c->tsin_rows < 1) return fail(CFD_E_STATE, "timestep table not set");
@@ -903,6 +937,14 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
     HIPCHK(hipMemcpy(c->w->iota.p, id.data(), (size_t)Be * 4, hipMemcpyHostToDevice));
   }
   Problem& p = c->w->pb;
+  // (whatever this call is, it may overwrite the memory-side buffers: the previous forward's projections are current only if cfd_forward
+  //  says so again at its end)
+  bool prev_same = c->w->fwd_mem_valid && c->w->fwd_wver == (unsigned long long)c->wver && c->w->fwd_Be == Be && tmode == 0;
+  c->w->fwd_mem_valid = false;
+  for (int j = 0; j < CFD_NMEM && prev_same; ++j)
+    prev_same = c->w->fwd_U[j] == mem[j].U && c->w->fwd_S[j] == mem[j].S && c->w->fwd_mask[j] == (mem[j].key_padding_mask != nullptr) &&
+                c->w->fwd_map[j] == (mem[j].row_map != nullptr);
+  p.prev_same = prev_same;
   p.Be = Be; p.L = L; p.Lp = (L + 31) / 32 * 32; p.M = (long long)Be * L; p.tmode = tmode; p.T = T;
   p.share_B = 0;
   if (p.Lp > SM_MAX_CHUNKS * 512) return fail(CFD_E_SHAPE, "L = %d exceeds the in-register softmax limit (%d)", L, SM_MAX_CHUNKS * 512);
@@ -982,7 +1024,17 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
     CHK(c->w->rt_vt.ensure((size_t)Be * CFD_D * RT_MAX_L * 4));
     HIPCHK(hipMemset(c->w->rt_vt.p, 0, (size_t)Be * CFD_D * RT_MAX_L * 4));   // keys beyond L stay zero
   }
+  // A forward that returns att_mats, beyond the row-tile path: the fused cross-attention kernel keeps every row's maps itself (its ATT
+  // instance + att_fixup_kernel) instead of the three-launch path with its per-call memory-side projections.
+  {
+    bool any_att = false;
+    for (int j = 0; j < CFD_NMEM; ++j) any_att = any_att || p.att[j];
+    p.att_fused = any_att && !p.rt && tmode == 0 && c->att_fused && c->fused_xattn && c->hoist_memside && !g_cfd_naive_gemm && c->xa_pp != 1;
+    if (p.att_fused) { p.att_b0 = 0; p.att_nb = Be; }
+  }
   CHK(build_xattn_worklist(c, mem));
+  if (p.att_fused && p.xa_nwg <= 0) { p.att_fused = false; p.att_nb = 0; }   // (a list too short for the fused kernel: three-launch path)
+  if (p.att_fused) CHK(setup_att_fused(c));
   const long long M = p.M;
   const int nl = c->nl;
   CHK(c->w->x.ensure((size_t)M * CFD_D * 4));
@@ -1064,7 +1116,7 @@ __global__ void fill_f32_kernel(float* p, long long n, float v) {
 // timestep (see rows.hpp, mem_center_kernel, and xattn_fused.hpp).  Memories in `dynamic_mask` (contents rewritten between the
 // iterations of a run: the dyadic rollout's partner projection) keep their per-step projections, and so does every memory when
 // the fused cross-attention kernel is not the one that runs (att_mats wanted, small problems, per-row timesteps).
-static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool want_att) {
+static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool want_att, bool reuse = false) {
   Problem& p = c->w->pb;
   const int nl = c->nl;
   const long long ROWB = CFD_D * 4;
@@ -1117,8 +1169,9 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
     const bool have_tb = (c->w->tt_mem_mask >> j) & 1;   // A_l b_t / VV_l b_t of this memory are already there for this timestep list
     MemCenterArgs ma{p.mem[j], p.U[j], p.S[j], p.Sp[j], rawp(c, "condition_embedding.weight") + (size_t)j * CFD_D, rawp(c, "mem_pos.pe"),
                      c->w->n_sp[j].as<char>(), c->w->asq[j].as<float>(), c->sat_mem()};
-    LAUNCH(CFD_PROF_ROWS, mem_center_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), st, ma);
-    {  // KA = A a_s for all layers, ca = c_l . a_s (-inf on dead keys)
+    // (`reuse`: the previous cfd_forward's memories again, cfd_forward_same_memories -- a_s, KA, ca and VA^T are in place)
+    if (!reuse) LAUNCH(CFD_PROF_ROWS, mem_center_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), st, ma);
+    if (!reuse) {  // KA = A a_s for all layers, ca = c_l . a_s (-inf on dead keys)
       GemmArgs a = gemm_args();
       a.X[0] = c->wk_all_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = NK; a.Iclamp[0] = NK; a.kt[0] = CFD_D / 32;
       a.Y = c->w->n_sp[j].as<char>(); a.ldy = ROWB; a.J = rows; a.Jclamp = rows;
@@ -1126,7 +1179,7 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
       EpiMemK e{c->w->kall_sp[j].as<char>(), (long long)rows, c->w->ca[j].as<float>(), nl * CFD_D, nl, p.mask[j], p.S[j], p.Sp[j], c->sat_mem()};
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_MEM, a, e, 1, 1, st)));
     }
-    {  // VA^T
+    if (!reuse) {  // VA^T
       GemmArgs a = gemm_args();
       a.X[0] = c->w->n_sp[j].as<char>(); a.ldx[0] = ROWB; a.I[0] = rows; a.Iclamp[0] = rows; a.kt[0] = CFD_D / 32;
       a.Y = c->wv_all_sp[j].as<char>(); a.ldy = ROWB; a.J = nl * CFD_D; a.Jclamp = nl * CFD_D;
@@ -1156,7 +1209,7 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
     }
     p.static_mask |= 1 << j;
   }
-  if (p.xa_one >= 0 && !p.rt) {   // the one-key memory's value rows as float32 vectors (xattn_fused.hpp, XAttnArgs::one_va)
+  if (p.xa_one >= 0 && !p.rt && !reuse) {   // the one-key memory's value rows as float32 vectors (xattn_fused.hpp, XAttnArgs::one_va)
     const int j = p.xa_one;
     const long long n = (long long)nl * p.U[j] * CFD_D;
     CHK(c->w->xa_one_va.ensure((size_t)n * 4));
@@ -1758,7 +1811,9 @@ extern "C" int cfd_forward(cfd_handle c, const float* sample, int Be, int L, con
   {
     bool want_att = false;
     for (int j = 0; j < CFD_NMEM; ++j) want_att = want_att || (att && att[j]);
-    CHK(prepare_static_memside(c, st, 0, want_att));
+    const bool reuse = c->hint_same_mem && c->w->pb.prev_same;
+    c->hint_same_mem = false;
+    CHK(prepare_static_memside(c, st, 0, want_att && !c->w->pb.att_fused, reuse));
     if (c->w->pb.static_mask) {   // once-per-call projections of the caller's memories: the census is read before they are used
       HIPCHK(hipStreamSynchronize(st));
       CHK(check_saturation(c, "cfd_forward (sample, memories / their projections)"));
@@ -1775,6 +1830,22 @@ extern "C" int cfd_forward(cfd_handle c, const float* sample, int Be, int L, con
     c->memside_in_forward = false;
     CHK(check_saturation(c, "cfd_forward (sample, memories / their per-call projections)"));
   }
+  {   // what the next call may reuse (cfd_forward_same_memories): all five memories' timestep-independent projections are in the workspace
+    Work* w = c->w;
+    const Problem& p = w->pb;
+    w->fwd_mem_valid = p.tmode == 0 && p.static_mask == (1 << CFD_NMEM) - 1;
+    w->fwd_wver = (unsigned long long)c->wver;
+    w->fwd_Be = p.Be;
+    for (int j = 0; j < CFD_NMEM; ++j) {
+      w->fwd_U[j] = p.U[j]; w->fwd_S[j] = p.S[j]; w->fwd_mask[j] = mem[j].key_padding_mask != nullptr; w->fwd_map[j] = mem[j].row_map != nullptr;
+    }
+  }
+  return CFD_OK;
+}
+
+extern "C" int cfd_forward_same_memories(cfd_handle c) {
+  if (!c) return fail(CFD_E_ARG, "null handle");
+  c->hint_same_mem = true;
   return CFD_OK;
 }
 
@@ -1948,22 +2019,7 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
     }
     if (!pb.rt) {
       pb.att_fused = true;
-      XaAtt d;
-      memset(&d, 0, sizeof(d));
-      d.nb = pb.att_nb;
-      for (int j = 0; j < CFD_NMEM; ++j) { d.off[j] = d.sp_tot; d.t0[j] = d.nt; d.sp_tot += pb.Sp[j]; d.nt += pb.Sp[j] / XA_KEYS; }
-      const size_t rows = (size_t)pb.att_nb * s.L;
-      CHK(c->w->xa_att_raw.ensure(c->nl * rows * d.sp_tot * 4));
-      CHK(c->w->xa_att_mc.ensure(c->nl * rows * d.nt * 4));
-      CHK(c->w->xa_att_fin.ensure(c->nl * rows * CFD_NMEM * 2 * 4));
-      CHK(c->w->xa_att_desc.ensure(c->nl * sizeof(XaAtt)));
-      std::vector<XaAtt> desc(c->nl, d);
-      for (int l = 0; l < c->nl; ++l) {
-        desc[l].raw = c->w->xa_att_raw.as<float>() + (size_t)l * rows * d.sp_tot;
-        desc[l].mc = c->w->xa_att_mc.as<float>() + (size_t)l * rows * d.nt;
-        desc[l].fin = c->w->xa_att_fin.as<float>() + (size_t)l * rows * CFD_NMEM * 2;
-      }
-      HIPCHK(hipMemcpy(c->w->xa_att_desc.p, desc.data(), c->nl * sizeof(XaAtt), hipMemcpyHostToDevice));
+      CHK(setup_att_fused(c));
       CHK(build_xattn_worklist(c, mem_in));   // (once more: the list now says which tiles keep their maps)
       if (pb.xa_nwg <= 0) return fail(CFD_E_SHAPE, "att_ring: the fused cross-attention work list is empty");
     }

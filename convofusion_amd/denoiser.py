@@ -275,7 +275,19 @@ class Denoiser(nn.Module):
                 att.append(a)
                 att_ptrs[j] = a.data_ptr()
         stream = torch.cuda.current_stream(x.device).cuda_stream
+        # The reference's own loop (no convofusion_amd.install) calls this once per iteration with the SAME conditioning tensors
+        # (convofusion.py:499-513): the same tensor objects at the same version counter as in the previous call on this handle are the same
+        # contents (the previous call's tensors are kept alive here, so an address cannot come back with other data), and the library
+        # then reuses their timestep-independent projections (cfd_forward_same_memories; it checks shapes, weights and what ran in between).
+        srcs = list(encoder_hidden_states) + [(mem_mask_dict or {}).get(name) for name in MEM_NAMES]
+        vers = [None if s is None else s._version for s in srcs]
+        last = getattr(self, "_last_forward_memories", None)
+        same = (last is not None and last[0] == h and len(last[1]) == len(srcs) and all(a is b for a, b in zip(last[1], srcs)) and last[2] == vers)
+        self._last_forward_memories = None
         with torch.cuda.device(x.device):
+            if same:
+                _lib.check(lib.cfd_forward_same_memories(h))
             _lib.check(lib.cfd_forward(h, C.c_void_p(x.data_ptr()), Be, L, ts_arr, len(ts), mems, C.c_void_p(out.data_ptr()),
                                        att_ptrs if self.return_attention else None, C.c_void_p(stream)))
+        self._last_forward_memories = (h, srcs, vers)
         return (out, att)

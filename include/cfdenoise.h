@@ -93,6 +93,13 @@ typedef struct {
 int cfd_forward(cfd_handle h, const float* sample, int Be, int L, const int32_t* timesteps, int n_t,
                 const cfd_memory mem[CFD_NUM_MEM], float* out, float* const att[CFD_NUM_MEM], void* stream);
 
+/* The caller's promise for the NEXT cfd_forward on this handle: its memories (data, key-padding masks, row maps, shapes) are bit-identical
+ * to those of the previous cfd_forward.  That call then reuses their timestep-independent projections (the folded keys / values of all
+ * layers: most of a call's work when the reference's own Python loop calls the denoiser once per iteration with an un-de-duplicated 7 x B
+ * conditioning batch, convofusion.py:499-513).  Ignored -- the projections are made -- whenever the handle cannot honour it: anything else
+ * ran on the handle in between (a sampling run, a WEG evaluation, a forward with per-row timesteps), other shapes, weights reloaded. */
+int cfd_forward_same_memories(cfd_handle h);
+
 /* Replaces Convofusion._diffusion_reverse (convofusion/models/modeltype/convofusion.py:391-549) and
  * its in-painting copy diffusion_reverse_forecast (unbounded_synthesis.py:28-187), together with the
  * diffusers-0.14.0 scheduler calls inside them (set_timesteps / step / add_noise). */

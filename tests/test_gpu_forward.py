@@ -367,3 +367,52 @@ def test_key_padding_masks_with_holes(shape):
                     np.testing.assert_allclose(a.sum(-1), 1.0, atol=1e-5)
     finally:
         m.return_attention = keep
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Be", [14, 70])
+def test_repeated_forwards_with_the_same_memories_reuse_their_projections(Be):
+    """The reference's own loop calls the denoiser once per iteration with the same conditioning tensors (convofusion.py:499-513).
+    Denoiser.forward recognises the same tensor objects at the same version and lets the library reuse the memories' timestep-independent
+    projections (cfd_forward_same_memories) -- on the row-tile path (14 rows) and on the tile kernels (70 rows of 16 tokens).  Every call
+    must equal the same call on a denoiser that has never seen the memories: a second and third timestep, after an in-place change of a
+    memory (version counter: projections made again), after a change of a mask, and with a sampling run on the handle in between."""
+    import torch
+    from convofusion_amd.sampler import sample
+    from tests.gpu_helpers import SCHED_KW, hip_denoiser, to_dev
+    from convofusion_amd import scheduler
+    L, S = 16, (6, 40, 6, 8, 1)
+    inp = inputs.make_plain_batch(seed=77, Be=Be, L=L, S=S, pad_tail=(2, 5, 1, 0, 0))
+    x = to_dev(inp["sample"])
+    mems = [to_dev(m) for m in inp["memories"]]
+    masks = {k: to_dev(v) for k, v in inp["masks"].items()}
+    m = hip_denoiser(1234, 1.0)
+
+    def fresh(t):
+        f = hip_denoiser(1234, 1.0)
+        with torch.no_grad():
+            return f(x, torch.tensor(t), [q.clone() for q in mems], mem_mask_dict={k: (None if v is None else v.clone()) for k, v in masks.items()})
+
+    def call(t):
+        with torch.no_grad():
+            return m(x, torch.tensor(t), mems, mem_mask_dict=masks)
+
+    def same(a, b):     # (bit-identical; NaN -- the rows whose memory the changed mask covers completely -- in the same places)
+        eq = lambda p, q: torch.equal(torch.isnan(p), torch.isnan(q)) and torch.equal(p.nan_to_num(nan=0.0), q.nan_to_num(nan=0.0))
+        return eq(a[0], b[0]) and all(eq(p, q) for p, q in zip(a[1], b[1]))
+
+    assert same(call(900), fresh(900))
+    assert same(call(500), fresh(500))              # reused
+    assert same(call(37), fresh(37))                # reused again
+    mems[1].mul_(1.5)                               # in place: the version counter moves, the projections are made again
+    assert same(call(36), fresh(36))
+    assert same(call(35), fresh(35))
+    name = [k for k, v in masks.items() if v is not None][0]
+    masks[name][:, 0] = ~masks[name][:, 0] if masks[name].dtype == torch.bool else 1 - masks[name][:, 0]
+    assert same(call(34), fresh(34))
+    # something else on the handle in between: the library refuses the promise by itself
+    sch = scheduler.DDPMScheduler(variance_type="fixed_small", **SCHED_KW)
+    cb = inputs.make_cfg_batch(seed=3, B=2, L=L, S=S, pad_tail=(2, 0, 1, 0, 0))
+    sample(m, sch, [to_dev(q) for q in cb["memories"]], {k: to_dev(v) for k, v in cb["masks"].items()}, B=2, L=L, num_inference_steps=2, seed=1)
+    assert same(call(33), fresh(33))
+    assert same(call(32), fresh(32))
