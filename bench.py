@@ -256,8 +256,25 @@ def secondary_configs(model, device):
         dt_ring = time.perf_counter() - t0
         run.close()
         del run
+        # ... and what a caller gets WITHOUT convofusion_amd.install() (only the yaml edits): the reference's own Python loop (convofusion.py:499-544:
+        # replicate x 7, denoiser, guidance combine, scheduler.step) on the HIP Denoiser.forward -- one cfd_forward with att_mats per iteration
+        ddpm.set_timesteps(1000)
+        lat_py = torch.randn((B_PER_GPU, L, 128), device=device)
+        t_py = 0.0
+        for it, t in enumerate(ddpm.timesteps[:45]):
+            if it == 5:
+                sync()
+                t0 = time.perf_counter()
+            with torch.no_grad():
+                npred, _ = model(sample=torch.cat([lat_py] * G), timestep=t, encoder_hidden_states=mems, mem_mask_dict=masks)
+            u_, tx_, a_, s_, p_, i_, f_ = npred.chunk(G)
+            npred = u_ + 7.5 * (tx_ - u_) + 7.5 * (a_ - u_) + 7.5 * (s_ - u_) + 7.5 * (p_ - u_) + 7.5 * (i_ - u_) + 7.5 * 0 * (f_ - u_)
+            lat_py = ddpm.step(npred, t, lat_py).prev_sample
+        sync()
+        t_py = (time.perf_counter() - t0) / 40
         out["r_product_shape_b32"] = {"steps_per_s": 50 / dt, "ms_per_step": 1000 * dt / 50, "workload": f"B={B_PER_GPU}, L={L}, S={S}",
-                                      "all_attention_maps_ms_per_step": 1000 * dt_ring / 50, "all_attention_maps_over_none": dt_ring / dt}
+                                      "all_attention_maps_ms_per_step": 1000 * dt_ring / 50, "all_attention_maps_over_none": dt_ring / dt,
+                                      "reference_python_loop_on_hip_denoiser_ms_per_step": 1000 * t_py}
         mems, masks = make_inputs(1, device, seed=1234)
         run = SamplingRun(model, ddpm, mems, masks, 1, L, 1000, guidance_scale=7.5, seed=0)
         run.steps(2)
