@@ -209,7 +209,8 @@ struct cfd_handle_s {
   bool hint_same_mem = false;   // cfd_forward_same_memories: consumed by the next cfd_forward
   int att_fused = 1;            // CFD_ATT_FUSED=0: a forward that returns att_mats takes the three-launch cross-attention on the tile kernels (the fused
                                 // kernel's ATT instance keeps the maps otherwise: xattn_fused.hpp, XaAtt)
-  int qkv_fused = 1;            // CFD_QKV_FUSED=0: batch rows of 16 tokens keep the separate v^T product (EpiQkvT, gemm_sp.hpp)
+  int qkv_fused = 1;            // CFD_QKV_FUSED=0: batch rows of 16 tokens keep the separate v^T product (EpiQkvT, gemm_sp.hpp); 2: one launch, but
+                                // the flash self-attention kernel behind it (1: the row-tile path's attention core)
   int l0_dedup = 1;             // CFD_L0_DEDUP=0: layer 0's cross-attention as one launch over all rows (build_xattn_layer0_lists)
   // Row-tile path for small problems (rowtile.hpp): chosen by SHAPE -- at most rt_max_rows token rows of at most RT_MAX_L tokens per batch
   // row, one timestep for all rows, no dynamic memories.  CFD_ROWTILE=0 turns it off (parity A/B against the tile kernels),
@@ -382,7 +383,7 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   env = getenv("CFD_ATT_FUSED");
   if (env) c->att_fused = atoi(env) != 0;
   env = getenv("CFD_QKV_FUSED");
-  if (env) c->qkv_fused = atoi(env) != 0;
+  if (env) c->qkv_fused = atoi(env);
   env = getenv("CFD_ROWTILE");
   c->rt_on = !(env && atoi(env) == 0);
   env = getenv("CFD_WEG_ROWTILE");
@@ -1561,6 +1562,7 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     // (norm1 of layers 1.. is made by the previous layer's last residual product when that ran row-complete: `h_ready`)
     if (!h_ready) CHK(ln(w.ln1g, w.ln1b, 0, 0, c->w->h_sp.as<char>(), Ma));
     h_ready = false;
+    bool qkv_one_launch = false;
     const int Lv = (L + 31) / 32 * 32;   // (whole 32-key blocks: at L = 16 a 64-key pitch made the v^T product twice the work of the q | k one)
     {
       // q (pre-scaled) and k, token-major ...
@@ -1578,14 +1580,22 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
         GemmArgs ag = a;
         ag.nslot = 2;
         ag.X[1] = w.wv_sp.as<char>(); ag.ldx[1] = ROWB; ag.I[1] = CFD_D; ag.Iclamp[1] = CFD_D; ag.kt[1] = CFD_D / 32;
-        EpiQkvT eg{c->w->qk_sp.as<char>(), 2 * ROWB, w.bqk.as<float>(), c->w->vts_sp.as<char>()};
+        EpiQkvT eg{c->w->qk_sp.as<char>(), 2 * ROWB, w.bqk.as<float>(), c->w->vts_sp.as<char>(), c->qkv_fused == 1 ? 1 : 0};
         CHK((run_gemm<MODE_GROUPED>(c, CFD_PROF_GEMM_TOKEN, ag, eg, 1, 1, st)));
+        qkv_one_launch = true;
       } else {
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, av, ev, Ba, 1, st)));
       }
     }
-    {
+    if (qkv_one_launch && c->qkv_fused == 1) {
+      // one query tile and one key tile per (row, head): the row-tile path's attention core (4 waves that all compute; V^T in natural key
+      // order, which EpiQkvT wrote) instead of the flash kernel's 8-wave workgroup with one busy wave
+      RtSelfArgs a{c->w->qk_sp.as<char>(), c->w->vts_sp.as<char>(), c->w->o_sp.as<char>(), L, 1};
+      Bracket br(c, CFD_PROF_GEMM_ATTN, st);
+      hipLaunchKernelGGL(rt_selfattn_kernel, dim3(CFD_NHEAD, Ba), dim3(256), 40 * 1024, st, a);
+      HIPCHK(hipGetLastError());
+    } else {
       SelfAttnArgs a{c->w->qk_sp.as<char>(), c->w->vts_sp.as<char>(), c->w->o_sp.as<char>(), L, Lv};
       Bracket br(c, CFD_PROF_GEMM_ATTN, st);
       hipLaunchKernelGGL(self_attn_fused_kernel, dim3((L + SELF_ATTN_WAVES * 16 - 1) / (SELF_ATTN_WAVES * 16), CFD_NHEAD, Ba), dim3(SELF_ATTN_WAVES * 64), 65536, st, a);

@@ -160,6 +160,7 @@ struct EpiQkvT {
   long long ldo;         // bytes per q | k row
   const float* bias;     // [1024] (the value bias is folded into the out-projection's)
   char* vts;             // SP [Be][512][32]
+  int natural;           // 1: keys in natural order (rt_selfattn_kernel, rowtile.hpp): tokens 8 h .. 8 h + 7 at positions [8 h, 8 h + 8), zeros from 16 on
   static constexpr bool kPrefetch = false;
   static constexpr bool kStore8 = true;
   static constexpr bool kBias8 = true;
@@ -187,6 +188,19 @@ struct EpiQkvT {
       split_f32(v[4 + e], a, c);
       hi1[e] = a; lo1[e] = c;
       hi0[4 + e] = (sp_t)0.f; lo0[4 + e] = (sp_t)0.f; hi1[4 + e] = (sp_t)0.f; lo1[4 + e] = (sp_t)0.f;
+    }
+    if (natural) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hi0[4 + e] = hi1[e]; lo0[4 + e] = lo1[e];      // tokens 8 h .. 8 h + 7 side by side ...
+        hi1[e] = (sp_t)0.f; lo1[e] = (sp_t)0.f;        // ... and 8 padding keys
+      }
+      char* p = vts + ((long long)(jb >> 4) * CFD_D + i) * 128 + h * 16;
+      *reinterpret_cast<spx8*>(p) = hi0;
+      *reinterpret_cast<spx8*>(p + 32) = hi1;
+      *reinterpret_cast<spx8*>(p + 64) = lo0;
+      *reinterpret_cast<spx8*>(p + 96) = lo1;
+      return;
     }
     char* p = vts + ((long long)(jb >> 4) * CFD_D + i) * 128 + h * 32;
     *reinterpret_cast<spx8*>(p) = hi0;
