@@ -207,6 +207,7 @@ struct cfd_handle_s {
   int xa_pp = 0;                // form of the fused cross-attention kernel (xattn_fused.hpp): CFD_XA_PP=0 lock-step, every wave requests its share of every
                                 // sub-buffer (rounds 2-4); 1 ping-pong (two wave groups one sub-phase apart); 2 lock-step, requests divided between the groups
   bool hint_same_mem = false;   // cfd_forward_same_memories: consumed by the next cfd_forward
+  int step_rows = 1;            // CFD_STEP_ROWS=0: the tile kernels index the per-step tables with the device step counter themselves
   int att_fused = 1;            // CFD_ATT_FUSED=0: a forward that returns att_mats takes the three-launch cross-attention on the tile kernels (the fused
                                 // kernel's ATT instance keeps the maps otherwise: xattn_fused.hpp, XaAtt)
   int qkv_fused = 1;            // CFD_QKV_FUSED=0: batch rows of 16 tokens keep the separate v^T product (EpiQkvT, gemm_sp.hpp); 2: one launch, but
@@ -380,6 +381,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   if (env) c->xa_pp = atoi(env);
   env = getenv("CFD_ONE_KEY");
   if (env) c->one_key = atoi(env) != 0;
+  env = getenv("CFD_STEP_ROWS");
+  if (env) c->step_rows = atoi(env) != 0;
   env = getenv("CFD_ATT_FUSED");
   if (env) c->att_fused = atoi(env) != 0;
   env = getenv("CFD_QKV_FUSED");
@@ -1523,9 +1526,37 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
   }
   if (c->stop_stage == 1) return CFD_OK;
+  // This step's rows of the per-step tables (as on the row-tile path, enqueue_rows_rt): with one timestep for all rows, a sampling run
+  // refreshes fixed buffers with ONE launch at the start of the iteration and cfd_forward points at its single table row, so that no
+  // launch has the step index as a dependent scalar load in front of its operand loads (a load that misses in every XCD's L2 after the
+  // previous iteration's last workgroup has written it: ~1 us on 18 AdaLN launches and 9 cross-attention prologues per step).
+  const float* ss_now = c->w->ss_tab.as<float>();
+  const float *kb_now[CFD_NMEM], *vb_now[CFD_NMEM];
+  for (int j = 0; j < CFD_NMEM; ++j) { kb_now[j] = c->w->kbtab[j].as<float>(); vb_now[j] = c->w->vbtab[j].as<float>(); }
+  const bool rows_now = p.tmode == 0 && c->step_rows;
+  if (rows_now && p.T > 1) {
+    RtStepRowsArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    size_t off4 = 0;
+    int nt = 0, nwg = 0;
+    auto add = [&](const float*& now, int nfloat) {
+      float* dst = c->w->rt_cur.as<float>() + off4 * 4;
+      ra.src[nt] = now; ra.dst[nt] = dst; ra.n4[nt] = nfloat / 4; ra.first[nt] = nwg;
+      nwg += (nfloat / 4 + 255) / 256; off4 += (size_t)(nfloat / 4 + 63) / 64 * 64; ++nt;
+      now = dst;
+    };
+    size_t need4 = (size_t)(nl * 4 * CFD_D / 4 + 64);
+    for (int j = 0; j < CFD_NMEM; ++j) need4 += (size_t)((nl * CFD_D + 32) / 4 + 64) + (size_t)(nl * CFD_D / 4 + 64);
+    CHK(c->w->rt_cur.ensure(need4 * 16));
+    add(ss_now, nl * 4 * CFD_D);
+    for (int j = 0; j < CFD_NMEM; ++j)
+      if ((p.static_mask >> j) & 1) { add(kb_now[j], nl * CFD_D + 32); add(vb_now[j], nl * CFD_D); }
+    ra.ntab = nt; ra.first[nt] = nwg; ra.d_step = dstep;
+    LAUNCH(CFD_PROF_OTHER, rt_step_rows_kernel, dim3(nwg), dim3(256), st, ra);
+  }
   auto ln = [&](const float* g, const float* b, int adaln, int tbidx, char* out, long long rows) -> int {
-    LnArgs a{c->w->x.as<float>(), out, rows, g, b, adaln, c->w->ss_tab.as<float>() + (size_t)tbidx * 2 * CFD_D,
-             (long long)nl * 2 * 2 * CFD_D, dstep, p.tmode, L, row0};
+    LnArgs a{c->w->x.as<float>(), out, rows, g, b, adaln, (rows_now ? ss_now : c->w->ss_tab.as<float>()) + (size_t)tbidx * 2 * CFD_D,
+             (long long)nl * 2 * 2 * CFD_D, rows_now ? nullptr : dstep, p.tmode, L, row0};
     LAUNCH(CFD_PROF_ROWS, ln_rows_kernel, dim3((unsigned)((rows + 3) / 4)), blk, st, a);
     return CFD_OK;
   };
@@ -1625,12 +1656,12 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
         a.Sp[j] = p.Sp[j];
         const bool stat = (p.static_mask >> j) & 1;
         a.rs_off[j] = (unsigned)((size_t)(nl - l) * rows * 4);
-        a.kb[j] = stat ? c->w->kbtab[j].as<float>() + (size_t)l * CFD_D : c->w->zeros512.as<float>();
+        a.kb[j] = stat ? kb_now[j] + (size_t)l * CFD_D : c->w->zeros512.as<float>();
         a.kb_stride[j] = stat ? nl * CFD_D + 32 : 0;
-        a.vb[j] = stat ? c->w->vbtab[j].as<float>() + (size_t)l * CFD_D : c->w->zeros512.as<float>();
+        a.vb[j] = stat ? vb_now[j] + (size_t)l * CFD_D : c->w->zeros512.as<float>();
         a.vb_stride[j] = stat ? nl * CFD_D : 0;
       }
-      a.d_step = dstep;
+      a.d_step = rows_now ? nullptr : dstep;
       a.one_j = -1;
       if (p.xa_one >= 0) {   // (the work lists hold no segments for it: build_xattn_worklist)
         const int j = p.xa_one;

@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const LnArgs a) {
   const float* xr = a.x + row * CFD_D + lane * 8;
   // every operand is requested before the first is used: the AdaLN rows used to be loaded inside `if (a.adaln)`, behind the statistics,
   // i.e. a second round trip per row (half of the launches of a step are AdaLN ones)
-  const long long trow = a.tmode ? (a.trow0 + row / a.L) : (long long)(*a.d_step);
+  const long long trow = a.tmode ? (a.trow0 + row / a.L) : (a.d_step ? (long long)(*a.d_step) : 0);   // (null: `ss` is this step's row already)
   const float* sc = a.adaln ? a.ss + trow * a.ss_tstride + lane * 8 : a.g + lane * 8;   // (plain LayerNorm: a valid address, values unused)
   const float* sh = a.adaln ? sc + CFD_D : sc;
   const float4 p = *reinterpret_cast<const float4*>(xr), q = *reinterpret_cast<const float4*>(xr + 4);

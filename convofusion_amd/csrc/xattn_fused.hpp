@@ -120,7 +120,7 @@ struct XAttnArgs {
   const float* kb[CFD_NMEM];  // A_l b  [512] of table row *d_step: kb[j] + *d_step * kb_stride[j]   (zeros, stride 0: projections made per step)
   const float* vb[CFD_NMEM];  // VV_l b [512], likewise
   long long kb_stride[CFD_NMEM], vb_stride[CFD_NMEM];
-  const int* d_step;
+  const int* d_step;          // or null: kb / vb point at this step's rows
   const char* VT[CFD_NMEM];   // this layer's folded values^T: SP [U_j][512][Sp_j]
   int Sp[CFD_NMEM];
   int L;
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   spx8 qh[8], ql[8];
   float* cq_mine = reinterpret_cast<float*>(smem + XA_CQOFF + wid * XA_CQW);
   float* wq_mine = cq_mine + 80;
-  const int trow = *a.d_step;
+  const int trow = a.d_step ? *a.d_step : 0;   // (null: kb / vb are this step's rows already -- no dependent scalar load in front of the A b request)
   // A b of the five memories (2 KB each) -> LDS by the LDS-DMA, issued before anything else so that its round trip runs under the
   // row loads and the LayerNorm below.  Parked in the part of the V^T tile buffer that is first filled after the first step's mid-A0
   // barrier (Vb, row groups 16-31); c_q is computed from there behind the first barrier.

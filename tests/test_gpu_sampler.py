@@ -312,7 +312,7 @@ def test_ddim_with_eta_matches_oracle():
 
 
 @pytest.mark.parametrize("env", [{"CFD_NAIVE_GEMM": "1"}, {"CFD_RUNS": "0", "CFD_FUSED_XATTN": "0"}, {"CFD_FUSED_XATTN": "0"},
-                                 {"CFD_HOIST_MEMSIDE": "0"}, {"CFD_ROWTILE": "0"}, {"CFD_ROWTILE": "0", "CFD_QKV_FUSED": "0"}, {"CFD_ROWTILE": "0", "CFD_QKV_FUSED": "2"}, {"CFD_ROWTILE": "0", "CFD_ATT_FUSED": "0"},
+                                 {"CFD_HOIST_MEMSIDE": "0"}, {"CFD_ROWTILE": "0"}, {"CFD_ROWTILE": "0", "CFD_QKV_FUSED": "0"}, {"CFD_ROWTILE": "0", "CFD_QKV_FUSED": "2"}, {"CFD_ROWTILE": "0", "CFD_ATT_FUSED": "0"}, {"CFD_STEP_ROWS": "0"},
                                  {"CFD_ONE_KEY": "0", "CFD_L0_DEDUP": "0"}, {"CFD_XA_PP": "0"}, {"CFD_XA_PP": "1"}])
 def test_developer_knobs_keep_parity(env):
     """The debug switches that select another code path for the same arithmetic (read once at cfd_create) must not change
@@ -324,7 +324,8 @@ def test_developer_knobs_keep_parity(env):
     q | k and v^T in one grouped launch whose epilogue stores the value projection transposed), the same with CFD_QKV_FUSED=0 (the separate
     batched v^T product, which is what every other length runs) and = 2 (one launch, but the flash self-attention kernel behind it instead of the
     row-tile path's attention core), CFD_ROWTILE=0 with CFD_ATT_FUSED=0 (forwards that return att_mats on the
-    three-launch cross-attention instead of the fused kernel's attention-map instance), CFD_ONE_KEY=0 with CFD_L0_DEDUP=0
+    three-launch cross-attention instead of the fused kernel's attention-map instance), CFD_STEP_ROWS=0 (the tile kernels index the per-step
+    tables with the device step counter themselves instead of reading rows a launch at the start of the iteration has staged), CFD_ONE_KEY=0 with CFD_L0_DEDUP=0
     (the fused cross-attention in its plain form: the one-key memory as a 32-key tile step, layer 0 as one launch), CFD_XA_PP=0 / 1 (the other
     two forms of the fused cross-attention kernel: every wave requesting its share of every tile piece; ping-pong).  Each leg runs the golden forward, the 20-step trajectory, the run-path
     test and the headline-shape loop rows in a child process."""
