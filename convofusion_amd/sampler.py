@@ -328,6 +328,8 @@ def _open_run(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_
         except _lib.CfdError as e:
             if e.code != -2:      # CFD_E_SHAPE: a run whose maps the captured iteration cannot keep
                 raise
+        except torch.cuda.OutOfMemoryError:
+            pass                  # the ring did not fit beside what the caller holds: the maps are taken the other way
     return SamplingRun(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps, **kw)
 
 
