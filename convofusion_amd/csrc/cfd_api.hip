@@ -1324,6 +1324,8 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
     RT_SET_LDS((rt_gemm_kernel<RT_PRO_LN, RT_EPI_SPLIT, 512, CFD_D / 32, 2>), rt_gemm_lds(RT_PRO_LN, 512, CFD_D / 32, 2));
     RT_SET_LDS((rt_gemm_kernel<RT_PRO_SP, RT_EPI_RESID, 512, CFD_FF / 32, 1>), rt_gemm_lds(RT_PRO_SP, 512, CFD_FF / 32, 1));
     RT_SET_LDS((rt_gemm_kernel<RT_PRO_LN, RT_EPI_F32, 512, CFD_D / 32, 1>), rt_gemm_lds(RT_PRO_LN, 512, CFD_D / 32, 1));
+    RT_SET_LDS((rt_gemm_kernel<RT_PRO_SP, RT_EPI_RESID, 256, CFD_D / 32, 2>), rt_gemm_lds(RT_PRO_SP, 256, CFD_D / 32, 2));
+    RT_SET_LDS((rt_gemm_kernel<RT_PRO_ADALN, RT_EPI_RESID, 512, CFD_D / 32, 2>), rt_gemm_lds(RT_PRO_ADALN, 512, CFD_D / 32, 2));
     RT_SET_LDS(rt_xscore_kernel, RT_XS_LDS);
     RT_SET_LDS(rt_xpv_kernel<512>, (512 / 32) * 2048 + 8 * 2 * 2048 + 16 * 32 * 16 + 512 + 2048);
     RT_SET_LDS(rt_xpv_kernel<RT_MAX_KEYS>, (RT_MAX_KEYS / 32) * 2048 + 8 * 4 * 2048 + 16 * 32 * 16 + 512 + 2048);
@@ -1367,6 +1369,11 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
   RtGemmArgs base;
   memset(&base, 0, sizeof(base));
   base.L = L; base.tpr = tpr;
+  // Two 16-feature blocks per workgroup for the 512 x 512 residual products from two utterances on: half the workgroups, each normalising
+  // its 16 rows once for two blocks (one utterance: 0.411 -> 0.421 s per 1000 steps, two: 0.544 -> 0.528, four: 0.882 -> 0.869; same sums
+  // in the same order, so bit-identical).  CFD_RT_NFB2_TILES=<token tiles> moves the threshold (developer A/B).
+  static const int nfb2_tiles = getenv("CFD_RT_NFB2_TILES") ? atoi(getenv("CFD_RT_NFB2_TILES")) : 14;
+  const bool nfb2 = ntile >= nfb2_tiles && !sv;
 #define RT_LAUNCH(cls, PRO, EPI, NT, KT, NFB, nfeat, args)                                                        \
   do {                                                                                                          \
     Bracket _br(c, cls, st);                                                                                    \
@@ -1386,7 +1393,8 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
     RtGemmArgs a = base;
     a.x = xin; a.xr = xin; a.xo = xout;
     a.g = g; a.b = b; a.ss = ss_now + (size_t)tbidx * 2 * CFD_D; a.w = w.as<char>(); a.bias = bias;
-    RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_ADALN, RT_EPI_RESID, 512, CFD_D / 32, 1, CFD_D, a);
+    if (nfb2) RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_ADALN, RT_EPI_RESID, 512, CFD_D / 32, 2, CFD_D, a);
+    else RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_ADALN, RT_EPI_RESID, 512, CFD_D / 32, 1, CFD_D, a);
     return CFD_OK;
   };
   RtXArgs xa;
@@ -1425,7 +1433,8 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
       RtGemmArgs a = base;   // out-projection + residual
       a.xr = X(l, 0); a.xo = X(l, 1);
       a.a_sp = c->w->o_sp.as<char>(); a.w = w.wo_sp.as<char>(); a.bias = w.bo2.as<float>();
-      RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_RESID, 256, CFD_D / 32, 1, CFD_D, a);
+      if (nfb2) RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_RESID, 256, CFD_D / 32, 2, CFD_D, a);
+      else RT_LAUNCH(CFD_PROF_GEMM_TOKEN, RT_PRO_SP, RT_EPI_RESID, 256, CFD_D / 32, 1, CFD_D, a);
     }
     if (c->stop_stage == 2 + 4 * l) return CFD_OK;
     // ---- b. time block 1                                                        (:575, :426-439)
