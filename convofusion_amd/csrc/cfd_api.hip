@@ -142,7 +142,8 @@ struct Work {
   // the timestep-independent memory-side projections the last cfd_forward left in this workspace (cfd_forward_same_memories): valid only
   // from the end of a cfd_forward that made (or reused) all five until the next setup_problem on this workspace
   bool fwd_mem_valid = false;
-  int fwd_U[CFD_NMEM] = {0, 0, 0, 0, 0}, fwd_S[CFD_NMEM] = {0, 0, 0, 0, 0}, fwd_Be = 0;
+  int fwd_U[CFD_NMEM] = {0, 0, 0, 0, 0}, fwd_S[CFD_NMEM] = {0, 0, 0, 0, 0}, fwd_Be = 0, fwd_L = 0;
+  bool fwd_att = false;
   bool fwd_mask[CFD_NMEM] = {false, false, false, false, false}, fwd_map[CFD_NMEM] = {false, false, false, false, false};
   unsigned long long fwd_wver = 0;
   DBuf rt_vt, rt_cbt[CFD_NMEM];   // row-tile path: V^T of the self-attention, per-step key tables
@@ -949,6 +950,11 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
     prev_same = c->w->fwd_U[j] == mem[j].U && c->w->fwd_S[j] == mem[j].S && c->w->fwd_mask[j] == (mem[j].key_padding_mask != nullptr) &&
                 c->w->fwd_map[j] == (mem[j].row_map != nullptr);
   p.prev_same = prev_same;
+  // ... and with the caller's promise that they ARE the same memories (cfd_forward_same_memories covers the row maps and masks), the work
+  // lists and instance tables made from them -- several device-to-host reads per call -- are kept as well
+  bool any_att_in = false;
+  for (int j = 0; j < CFD_NMEM; ++j) any_att_in = any_att_in || (att && att[j]);
+  const bool keep_lists = prev_same && c->hint_same_mem && c->w->fwd_L == L && c->w->fwd_att == any_att_in;
   p.Be = Be; p.L = L; p.Lp = (L + 31) / 32 * 32; p.M = (long long)Be * L; p.tmode = tmode; p.T = T;
   p.share_B = 0;
   if (p.Lp > SM_MAX_CHUNKS * 512) return fail(CFD_E_SHAPE, "L = %d exceeds the in-register softmax limit (%d)", L, SM_MAX_CHUNKS * 512);
@@ -1014,8 +1020,8 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
   }
   p.rt = c->rt_on && tmode == 0 && !g_cfd_naive_gemm && L <= RT_MAX_L && p.M <= c->rt_max_rows && p.Sp_tot <= RT_MAX_KEYS && c->hoist_memside;
   if (p.rt) {
-    p.rt_use_inst = Be <= RT_ARG_ROWS;
-    for (int j = 0; j < CFD_NMEM && p.rt_use_inst; ++j) {
+    if (!keep_lists) p.rt_use_inst = Be <= RT_ARG_ROWS;
+    for (int j = 0; j < CFD_NMEM && p.rt_use_inst && !keep_lists; ++j) {
       std::vector<int> hm(Be);
       if (mem[j].row_map) HIPCHK(hipMemcpy(hm.data(), mem[j].row_map, (size_t)Be * 4, hipMemcpyDeviceToHost));
       else for (int b = 0; b < Be; ++b) hm[b] = b;
@@ -1036,9 +1042,9 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
     p.att_fused = any_att && !p.rt && tmode == 0 && c->att_fused && c->fused_xattn && c->hoist_memside && !g_cfd_naive_gemm && c->xa_pp != 1;
     if (p.att_fused) { p.att_b0 = 0; p.att_nb = Be; }
   }
-  CHK(build_xattn_worklist(c, mem));
+  if (!keep_lists) CHK(build_xattn_worklist(c, mem));
   if (p.att_fused && p.xa_nwg <= 0) { p.att_fused = false; p.att_nb = 0; }   // (a list too short for the fused kernel: three-launch path)
-  if (p.att_fused) CHK(setup_att_fused(c));
+  if (p.att_fused && !keep_lists) CHK(setup_att_fused(c));
   const long long M = p.M;
   const int nl = c->nl;
   CHK(c->w->x.ensure((size_t)M * CFD_D * 4));
@@ -1886,6 +1892,9 @@ extern "C" int cfd_forward(cfd_handle c, const float* sample, int Be, int L, con
     w->fwd_mem_valid = p.tmode == 0 && p.static_mask == (1 << CFD_NMEM) - 1;
     w->fwd_wver = (unsigned long long)c->wver;
     w->fwd_Be = p.Be;
+    w->fwd_L = p.L;
+    w->fwd_att = false;
+    for (int j = 0; j < CFD_NMEM; ++j) w->fwd_att = w->fwd_att || (att && att[j]);
     for (int j = 0; j < CFD_NMEM; ++j) {
       w->fwd_U[j] = p.U[j]; w->fwd_S[j] = p.S[j]; w->fwd_mask[j] = mem[j].key_padding_mask != nullptr; w->fwd_map[j] = mem[j].row_map != nullptr;
     }
