@@ -147,7 +147,7 @@ def roofline():
             return "xattn"
         if "self_attn_fused_kernel" in name:
             return "gemm_attn"
-        if name.startswith(("ln_rows_kernel", "mem_scale", "replicate_rows", "begin_step", "cfg_step")):
+        if "ln_rows_kernel" in name or name.startswith(("mem_scale", "replicate_rows", "begin_step", "cfg_step", "rt_step_rows", "att_fixup")):
             return "rows"
         return None
     rows, cms = [], defaultdict(float)
