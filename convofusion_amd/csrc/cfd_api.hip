@@ -208,6 +208,7 @@ struct cfd_handle_s {
   int xa_pp = 0;                // form of the fused cross-attention kernel (xattn_fused.hpp): CFD_XA_PP=0 lock-step, every wave requests its share of every
                                 // sub-buffer (rounds 2-4); 1 ping-pong (two wave groups one sub-phase apart); 2 lock-step, requests divided between the groups
   bool hint_same_mem = false;   // cfd_forward_same_memories: consumed by the next cfd_forward
+  int rt_nfb2_tiles = 14;       // CFD_RT_NFB2_TILES=<token tiles>: from how many token tiles on the row-tile path's 512 x 512 residual products take two feature blocks per workgroup
   int step_rows = 1;            // CFD_STEP_ROWS=0: the tile kernels index the per-step tables with the device step counter themselves
   int att_fused = 1;            // CFD_ATT_FUSED=0: a forward that returns att_mats takes the three-launch cross-attention on the tile kernels (the fused
                                 // kernel's ATT instance keeps the maps otherwise: xattn_fused.hpp, XaAtt)
@@ -382,6 +383,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   if (env) c->xa_pp = atoi(env);
   env = getenv("CFD_ONE_KEY");
   if (env) c->one_key = atoi(env) != 0;
+  env = getenv("CFD_RT_NFB2_TILES");
+  if (env) c->rt_nfb2_tiles = atoi(env);
   env = getenv("CFD_STEP_ROWS");
   if (env) c->step_rows = atoi(env) != 0;
   env = getenv("CFD_ATT_FUSED");
@@ -1377,9 +1380,8 @@ static int enqueue_rows_rt(Ctx* c, hipStream_t st, const RtSave* sv) {
   base.L = L; base.tpr = tpr;
   // Two 16-feature blocks per workgroup for the 512 x 512 residual products from two utterances on: half the workgroups, each normalising
   // its 16 rows once for two blocks (one utterance: 0.411 -> 0.421 s per 1000 steps, two: 0.544 -> 0.528, four: 0.882 -> 0.869; same sums
-  // in the same order, so bit-identical).  CFD_RT_NFB2_TILES=<token tiles> moves the threshold (developer A/B).
-  static const int nfb2_tiles = getenv("CFD_RT_NFB2_TILES") ? atoi(getenv("CFD_RT_NFB2_TILES")) : 14;
-  const bool nfb2 = ntile >= nfb2_tiles && !sv;
+  // in the same order, so bit-identical).  CFD_RT_NFB2_TILES=<token tiles> moves the threshold (read at cfd_create).
+  const bool nfb2 = ntile >= c->rt_nfb2_tiles && !sv;
 #define RT_LAUNCH(cls, PRO, EPI, NT, KT, NFB, nfeat, args)                                                        \
   do {                                                                                                          \
     Bracket _br(c, cls, st);                                                                                    \
