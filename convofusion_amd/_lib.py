@@ -60,7 +60,8 @@ class SampleArgs(C.Structure):
                 ("step_noise", C.c_void_p), ("seed", C.c_uint64), ("first_utterance", C.c_uint32),
                 ("preseq", C.c_void_p), ("preseq_len", C.c_int), ("mem", Memory * NUM_MEM),
                 ("skip_zero_weight_chunks", C.c_int), ("dynamic_memory_mask", C.c_int),
-                ("timesteps", C.c_void_p), ("num_timesteps", C.c_int), ("att_ring", C.c_void_p * NUM_MEM)]
+                ("timesteps", C.c_void_p), ("num_timesteps", C.c_int), ("att_ring", C.c_void_p * NUM_MEM),
+                ("operand_policy", C.c_int)]
 
 
 class WegArgs(C.Structure):
@@ -173,6 +174,15 @@ def load():
             fn.restype = C.c_int
     _lib = lib
     return lib
+
+
+def wrote(*tensors):
+    """Tell torch that the library wrote these caller-owned tensors through their raw pointers: bumps their version counters
+    (``torch.autograd.graph.increment_version``), which is what ``Denoiser.forward`` keys its reuse of the memories' projections on --
+    a ctypes write is otherwise invisible to it (the same-memories staleness hole of round 5)."""
+    live = [t for t in tensors if t is not None]
+    if live:
+        torch.autograd.graph.increment_version(live)
 
 
 def check(code):

@@ -50,6 +50,7 @@ def linear_act(x, weight, bias, act=ACT_NONE, out=None):
     xf = x.detach().to(torch.float32).contiguous().reshape(-1, K)
     w = weight.detach().to(device=x.device, dtype=torch.float32).contiguous()
     b = bias.detach().to(device=x.device, dtype=torch.float32).contiguous() if bias is not None else None
+    fresh = out is None
     if out is None:
         out = torch.empty((*x.shape[:-1], N), dtype=torch.float32, device=x.device)
     elif not (out.is_contiguous() and out.dtype == torch.float32 and out.numel() == xf.shape[0] * N):
@@ -59,6 +60,8 @@ def linear_act(x, weight, bias, act=ACT_NONE, out=None):
         _lib.check(_lib.load().cfd_linear_act(_engine_handle(x.device), C.c_void_p(xf.data_ptr()), xf.shape[0], K,
                                               C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()) if b is not None else None,
                                               N, int(act), C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
+    if not fresh:
+        _lib.wrote(out)      # a caller's tensor rewritten through its raw pointer: torch must see it (it may be a memory of the next forward)
     return out
 
 

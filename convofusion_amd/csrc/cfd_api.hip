@@ -100,6 +100,8 @@ struct Problem {
   int xa0_nwg_a = 0, xa0_nwg_b = 0;   // layer-0 de-duplication lists (build_xattn_layer0_lists); 0: one launch
   bool xa_flush = false;               // some work list flushes the accumulator between two online memories (XA_FLUSH): lock-step kernel only
   int xa_one = -1;                     // the one-key memory the fused cross-attention adds as a vector (xattn_fused.hpp, XAttnArgs::one_j), or -1
+  int xa_opf = 0;                      // operand format of the fused cross-attention's key tiles in this problem (XA_V16 | XA_K16; 0: split pairs).  Only a
+                                       // sampling run sets it (cfd_sample_args::operand_policy), and only when every memory is static and no maps are kept
   // memories (bit j) whose folded projections were computed once for the run from the centred static part of the memory
   // (prepare_static_memside); per step they only get their per-key scale and bias (mem_scale_all_kernel)
   int static_mask = 0;
@@ -147,6 +149,7 @@ struct Work {
   bool fwd_mask[CFD_NMEM] = {false, false, false, false, false}, fwd_map[CFD_NMEM] = {false, false, false, false, false};
   unsigned long long fwd_wver = 0;
   DBuf rt_vt, rt_cbt[CFD_NMEM];   // row-tile path: V^T of the self-attention, per-step key tables
+  DBuf k16[CFD_NMEM], v16[CFD_NMEM];   // single-fp16 key / value tiles of the static memories (xa_pack16_kernel), when pb.xa_opf asks for them
   DBuf rt_cur;                    // row-tile path, sampling run: this step's rows of every per-step table (rt_step_rows_kernel)
   // What the timestep-only tables of this workspace were built from: the table rows' timesteps and the weights' generation.  temb / AdaLN
   // rows (20 launches) and, per memory, A_l b_t / VV_l b_t (kbtab / vbtab: two products each) depend on nothing else, so a run that
@@ -165,7 +168,7 @@ struct Work {
     for (DBuf* b : all) b->release();
     for (int j = 0; j < CFD_NMEM; ++j) {
       n_sp[j].release(); kall_sp[j].release(); cb[j].release(); vt_all[j].release(); ca[j].release(); asq[j].release(); kbtab[j].release();
-      vbtab[j].release(); rt_cbt[j].release();
+      vbtab[j].release(); rt_cbt[j].release(); k16[j].release(); v16[j].release();
     }
   }
 };
@@ -205,9 +208,11 @@ struct cfd_handle_s {
   bool fused_xattn = true;
   int fused_xattn_min_wgs = 6;
   int one_key = 1;              // CFD_ONE_KEY=0: a one-key memory (lsnemb) keeps its 32-key tile step in the fused cross-attention
-  int xa_pp = 0;                // form of the fused cross-attention kernel (xattn_fused.hpp): CFD_XA_PP=0 lock-step, every wave requests its share of every
-                                // sub-buffer (rounds 2-4); 1 ping-pong (two wave groups one sub-phase apart); 2 lock-step, requests divided between the groups
-  bool hint_same_mem = false;   // cfd_forward_same_memories: consumed by the next cfd_forward
+  int xa_operands = -1;         // CFD_XA_OPERANDS=<0..3>: overrides cfd_sample_args.operand_policy (developer A/B of the fused cross-attention's tile formats)
+  bool hint_same_mem = false;   // cfd_forward_same_memories: the promise for the NEXT cfd_forward ...
+  bool hint_now = false;        // ... taken (and cleared) at that call's very first line, before anything can fail: a call that returns early
+                                // must not leave the promise standing for the call after it
+  bool census_pending = false;  // a cfd_weg_eval without loss_host left its census unread (it does not wait): settled by the next entry point
   int rt_nfb2_tiles = 14;       // CFD_RT_NFB2_TILES=<token tiles>: from how many token tiles on the row-tile path's 512 x 512 residual products take two feature blocks per workgroup
   int step_rows = 1;            // CFD_STEP_ROWS=0: the tile kernels index the per-step tables with the device step counter themselves
   int att_fused = 1;            // CFD_ATT_FUSED=0: a forward that returns att_mats takes the three-launch cross-attention on the tile kernels (the fused
@@ -287,6 +292,15 @@ static int check_saturation(Ctx* c, const char* what) {
     return fail(CFD_E_RANGE, "%s: %u groups of values exceed +-65504, the range of the fp16 split-pair operands (weights, centred memories and their "
                              "folded key / value projections must stay inside it); rescale the conditioning input", what, n[CFD_SAT_MEM]);
   return fail(CFD_E_RANGE, "%s: %u groups of values of the sample / latents exceed +-65504, the range of the fp16 split-pair operands", what, n[CFD_SAT_IN]);
+}
+
+// A cfd_weg_eval that does not wait (loss_host == NULL) cannot read its own census.  The next entry point of the handle does, before it
+// zeroes or reads the counters for its own launches: nothing is dropped and nothing is blamed on the wrong call.
+static int settle_deferred_census(Ctx* c) {
+  if (!c->census_pending) return CFD_OK;
+  c->census_pending = false;
+  HIPCHK(hipStreamSynchronize(c->own_stream));
+  return check_saturation(c, "an earlier cfd_weg_eval (latents, memories / their projections)");
 }
 
 static const float* rawp(Ctx* c, const std::string& name) {
@@ -379,8 +393,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   if (env) c->fused_xattn_min_wgs = atoi(env);
   env = getenv("CFD_L0_DEDUP");
   if (env) c->l0_dedup = atoi(env) != 0;
-  env = getenv("CFD_XA_PP");
-  if (env) c->xa_pp = atoi(env);
+  env = getenv("CFD_XA_OPERANDS");
+  if (env) c->xa_operands = atoi(env) & 3;
   env = getenv("CFD_ONE_KEY");
   if (env) c->one_key = atoi(env) != 0;
   env = getenv("CFD_RT_NFB2_TILES");
@@ -933,6 +947,10 @@ static int setup_att_fused(Ctx* c) {
 }
 
 static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], float* const att[CFD_NMEM], int tmode, int T) {
+  // (whatever this call is and however it ends, it may overwrite the memory-side buffers: the previous forward's projections are current
+  //  only if cfd_forward says so again at its end)
+  const bool mem_was_valid = c->w->fwd_mem_valid;
+  c->w->fwd_mem_valid = false;
   if (!c->finalized) return fail(CFD_E_STATE, "weights not finalized");
   if (c->tsin_rows < 1) return fail(CFD_E_STATE, "timestep table not set");
   if (Be < 1 || L < 2) return fail(CFD_E_ARG, "bad batch / length");
@@ -945,10 +963,7 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
     HIPCHK(hipMemcpy(c->w->iota.p, id.data(), (size_t)Be * 4, hipMemcpyHostToDevice));
   }
   Problem& p = c->w->pb;
-  // (whatever this call is, it may overwrite the memory-side buffers: the previous forward's projections are current only if cfd_forward
-  //  says so again at its end)
-  bool prev_same = c->w->fwd_mem_valid && c->w->fwd_wver == (unsigned long long)c->wver && c->w->fwd_Be == Be && tmode == 0;
-  c->w->fwd_mem_valid = false;
+  bool prev_same = mem_was_valid && c->w->fwd_wver == (unsigned long long)c->wver && c->w->fwd_Be == Be && tmode == 0;
   for (int j = 0; j < CFD_NMEM && prev_same; ++j)
     prev_same = c->w->fwd_U[j] == mem[j].U && c->w->fwd_S[j] == mem[j].S && c->w->fwd_mask[j] == (mem[j].key_padding_mask != nullptr) &&
                 c->w->fwd_map[j] == (mem[j].row_map != nullptr);
@@ -957,7 +972,7 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
   // lists and instance tables made from them -- several device-to-host reads per call -- are kept as well
   bool any_att_in = false;
   for (int j = 0; j < CFD_NMEM; ++j) any_att_in = any_att_in || (att && att[j]);
-  const bool keep_lists = prev_same && c->hint_same_mem && c->w->fwd_L == L && c->w->fwd_att == any_att_in;
+  const bool keep_lists = prev_same && c->hint_now && c->w->fwd_L == L && c->w->fwd_att == any_att_in;
   p.Be = Be; p.L = L; p.Lp = (L + 31) / 32 * 32; p.M = (long long)Be * L; p.tmode = tmode; p.T = T;
   p.share_B = 0;
   if (p.Lp > SM_MAX_CHUNKS * 512) return fail(CFD_E_SHAPE, "L = %d exceeds the in-register softmax limit (%d)", L, SM_MAX_CHUNKS * 512);
@@ -977,6 +992,7 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
     p.att_slot[j] = 0;
     p.att_b0 = p.att_nb = 0;      // (a sampling run with an attention ring sets them after this call)
     p.att_fused = false;
+    p.xa_opf = 0;                 // (a sampling run's operand policy likewise)
   }
   p.Sp_tot = off;
   {  // memories without a key-padding mask get an all-zero one, so the softmax kernel needs no null test
@@ -1042,7 +1058,7 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
   {
     bool any_att = false;
     for (int j = 0; j < CFD_NMEM; ++j) any_att = any_att || p.att[j];
-    p.att_fused = any_att && !p.rt && tmode == 0 && c->att_fused && c->fused_xattn && c->hoist_memside && !g_cfd_naive_gemm && c->xa_pp != 1;
+    p.att_fused = any_att && !p.rt && tmode == 0 && c->att_fused && c->fused_xattn && c->hoist_memside && !g_cfd_naive_gemm;
     if (p.att_fused) { p.att_b0 = 0; p.att_nb = Be; }
   }
   if (!keep_lists) CHK(build_xattn_worklist(c, mem));
@@ -1157,7 +1173,7 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
     CHK(r);
   }
   const bool fused = p.rt || (c->fused_xattn && p.xa_nwg > 0 && !want_att && !g_cfd_naive_gemm);
-  if (!fused || !c->hoist_memside || p.tmode != 0) return CFD_OK;
+  if (!fused || !c->hoist_memside || p.tmode != 0) { p.xa_opf = 0; return CFD_OK; }
   const int T = p.T;
   if (c->w->b_tab.bytes < (size_t)T * CFD_D * 4 || c->w->b_sp.bytes < (size_t)T * CFD_D * 4 || c->w->bsq.bytes < (size_t)T * 4)
     c->w->tt_mem_mask = 0;       // (a table that is reallocated is an empty one)
@@ -1222,7 +1238,23 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
     }
     p.static_mask |= 1 << j;
   }
-  if (p.xa_one >= 0 && !p.rt && !reuse) {   // the one-key memory's value rows as float32 vectors (xattn_fused.hpp, XAttnArgs::one_va)
+  if (p.xa_opf && (p.rt || p.static_mask != (1 << CFD_NMEM) - 1)) p.xa_opf = 0;   // (single-fp16 tiles: every memory static, tile kernels)
+  if (p.xa_opf) {   // this run's operand policy: the key / value tiles of the fused cross-attention as single fp16, packed tile by tile
+    for (int j = 0; j < CFD_NMEM; ++j) {
+      if (j == p.xa_one) continue;   // (no segments: its value row goes through one_va)
+      const long long tiles = (long long)nl * p.U[j] * (p.Sp[j] / XA_KEYS), chunks = tiles * 2048;
+      if (p.xa_opf & XA_V16) {
+        CHK(c->w->v16[j].ensure((size_t)tiles * 32768));
+        LAUNCH(CFD_PROF_ROWS, xa_pack16_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), st, c->w->vt_all[j].as<char>(), c->w->v16[j].as<char>(), chunks, p.Sp[j], 0);
+      }
+      if (p.xa_opf & XA_K16) {
+        CHK(c->w->k16[j].ensure((size_t)tiles * 32768));
+        LAUNCH(CFD_PROF_ROWS, xa_pack16_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), st, c->w->kall_sp[j].as<char>(), c->w->k16[j].as<char>(), chunks, p.Sp[j], 1);
+      }
+    }
+  }
+  if (p.xa_one >= 0 && !p.rt) {   // the one-key memory's value rows as float32 vectors (xattn_fused.hpp, XAttnArgs::one_va).  Also with `reuse`:
+                                  // the previous forward of these memories may have had another L or the row-tile path and never made them (one tiny launch)
     const int j = p.xa_one;
     const long long n = (long long)nl * p.U[j] * CFD_D;
     CHK(c->w->xa_one_va.ensure((size_t)n * 4));
@@ -1593,10 +1625,11 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
   static unsigned long long attr = 0;   // per device (one bit per ordinal): a process may hold handles on several GPUs
   if (!((attr >> (c->cfg.device & 63)) & 1ull)) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
     attr |= 1ull << (c->cfg.device & 63);
   }
 
@@ -1667,9 +1700,10 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       a.x = c->w->x.as<float>(); a.ln_g = w.ln2g; a.ln_b = w.ln2b; a.bias = w.cross_bias.as<float>(); a.L = L;
       for (int j = 0; j < CFD_NMEM; ++j) {
         const size_t rows = (size_t)p.U[j] * p.Sp[j];
-        a.K[j] = c->w->kall_sp[j].as<char>() + (size_t)l * rows * ROWB;
+        // (single-fp16 tiles, Problem::xa_opf: 32 KB per 32 keys = 1 KB per key, tile-major per (layer, instance))
+        a.K[j] = (p.xa_opf & XA_K16) ? c->w->k16[j].as<char>() + (size_t)l * rows * 1024 : c->w->kall_sp[j].as<char>() + (size_t)l * rows * ROWB;
         a.cb[j] = c->w->cb[j].as<float>() + (size_t)l * rows;
-        a.VT[j] = c->w->vt_all[j].as<char>() + (size_t)l * rows * ROWB;
+        a.VT[j] = (p.xa_opf & XA_V16) ? c->w->v16[j].as<char>() + (size_t)l * rows * 1024 : c->w->vt_all[j].as<char>() + (size_t)l * rows * ROWB;
         a.Sp[j] = p.Sp[j];
         const bool stat = (p.static_mask >> j) & 1;
         a.rs_off[j] = (unsigned)((size_t)(nl - l) * rows * 4);
@@ -1693,13 +1727,14 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       a.stamps = c->w->xa_stamps.as<long long>();
 #endif
       Bracket br(c, CFD_PROF_XATTN, st);
-      const int form = (c->xa_pp == 1 && p.xa_flush) ? 2 : c->xa_pp;   // the ping-pong form has no flush between two online memories
       if (p.att_fused) a.att = c->w->xa_att_desc.as<XaAtt>() + l;
+      const int opf = p.att_fused ? 0 : p.xa_opf;
       auto launch_xa = [&](int nwg, const XAttnArgs& xa) {
-        if (p.att_fused) hipLaunchKernelGGL((xattn_fused_kernel<0, true>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
-        else if (form == 1) hipLaunchKernelGGL(xattn_fused_kernel<1>, dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
-        else if (form == 2) hipLaunchKernelGGL(xattn_fused_kernel<2>, dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
-        else hipLaunchKernelGGL(xattn_fused_kernel<0>, dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
+        if (p.att_fused) hipLaunchKernelGGL((xattn_fused_kernel<true, 0>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
+        else if (opf == 1) hipLaunchKernelGGL((xattn_fused_kernel<false, 1>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
+        else if (opf == 2) hipLaunchKernelGGL((xattn_fused_kernel<false, 2>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
+        else if (opf == 3) hipLaunchKernelGGL((xattn_fused_kernel<false, 3>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
+        else hipLaunchKernelGGL((xattn_fused_kernel<false, 0>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
       };
       if (l == 0 && share && p.xa0_nwg_a > 0) {   // layer-0 de-duplication (build_xattn_layer0_lists): the longest memory once per distinct (utterance, instance) ...
         XAttnArgs a0 = a;
@@ -1851,9 +1886,13 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
 // ---- cfd_forward ---------------------------------------------------------------------------------------
 extern "C" int cfd_forward(cfd_handle c, const float* sample, int Be, int L, const int32_t* timesteps, int n_t,
                            const cfd_memory mem[CFD_NUM_MEM], float* out, float* const att[CFD_NUM_MEM], void* stream) {
-  if (!c || !sample || !timesteps || !mem || !out) return fail(CFD_E_ARG, "null argument");
+  if (!c) return fail(CFD_E_ARG, "null argument");
+  c->hint_now = c->hint_same_mem;   // the promise covers THIS call only, however it ends
+  c->hint_same_mem = false;
+  if (!sample || !timesteps || !mem || !out) return fail(CFD_E_ARG, "null argument");
   if (c->run_open) return fail(CFD_E_STATE, "a sampling run is open on this handle");
   HIPCHK(hipSetDevice(c->cfg.device));
+  CHK(settle_deferred_census(c));
   if (n_t != 1 && n_t != Be) return fail(CFD_E_ARG, "n_t must be 1 or Be");
   hipStream_t st = (hipStream_t)stream;
   const int tmode = (n_t == 1) ? 0 : 1;
@@ -1869,8 +1908,7 @@ extern "C" int cfd_forward(cfd_handle c, const float* sample, int Be, int L, con
   {
     bool want_att = false;
     for (int j = 0; j < CFD_NMEM; ++j) want_att = want_att || (att && att[j]);
-    const bool reuse = c->hint_same_mem && c->w->pb.prev_same;
-    c->hint_same_mem = false;
+    const bool reuse = c->hint_now && c->w->pb.prev_same;
     CHK(prepare_static_memside(c, st, 0, want_att && !c->w->pb.att_fused, reuse));
     if (c->w->pb.static_mask) {   // once-per-call projections of the caller's memories: the census is read before they are used
       HIPCHK(hipStreamSynchronize(st));
@@ -1984,6 +2022,8 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
   if (!c || !args) return fail(CFD_E_ARG, "null argument");
   if (c->run_open) return fail(CFD_E_STATE, "a sampling run is already open");
   HIPCHK(hipSetDevice(c->cfg.device));
+  c->hint_now = c->hint_same_mem = false;
+  CHK(settle_deferred_census(c));
   const cfd_sample_args& s = *args;
   if (s.B < 1 || (s.G != 1 && s.G != 7 && (s.G < 1 || s.G > 8))) return fail(CFD_E_ARG, "bad B / G");
   if (s.scheduler != 0 && s.scheduler != 1) return fail(CFD_E_ARG, "scheduler must be 0 (DDPM) or 1 (DDIM)");
@@ -2068,7 +2108,7 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
     // ... and on the tile kernels the fused cross-attention kernel has them in its softmax: its ATT instance keeps them, att_fixup_kernel
     // normalises them once per step (xattn_fused.hpp, XaAtt).  What cannot keep them: a run without the fused kernel (memories made per
     // step: dynamic memories; the developer switches that turn it off).
-    const bool fused_ok = c->fused_xattn && pb.xa_nwg > 0 && c->hoist_memside && !g_cfd_naive_gemm && c->xa_pp != 1;
+    const bool fused_ok = c->fused_xattn && pb.xa_nwg > 0 && c->hoist_memside && !g_cfd_naive_gemm;
     if ((!pb.rt && !fused_ok) || s.dynamic_memory_mask)
       return fail(CFD_E_SHAPE, "att_ring needs the row-tile path or the fused cross-attention kernel (one timestep per step, no dynamic memory): "
                                "this run has L = %d, %lld token rows; take the maps with one forward per iteration instead", s.L, (long long)Be * s.L);
@@ -2086,6 +2126,13 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
     }
   }
   CHK(build_xattn_layer0_lists(c, mem_in));
+  {   // operand policy of the run (cfd_sample_args::operand_policy): single-fp16 key / value tiles for the fused cross-attention kernel --
+      // only where that kernel runs on projections made once per run and keeps no maps (prepare_static_memside checks the rest)
+    Problem& pb = c->w->pb;
+    const int want = c->xa_operands >= 0 ? c->xa_operands : (s.operand_policy & 3);
+    const bool fused_run = !pb.rt && c->fused_xattn && pb.xa_nwg > 0 && c->hoist_memside && !g_cfd_naive_gemm && !pb.att_fused && !s.dynamic_memory_mask;
+    pb.xa_opf = fused_run ? want : 0;
+  }
   // timesteps: (arange(N) * (T // N)).round()[::-1] (+ steps_offset for DDIM)
   std::vector<int32_t> ts(N);
   std::vector<StepCoef> coef(N);
@@ -2100,6 +2147,7 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
   CHK(c->coef.ensure((size_t)N * sizeof(StepCoef)));
   HIPCHK(hipMemcpyAsync(c->coef.p, coef.data(), (size_t)N * sizeof(StepCoef), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemsetAsync(c->w->d_step.p, 0, 16, st));
+  CHK(sat_begin(c, st));    // the census this call reads below counts ITS launches only
   CHK(build_time_tables(c, ts.data(), N, st));
   CHK(prepare_static_memside(c, st, s.dynamic_memory_mask, false));
   HIPCHK(hipStreamSynchronize(st));  // ts / coef host vectors go out of scope
@@ -2228,6 +2276,7 @@ extern "C" int cfd_sample_read(cfd_handle c, float* out, int close) {
   const size_t lat_bytes = (size_t)c->sargs.B * c->sargs.L * CFD_LAT * 4;
   HIPCHK(hipMemcpyAsync(out, c->latents.p, lat_bytes, hipMemcpyDeviceToDevice, c->run_stream));
   HIPCHK(hipStreamSynchronize(c->run_stream));
+  CHK(settle_deferred_census(c));
   // the census of everything the run's iterations counted (per-step projections of a dynamic memory, CFD_HOIST_MEMSIDE=0): read on
   // every read of a run whose captured iteration has such launches, BEFORE the run is closed -- a run that fails here stays open and can be
   // inspected or closed by the caller
@@ -2437,6 +2486,8 @@ extern "C" int cfd_weg_eval(cfd_handle c, const cfd_weg_args* a, float* losses, 
   for (int t = 0; t < n_tok; ++t)
     if (a->tok_idx[t] < 1 || a->tok_idx[t] > a->last - 1) return fail(CFD_E_ARG, "focus index %d is outside the text slice [1, %d)", a->tok_idx[t], a->last);
   HIPCHK(hipSetDevice(c->cfg.device));
+  c->hint_now = c->hint_same_mem = false;
+  CHK(settle_deferred_census(c));
   hipStream_t caller = (hipStream_t)stream;
   // the evaluation runs on the handle's own stream (capturable, and the one the sampling graph replays on: the two
   // serialise); it starts behind whatever the caller has queued on `stream`
@@ -2571,6 +2622,7 @@ extern "C" int cfd_weg_eval(cfd_handle c, const cfd_weg_args* a, float* losses, 
     for (int b = 0; b < B; ++b) sum += l[b];
     *loss_host = sum / (float)B;
   } else {                                           // the caller's stream continues behind the evaluation
+    c->census_pending = true;                        // (read by the handle's next entry point: settle_deferred_census)
     HIPCHK(hipEventRecord(c->weg_ev, st));
     HIPCHK(hipStreamWaitEvent(caller, c->weg_ev, 0));
   }

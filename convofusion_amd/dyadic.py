@@ -109,6 +109,7 @@ class DyadicRun:
         if n <= 0:
             return
         _lib.check(_lib.load().cfd_dyadic_steps(self.runs[0].handle, None if self.merged else self.runs[1].handle, C.byref(self._proj), n))
+        _lib.wrote(*self.spk)     # (the partner projections landed in these speaker-memory rows)
         self.position += n
 
     def read(self, close=False):

@@ -18,6 +18,11 @@ from .denoiser import Denoiser
 # which guidance chunk carries which conditional memory (reference convofusion.py:909-929, 527-541)
 CFG_CHUNKS = 7
 
+# Operand policy of a run's fused cross-attention (cfd_sample_args.operand_policy: bit 0 = folded values as single fp16, bit 1 = folded
+# keys too; 0 = fp16 split pairs), per scheduler kind (scheduler.KIND: 0 DDPM, 1 DDIM).  The DDPM loop re-injects noise every step and
+# contracts perturbations; DDIM (eta = 0) amplifies any per-forward perturbation ~100x over 50 steps and keeps pairs.
+OPERAND_POLICY = {0: 0, 1: 0}
+
 
 def _dedup_rows_exact(m, mk):
     """Row-by-row grouping with exact comparisons (the fallback when two different rows share a hash)."""
@@ -113,7 +118,7 @@ class SamplingRun:
     def __init__(self, denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
                  guidance_scale=7.5, guidance_chunks=CFG_CHUNKS, eta=0.0, init_latents=None, step_noise=None,
                  seed=0, first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False, row_maps=None,
-                 dynamic_memories=(), side_engine=False, attention_ring=False):
+                 dynamic_memories=(), side_engine=False, attention_ring=False, operands=None):
         """attention_ring: keep the attention maps of the full-conditioning chunk of EVERY iteration (the reference's per-iteration dict,
         convofusion.py:517-523): the captured iteration stores them into ``self.att_ring`` -- five tensors [iterations, B, layers, L, S_j]
         -- with no extra forward and no host round trip (cfd_sample_args.att_ring: the row-tile kernels store them from their second
@@ -121,6 +126,7 @@ class SamplingRun:
         memories -- gets CFD_E_SHAPE and ``sample`` then takes the maps with one forward per iteration).  The ring is
         iterations x B x layers x L x keys floats: ``sample`` / ``diffusion_reverse`` ask for it only up to ATT_RING_MAX_BYTES.
         ``attention_dict()`` turns the ring into the dict.
+        operands: cfd_sample_args.operand_policy of this run (None: OPERAND_POLICY of the scheduler kind).
         side_engine: open the run on the denoiser's second library handle (its own weights copy, workspace and stream), so that
         two runs on one module can be open at once (the attention forward of ``last_step_attention`` uses it for a plain forward).
         dynamic_memories: indices j of memories whose CONTENTS the caller rewrites between iterations (DyadicRun's partner
@@ -194,6 +200,7 @@ class SamplingRun:
         # the per-step attention maps it logs)
         a.skip_zero_weight_chunks = 1 if skip_zero_weight_chunks else 0
         a.dynamic_memory_mask = sum(1 << int(j) for j in set(dynamic_memories))
+        a.operand_policy = int(OPERAND_POLICY.get(scheduler.KIND, 0) if operands is None else operands)
         ts = (C.c_int32 * self.N)(*self.timesteps)
         self._keep.append(ts)
         a.timesteps, a.num_timesteps = C.cast(ts, C.c_void_p), self.N
@@ -309,8 +316,12 @@ def last_step_attention(run, denoiser, timestep, encoder_hidden_states, cond_mas
 
 
 # Largest attention ring the loop drop-ins allocate by themselves (bytes): the product shape with 32 utterances and 1000 iterations is
-# 4.0 GB; the headline shape (196 tokens, 1500 audio keys) would be 356 MB PER ITERATION.  Beyond it "auto" keeps the last entry.
-ATT_RING_MAX_BYTES = 16 << 30
+# 4.0 GB (test.py's batch: it must fit); the headline shape (196 tokens, 1500 audio keys) would be 356 MB PER ITERATION.  Beyond it -- or
+# beyond half of the memory that is free on the device right now -- "auto" keeps the last entry.  What the ring costs where it is kept:
+# the zero-weight full-conditioning chunk is evaluated (it is what the maps come from; "last" skips it: 1/7 of the rows) plus 2 - 5 % for
+# the stores, i.e. ~ +20 % run time against attention_steps="last" (DESIGN.md section 11.4); the ring stays alive as long as the
+# returned dict's views do.
+ATT_RING_MAX_BYTES = 6 << 30
 
 
 def _open_run(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps, want_ring, **kw):
@@ -320,13 +331,19 @@ def _open_run(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_
     if want_ring:
         n_it = len(scheduler.timestep_table(num_inference_steps)[1])
         keys = sum(int(m.shape[1]) for m in encoder_hidden_states)
-        want_ring = 4 * n_it * B * int(denoiser.num_layers) * L * keys <= ATT_RING_MAX_BYTES
+        budget = ATT_RING_MAX_BYTES
+        dev = encoder_hidden_states[0].device
+        if dev.type == "cuda":
+            budget = min(budget, torch.cuda.mem_get_info(dev)[0] // 2)
+        want_ring = 4 * n_it * B * int(denoiser.num_layers) * L * keys <= budget
     if want_ring:
         try:
             return SamplingRun(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps,
                                **dict(kw, attention_ring=True, skip_zero_weight_chunks=False))
         except _lib.CfdError as e:
-            if e.code != -2:      # CFD_E_SHAPE: a run whose maps the captured iteration cannot keep
+            # CFD_E_SHAPE: a run whose maps the captured iteration cannot keep; CFD_E_HIP: the library's own buffers for the maps did not
+            # fit (hipMalloc failed) -- either way the maps are taken the other way; anything else is the caller's error
+            if e.code not in (-2, -4):
                 raise
         except torch.cuda.OutOfMemoryError:
             pass                  # the ring did not fit beside what the caller holds: the maps are taken the other way
@@ -335,7 +352,7 @@ def _open_run(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_
 
 def sample(denoiser, scheduler, encoder_hidden_states, cond_masks=None, *, B, L=16, num_inference_steps=1000,
            guidance_scale=7.5, guidance_chunks=CFG_CHUNKS, eta=0.0, init_latents=None, step_noise=None, seed=0,
-           first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False, row_maps=None, return_attention=False):
+           first_utterance=0, preseq=None, dedup=True, skip_zero_weight_chunks=False, row_maps=None, return_attention=False, operands=None):
     """Run the whole loop; returns latents [B, L, 128] (batch-first); with ``return_attention=True`` also the last
     iteration's attention maps (``last_step_attention``), with ``return_attention="all"`` a dict {timestep: maps} over every
     iteration like the reference's: kept by the captured iteration itself (``SamplingRun(attention_ring=True)``) while the ring fits
@@ -344,7 +361,7 @@ def sample(denoiser, scheduler, encoder_hidden_states, cond_masks=None, *, B, L=
     run = _open_run(denoiser, scheduler, encoder_hidden_states, cond_masks, B, L, num_inference_steps, return_attention in ("all", "auto"),
                     guidance_scale=guidance_scale, guidance_chunks=guidance_chunks, eta=eta, init_latents=init_latents, step_noise=step_noise,
                     seed=seed, first_utterance=first_utterance, preseq=preseq, dedup=dedup, skip_zero_weight_chunks=skip_zero_weight_chunks,
-                    row_maps=row_maps)
+                    row_maps=row_maps, operands=operands)
     try:
         if not return_attention:
             run.steps(run.N)

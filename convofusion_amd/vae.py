@@ -46,6 +46,7 @@ def add_(x, y):
     """x += y on the device (x, y contiguous float32 of equal size)."""
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().cfd_add(_engine_handle(x.device), _ptr(x), _ptr(y), x.numel(), _stream(x)))
+        _lib.wrote(x)
     return x
 
 
@@ -196,6 +197,7 @@ class ConvoFusionVae(nn.Module):
         keep = mask.t().contiguous().to(torch.uint8)                                          # rows are (frame, batch)
         with torch.cuda.device(dev):
             _lib.check(_lib.load().cfd_zero_rows(_engine_handle(dev), _ptr(out), _ptr(keep), nframes * bs, out.shape[-1], _stream(out)))
+            _lib.wrote(out)
         return out.permute(1, 0, 2)                                                           # :370
 
 

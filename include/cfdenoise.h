@@ -149,6 +149,14 @@ typedef struct {
                                  Needs skip_zero_weight_chunks == 0 and no dynamic memory (such a run has no fused cross-attention:
                                  cfd_sample_begin fails with CFD_E_SHAPE and the caller takes the maps with one cfd_forward per
                                  iteration).  The ring's size is the caller's business: iterations x B x layers x L x keys. */
+  int operand_policy;         /* Operand format of the fused cross-attention's key / value tiles in THIS run (csrc/xattn_fused.hpp, OPF):
+                                 0 = fp16 split pairs everywhere (3 MFMAs per product, ~2^-22 operand error: what cfd_forward always uses);
+                                 bit 0 = the folded VALUES of the memories as single fp16 (the linear path of the attention; halves their
+                                 L2 -> LDS traffic, 2 MFMAs per product); bit 1 = the folded KEYS as single fp16 as well (the
+                                 exponentiated path).  The reference is float32 throughout (cross_attention.py:593-652); which runs
+                                 tolerate which bits is measured per scheduler in DESIGN.md section 2 -- convofusion_amd.sampler sets
+                                 bit 0 for DDPM runs only, and nothing for DDIM.  Ignored (pairs) on the row-tile path, with att_ring,
+                                 and with a dynamic memory. */
 } cfd_sample_args;
 
 /* Opens a sampling run: builds the per-step coefficient and timestep-embedding tables, draws / copies

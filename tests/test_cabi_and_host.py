@@ -32,9 +32,10 @@ def test_struct_layouts_match_header():
     # natural C layout of the header's structs on x86-64
     assert C.sizeof(_lib.Config) == 24
     assert C.sizeof(_lib.Memory) == 32
-    assert _lib.SampleArgs.mem.offset % 8 == 0 and C.sizeof(_lib.SampleArgs) == _lib.SampleArgs.mem.offset + 5 * 32 + 8 + 16 + 5 * 8
+    assert _lib.SampleArgs.mem.offset % 8 == 0 and C.sizeof(_lib.SampleArgs) == _lib.SampleArgs.mem.offset + 5 * 32 + 8 + 16 + 5 * 8 + 8
     assert _lib.SampleArgs.timesteps.offset == _lib.SampleArgs.mem.offset + 5 * 32 + 8   # (8-aligned pointer behind the two ints)
     assert _lib.SampleArgs.att_ring.offset == _lib.SampleArgs.timesteps.offset + 16      # (pointer, int, padding; then the five ring pointers)
+    assert _lib.SampleArgs.operand_policy.offset == _lib.SampleArgs.att_ring.offset + 5 * 8   # (int + tail padding to the struct's 8-byte alignment)
 
 
 def test_weg_host_logic():

@@ -388,31 +388,148 @@ def test_repeated_forwards_with_the_same_memories_reuse_their_projections(Be):
     masks = {k: to_dev(v) for k, v in inp["masks"].items()}
     m = hip_denoiser(1234, 1.0)
 
-    def fresh(t):
-        f = hip_denoiser(1234, 1.0)
-        with torch.no_grad():
-            return f(x, torch.tensor(t), [q.clone() for q in mems], mem_mask_dict={k: (None if v is None else v.clone()) for k, v in masks.items()})
+    other = hip_denoiser.__wrapped__(1234, 1.0)     # (a second module with its own handle: hip_denoiser itself is cached and would return m)
+    other.assume_constant_memories = False
 
-    def call(t):
+    def fresh(t):
         with torch.no_grad():
-            return m(x, torch.tensor(t), mems, mem_mask_dict=masks)
+            return other(x, torch.tensor(t), [q.clone() for q in mems], mem_mask_dict={k: (None if v is None else v.clone()) for k, v in masks.items()})
+
+    def call(t, reused):
+        with torch.no_grad():
+            out = m(x, torch.tensor(t), mems, mem_mask_dict=masks)
+        assert m.last_forward_reused == reused, (t, m.last_forward_reused)
+        return out
 
     def same(a, b):     # (bit-identical; NaN -- the rows whose memory the changed mask covers completely -- in the same places)
         eq = lambda p, q: torch.equal(torch.isnan(p), torch.isnan(q)) and torch.equal(p.nan_to_num(nan=0.0), q.nan_to_num(nan=0.0))
         return eq(a[0], b[0]) and all(eq(p, q) for p, q in zip(a[1], b[1]))
 
-    assert same(call(900), fresh(900))
-    assert same(call(500), fresh(500))              # reused
-    assert same(call(37), fresh(37))                # reused again
+    m._last_forward_memories = None
+    assert same(call(900, False), fresh(900))
+    assert same(call(500, True), fresh(500))              # reused
+    assert same(call(37, True), fresh(37))                # reused again
     mems[1].mul_(1.5)                               # in place: the version counter moves, the projections are made again
-    assert same(call(36), fresh(36))
-    assert same(call(35), fresh(35))
+    assert same(call(36, False), fresh(36))
+    assert same(call(35, True), fresh(35))
     name = [k for k, v in masks.items() if v is not None][0]
     masks[name][:, 0] = ~masks[name][:, 0] if masks[name].dtype == torch.bool else 1 - masks[name][:, 0]
-    assert same(call(34), fresh(34))
+    assert same(call(34, False), fresh(34))
     # something else on the handle in between: the library refuses the promise by itself
     sch = scheduler.DDPMScheduler(variance_type="fixed_small", **SCHED_KW)
     cb = inputs.make_cfg_batch(seed=3, B=2, L=L, S=S, pad_tail=(2, 0, 1, 0, 0))
     sample(m, sch, [to_dev(q) for q in cb["memories"]], {k: to_dev(v) for k, v in cb["masks"].items()}, B=2, L=L, num_inference_steps=2, seed=1)
-    assert same(call(33), fresh(33))
-    assert same(call(32), fresh(32))
+    assert same(call(33, True), fresh(33))          # (the Python side promises; the LIBRARY ignores the promise: a run was on the handle)
+    assert same(call(32, True), fresh(32))
+
+
+@pytest.mark.parametrize("Be", [14, 70])
+def test_a_memory_rewritten_through_a_raw_pointer_is_not_served_from_the_previous_forward(Be):
+    """The same-memories reuse keys on tensor identity + torch's version counter, which a write through a raw pointer does not move
+    (round 5's staleness hole).  (i) the package's own raw-pointer writers bump the counter themselves: ``linear_act(..., out=mem)`` between
+    two forwards gives the answer of a denoiser that has never seen the memories; (ii) ``mem.data.copy_()`` -- invisible to the counter by
+    torch's own rules -- is refused with a RuntimeError when ``verify_constant_memories`` is on (a device checksum per tensor), gives the
+    right answer with ``assume_constant_memories = False``, and is the documented caveat otherwise (INTEGRATION.md section 3);
+    (iii) a changed layer-0 shape or path between two forwards of the same memories (row-tile path first, tile kernels second: the one-key
+    memory's value rows were only made by the second kind) still reuses correctly."""
+    import torch
+    from convofusion_amd.conditioning import ACT_GELU, linear_act
+    from tests.gpu_helpers import hip_denoiser, to_dev
+    L, S = 16, (6, 40, 6, 8, 1)
+    inp = inputs.make_plain_batch(seed=78, Be=Be, L=L, S=S, pad_tail=(2, 5, 1, 0, 0))
+    x = to_dev(inp["sample"])
+    mems = [to_dev(m) for m in inp["memories"]]
+    masks = {k: to_dev(v) for k, v in inp["masks"].items()}
+    m = hip_denoiser(1234, 1.0)
+
+    other = hip_denoiser.__wrapped__(1234, 1.0)     # (a second module with its own handle: hip_denoiser itself is cached and would return m)
+    other.assume_constant_memories = False
+
+    def fresh(t, xx=None):
+        with torch.no_grad():
+            return other(x if xx is None else xx, torch.tensor(t), [q.clone() for q in mems], mem_mask_dict={k: (None if v is None else v.clone()) for k, v in masks.items()})
+
+    def call(t, xx=None, reused=None):
+        with torch.no_grad():
+            out = m(x if xx is None else xx, torch.tensor(t), mems, mem_mask_dict=masks)
+        assert reused is None or m.last_forward_reused == reused, (t, m.last_forward_reused)
+        return out
+
+    def same(a, b):
+        eq = lambda p, q: torch.equal(torch.isnan(p), torch.isnan(q)) and torch.equal(p.nan_to_num(nan=0.0), q.nan_to_num(nan=0.0))
+        return eq(a[0], b[0]) and all(eq(p, q) for p, q in zip(a[1], b[1]))
+
+    m._last_forward_memories = None
+    assert same(call(900, reused=False), fresh(900)) and same(call(800, reused=True), fresh(800))
+    # (i) a product API that writes a caller tensor through its raw pointer
+    g = torch.Generator(device="cpu").manual_seed(5)
+    w = (torch.randn(512, 512, generator=g) * 0.05).cuda()
+    src = mems[1].clone()
+    v0 = mems[1]._version
+    linear_act(src, w, None, ACT_GELU, out=mems[1])
+    assert mems[1]._version > v0, "linear_act(out=...) must move the version counter of the tensor it rewrote"
+    assert not torch.equal(mems[1], src)
+    assert same(call(700, reused=False), fresh(700)) and same(call(600, reused=True), fresh(600))
+    # (ii) a write torch's counter cannot see
+    try:
+        m.verify_constant_memories = True
+        assert same(call(500), fresh(500))              # (records the checksums)
+        v0 = mems[0]._version
+        mems[0].data.copy_(mems[0] * 0.5)
+        assert mems[0]._version == v0                   # ... which is the whole problem
+        with pytest.raises(RuntimeError, match="rewritten between two forwards"):
+            call(400)
+        assert same(call(400, reused=False), fresh(400))   # after the refusal the projections are made again
+        m.verify_constant_memories = False
+        m.assume_constant_memories = False
+        mems[0].data.copy_(mems[0] * 2.0)
+        assert same(call(300, reused=False), fresh(300))
+    finally:
+        m.verify_constant_memories = False
+        m.assume_constant_memories = True
+    # (iii) same memories, another query length: 16 tokens (Be = 14: row-tile path) then 34 (tile kernels)
+    x2 = to_dev(inputs.make_plain_batch(seed=79, Be=Be, L=34, S=S, pad_tail=(2, 5, 1, 0, 0))["sample"])
+    assert same(call(250, reused=False), fresh(250))
+    assert same(call(200, x2, reused=True), fresh(200, x2))
+    assert same(call(150, reused=True), fresh(150))
+
+
+def test_forward_and_attention_sampling_under_inference_mode():
+    """pytorch_lightning's Trainer runs the reference's test loop under torch.inference_mode(): every conditioning tensor is an inference
+    tensor, whose version counter cannot be read (RuntimeError).  Denoiser.forward must work there -- the same-memories reuse then keys on a
+    device checksum instead -- and so must the loop drop-in's attention forward (last_step_attention calls the denoiser)."""
+    import torch
+    from convofusion_amd.sampler import sample
+    from tests.gpu_helpers import SCHED_KW, hip_denoiser, to_dev
+    from convofusion_amd import scheduler
+    L, S, Be = 16, (6, 40, 6, 8, 1), 14
+    inp = inputs.make_plain_batch(seed=81, Be=Be, L=L, S=S, pad_tail=(2, 5, 1, 0, 0))
+    m = hip_denoiser(1234, 1.0)
+    with torch.no_grad():
+        want = [m(to_dev(inp["sample"]), torch.tensor(t), [to_dev(q) for q in inp["memories"]], mem_mask_dict={k: to_dev(v) for k, v in inp["masks"].items()})
+                for t in (900, 500)]
+    with torch.inference_mode():
+        x = to_dev(inp["sample"])
+        mems = [to_dev(q) for q in inp["memories"]]
+        masks = {k: to_dev(v) for k, v in inp["masks"].items()}
+        assert mems[0].is_inference()
+        got = [m(x, torch.tensor(t), mems, mem_mask_dict=masks) for t in (900, 500)]     # the second call reuses (checksum signature)
+        assert m.last_forward_reused
+        mems[1].mul_(1.5)                                                                 # no version counter to move: the checksum sees it
+        moved = m(x, torch.tensor(500), mems, mem_mask_dict=masks)
+        assert not m.last_forward_reused
+    for g, w in zip(got, want):
+        assert torch.equal(g[0], w[0]) and all(torch.equal(p, q) for p, q in zip(g[1], w[1]))
+    with torch.no_grad():
+        mm = [to_dev(q) for q in inp["memories"]]
+        mm[1].mul_(1.5)
+        want_moved = hip_denoiser(1234, 1.0)(to_dev(inp["sample"]), torch.tensor(500), mm, mem_mask_dict={k: to_dev(v) for k, v in inp["masks"].items()})
+    assert torch.equal(moved[0], want_moved[0])
+    sch = scheduler.DDPMScheduler(variance_type="fixed_small", **SCHED_KW)
+    cb = inputs.make_cfg_batch(seed=3, B=2, L=L, S=S, pad_tail=(2, 0, 1, 0, 0))
+    plain = sample(m, sch, [to_dev(q) for q in cb["memories"]], {k: to_dev(v) for k, v in cb["masks"].items()}, B=2, L=L, num_inference_steps=3, seed=1,
+                   return_attention=True)
+    with torch.inference_mode():
+        lat, att = sample(m, sch, [to_dev(q) for q in cb["memories"]], {k: to_dev(v) for k, v in cb["masks"].items()}, B=2, L=L, num_inference_steps=3,
+                          seed=1, return_attention=True)
+    assert torch.equal(lat, plain[0]) and all(torch.equal(a, b) for a, b in zip(att, plain[1]))

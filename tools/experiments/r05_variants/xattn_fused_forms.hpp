@@ -61,6 +61,7 @@
 // between the workgroup's batch rows is split into passes.
 #pragma once
 #include "cfd_common.hpp"
+#include <type_traits>
 
 #define XA_TILES 4     // query tiles (of 16 queries) per workgroup
 #define XA_WAVES 8     // two waves per query tile
@@ -73,7 +74,8 @@
 #define XA_MAXSEG 24
 #define XA_CQOFF (XA_SEGOFF + XA_MAXSEG * 16)   // per wave: c_q partial sums [16 queries][5 memories], then sum_s P' [16][5]
 #define XA_CQW 640
-#define XA_LDS (XA_CQOFF + XA_WAVES * XA_CQW)
+#define XA_FLAGOFF (XA_CQOFF + XA_WAVES * XA_CQW)   // ping-pong form: per wave, the number of key-tile steps whose partial scores it has published
+#define XA_LDS (XA_FLAGOFF + 64)
 
 struct XaSeg {
   int j;        // memory 0..4
@@ -149,33 +151,6 @@ __global__ void __launch_bounds__(256) one_key_va_kernel(const char* vt, long lo
   out[i] = (float)*reinterpret_cast<const sp_t*>(p) + (float)*reinterpret_cast<const sp_t*>(p + 64);
 }
 
-// Single-fp16 key tiles for the fused kernel's OPF instances (once per run, from the split-pair projections; layouts: see the staging
-// comment in the kernel).  One thread per 16-byte chunk (8 values: the `hi` halves, which are the values rounded to fp16).
-//   which = 0: V^T  in  SP [n_lu][512][Sp]      out [n_lu][T][512][64 B]
-//   which = 1: K    in  SP [n_lu * Sp][512]     out [n_lu][T][2][16][16][64 B]          (n_lu = layers x instances, T = Sp / 32)
-__global__ void __launch_bounds__(256) xa_pack16_kernel(const char* in, char* out, long long n_chunks, int Sp, int which) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_chunks) return;
-  const int T = Sp / XA_KEYS;
-  const int c = (int)(i & 3);                 // chunk of the 64-byte row: values 8 c .. 8 c + 7
-  const int r = (int)((i >> 2) & 511);        // row inside the 32 KB tile
-  const long long tile = i >> 11;             // (lu, kt)
-  const int kt = (int)(tile % T);
-  const long long lu = tile / T;
-  const char* src;
-  int sw;
-  if (which == 0) {                            // r = feature
-    src = in + (lu * CFD_D + r) * ((long long)Sp * 4) + kt * 128 + c * 16;
-    sw = (r >> 2) & 3;
-  } else {                                     // r = (t, ks, row i)
-    const int t = r >> 8, ks = (r >> 4) & 15, ri = r & 15;
-    const int key = kt * XA_KEYS + 8 * (ri >> 2) + 4 * t + (ri & 3);
-    src = in + (lu * Sp + key) * (long long)(CFD_D * 4) + ks * 128 + c * 16;
-    sw = (ri >> 2) & 3;
-  }
-  *reinterpret_cast<uint4*>(out + tile * 32768 + r * 64 + ((c ^ sw) << 4)) = *reinterpret_cast<const uint4*>(src);
-}
-
 template <class T>
 __device__ __forceinline__ T xa_sel(const T (&arr)[CFD_NMEM], int j) {
   T v = arr[0];
@@ -213,21 +188,17 @@ __device__ __forceinline__ T xa_sel(const T (&arr)[CFD_NMEM], int j) {
 #define XA_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | (0xF << 8) | ((((N) >> 4) & 3) << 14))
 #define XA_WAIT_VM_LGKM0(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | ((((N) >> 4) & 3) << 14))
 
-// ATT: the rows of XaAtt also store their attention maps.
-// OPF (operand format of the key tiles, round 6; DESIGN.md section 5.2 "operand policy"): the kernel is paced by the L2 -> LDS fills of
-// the K / V^T tiles (64 KB each as split pairs), so a run whose scheduler tolerates it may carry them as ONE fp16 per value:
-//   bit 0 (XA_V16): V^T tiles hold VA as single fp16 (32 KB per 32 keys); P' stays a pair, so P.V is 2 MFMAs per product
-//                   (VA_hi . P'_lo + VA_hi . P'_hi) -- the LINEAR path of the attention: the rounding of VA (2^-12 relative per value,
-//                   independent signs) averages over the keys;
-//   bit 1 (XA_K16): K tiles hold KA as single fp16; Q stays a pair (2 MFMAs: KA_hi . q_lo + KA_hi . q_hi) -- the EXPONENTIATED path.
-// The single-fp16 tiles come from xa_pack16_kernel (once per run, from the split-pair projections): tile-major and already in the LDS
-// image's order, so a fill is a linear copy of 1 KB pieces.  cfd_forward, DDIM runs, runs that keep attention maps and the memories of a
-// dynamic run keep pairs (cfd_api.hip: operand policy of cfd_sample_begin).
-enum { XA_V16 = 1, XA_K16 = 2 };
-template <bool ATT, int OPF>
+// PP = 0: the lock-step form described above (every wave in the same sub-phase; pairs (w, w + 4) share a SIMD).
+// PP = 1: the ping-pong form (round 5; see the comment in front of its loop): waves 0-3 run one sub-phase AHEAD of waves 4-7, so that
+//         on every SIMD one wave's softmax / waits / fill issue lie next to the other wave's MFMAs; pairs are (w, w ^ 1).
+// PP = 2: the lock-step form with the REQUESTS divided between the wave groups instead of among all waves (round 5): waves 0-3 request
+//         the K sub-buffers, waves 4-7 the V^T ones, eight pieces per wave (fill_k8 / fill_v8).  With every wave requesting, both waves
+//         of a SIMD sit in the LDS-DMA issue together (100+ cycles per piece: the CU's one texture path takes the pieces one after the
+//         other) and the matrix pipe idles; a requesting wave beside a computing one costs the computing wave nothing.
+// ATT: the rows of XaAtt also store their attention maps (lock-step form only).
+template <int PP, bool ATT = false>
 __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAttnArgs a) {
-  constexpr bool V16 = (OPF & XA_V16) != 0, K16 = (OPF & XA_K16) != 0;
-  static_assert(!ATT || OPF == 0, "attention maps: split-pair tiles");
+  static_assert(!ATT || PP == 0, "attention maps: the lock-step form");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KOFF = 0, VOFF = 65536;
 #if XA_STAMP
@@ -236,9 +207,12 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
 #endif
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tile = wid & 3;      // query tile of the pair (w, w + 4): the two waves share a SIMD
-  const int half = wid >> 2;     // which half of the 512-long axes
-  const int partner = wid ^ 4;
+  const int tile = PP == 1 ? (wid >> 2) * 2 + ((wid >> 1) & 1) : (wid & 3);   // query tile of the pair
+  int half_ = PP == 1 ? (wid & 1) : (wid >> 2);                                 // which half of the 512-long axes
+  if (PP == 1) asm volatile("" : "+s"(half_));   // (opaque: knowing that it is 0 or 1, hipcc turns the prologue's `half ? r[16 + i] : r[i]` selects into an INDEXED row array in scratch memory)
+  const int half = half_;
+  const int grp = PP ? (wid >> 2) : 0;                                     // ping-pong form: 0 = the early group, 1 = the late one; PP = 2: who requests what
+  const int partner = PP == 1 ? (wid ^ 1) : (wid ^ 4);
   const int l15 = lane & 15, q4 = lane >> 4, sw = l15 >> 1;
   const int cpos = lane & 7, rsub = lane >> 3;
 
@@ -257,6 +231,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
 
   // the segment list of this workgroup -> LDS (read back with ds_read: no vector-memory traffic inside the loop)
   if (threadIdx.x < nseg) reinterpret_cast<int4*>(smem + XA_SEGOFF)[threadIdx.x] = reinterpret_cast<const int4*>(a.segs + seg0)[threadIdx.x];
+  if (PP == 1 && threadIdx.x < XA_WAVES) reinterpret_cast<int*>(smem + XA_FLAGOFF)[threadIdx.x] = 0;
 
   // Q fragments (B operand) of this wave's half of the feature axis, made here from the residual stream:
   //   q = LayerNorm2(x[token])  (cross_attention.py:578; two-pass mean / variance like ln_rows_kernel, eps 1e-5).
@@ -268,9 +243,8 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   const int trow = a.d_step ? *a.d_step : 0;   // (null: kb / vb are this step's rows already -- no dependent scalar load in front of the A b request)
   // A b of the five memories (2 KB each) -> LDS by the LDS-DMA, issued before anything else so that its round trip runs under the
   // row loads and the LayerNorm below.  Parked in the part of the V^T tile buffer that is first filled after the first step's mid-A0
-  // barrier (Vb, row groups 16-31; single-fp16 V^T tiles: the upper half of the buffer, which no fill touches); c_q is computed from
-  // there behind the first barrier.
-  constexpr int KBOFF = VOFF + (V16 ? 32 : 16) * 1024;
+  // barrier (Vb, row groups 16-31); c_q is computed from there behind the first barrier.
+  constexpr int KBOFF = VOFF + 16 * 1024;
   if (wid < CFD_NMEM) {
     const char* kp = reinterpret_cast<const char*>(xa_sel(a.kb, wid) + (long long)trow * xa_sel(a.kb_stride, wid)) + lane * 16;
     __builtin_amdgcn_global_load_lds((gptr_t)kp, (lptr_t)(smem + KBOFF + wid * 2048), 16, 0, 0);
@@ -367,13 +341,12 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   //      V^T tile LDS image: [feature 512][128 B]; Va = features [0,128) + [256,384), Vb = the rest.  Piece n of wave `wid`:
   //      8-row group g = wid + 8 (n&1) + 32 (n>>1) (+16 for Vb); swizzle ((f>>1)&7) = ((wid&1)<<2) | (rsub>>1)
   const int vsw = (cpos ^ (((wid & 1) << 2) | (rsub >> 1))) << 4;
-  //      Single-fp16 tiles (OPF): a tile is 32 KB, contiguous in memory and already in the LDS image's order (xa_pack16_kernel):
-  //        K  [half t 2][k-step 16][row i 16][64 B], row 16 t + i = key 8 (i>>2) + 4 t + (i&3) as above, 16-byte chunk c at (c ^ (i>>2)&3);
-  //           Ka / Kb = the two halves, 16 pieces each = 2 per wave (k-steps wid, wid + 8)
-  //        V^T [feature 512][64 B], chunk c at (c ^ (f>>2)&3); Va / Vb as above in 16-row groups: 2 pieces per wave (groups wid, wid + 16, + 8 for Vb)
-  //      so a piece's source is tile base + piece * 1 KB + lane * 16.
-  constexpr int NKP = K16 ? 2 : 4, NVP = V16 ? 2 : 4;   // pieces per wave and sub-buffer: what the counted waits count
-  const unsigned lane16 = (unsigned)lane * 16u;
+  //      ping-pong form (fill_k8 / fill_v8 below: eight pieces per wave of ONE group): the same images cut over w4 = the wave's index in its group
+  const int w4 = wid & 3;
+  const int kr8 = (w4 & 1) * 8 + rsub;
+  const int ksrc8_lane = (8 * (kr8 >> 2) + (kr8 & 3)) * (CFD_D * 4) + (w4 >> 1) * 128 + ((cpos ^ ((kr8 >> 1) & 7)) << 4);
+  const int kdst8_wave = KOFF + (w4 >> 1) * 4096 + (w4 & 1) * 1024;
+  const int vsw8 = (cpos ^ (((w4 & 1) << 2) | (rsub >> 1))) << 4;
 
   // A tile = 32 keys of one memory instance: its K rows, its V^T column block, its key bias; rowb = bytes per V^T feature
   // row of that memory; vlane = this lane's byte offset inside a V^T piece (depends on rowb).  All but vlane are wave-uniform.
@@ -387,11 +360,11 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     wm = seg_field(si, 2); fl = seg_field(si, 3);
     const int Sp = xa_sel(a.Sp, j);
     T = Sp / XA_KEYS;
-    t.k = xa_sel(a.K, j) + (K16 ? (long long)u * T * 32768 : (long long)u * Sp * (CFD_D * 4));
-    t.v = xa_sel(a.VT, j) + (V16 ? (long long)u * T * 32768 : (long long)u * CFD_D * Sp * 4);
+    t.k = xa_sel(a.K, j) + (long long)u * Sp * (CFD_D * 4);
+    t.v = xa_sel(a.VT, j) + (long long)u * CFD_D * Sp * 4;
     t.cb = xa_sel(a.cb, j) + (long long)u * Sp;
     t.rowb = (long long)Sp * 4;
-    t.vlane = (unsigned)((wid * 8 + rsub) * Sp * 4 + vsw);    // (512 rows x Sp x 4 B < 4 GiB)
+    t.vlane = PP ? (unsigned)((w4 * 8 + rsub) * Sp * 4 + vsw8) : (unsigned)((wid * 8 + rsub) * Sp * 4 + vsw);    // (512 rows x Sp x 4 B < 4 GiB)
     t.cblane = (unsigned)((lane & 31) * 4) + (lane >= 32 ? xa_sel(a.rs_off, j) : 0u);   // lanes 0-31: key bias, lanes 32-63: key scale
   };
   // fills: K half `hb` (0: Ka, 1: Kb) of tile `t`; with Ka travels the key bias and key scale of the tile (1 piece: 64 x 4 B:
@@ -400,22 +373,12 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   // use: otherwise hipcc hoists base + lane offset out of the loop as a 64-bit per-lane pointer and pays vector adds per fill.)
   auto fill_k = [&](const Tile& t, int hb, int slot) __attribute__((always_inline)) {
     if (XA_ABLATE & 1) return;
-    if constexpr (K16) {
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        unsigned kl = lane16;
-        const char* b = t.k + hb * 16384 + (wid + 8 * n) * 1024;
-        asm volatile("" : "+v"(kl), "+s"(b));
-        __builtin_amdgcn_global_load_lds((gptr_t)(b + kl), (lptr_t)(smem + KOFF + hb * 16384 + (wid + 8 * n) * 1024), 16, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        unsigned kl = (unsigned)ksrc_lane;
-        const char* b = t.k + hb * (4 * CFD_D * 4) + n * 512;
-        asm volatile("" : "+v"(kl), "+s"(b));
-        __builtin_amdgcn_global_load_lds((gptr_t)(b + kl), (lptr_t)(smem + kdst_wave + hb * 2048 + n * 16384), 16, 0, 0);
-      }
+    for (int n = 0; n < 4; ++n) {
+      unsigned kl = (unsigned)ksrc_lane;
+      const char* b = t.k + hb * (4 * CFD_D * 4) + n * 512;
+      asm volatile("" : "+v"(kl), "+s"(b));
+      __builtin_amdgcn_global_load_lds((gptr_t)(b + kl), (lptr_t)(smem + kdst_wave + hb * 2048 + n * 16384), 16, 0, 0);
     }
     if (hb == 0) {
       unsigned cl = t.cblane;
@@ -425,24 +388,45 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   };
   auto fill_v = [&](const Tile& t, int hb) __attribute__((always_inline)) {
     if (XA_ABLATE & 1) return;
-    if constexpr (V16) {
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        unsigned vl = lane16;
-        const int g = wid + 16 * n + 8 * hb;                       // 16-row group (1 KB)
-        const char* b = t.v + g * 1024;
-        asm volatile("" : "+v"(vl), "+s"(b));
-        __builtin_amdgcn_global_load_lds((gptr_t)(b + vl), (lptr_t)(smem + VOFF + g * 1024), 16, 0, 0);
-      }
-    } else {
+    for (int n = 0; n < 4; ++n) {
+      unsigned vl = t.vlane;
+      const int g = 8 * (n & 1) + 32 * (n >> 1) + 16 * hb;       // uniform part of the 8-row group index (+ wid per wave)
+      const char* b = t.v + (long long)g * 8 * t.rowb;
+      asm volatile("" : "+v"(vl), "+s"(b));
+      __builtin_amdgcn_global_load_lds((gptr_t)(b + vl), (lptr_t)(smem + VOFF + (wid + g) * 1024), 16, 0, 0);
+    }
+  };
+
+  // Ping-pong form: a sub-buffer is requested by ONE group (four waves, one per SIMD), eight pieces per wave, while the other group
+  // computes: with all eight waves issuing together both waves of every SIMD are held by the LDS-DMA issue at the same time (100+ cycles
+  // per piece, the CU's one texture path takes them one after the other) and the matrix pipe idles; a filling wave beside a computing
+  // wave costs the computing wave nothing.  w4 = the wave's index in its group.  K half hb: piece n = rows (w4 & 1) * 8 .. + 7 of
+  // k-step (w4 >> 1) + 2 n; V^T half hb: 8-row groups w4 + 4 (n & 3) + 32 (n >> 2) + 16 hb (swizzle parity = w4 & 1 as above).
+  auto fill_k8 = [&](const Tile& t, int hb, int slot) __attribute__((always_inline)) {
+    if (XA_ABLATE & 1) return;
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        unsigned vl = t.vlane;
-        const int g = 8 * (n & 1) + 32 * (n >> 1) + 16 * hb;       // uniform part of the 8-row group index (+ wid per wave)
-        const char* b = t.v + (long long)g * 8 * t.rowb;
-        asm volatile("" : "+v"(vl), "+s"(b));
-        __builtin_amdgcn_global_load_lds((gptr_t)(b + vl), (lptr_t)(smem + VOFF + (wid + g) * 1024), 16, 0, 0);
-      }
+    for (int n = 0; n < 8; ++n) {
+      unsigned kl = (unsigned)ksrc8_lane;
+      const char* b = t.k + hb * (4 * CFD_D * 4) + n * 256;
+      asm volatile("" : "+v"(kl), "+s"(b));
+      __builtin_amdgcn_global_load_lds((gptr_t)(b + kl), (lptr_t)(smem + kdst8_wave + hb * 2048 + n * 8192), 16, 0, 0);
+    }
+    if (hb == 0) {
+      unsigned cl = t.cblane;
+      asm volatile("" : "+v"(cl));
+      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(t.cb) + cl), (lptr_t)(smem + XA_CBOFF + slot * 256), 4, 0, 0);
+    }
+  };
+  auto fill_v8 = [&](const Tile& t, int hb) __attribute__((always_inline)) {
+    if (XA_ABLATE & 1) return;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      unsigned vl = t.vlane;
+      const int g = 4 * (n & 3) + 32 * (n >> 2) + 16 * hb;
+      const char* b = t.v + (long long)g * 8 * t.rowb;
+      asm volatile("" : "+v"(vl), "+s"(b));
+      __builtin_amdgcn_global_load_lds((gptr_t)(b + vl), (lptr_t)(smem + VOFF + (w4 + g) * 1024), 16, 0, 0);
     }
   };
 
@@ -526,59 +510,37 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   const char* kfrag = smem + KOFF + (8 * half) * 4096 + l15 * 128;
   const char* vfrag = smem + VOFF + (16 * half * 16 + l15) * 128;
   const int off_h = (q4 ^ sw) << 4, off_l = ((4 + q4) ^ sw) << 4;
-  // single-fp16 tiles: rows of 64 B, chunk q4 of row l15 at (q4 ^ (l15 >> 2) & 3)
-  const char* kfrag16 = smem + KOFF + (8 * half) * 1024 + l15 * 64 + ((q4 ^ ((l15 >> 2) & 3)) << 4);
-  const char* vfrag16 = smem + VOFF + (16 * half * 16 + l15) * 64 + ((q4 ^ ((l15 >> 2) & 3)) << 4);
-  // (pairs: fr[2 i] = hi, fr[2 i + 1] = lo of fragment i; single fp16: fr[i] = the fragment, fr[4..7] unused)
   auto read_k = [&](spx8 (&fr)[8], int t, int hf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if constexpr (K16) {
-        fr[i] = XA_FRAG(kfrag16 + t * 16384 + (4 * hf + i) * 1024);
-      } else {
-        const char* kp = kfrag + (4 * hf + i) * 4096 + t * 2048;
-        fr[2 * i] = XA_FRAG(kp + off_h);
-        fr[2 * i + 1] = XA_FRAG(kp + off_l);
-      }
+      const char* kp = kfrag + (4 * hf + i) * 4096 + t * 2048;
+      fr[2 * i] = XA_FRAG(kp + off_h);
+      fr[2 * i + 1] = XA_FRAG(kp + off_l);
     }
   };
   auto read_v = [&](spx8 (&fr)[8], int qf) __attribute__((always_inline)) {   // qf = 0..3: feature tiles 4 qf .. 4 qf + 3 of this half
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if constexpr (V16) {
-        fr[i] = XA_FRAG(vfrag16 + (4 * qf + i) * 1024);
-      } else {
-        const char* vp = vfrag + (4 * qf + i) * 2048;
-        fr[2 * i] = XA_FRAG(vp + off_h);
-        fr[2 * i + 1] = XA_FRAG(vp + off_l);
-      }
+      const char* vp = vfrag + (4 * qf + i) * 2048;
+      fr[2 * i] = XA_FRAG(vp + off_h);
+      fr[2 * i + 1] = XA_FRAG(vp + off_l);
     }
   };
   auto mfma_k = [&](f32x4& acc, const spx8 (&fr)[8], int hf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if constexpr (K16) {
-        acc = XA_MFMA(fr[i], ql[4 * hf + i], acc);
-        acc = XA_MFMA(fr[i], qh[4 * hf + i], acc);
-      } else {
-        acc = XA_MFMA(fr[2 * i + 1], qh[4 * hf + i], acc);
-        acc = XA_MFMA(fr[2 * i], ql[4 * hf + i], acc);
-        acc = XA_MFMA(fr[2 * i], qh[4 * hf + i], acc);
-      }
+      acc = XA_MFMA(fr[2 * i + 1], qh[4 * hf + i], acc);
+      acc = XA_MFMA(fr[2 * i], ql[4 * hf + i], acc);
+      acc = XA_MFMA(fr[2 * i], qh[4 * hf + i], acc);
     }
   };
   spx8 ph, pl;
   auto mfma_v = [&](const spx8 (&fr)[8], int qf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if constexpr (V16) {
-        o[4 * qf + i] = XA_MFMA(fr[i], pl, o[4 * qf + i]);
-        o[4 * qf + i] = XA_MFMA(fr[i], ph, o[4 * qf + i]);
-      } else {
-        o[4 * qf + i] = XA_MFMA(fr[2 * i + 1], ph, o[4 * qf + i]);
-        o[4 * qf + i] = XA_MFMA(fr[2 * i], pl, o[4 * qf + i]);
-        o[4 * qf + i] = XA_MFMA(fr[2 * i], ph, o[4 * qf + i]);
-      }
+      o[4 * qf + i] = XA_MFMA(fr[2 * i + 1], ph, o[4 * qf + i]);
+      o[4 * qf + i] = XA_MFMA(fr[2 * i], pl, o[4 * qf + i]);
+      o[4 * qf + i] = XA_MFMA(fr[2 * i], ph, o[4 * qf + i]);
     }
   };
   // softmax of one key tile from the pair's two partial score sets (this wave's s0 / s1 in registers, the partner's in the exchange area):
@@ -679,6 +641,168 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   int cT = 1, cmask = 0, cflags = 0, cj = 0, nT = 1, nmask = 0, nflags = 0, nj = 0;
   if (nseg > 0) seg_tile(0, cur, cT, cmask, cflags, cj);
   XA_T(0);
+  if constexpr (PP == 1) {
+  // ---- The ping-pong form (round 5) -------------------------------------------------------------------------------------------
+  // In the lock-step form both waves of a SIMD are in the same sub-phase all the time: they want the matrix pipe together, do the
+  // softmax together (the pipe idles), issue their fills together (LDS-DMA issue holds a wave for 100+ cycles per piece) and meet
+  // every barrier together.  Here the workgroup is two GROUPS of four waves, one wave of each per SIMD -- group 0 = waves 0-3 =
+  // query tiles 0, 1, group 1 = waves 4-7 = tiles 2, 3; the two waves of a pair (w, w ^ 1) sit on different SIMDs -- and group 1
+  // runs the SAME program ONE SUB-PHASE behind group 0.  The key-tile stream is a sequence of 32 KB pieces
+  //     piece 4 n = Ka(n), 4 n + 1 = Kb(n), 4 n + 2 = Va(n), 4 n + 3 = Vb(n)        (n = key-tile step, the four sub-buffers of the lock-step form)
+  // that group 0 consumes in slot p and group 1 in slot p + 1.  There is ONE kind of barrier, b(k), in the MIDDLE of slot k
+  // (four per step): in front of it every wave has seen its share of piece k + 1 land (counted vmcnt) and finished its LDS reads of
+  // everything older (lgkmcnt 0); behind it group 0 starts reading piece k + 1 (under the second half of its MFMAs on piece k, as in
+  // the lock-step form), group 1 starts reading piece k, nobody reads piece k - 1 any more, so its sub-buffer is refilled with piece
+  // k + 3 right there: every piece is requested two slots before its first use, the same lead as in the lock-step form, with the same
+  // four sub-buffers.  On a SIMD the pairing per slot is  (A0 | B1')  (A1 | A0)  (softmax + B0 | A1)  (B1 | softmax + B0): one wave's
+  // softmax runs next to the other wave's MFMAs, in two of the four slots.
+  // The pair's partial scores cannot meet at a barrier any more (a barrier in the middle of a slot is no boundary of both groups):
+  // each wave publishes a step counter in LDS once its partial scores are written (ds_write, wait, ds_write of the flag) and its partner
+  // polls that word -- the two finish A1 within a few hundred cycles of each other, and a poll costs the polling wave only.
+  // Work lists with a flush between two online memories (XA_FLUSH: never at the shipped shapes) stay on the lock-step form.
+  // (the flag words are written and polled with ds instructions in inline assembly: a volatile access makes hipcc drain vmcnt(0) -- the
+  //  fills in flight -- in front of it)
+  const unsigned flag_mine = (unsigned)(unsigned long)(lptr_t)(smem + XA_FLAGOFF + wid * 4);
+  const unsigned flag_other = (unsigned)(unsigned long)(lptr_t)(smem + XA_FLAGOFF + partner * 4);
+  // The two groups run two instances of the loop (chosen once, by a wave-uniform branch): what differs between them -- which piece a
+  // barrier requests, how many younger requests a wait leaves in flight -- is then compile-time, and every fill keeps its
+  // SGPR-base + lane-offset address form (as branches inside one loop hipcc merged the branches' tails into 64-bit per-lane addresses).
+  auto pp_loop = [&](auto grp_c) __attribute__((always_inline)) {
+  constexpr int GRP = decltype(grp_c)::value;
+  // Piece p is requested at b(p - 3) by ONE group, alternately: Ka (+ key bias) and Va by the late group, Kb and Vb by the early one --
+  // at every barrier the requesting group is the one whose SIMD partner is busiest (Ka goes out while the early group does its softmax,
+  // Kb while the late group does).  A wave therefore has at most one request (8 - 9 pieces) in flight, and "my share of piece k + 1 has
+  // landed" is vmcnt(0) at every second barrier and nothing at the others.  Pieces 0 - 2 of the stream:
+  if constexpr (GRP) { fill_k8(cur, 0, 0); fill_v8(cur, 0); } else { fill_k8(cur, 1, 0); }
+  if constexpr (GRP) XA_WAIT_VM_LGKM0(8); else XA_WAIT_VM_LGKM0(63);   // Ka + key bias landed (Va is younger)
+  __builtin_amdgcn_s_barrier();      // b(-1)
+  if constexpr (GRP) {               // the late group: its slot 0 is b(0) .. b(1)
+    XA_WAIT_VM_LGKM0(63);
+    __builtin_amdgcn_s_barrier();    // b(0)  (the early group requests Vb behind it)
+  }
+  read_k(fa, 0, 0);
+  XA_T(0);
+  for (int si = 0; si < nseg; ++si) {
+    const bool in_seg = active && ((cmask >> tile) & 1);   // wave-uniform, the same for both waves of a pair
+    const bool online = (cflags & XA_ONLINE) != 0;
+    const bool seg_follows = si + 1 < nseg;
+    nseg_t = cur; nT = cT; nmask = cmask; nflags = cflags; nj = cj;
+    if (seg_follows) seg_tile(si + 1, nseg_t, nT, nmask, nflags, nj);
+    const float cqh = cq_mine[l15 * 5 + cj];
+    XA_T(11);
+    for (int kt = 0; kt < cT; ++kt) {
+    const bool last_in_seg = kt + 1 == cT;
+    Tile nxt;   // the tile of the step after this one
+    nxt.k = last_in_seg ? nseg_t.k : cur.k + XA_KEYS * CFD_D * 4;
+    nxt.v = last_in_seg ? nseg_t.v : cur.v + 128;
+    nxt.cb = last_in_seg ? nseg_t.cb : cur.cb + XA_KEYS;
+    nxt.rowb = last_in_seg ? nseg_t.rowb : cur.rowb;
+    nxt.vlane = last_in_seg ? nseg_t.vlane : cur.vlane;
+    nxt.cblane = last_in_seg ? nseg_t.cblane : cur.cblane;
+    const int slot = step & 1;
+    // ---- A0 (fa holds its first half) --------------------------------------------------------------------------------
+    f32x4 s0 = f32x4{cqh, cqh, cqh, cqh}, s1 = s0;
+    read_k(fb, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_k(s0, fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    XA_T(1);
+    XA_WAIT_VM_LGKM0(0);                 // group 0: its Kb has landed; group 1: its Va has landed
+    __builtin_amdgcn_s_barrier();        // mid-A0
+    XA_T(2);
+    if constexpr (GRP) fill_k8(nxt, 0, slot ^ 1); else fill_v8(cur, 1);
+    read_k(fa, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) {
+      mfma_k(s0, fb, 1);
+      *reinterpret_cast<f32x4*>(xch_mine) = s0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- A1 ---------------------------------------------------------------------------------------------------------
+    read_k(fb, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_k(s1, fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    XA_T(3);
+    XA_WAIT_VM_LGKM0(63);                // (the piece this barrier publishes belongs to the other group; this group's request stays in flight)
+    __builtin_amdgcn_s_barrier();        // mid-A1
+    XA_T(4);
+    read_v(fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) {
+      mfma_k(s1, fb, 1);
+      *reinterpret_cast<f32x4*>(xch_mine + 1024) = s1;
+      XA_WAIT_VM_LGKM0(63);              // lgkmcnt(0): both partial score sets are in LDS ...
+      asm volatile("ds_write_b32 %0, %1" ::"v"(flag_mine), "v"(step + 1) : "memory");   // ... before the step counter that says so
+      for (;;) {
+        int seen;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(flag_other) : "memory");
+        if (__builtin_amdgcn_readfirstlane(seen) > step) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!(XA_ABLATE & 8)) softmax_tile(s0, s1, slot, online, cj, kt);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- B0 (fa holds its first half) --------------------------------------------------------------------------------
+    XA_T(10);
+    read_v(fb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    XA_T(5);
+    XA_WAIT_VM_LGKM0(0);                 // group 0: its Vb has landed; group 1: its next Ka + key bias
+    __builtin_amdgcn_s_barrier();        // mid-B0
+    if constexpr (GRP) fill_v8(nxt, 0); else fill_k8(nxt, 1, slot ^ 1);
+    read_v(fa, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- B1 ---------------------------------------------------------------------------------------------------------
+    read_v(fb, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fa, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    XA_T(7);
+    XA_WAIT_VM_LGKM0(63);
+    __builtin_amdgcn_s_barrier();        // mid-B1
+    XA_T(8);
+    read_k(fa, 0, 0);                    // first half of the next step's A0
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fb, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+    ++step;
+    XA_T(9);
+    }   // kt
+    if (in_seg) {
+      float wsum = xlane_sum(wl);
+      if (online) {   // normalise the finished online memory in registers (all keys dead: 0 * inf = NaN)
+        const float inv = 1.0f / lsum;
+#pragma unroll
+        for (int f = 0; f < 16; ++f) { o[f][0] *= inv; o[f][1] *= inv; o[f][2] *= inv; o[f][3] *= inv; }
+        wsum *= inv;
+      }
+      if (q4 == 0) wq_mine[l15 * 5 + cj] = wsum;
+    }
+    m = -INFINITY;
+    mc_run = -INFINITY;
+    lsum = 0.f;
+    wl = 0.f;
+    cT = nT; cmask = nmask; cflags = nflags; cj = nj;
+  }
+  if constexpr (!GRP) {                  // the early group waits out the late group's last slot
+    XA_WAIT_VM_LGKM0(63);
+    __builtin_amdgcn_s_barrier();
+  }
+  };   // pp_loop
+  if (nseg > 0) {   // (the idle workgroups that pad the list have no tile to request; the branch is uniform over the workgroup)
+    if (grp) pp_loop(std::integral_constant<int, 1>{}); else pp_loop(std::integral_constant<int, 0>{});
+  }
+  } else {
+  // (PP = 2: one instance of the loop per group, chosen once: which group requests what is then compile-time and the fills keep their
+  //  SGPR-base + lane-offset form -- see the ping-pong form)
+  auto ls_loop = [&](auto grp_c) __attribute__((always_inline)) {
+  constexpr int GRP = decltype(grp_c)::value;     // PP = 0: always 0
   for (int si = 0; si < nseg; ++si) {
     const bool in_seg = active && ((cmask >> tile) & 1);   // wave-uniform, the same for both waves of a pair
     const bool online = (cflags & XA_ONLINE) != 0;
@@ -694,18 +818,22 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     for (int kt = 0; kt < cT; ++kt) {
     const bool last_in_seg = kt + 1 == cT;
     Tile nxt;   // the tile of the step after this one
-    nxt.k = last_in_seg ? nseg_t.k : cur.k + (K16 ? 32768 : XA_KEYS * CFD_D * 4);
-    nxt.v = last_in_seg ? nseg_t.v : cur.v + (V16 ? 32768 : 128);
+    nxt.k = last_in_seg ? nseg_t.k : cur.k + XA_KEYS * CFD_D * 4;
+    nxt.v = last_in_seg ? nseg_t.v : cur.v + 128;
     nxt.cb = last_in_seg ? nseg_t.cb : cur.cb + XA_KEYS;
     nxt.rowb = last_in_seg ? nseg_t.rowb : cur.rowb;
     nxt.vlane = last_in_seg ? nseg_t.vlane : cur.vlane;
     nxt.cblane = last_in_seg ? nseg_t.cblane : cur.cblane;
     const int slot = step & 1;
     if (!primed) {   // (re)start of the pipeline: Ka (+ key bias), Kb, Va of this step; Vb follows behind mid-A0
+      if constexpr (PP == 2) {
+        if constexpr (GRP) { fill_v8(cur, 0); XA_WAIT_VM_LGKM0(63); } else { fill_k8(cur, 0, slot); fill_k8(cur, 1, slot); XA_WAIT_VM_LGKM0(8); }
+      } else {
       fill_k(cur, 0, slot);
       fill_k(cur, 1, slot);
       fill_v(cur, 0);
-      XA_WAIT_VM_LGKM0(NKP + NVP);       // Ka + key bias landed (Kb and Va are younger)
+      XA_WAIT_VM_LGKM0(8);               // Ka + key bias landed
+      }
       __builtin_amdgcn_s_barrier();
       read_k(fa, 0, 0);
       primed = true;
@@ -718,10 +846,11 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     if (in_seg) mfma_k(s0, fa, 0);
     __builtin_amdgcn_sched_barrier(0);
     XA_T(1);
-    XA_WAIT_VM_LGKM0(NVP);               // Kb landed (Va's pieces are younger); this wave's reads of Ka's first half are done
+    if constexpr (PP == 2) { if constexpr (GRP) XA_WAIT_VM_LGKM0(63); else XA_WAIT_VM_LGKM0(0); }   // the K group's Kb has landed
+    else XA_WAIT_VM_LGKM0(4);            // Kb landed (one fill of 4 pieces is younger); this wave's reads of Ka's first half are done
     __builtin_amdgcn_s_barrier();        // mid-A0: Kb ready; every wave is done with Vb
     XA_T(2);
-    fill_v(cur, 1);
+    if constexpr (PP == 2) { if constexpr (GRP) fill_v8(cur, 1); } else fill_v(cur, 1);
     read_k(fa, 1, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (in_seg) {
@@ -742,8 +871,11 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     XA_WAIT_VM_LGKM0(0);                 // Va and Vb landed (nothing younger is in flight); partial scores written
     __builtin_amdgcn_s_barrier();        // end of A1: the whole V^T tile ready, partial scores visible, every wave is done with Ka and Kb
     XA_T(4);
+    if constexpr (PP == 2) { if constexpr (!GRP) { fill_k8(nxt, 0, slot ^ 1); fill_k8(nxt, 1, slot ^ 1); } }
+    else {
     fill_k(nxt, 0, slot ^ 1);
     fill_k(nxt, 1, slot ^ 1);
+    }
     read_v(fa, 0);
     if (in_seg && !(XA_ABLATE & 8)) softmax_tile(s0, s1, slot, online, cj, kt);
     // ---- B0 (fa holds its first half) --------------------------------------------------------------------------------
@@ -763,10 +895,11 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     if (in_seg) mfma_v(fa, 2);
     __builtin_amdgcn_sched_barrier(0);
     XA_T(7);
-    XA_WAIT_VM_LGKM0(NKP);               // next Ka + key bias landed (the next Kb's pieces are younger)
+    if constexpr (PP == 2) { if constexpr (GRP) XA_WAIT_VM_LGKM0(63); else XA_WAIT_VM_LGKM0(8); }   // the K group's next Ka + key bias (its Kb, 8 pieces, is younger)
+    else XA_WAIT_VM_LGKM0(4);            // next Ka + key bias landed (the next Kb, 4 pieces, is younger)
     __builtin_amdgcn_s_barrier();        // mid-B1: next Ka ready; every wave is done with Va
     XA_T(8);
-    fill_v(nxt, 0);
+    if constexpr (PP == 2) { if constexpr (GRP) fill_v8(nxt, 0); } else fill_v(nxt, 0);
     read_k(fa, 0, 0);                    // first half of the next step's A0
     __builtin_amdgcn_sched_barrier(0);
     if (in_seg) mfma_v(fb, 3);
@@ -800,6 +933,10 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     wl = 0.f;
     cT = nT; cmask = nmask; cflags = nflags; cj = nj;   // (cur already points at the next segment's first tile)
   }
+  };   // ls_loop
+  if constexpr (PP == 2) { if (grp) ls_loop(std::integral_constant<int, 1>{}); else ls_loop(std::integral_constant<int, 0>{}); }
+  else ls_loop(std::integral_constant<int, 0>{});
+  }   // lock-step form
   XA_WAIT_VM_LGKM0(0);
   __builtin_amdgcn_s_barrier();   // last B1 done everywhere and the trailing (unused) fills have landed: the tile buffers become the epilogue strips
   XA_T(11);
