@@ -100,8 +100,10 @@ struct Problem {
   int xa0_nwg_a = 0, xa0_nwg_b = 0;   // layer-0 de-duplication lists (build_xattn_layer0_lists); 0: one launch
   bool xa_flush = false;               // some work list flushes the accumulator between two online memories (XA_FLUSH): lock-step kernel only
   int xa_one = -1;                     // the one-key memory the fused cross-attention adds as a vector (xattn_fused.hpp, XAttnArgs::one_j), or -1
-  int xa_opf = 0;                      // operand format of the fused cross-attention's key tiles in this problem (XA_V16 | XA_K16; 0: split pairs).  Only a
-                                       // sampling run sets it (cfd_sample_args::operand_policy), and only when every memory is static and no maps are kept
+  int xa_opf = 0;                      // operand format of the fused cross-attention's key tiles of LONG memories in this problem (XA_V16 | XA_K16; 0: split
+                                       // pairs).  Only a sampling run sets it (cfd_sample_args::operand_policy), and only when every memory is static and no
+                                       // maps are kept
+  int xa_f16_mask = 0;                 // bit j: memory j is long enough (XA_F16_MIN_KEYS) for single-fp16 tiles; its segments carry XA_F16
   // memories (bit j) whose folded projections were computed once for the run from the centred static part of the memory
   // (prepare_static_memside); per step they only get their per-key scale and bias (mem_scale_all_kernel)
   int static_mask = 0;
@@ -208,6 +210,7 @@ struct cfd_handle_s {
   bool fused_xattn = true;
   int fused_xattn_min_wgs = 6;
   int one_key = 1;              // CFD_ONE_KEY=0: a one-key memory (lsnemb) keeps its 32-key tile step in the fused cross-attention
+  int want_opf = 0;             // cfd_sample_begin -> setup_problem: the operand policy the run asks for (0 everywhere else)
   int xa_operands = -1;         // CFD_XA_OPERANDS=<0..3>: overrides cfd_sample_args.operand_policy (developer A/B of the fused cross-attention's tile formats)
   bool hint_same_mem = false;   // cfd_forward_same_memories: the promise for the NEXT cfd_forward ...
   bool hint_now = false;        // ... taken (and cleared) at that call's very first line, before anything can fail: a call that returns early
@@ -746,7 +749,7 @@ static void make_xattn_worklist(const Problem& p, const std::vector<XaRow>& rows
         for (int k = 0; k < XA_TILES; ++k) {
           if (vr[k] < 0 || (done >> k) & 1) continue;
           XaSeg sg;
-          sg.j = j; sg.u = rows[vr[k]].inst[j]; sg.wmask = 0; sg.flags = online ? XA_ONLINE : 0;
+          sg.j = j; sg.u = rows[vr[k]].inst[j]; sg.wmask = 0; sg.flags = (online ? XA_ONLINE : 0) | (((p.xa_f16_mask >> j) & 1) ? XA_F16 : 0);
           for (int k2 = k; k2 < XA_TILES; ++k2)
             if (vr[k2] >= 0 && rows[vr[k2]].inst[j] == sg.u) sg.wmask |= 1 << k2;
           done |= sg.wmask;
@@ -756,7 +759,9 @@ static void make_xattn_worklist(const Problem& p, const std::vector<XaRow>& rows
         if (online && online_seen < n_online && segs.size() > first_seg) { segs.back().flags |= XA_FLUSH; has_flush = true; }
       }
       w.nseg = (int)segs.size() - w.seg0;
-      w.pf_slot = (int)g;   // (the group, until the queues are built)
+      w.n16 = 0;            // the segments with single-fp16 tiles: a prefix of the list (memories in descending length, XA_F16 <=> long enough)
+      while (w.n16 < w.nseg && (segs[w.seg0 + w.n16].flags & XA_F16)) ++w.n16;
+      for (int k = w.n16; k < w.nseg; ++k) segs[w.seg0 + k].flags &= ~XA_F16;   // (never: the order guarantees it; a flag behind the prefix would be read in the wrong format)
       group_wgs[g].push_back(w);
     }
   }
@@ -769,18 +774,6 @@ static void make_xattn_worklist(const Problem& p, const std::vector<XaRow>& rows
   for (size_t g : gorder) {
     if (group_wgs[g].size() > 32) { for (const XaWg& w : group_wgs[g]) queue[shortest()].push_back(w); }
     else { const int q = shortest(); for (const XaWg& w : group_wgs[g]) queue[q].push_back(w); }
-  }
-  // L2 prefetch shares: consecutive workgroups of one group in one XCD's queue run at about the same time (one per CU, 32 CUs) and
-  // walk the same key stream; each of them warms 1 / n of the tile two steps ahead
-  for (int x = 0; x < 8; ++x) {
-    size_t i = 0;
-    while (i < queue[x].size()) {
-      size_t e = i;
-      while (e < queue[x].size() && queue[x][e].pf_slot == queue[x][i].pf_slot) ++e;
-      const int n = (int)std::min<size_t>(e - i, 32);
-      for (size_t k = i; k < e; ++k) { queue[x][k].pf_slot = (int)((k - i) % n); queue[x][k].pf_n = n; }
-      i = e;
-    }
   }
   size_t qlen = 0;
   for (int x = 0; x < 8; ++x) qlen = std::max(qlen, queue[x].size());
@@ -992,9 +985,17 @@ static int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], 
     p.att_slot[j] = 0;
     p.att_b0 = p.att_nb = 0;      // (a sampling run with an attention ring sets them after this call)
     p.att_fused = false;
-    p.xa_opf = 0;                 // (a sampling run's operand policy likewise)
+    p.xa_opf = 0; p.xa_f16_mask = 0;
   }
   p.Sp_tot = off;
+  // The run's operand policy (cfd_sample_begin): which memories are long enough for single-fp16 tiles.  The work lists flag their segments
+  // (XA_F16); whether the run really takes the single-fp16 kernel instance is decided when everything else about it is known
+  // (cfd_sample_begin, prepare_static_memside) -- the pair instance ignores the flag.
+  p.xa_opf = c->want_opf;
+  if (p.xa_opf)
+    for (int j = 0; j < CFD_NMEM; ++j)
+      if (p.Sp[j] >= XA_F16_MIN_KEYS) p.xa_f16_mask |= 1 << j;
+  if (!p.xa_f16_mask) p.xa_opf = 0;
   {  // memories without a key-padding mask get an all-zero one, so the softmax kernel needs no null test
     size_t need = (size_t)Be * L;   // (the un-fused self-attention softmax indexes it per batch row)
     for (int j = 0; j < CFD_NMEM; ++j) need = std::max(need, (size_t)p.U[j] * p.S[j]);
@@ -1241,7 +1242,7 @@ static int prepare_static_memside(Ctx* c, hipStream_t st, int dynamic_mask, bool
   if (p.xa_opf && (p.rt || p.static_mask != (1 << CFD_NMEM) - 1)) p.xa_opf = 0;   // (single-fp16 tiles: every memory static, tile kernels)
   if (p.xa_opf) {   // this run's operand policy: the key / value tiles of the fused cross-attention as single fp16, packed tile by tile
     for (int j = 0; j < CFD_NMEM; ++j) {
-      if (j == p.xa_one) continue;   // (no segments: its value row goes through one_va)
+      if (!((p.xa_f16_mask >> j) & 1)) continue;   // (short memories keep pairs: xattn_fused.hpp, OPF)
       const long long tiles = (long long)nl * p.U[j] * (p.Sp[j] / XA_KEYS), chunks = tiles * 2048;
       if (p.xa_opf & XA_V16) {
         CHK(c->w->v16[j].ensure((size_t)tiles * 32768));
@@ -1700,10 +1701,11 @@ static int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       a.x = c->w->x.as<float>(); a.ln_g = w.ln2g; a.ln_b = w.ln2b; a.bias = w.cross_bias.as<float>(); a.L = L;
       for (int j = 0; j < CFD_NMEM; ++j) {
         const size_t rows = (size_t)p.U[j] * p.Sp[j];
-        // (single-fp16 tiles, Problem::xa_opf: 32 KB per 32 keys = 1 KB per key, tile-major per (layer, instance))
-        a.K[j] = (p.xa_opf & XA_K16) ? c->w->k16[j].as<char>() + (size_t)l * rows * 1024 : c->w->kall_sp[j].as<char>() + (size_t)l * rows * ROWB;
+        // (single-fp16 tiles of a long memory, Problem::xa_opf / xa_f16_mask: 32 KB per 32 keys = 1 KB per key, tile-major per (layer, instance))
+        const bool f16 = (p.xa_f16_mask >> j) & 1;
+        a.K[j] = (f16 && (p.xa_opf & XA_K16)) ? c->w->k16[j].as<char>() + (size_t)l * rows * 1024 : c->w->kall_sp[j].as<char>() + (size_t)l * rows * ROWB;
         a.cb[j] = c->w->cb[j].as<float>() + (size_t)l * rows;
-        a.VT[j] = (p.xa_opf & XA_V16) ? c->w->v16[j].as<char>() + (size_t)l * rows * 1024 : c->w->vt_all[j].as<char>() + (size_t)l * rows * ROWB;
+        a.VT[j] = (f16 && (p.xa_opf & XA_V16)) ? c->w->v16[j].as<char>() + (size_t)l * rows * 1024 : c->w->vt_all[j].as<char>() + (size_t)l * rows * ROWB;
         a.Sp[j] = p.Sp[j];
         const bool stat = (p.static_mask >> j) & 1;
         a.rs_off[j] = (unsigned)((size_t)(nl - l) * rows * 4);
@@ -2097,7 +2099,12 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
       }
     }
   }
-  CHK(setup_problem(c, Be, s.L, mem_in, nullptr, 0, N));
+  // operand policy of the run (cfd_sample_args::operand_policy): single-fp16 key / value tiles of the long memories for the fused
+  // cross-attention kernel -- only where that kernel runs on projections made once per run and keeps no maps
+  c->want_opf = (n_ring || s.dynamic_memory_mask) ? 0 : (c->xa_operands >= 0 ? c->xa_operands : (s.operand_policy & 3));
+  const int r_setup = setup_problem(c, Be, s.L, mem_in, nullptr, 0, N);
+  c->want_opf = 0;
+  CHK(r_setup);
   if (c->share0 && c->sargs.G > 1) c->w->pb.share_B = s.B;   // begin_step_kernel writes G identical copies of the B rows
   c->w->pb.att_nb = 0;
   if (n_ring) {
@@ -2126,12 +2133,10 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
     }
   }
   CHK(build_xattn_layer0_lists(c, mem_in));
-  {   // operand policy of the run (cfd_sample_args::operand_policy): single-fp16 key / value tiles for the fused cross-attention kernel --
-      // only where that kernel runs on projections made once per run and keeps no maps (prepare_static_memside checks the rest)
+  {   // (the rest of the operand policy's conditions; prepare_static_memside checks that every memory's projections are made once per run)
     Problem& pb = c->w->pb;
-    const int want = c->xa_operands >= 0 ? c->xa_operands : (s.operand_policy & 3);
     const bool fused_run = !pb.rt && c->fused_xattn && pb.xa_nwg > 0 && c->hoist_memside && !g_cfd_naive_gemm && !pb.att_fused && !s.dynamic_memory_mask;
-    pb.xa_opf = fused_run ? want : 0;
+    if (!fused_run) pb.xa_opf = 0;
   }
   // timesteps: (arange(N) * (T // N)).round()[::-1] (+ steps_offset for DDIM)
   std::vector<int32_t> ts(N);

@@ -61,10 +61,12 @@
 // between the workgroup's batch rows is split into passes.
 #pragma once
 #include "cfd_common.hpp"
+#include <type_traits>
 
 #define XA_TILES 4     // query tiles (of 16 queries) per workgroup
 #define XA_WAVES 8     // two waves per query tile
 #define XA_KEYS 32
+#define XA_F16_MIN_KEYS 128   // padded keys from which a memory counts as LONG for the operand policy (single-fp16 tiles; see OPF below)
 // LDS map: K tile | V^T tile (the epilogue strips alias these two and 2 KB more) | partial-score exchange | key bias of
 // two steps | the workgroup's segment list
 #define XA_XOFF 133120
@@ -81,7 +83,7 @@ struct XaSeg {
   int wmask;    // query tiles (bit t) whose batch row uses this instance
   int flags;    // XA_ONLINE | XA_FLUSH
 };
-enum { XA_ONLINE = 1, XA_FLUSH = 2 };
+enum { XA_ONLINE = 1, XA_FLUSH = 2, XA_F16 = 4 };   // XA_F16: the segment's memory has single-fp16 tiles in the formats the kernel instance's OPF names
 
 struct XaWg {
   int row[XA_TILES];   // effective-batch row of query tile t, or -1 (idle)
@@ -90,8 +92,8 @@ struct XaWg {
   int one[XA_TILES];   // one-key memory (XAttnArgs::one_j): its instance for this tile's row (-1: none)
   int att[XA_TILES];   // the ATT instance: row of XaAtt's blocks this tile's attention maps go to (-1: the tile keeps none)
   int seg0, nseg;
-  int pf_slot, pf_n;   // L2 prefetch share (used by the archived role-split kernel, tools/experiments/r03_variants/xattn_role.hpp): this workgroup is number pf_slot of pf_n that stream the same instance of the
-                       // longest memory on one XCD at about the same time (0, 0: no prefetch)
+  int n16;             // how many of the segments -- a prefix of the list: the long memories come first -- carry XA_F16 (single-fp16 tiles)
+  int pf_n;            // (unused)
 };
 
 // Attention maps kept by the kernel itself (the ATT instance; round 5): a sampling run that wants the reference's per-iteration attention
@@ -197,6 +199,9 @@ __device__ __forceinline__ T xa_sel(const T (&arr)[CFD_NMEM], int j) {
 #else
 #define XA_T(k) do { } while (0)
 #endif
+#ifndef XA_DB
+#define XA_DB 1       // 0: developer A/B -- the long memories' steps of the both-single-fp16 instance on the three-barrier loop instead of the double-buffered one
+#endif
 #ifndef XA_ABLATE
 #define XA_ABLATE 0   // developer timing experiments, bit mask: 1 = no fills, 2 = no MFMAs, 4 = no fragment reads, 8 = no softmax (results are garbage)
 #endif
@@ -214,20 +219,25 @@ __device__ __forceinline__ T xa_sel(const T (&arr)[CFD_NMEM], int j) {
 #define XA_WAIT_VM_LGKM0(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | ((((N) >> 4) & 3) << 14))
 
 // ATT: the rows of XaAtt also store their attention maps.
-// OPF (operand format of the key tiles, round 6; DESIGN.md section 5.2 "operand policy"): the kernel is paced by the L2 -> LDS fills of
-// the K / V^T tiles (64 KB each as split pairs), so a run whose scheduler tolerates it may carry them as ONE fp16 per value:
+// OPF (operand format of the key tiles of LONG memories, round 6; DESIGN.md section 2 "operand policy"): the kernel is paced by the
+// L2 -> LDS fills of the K / V^T tiles (64 KB each as split pairs), so a run whose scheduler tolerates it may carry the tiles of its long
+// memories (segments flagged XA_F16 by the host: cfd_api.hip, XA_F16_MIN_KEYS) as ONE fp16 per value:
 //   bit 0 (XA_V16): V^T tiles hold VA as single fp16 (32 KB per 32 keys); P' stays a pair, so P.V is 2 MFMAs per product
-//                   (VA_hi . P'_lo + VA_hi . P'_hi) -- the LINEAR path of the attention: the rounding of VA (2^-12 relative per value,
-//                   independent signs) averages over the keys;
+//                   (VA_hi . P'_lo + VA_hi . P'_hi) -- the LINEAR path of the attention;
 //   bit 1 (XA_K16): K tiles hold KA as single fp16; Q stays a pair (2 MFMAs: KA_hi . q_lo + KA_hi . q_hi) -- the EXPONENTIATED path.
+// Why long memories only: the rounding of a value (2^-12 relative, independent signs) enters the output weighted by its probability, so
+// over N attended keys the absolute error falls like 1 / sqrt(N) -- for the 1500-key audio memory it is ~8x below that of a 24-key text
+// memory, whose tiles are 3 of a row's 50 anyway (measured: profiles/r06_xa_operands_*).  Segments without the flag run the split-pair
+// loop body; at a change of format between two segments the pipeline drains and is primed again (once per workgroup at the shipped shapes).
 // The single-fp16 tiles come from xa_pack16_kernel (once per run, from the split-pair projections): tile-major and already in the LDS
 // image's order, so a fill is a linear copy of 1 KB pieces.  cfd_forward, DDIM runs, runs that keep attention maps and the memories of a
 // dynamic run keep pairs (cfd_api.hip: operand policy of cfd_sample_begin).
 enum { XA_V16 = 1, XA_K16 = 2 };
 template <bool ATT, int OPF>
 __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAttnArgs a) {
-  constexpr bool V16 = (OPF & XA_V16) != 0, K16 = (OPF & XA_K16) != 0;
   static_assert(!ATT || OPF == 0, "attention maps: split-pair tiles");
+  typedef std::integral_constant<int, OPF> fmt_long;     // format tags of the loop-body instances: flagged segments / all others
+  typedef std::integral_constant<int, 0> fmt_pair;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KOFF = 0, VOFF = 65536;
 #if XA_STAMP
@@ -268,9 +278,9 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   const int trow = a.d_step ? *a.d_step : 0;   // (null: kb / vb are this step's rows already -- no dependent scalar load in front of the A b request)
   // A b of the five memories (2 KB each) -> LDS by the LDS-DMA, issued before anything else so that its round trip runs under the
   // row loads and the LayerNorm below.  Parked in the part of the V^T tile buffer that is first filled after the first step's mid-A0
-  // barrier (Vb, row groups 16-31; single-fp16 V^T tiles: the upper half of the buffer, which no fill touches); c_q is computed from
-  // there behind the first barrier.
-  constexpr int KBOFF = VOFF + (V16 ? 32 : 16) * 1024;
+  // barrier (Vb, row groups 16-31; an instance with single-fp16 V^T tiles: row groups 48-63, which belong to Vb in the pair format and
+  // are beyond the 32 KB a single-fp16 tile takes); c_q is computed from there behind the first barrier.
+  constexpr int KBOFF = VOFF + ((OPF & XA_V16) ? 48 : 16) * 1024;
   if (wid < CFD_NMEM) {
     const char* kp = reinterpret_cast<const char*>(xa_sel(a.kb, wid) + (long long)trow * xa_sel(a.kb_stride, wid)) + lane * 16;
     __builtin_amdgcn_global_load_lds((gptr_t)kp, (lptr_t)(smem + KBOFF + wid * 2048), 16, 0, 0);
@@ -372,8 +382,11 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   //           Ka / Kb = the two halves, 16 pieces each = 2 per wave (k-steps wid, wid + 8)
   //        V^T [feature 512][64 B], chunk c at (c ^ (f>>2)&3); Va / Vb as above in 16-row groups: 2 pieces per wave (groups wid, wid + 16, + 8 for Vb)
   //      so a piece's source is tile base + piece * 1 KB + lane * 16.
-  constexpr int NKP = K16 ? 2 : 4, NVP = V16 ? 2 : 4;   // pieces per wave and sub-buffer: what the counted waits count
   const unsigned lane16 = (unsigned)lane * 16u;
+  // Per-lane addresses that depend on the FORMAT of the segment at hand live in one set of variables, set per segment (set_format below):
+  // an instance with two loop bodies (OPF != 0) otherwise keeps both bodies' loop invariants in registers at once and spills.
+  unsigned kfill_lane = (unsigned)ksrc_lane;      // source offset of this lane inside a K piece
+  const char *kf_a, *kf_b, *vf_a, *vf_b;          // fragment read bases: pairs: hi / lo chunk of the lane's row; single fp16: the chunk (b unused)
 
   // A tile = 32 keys of one memory instance: its K rows, its V^T column block, its key bias; rowb = bytes per V^T feature
   // row of that memory; vlane = this lane's byte offset inside a V^T piece (depends on rowb).  All but vlane are wave-uniform.
@@ -387,23 +400,25 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     wm = seg_field(si, 2); fl = seg_field(si, 3);
     const int Sp = xa_sel(a.Sp, j);
     T = Sp / XA_KEYS;
-    t.k = xa_sel(a.K, j) + (K16 ? (long long)u * T * 32768 : (long long)u * Sp * (CFD_D * 4));
-    t.v = xa_sel(a.VT, j) + (V16 ? (long long)u * T * 32768 : (long long)u * CFD_D * Sp * 4);
+    const bool f16 = OPF != 0 && (fl & XA_F16);     // (wave-uniform) this memory's tiles are single fp16 in the formats OPF names
+    t.k = xa_sel(a.K, j) + ((f16 && (OPF & XA_K16)) ? (long long)u * T * 32768 : (long long)u * Sp * (CFD_D * 4));
+    t.v = xa_sel(a.VT, j) + ((f16 && (OPF & XA_V16)) ? (long long)u * T * 32768 : (long long)u * CFD_D * Sp * 4);
     t.cb = xa_sel(a.cb, j) + (long long)u * Sp;
     t.rowb = (long long)Sp * 4;
-    t.vlane = (unsigned)((wid * 8 + rsub) * Sp * 4 + vsw);    // (512 rows x Sp x 4 B < 4 GiB)
+    t.vlane = (f16 && (OPF & XA_V16)) ? lane16 : (unsigned)((wid * 8 + rsub) * Sp * 4 + vsw);    // (512 rows x Sp x 4 B < 4 GiB)
     t.cblane = (unsigned)((lane & 31) * 4) + (lane >= 32 ? xa_sel(a.rs_off, j) : 0u);   // lanes 0-31: key bias, lanes 32-63: key scale
   };
   // fills: K half `hb` (0: Ka, 1: Kb) of tile `t`; with Ka travels the key bias and key scale of the tile (1 piece: 64 x 4 B:
   // 32 biases, 32 scales) into key-bias slot `slot`.  Every address is a wave-uniform 64-bit base
   // (SGPRs) + a loop-invariant 32-bit lane offset: no vector arithmetic per fill.  (The operands are made opaque at every
   // use: otherwise hipcc hoists base + lane offset out of the loop as a 64-bit per-lane pointer and pays vector adds per fill.)
-  auto fill_k = [&](const Tile& t, int hb, int slot) __attribute__((always_inline)) {
+  auto fill_k = [&](auto fc, const Tile& t, int hb, int slot) __attribute__((always_inline)) {
+    constexpr bool K16 = (decltype(fc)::value & XA_K16) != 0;
     if (XA_ABLATE & 1) return;
     if constexpr (K16) {
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
-        unsigned kl = lane16;
+        unsigned kl = kfill_lane;
         const char* b = t.k + hb * 16384 + (wid + 8 * n) * 1024;
         asm volatile("" : "+v"(kl), "+s"(b));
         __builtin_amdgcn_global_load_lds((gptr_t)(b + kl), (lptr_t)(smem + KOFF + hb * 16384 + (wid + 8 * n) * 1024), 16, 0, 0);
@@ -411,7 +426,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     } else {
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        unsigned kl = (unsigned)ksrc_lane;
+        unsigned kl = kfill_lane;
         const char* b = t.k + hb * (4 * CFD_D * 4) + n * 512;
         asm volatile("" : "+v"(kl), "+s"(b));
         __builtin_amdgcn_global_load_lds((gptr_t)(b + kl), (lptr_t)(smem + kdst_wave + hb * 2048 + n * 16384), 16, 0, 0);
@@ -423,12 +438,13 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(t.cb) + cl), (lptr_t)(smem + XA_CBOFF + slot * 256), 4, 0, 0);
     }
   };
-  auto fill_v = [&](const Tile& t, int hb) __attribute__((always_inline)) {
+  auto fill_v = [&](auto fc, const Tile& t, int hb) __attribute__((always_inline)) {
+    constexpr bool V16 = (decltype(fc)::value & XA_V16) != 0;
     if (XA_ABLATE & 1) return;
     if constexpr (V16) {
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
-        unsigned vl = lane16;
+        unsigned vl = t.vlane;
         const int g = wid + 16 * n + 8 * hb;                       // 16-row group (1 KB)
         const char* b = t.v + g * 1024;
         asm volatile("" : "+v"(vl), "+s"(b));
@@ -523,38 +539,46 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   char* xch_mine = smem + XA_XOFF + wid * 2048 + lane * 16;
   const char* xch_other = smem + XA_XOFF + partner * 2048 + lane * 16;
   // fragment reads: half `hf` (4 k-steps / 4 feature tiles) of a sub-phase -> 8 fragments (hi, lo alternating)
-  const char* kfrag = smem + KOFF + (8 * half) * 4096 + l15 * 128;
-  const char* vfrag = smem + VOFF + (16 * half * 16 + l15) * 128;
-  const int off_h = (q4 ^ sw) << 4, off_l = ((4 + q4) ^ sw) << 4;
-  // single-fp16 tiles: rows of 64 B, chunk q4 of row l15 at (q4 ^ (l15 >> 2) & 3)
-  const char* kfrag16 = smem + KOFF + (8 * half) * 1024 + l15 * 64 + ((q4 ^ ((l15 >> 2) & 3)) << 4);
-  const char* vfrag16 = smem + VOFF + (16 * half * 16 + l15) * 64 + ((q4 ^ ((l15 >> 2) & 3)) << 4);
+  // pairs: rows of 128 B, hi chunk q4 / lo chunk 4 + q4 of row l15 at (chunk ^ l15 >> 1); single fp16: rows of 64 B, chunk q4 at (q4 ^ (l15 >> 2) & 3)
+  auto set_format = [&](bool k16, bool v16) __attribute__((always_inline)) {
+    int ln = lane;
+    if constexpr (OPF != 0) asm volatile("" : "+v"(ln));      // (opaque: computed where the segment starts, not hoisted for both formats)
+    const int r15 = ln & 15, g4 = ln >> 4;
+    const int s16 = (g4 ^ ((r15 >> 2) & 3)) << 4, sh = (g4 ^ (r15 >> 1)) << 4, sl = ((4 + g4) ^ (r15 >> 1)) << 4;
+    kf_a = smem + KOFF + (k16 ? (8 * half) * 1024 + r15 * 64 + s16 : (8 * half) * 4096 + r15 * 128 + sh);
+    kf_b = smem + KOFF + (8 * half) * 4096 + r15 * 128 + sl;
+    vf_a = smem + VOFF + (v16 ? (16 * half * 16 + r15) * 64 + s16 : (16 * half * 16 + r15) * 128 + sh);
+    vf_b = smem + VOFF + (16 * half * 16 + r15) * 128 + sl;
+    kfill_lane = k16 ? (unsigned)ln * 16u : (unsigned)ksrc_lane;
+  };
+  set_format(false, false);
   // (pairs: fr[2 i] = hi, fr[2 i + 1] = lo of fragment i; single fp16: fr[i] = the fragment, fr[4..7] unused)
-  auto read_k = [&](spx8 (&fr)[8], int t, int hf) __attribute__((always_inline)) {
+  auto read_k = [&](auto fc, spx8 (&fr)[8], int t, int hf) __attribute__((always_inline)) {
+    constexpr bool K16 = (decltype(fc)::value & XA_K16) != 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if constexpr (K16) {
-        fr[i] = XA_FRAG(kfrag16 + t * 16384 + (4 * hf + i) * 1024);
+        fr[i] = XA_FRAG(kf_a + t * 16384 + (4 * hf + i) * 1024);
       } else {
-        const char* kp = kfrag + (4 * hf + i) * 4096 + t * 2048;
-        fr[2 * i] = XA_FRAG(kp + off_h);
-        fr[2 * i + 1] = XA_FRAG(kp + off_l);
+        fr[2 * i] = XA_FRAG(kf_a + (4 * hf + i) * 4096 + t * 2048);
+        fr[2 * i + 1] = XA_FRAG(kf_b + (4 * hf + i) * 4096 + t * 2048);
       }
     }
   };
-  auto read_v = [&](spx8 (&fr)[8], int qf) __attribute__((always_inline)) {   // qf = 0..3: feature tiles 4 qf .. 4 qf + 3 of this half
+  auto read_v = [&](auto fc, spx8 (&fr)[8], int qf) __attribute__((always_inline)) {   // qf = 0..3: feature tiles 4 qf .. 4 qf + 3 of this half
+    constexpr bool V16 = (decltype(fc)::value & XA_V16) != 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if constexpr (V16) {
-        fr[i] = XA_FRAG(vfrag16 + (4 * qf + i) * 1024);
+        fr[i] = XA_FRAG(vf_a + (4 * qf + i) * 1024);
       } else {
-        const char* vp = vfrag + (4 * qf + i) * 2048;
-        fr[2 * i] = XA_FRAG(vp + off_h);
-        fr[2 * i + 1] = XA_FRAG(vp + off_l);
+        fr[2 * i] = XA_FRAG(vf_a + (4 * qf + i) * 2048);
+        fr[2 * i + 1] = XA_FRAG(vf_b + (4 * qf + i) * 2048);
       }
     }
   };
-  auto mfma_k = [&](f32x4& acc, const spx8 (&fr)[8], int hf) __attribute__((always_inline)) {
+  auto mfma_k = [&](auto fc, f32x4& acc, const spx8 (&fr)[8], int hf) __attribute__((always_inline)) {
+    constexpr bool K16 = (decltype(fc)::value & XA_K16) != 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if constexpr (K16) {
@@ -568,7 +592,8 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     }
   };
   spx8 ph, pl;
-  auto mfma_v = [&](const spx8 (&fr)[8], int qf) __attribute__((always_inline)) {
+  auto mfma_v = [&](auto fc, const spx8 (&fr)[8], int qf) __attribute__((always_inline)) {
+    constexpr bool V16 = (decltype(fc)::value & XA_V16) != 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if constexpr (V16) {
@@ -679,19 +704,14 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   int cT = 1, cmask = 0, cflags = 0, cj = 0, nT = 1, nmask = 0, nflags = 0, nj = 0;
   if (nseg > 0) seg_tile(0, cur, cT, cmask, cflags, cj);
   XA_T(0);
-  for (int si = 0; si < nseg; ++si) {
-    const bool in_seg = active && ((cmask >> tile) & 1);   // wave-uniform, the same for both waves of a pair
-    const bool online = (cflags & XA_ONLINE) != 0;
-    const bool seg_follows = si + 1 < nseg;
-    // the first tile of the next segment (this segment's first tile again when there is none: the trailing fills then land
-    // in buffers nobody reads)
-    nseg_t = cur; nT = cT; nmask = cmask; nflags = cflags; nj = cj;
-    if (seg_follows) seg_tile(si + 1, nseg_t, nT, nmask, nflags, nj);
-    // this wave's half of c_q for the segment's memory: the score accumulators START from it, so the pair's partial scores already
-    // add up to S_raw + c_q (a + b = b + a: the same in both waves of the pair)
-    const float cqh = cq_mine[l15 * 5 + cj];
-    XA_T(11);
-    for (int kt = 0; kt < cT; ++kt) {
+  // One key-tile step in the format `fc` (fmt_long / fmt_pair): the tile `cur` and the tile after it, `nxt`, are BOTH in that format
+  // (the segment loop below sees to it), so every piece count behind a counted wait is a compile-time constant of the instance.
+  bool in_seg = false, online = false;
+  float cqh = 0.f;
+  auto kt_step = [&](auto fc, int kt) __attribute__((always_inline)) {
+    constexpr int F = decltype(fc)::value;
+    constexpr bool V16 = (F & XA_V16) != 0, K16 = (F & XA_K16) != 0;
+    constexpr int NKP = K16 ? 2 : 4, NVP = V16 ? 2 : 4;   // pieces per wave and sub-buffer: what the counted waits count
     const bool last_in_seg = kt + 1 == cT;
     Tile nxt;   // the tile of the step after this one
     nxt.k = last_in_seg ? nseg_t.k : cur.k + (K16 ? 32768 : XA_KEYS * CFD_D * 4);
@@ -702,79 +722,205 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     nxt.cblane = last_in_seg ? nseg_t.cblane : cur.cblane;
     const int slot = step & 1;
     if (!primed) {   // (re)start of the pipeline: Ka (+ key bias), Kb, Va of this step; Vb follows behind mid-A0
-      fill_k(cur, 0, slot);
-      fill_k(cur, 1, slot);
-      fill_v(cur, 0);
+      fill_k(fc, cur, 0, slot);
+      fill_k(fc, cur, 1, slot);
+      fill_v(fc, cur, 0);
       XA_WAIT_VM_LGKM0(NKP + NVP);       // Ka + key bias landed (Kb and Va are younger)
       __builtin_amdgcn_s_barrier();
-      read_k(fa, 0, 0);
+      read_k(fc, fa, 0, 0);
       primed = true;
       XA_T(0);
     }
-    // ---- A0 (fa holds its first half) --------------------------------------------------------------------------------
     f32x4 s0 = f32x4{cqh, cqh, cqh, cqh}, s1 = s0;
-    read_k(fb, 0, 1);
+    // ---- A0 (fa holds its first half) --------------------------------------------------------------------------------
+    read_k(fc, fb, 0, 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (in_seg) mfma_k(s0, fa, 0);
+    if (in_seg) mfma_k(fc, s0, fa, 0);
     __builtin_amdgcn_sched_barrier(0);
     XA_T(1);
     XA_WAIT_VM_LGKM0(NVP);               // Kb landed (Va's pieces are younger); this wave's reads of Ka's first half are done
     __builtin_amdgcn_s_barrier();        // mid-A0: Kb ready; every wave is done with Vb
     XA_T(2);
-    fill_v(cur, 1);
-    read_k(fa, 1, 0);
+    fill_v(fc, cur, 1);
+    read_k(fc, fa, 1, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (in_seg) {
-      mfma_k(s0, fb, 1);
+      mfma_k(fc, s0, fb, 1);
       *reinterpret_cast<f32x4*>(xch_mine) = s0;
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- A1 ---------------------------------------------------------------------------------------------------------
-    read_k(fb, 1, 1);
+    read_k(fc, fb, 1, 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (in_seg) mfma_k(s1, fa, 0);
+    if (in_seg) mfma_k(fc, s1, fa, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (in_seg) {
-      mfma_k(s1, fb, 1);
+      mfma_k(fc, s1, fb, 1);
       *reinterpret_cast<f32x4*>(xch_mine + 1024) = s1;
     }
     XA_T(3);
     XA_WAIT_VM_LGKM0(0);                 // Va and Vb landed (nothing younger is in flight); partial scores written
     __builtin_amdgcn_s_barrier();        // end of A1: the whole V^T tile ready, partial scores visible, every wave is done with Ka and Kb
     XA_T(4);
-    fill_k(nxt, 0, slot ^ 1);
-    fill_k(nxt, 1, slot ^ 1);
-    read_v(fa, 0);
+    fill_k(fc, nxt, 0, slot ^ 1);
+    fill_k(fc, nxt, 1, slot ^ 1);
+    read_v(fc, fa, 0);
     if (in_seg && !(XA_ABLATE & 8)) softmax_tile(s0, s1, slot, online, cj, kt);
     // ---- B0 (fa holds its first half) --------------------------------------------------------------------------------
     XA_T(10);
-    read_v(fb, 1);
+    read_v(fc, fb, 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (in_seg) mfma_v(fa, 0);
+    if (in_seg) mfma_v(fc, fa, 0);
     __builtin_amdgcn_sched_barrier(0);
     XA_T(5);
-    read_v(fa, 2);
+    read_v(fc, fa, 2);
     __builtin_amdgcn_sched_barrier(0);
-    if (in_seg) mfma_v(fb, 1);
+    if (in_seg) mfma_v(fc, fb, 1);
     __builtin_amdgcn_sched_barrier(0);
     // ---- B1 ---------------------------------------------------------------------------------------------------------
-    read_v(fb, 3);
+    read_v(fc, fb, 3);
     __builtin_amdgcn_sched_barrier(0);
-    if (in_seg) mfma_v(fa, 2);
+    if (in_seg) mfma_v(fc, fa, 2);
     __builtin_amdgcn_sched_barrier(0);
     XA_T(7);
     XA_WAIT_VM_LGKM0(NKP);               // next Ka + key bias landed (the next Kb's pieces are younger)
     __builtin_amdgcn_s_barrier();        // mid-B1: next Ka ready; every wave is done with Va
     XA_T(8);
-    fill_v(nxt, 0);
-    read_k(fa, 0, 0);                    // first half of the next step's A0
+    fill_v(fc, nxt, 0);
+    read_k(fc, fa, 0, 0);                // first half of the next step's A0
     __builtin_amdgcn_sched_barrier(0);
-    if (in_seg) mfma_v(fb, 3);
+    if (in_seg) mfma_v(fc, fb, 3);
     __builtin_amdgcn_sched_barrier(0);
     cur = nxt;
     ++step;
     XA_T(9);
-    }   // kt
+  };
+  // One key-tile step with BOTH tiles as single fp16 (OPF = XA_V16 | XA_K16), double-buffered.  A K tile and a V^T tile are 32 KB each, so
+  // the two 64 KB tile buffers hold TWO of each: step n computes out of slot n & 1 while tile n + 1 lands in the other slot -- its K
+  // requested behind the step's first barrier, its V^T behind the second, i.e. every fill has a whole step (four sub-phases) to land instead
+  // of 1.5 - 2.5, and a step has TWO barriers instead of three:
+  //   B0  K(n) has landed and is visible; every wave is done with the other slot's tiles (K since B1 of step n - 1, V^T just now)
+  //   B1  V^T(n) has landed; the pair's partial scores are in the exchange area
+  // A wave's requests complete in order: behind B0 it has K(n + 1) (4 pieces + the key-bias piece) in flight behind V^T(n) (4), behind B1
+  // V^T(n + 1) behind K(n + 1) -- which is what the two counted waits count.
+  auto kt_step_db = [&](int kt) __attribute__((always_inline)) {
+    const bool last_in_seg = kt + 1 == cT;
+    Tile nxt;
+    nxt.k = last_in_seg ? nseg_t.k : cur.k + 32768;
+    nxt.v = last_in_seg ? nseg_t.v : cur.v + 32768;
+    nxt.cb = last_in_seg ? nseg_t.cb : cur.cb + XA_KEYS;
+    nxt.rowb = cur.rowb;
+    nxt.vlane = cur.vlane;
+    nxt.cblane = last_in_seg ? nseg_t.cblane : cur.cblane;
+    const int slot = step & 1;
+    auto fill_k_full = [&](const Tile& t, int sl) __attribute__((always_inline)) {
+      if (XA_ABLATE & 1) return;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        unsigned kl = lane16;
+        const char* b = t.k + (wid + 8 * n) * 1024;
+        asm volatile("" : "+v"(kl), "+s"(b));
+        __builtin_amdgcn_global_load_lds((gptr_t)(b + kl), (lptr_t)(smem + KOFF + sl * 32768 + (wid + 8 * n) * 1024), 16, 0, 0);
+      }
+      unsigned cl = t.cblane;
+      asm volatile("" : "+v"(cl));
+      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(t.cb) + cl), (lptr_t)(smem + XA_CBOFF + sl * 256), 4, 0, 0);
+    };
+    auto fill_v_full = [&](const Tile& t, int sl) __attribute__((always_inline)) {
+      if (XA_ABLATE & 1) return;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        unsigned vl = lane16;
+        const char* b = t.v + (wid + 8 * n) * 1024;
+        asm volatile("" : "+v"(vl), "+s"(b));
+        __builtin_amdgcn_global_load_lds((gptr_t)(b + vl), (lptr_t)(smem + VOFF + sl * 32768 + (wid + 8 * n) * 1024), 16, 0, 0);
+      }
+    };
+    if (!primed) {   // (re)start of the pipeline
+      fill_k_full(cur, slot);
+      fill_v_full(cur, slot);
+      primed = true;
+    }
+    const char* kb = kf_a + slot * 32768;
+    const char* vb = vf_a + slot * 32768;
+    auto rd_k = [&](spx8 (&fr)[8], int t, int hf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fr[i] = XA_FRAG(kb + t * 16384 + (4 * hf + i) * 1024);
+    };
+    auto rd_v = [&](spx8 (&fr)[8], int qf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fr[i] = XA_FRAG(vb + (4 * qf + i) * 1024);
+    };
+    f32x4 s0 = f32x4{cqh, cqh, cqh, cqh}, s1 = s0;
+    XA_T(1);
+    XA_WAIT_VM_LGKM0(4);                 // K(n) landed (V^T(n)'s 4 pieces are younger)
+    __builtin_amdgcn_s_barrier();        // B0
+    XA_T(2);
+    rd_k(fa, 0, 0);
+    rd_k(fb, 0, 1);
+    fill_k_full(nxt, slot ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_k(fmt_long{}, s0, fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    rd_k(fa, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) {
+      mfma_k(fmt_long{}, s0, fb, 1);
+      *reinterpret_cast<f32x4*>(xch_mine) = s0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    rd_k(fb, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_k(fmt_long{}, s1, fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) {
+      mfma_k(fmt_long{}, s1, fb, 1);
+      *reinterpret_cast<f32x4*>(xch_mine + 1024) = s1;
+    }
+    XA_T(3);
+    XA_WAIT_VM_LGKM0(5);                 // V^T(n) landed (K(n + 1): 4 pieces + key bias are younger); partial scores written
+    __builtin_amdgcn_s_barrier();        // B1
+    XA_T(4);
+    rd_v(fa, 0);
+    fill_v_full(nxt, slot ^ 1);
+    if (in_seg && !(XA_ABLATE & 8)) softmax_tile(s0, s1, slot, online, cj, kt);
+    XA_T(10);
+    rd_v(fb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fmt_long{}, fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    XA_T(5);
+    rd_v(fa, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fmt_long{}, fb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    rd_v(fb, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fmt_long{}, fa, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    XA_T(7);
+    if (in_seg) mfma_v(fmt_long{}, fb, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+    ++step;
+    XA_T(9);
+  };
+  // The segments [s0, s1) of the workgroup's list, all in the format `fc`.
+  auto seg_loop = [&](auto fc, int s0, int s1) __attribute__((always_inline)) {
+  for (int si = s0; si < s1; ++si) {
+    in_seg = active && ((cmask >> tile) & 1);   // wave-uniform, the same for both waves of a pair
+    online = (cflags & XA_ONLINE) != 0;
+    const bool seg_follows = si + 1 < s1;
+    // the first tile of the next segment (this segment's first tile again when there is none in this format: the trailing fills of the
+    // last step then land in buffers nobody reads)
+    nseg_t = cur; nT = cT; nmask = cmask; nflags = cflags; nj = cj;
+    if (seg_follows) seg_tile(si + 1, nseg_t, nT, nmask, nflags, nj);
+    // this wave's half of c_q for the segment's memory: the score accumulators START from it, so the pair's partial scores already
+    // add up to S_raw + c_q (a + b = b + a: the same in both waves of the pair)
+    cqh = cq_mine[l15 * 5 + cj];
+    XA_T(11);
+    if constexpr (XA_DB && decltype(fc)::value == (XA_V16 | XA_K16)) { for (int kt = 0; kt < cT; ++kt) kt_step_db(kt); }
+    else { for (int kt = 0; kt < cT; ++kt) kt_step(fc, kt); }
     if (in_seg) {
       float wsum = xlane_sum(wl);
       if (online) {   // normalise the finished online memory in registers (all keys dead: 0 * inf = NaN)
@@ -799,6 +945,29 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     lsum = 0.f;
     wl = 0.f;
     cT = nT; cmask = nmask; cflags = nflags; cj = nj;   // (cur already points at the next segment's first tile)
+  }
+  };
+  if constexpr (OPF != 0) {
+    // The host lists a workgroup's long memories first (make_xattn_worklist): the segments with single-fp16 tiles are a PREFIX of the list,
+    // n16 of them.  Two loops one behind the other -- not two bodies inside one loop, which hipcc could not fit into 256 registers -- with
+    // the pipeline drained and primed again in between (once per workgroup).
+    const int n16 = min(wgp->n16, nseg);
+    if (n16 > 0) {
+      set_format((OPF & XA_K16) != 0, (OPF & XA_V16) != 0);
+      seg_loop(fmt_long{}, 0, n16);
+    }
+    if (n16 < nseg) {
+      if (n16 > 0) {
+        XA_WAIT_VM_LGKM0(0);
+        __builtin_amdgcn_s_barrier();   // nothing of the other format in flight or in use when the pair pipeline starts
+        primed = false;
+        set_format(false, false);
+        seg_tile(n16, cur, cT, cmask, cflags, cj);
+      }
+      seg_loop(fmt_pair{}, n16, nseg);
+    }
+  } else {
+    seg_loop(fmt_pair{}, 0, nseg);
   }
   XA_WAIT_VM_LGKM0(0);
   __builtin_amdgcn_s_barrier();   // last B1 done everywhere and the trailing (unused) fills have landed: the tile buffers become the epilogue strips

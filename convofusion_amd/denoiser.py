@@ -324,7 +324,10 @@ class Denoiser(nn.Module):
             last = getattr(self, "_last_forward_memories", None)
             sig = _contents_signature(srcs, force_checksum=self.verify_constant_memories)
             same = last is not None and last[0] == h and len(last[1]) == len(srcs) and all(a is b for a, b in zip(last[1], srcs))
-            if same and self.verify_constant_memories and [v for v, _ in last[2]] == [v for v, _ in sig] and last[2] != sig:
+            # (a refusal needs checksums on BOTH sides: the call before verify_constant_memories was switched on recorded none -- then the
+            #  signatures merely differ and the projections are made again)
+            both = same and all((a[1] is None) == (b[1] is None) for a, b in zip(last[2], sig))
+            if same and both and self.verify_constant_memories and [v for v, _ in last[2]] == [v for v, _ in sig] and last[2] != sig:
                 self._last_forward_memories = None
                 raise RuntimeError("convofusion_amd.Denoiser: a conditioning tensor was rewritten between two forwards without moving its version "
                                    "counter (t.data.copy_(), a DLPack / raw-pointer write): the reuse of its projections would be stale; bump it with "

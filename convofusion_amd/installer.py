@@ -47,7 +47,7 @@ def diffusion_reverse_forecast(model, encoder_hidden_states, lengths=None, prese
     return impl(model, encoder_hidden_states, lengths, preseq, cond_masks, focus_indices)
 
 
-def install(model, attention_steps="auto"):
+def install(model, attention_steps="auto", operands=None):
     """Bind the fused loop as ``model._diffusion_reverse``.  Returns the model.  ``uninstall`` removes the binding.
 
     ``attention_steps``: which entries the returned attention-matrix dict holds.  The reference keeps the full-conditioning
@@ -57,11 +57,16 @@ def install(model, attention_steps="auto"):
     floats, 4 GB for 32 utterances x 1000 iterations at the product shape); beyond ``sampler.ATT_RING_MAX_BYTES`` it costs one extra
     forward of the B full-conditioning rows and one host round trip per iteration.  "last" returns the final iteration's entry only --
     the loop then does not evaluate the zero-weight full-conditioning chunk.  "auto" (default): "all" while the ring fits the budget,
-    "last" beyond it."""
+    "last" beyond it.
+
+    ``operands``: the run's operand policy for the fused cross-attention (``cfd_sample_args.operand_policy``; None = the default of
+    ``convofusion_amd.sampler.OPERAND_POLICY`` for the model's scheduler: DDPM runs carry the long memories' folded keys / values as single
+    fp16).  ``operands=0`` keeps fp16 split pairs everywhere -- the precision escape, at ~8 % of the loop's throughput at the headline shape."""
     _check_model(model)
     if attention_steps not in ("auto", "last", "all"):
         raise ValueError("attention_steps must be 'auto', 'last' or 'all'")
     model._cfd_attention_steps = attention_steps
+    model._cfd_operands = operands
     model._diffusion_reverse = types.MethodType(_diffusion_reverse, model)
     return model
 
@@ -71,6 +76,7 @@ def uninstall(model):
     if "_diffusion_reverse" in vars(model):
         del model._diffusion_reverse
     vars(model).pop("_cfd_attention_steps", None)
+    vars(model).pop("_cfd_operands", None)
     return model
 
 

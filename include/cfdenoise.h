@@ -149,14 +149,15 @@ typedef struct {
                                  Needs skip_zero_weight_chunks == 0 and no dynamic memory (such a run has no fused cross-attention:
                                  cfd_sample_begin fails with CFD_E_SHAPE and the caller takes the maps with one cfd_forward per
                                  iteration).  The ring's size is the caller's business: iterations x B x layers x L x keys. */
-  int operand_policy;         /* Operand format of the fused cross-attention's key / value tiles in THIS run (csrc/xattn_fused.hpp, OPF):
+  int operand_policy;         /* Operand format of the fused cross-attention's key / value tiles of the LONG memories (>= 128 padded keys: the
+                                 audio memory) in THIS run (csrc/xattn_fused.hpp, OPF):
                                  0 = fp16 split pairs everywhere (3 MFMAs per product, ~2^-22 operand error: what cfd_forward always uses);
-                                 bit 0 = the folded VALUES of the memories as single fp16 (the linear path of the attention; halves their
-                                 L2 -> LDS traffic, 2 MFMAs per product); bit 1 = the folded KEYS as single fp16 as well (the
-                                 exponentiated path).  The reference is float32 throughout (cross_attention.py:593-652); which runs
-                                 tolerate which bits is measured per scheduler in DESIGN.md section 2 -- convofusion_amd.sampler sets
-                                 bit 0 for DDPM runs only, and nothing for DDIM.  Ignored (pairs) on the row-tile path, with att_ring,
-                                 and with a dynamic memory. */
+                                 bit 0 = their folded VALUES as single fp16 (the linear path of the attention; halves those tiles' L2 -> LDS
+                                 traffic, 2 MFMAs per product); bit 1 = their folded KEYS as single fp16 (the exponentiated path).
+                                 Short memories (the text / speaker / activity memories: few keys, little averaging of the rounding) always
+                                 keep pairs.  The reference is float32 throughout (cross_attention.py:593-652); which runs tolerate which bits
+                                 is measured per scheduler in DESIGN.md section 2 -- convofusion_amd.sampler.OPERAND_POLICY holds the default
+                                 per scheduler kind.  Ignored (pairs) on the row-tile path, with att_ring, and with a dynamic memory. */
 } cfd_sample_args;
 
 /* Opens a sampling run: builds the per-step coefficient and timestep-embedding tables, draws / copies
@@ -307,22 +308,6 @@ int cfd_philox_normal(cfd_handle h, float* out, int B, int per_utt, uint64_t see
 #define CFD_PROF_XATTN 5         /* fused cross-attention kernel (scores + softmax + P.V + residual of the five memories) */
 #define CFD_PROF_NCLASS 6
 int cfd_profile_forward(cfd_handle h, float ms[CFD_PROF_NCLASS], int launches[CFD_PROF_NCLASS]);
-
-/* Test hook: D[j][i] = sum_k X[i][k] Y[j][k] through the split-pair (fp16 hi/lo, 3 MFMAs per product) kernel.
- * X dev float32 [I][K], Y dev float32 [J][K], out dev float32 [J][I]; K % 32 == 0, I % 4 == 0.
- * tile_cfg: 0 = chosen from the shape; 1 = 128x128 (2-stage), 30 = 128x128 with the asymmetric ring (weights 2 stages,
- * activations 3 stages), 6 = 128x112, 19 = 64x64 (3-stage), 20 = 32x128 (3-stage), any other value = 128x16
- * (csrc/gemm_sp.hpp: launch_gemm). */
-int cfd_test_gemm(cfd_handle h, const float* X, const float* Y, float* out, int I, int J, int K, int tile_cfg,
-                  void* stream);
-
-/* Test hooks: stop the forward pipeline after tap point `stage` (0 = off; 1 = after the latent embedding;
- * 2+4l / 3+4l / 4+4l / 5+4l = layer l after self-attention / time block 1 / cross-attention / the layer),
- * and read an internal float32 buffer ("x" residual stream [M][512], "temb", "ss", "eps", "sc", "ssc"). */
-int cfd_debug_stop_stage(cfd_handle h, int stage);
-/* Micro-benchmark: average ms of `iters` launches of the [J x K] x [512 x K]^T residual GEMM (I must be 512). */
-int cfd_bench_gemm(cfd_handle h, int I, int J, int K, int tile_cfg, int iters, float* ms_out);
-int cfd_debug_read(cfd_handle h, const char* what, float* dst_dev, size_t numel);
 
 #ifdef __cplusplus
 }

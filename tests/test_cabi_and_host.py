@@ -191,21 +191,28 @@ def test_sharded_sampling_two_ranks_gloo():
     assert res[0] == want and res[1] == want
 
 
-def test_bench_gpus_flag_launches_that_many_ranks():
-    """`python bench.py --gpus 2` must start 2 ranks by itself (round 1: the flag was parsed and ignored).  The launch
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_gpus_flag_launches_that_many_ranks(n):
+    """`python bench.py --gpus N` must start N ranks by itself (round 1: the flag was parsed and ignored).  The launch
     path -- spawn, rendezvous on 127.0.0.1, the collate all_gather, one JSON line from rank 0 -- runs here over gloo
-    with the measurement itself switched off (`--selftest-cpu`); a mismatching launcher environment is an error."""
+    with the measurement itself switched off (`--selftest-cpu`), at 2 ranks and at the 8 of BASELINE configs[2] (one node of
+    8 MI355X; the pool has no such node, so this is the only place the 8-rank launch runs): every rank is seen by a real
+    collective, a RAGGED batch of 3 N + 1 utterances sharded over the ranks reproduces the single-rank rows, and there is
+    exactly one JSON line.  A mismatching launcher environment is an error."""
     import json
     import subprocess
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-cpu", "--steps", "2", "--warmup", "1"],
-                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    env["OMP_NUM_THREADS"] = "1"     # (8 ranks on this container's 8 cores)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--selftest-cpu", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["selftest"] is True and d["value"] is None and d["shards_reproduce_single_rank"] is True
+    assert d["n_gpus"] == n and d["ranks_seen"] == n and d["selftest"] is True and d["value"] is None and d["shards_reproduce_single_rank"] is True
+    if n != 2:
+        return
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--selftest-cpu"], capture_output=True, text=True,
                          timeout=120, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
     assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)
