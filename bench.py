@@ -42,9 +42,9 @@ def executed_gemm_flops(Be, Lq, Ss, U, nl=NL, shared_rows=None, l0_pairs=None, o
     """Algorithmic (single-product) FLOPs of the GEMMs the HIP pipeline actually launches, per class.
     Every product is issued as 3 f16 MFMAs, so MFMA-issued FLOPs are 3x these.  ``shared_rows``: rows that run the
     replica-independent head of the network (embedding, layer 0's self-attention and first time block) when the
-    batch is G replicas of them (cfd_api.hip Problem::share_B); the other rows do not launch those products.
+    batch is G replicas of them (csrc/cfd_internal.hpp Problem::share_B); the other rows do not launch those products.
     ``l0_pairs``: layer 0's attention against the audio memory is evaluated once per distinct (utterance, instance) pair
-    (cfd_api.hip build_xattn_layer0_lists; None: for every row).  ``one_key``: the one-key memory (lsnemb) has no tile
+    (csrc/cfd_problem.hip build_xattn_layer0_lists; None: for every row).  ``one_key``: the one-key memory (lsnemb) has no tile
     step in the fused kernel (XAttnArgs::one_j): its 32 padded keys are not multiplied at all."""
     M = Be * Lq
     M0 = (shared_rows if shared_rows else Be) * Lq

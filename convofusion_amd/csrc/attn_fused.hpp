@@ -22,6 +22,7 @@ struct SelfAttnArgs {
 
 #define SELF_ATTN_WAVES 8
 #define SA_WAIT_VM_LGKM0(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | ((((N) >> 4) & 3) << 14))
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(SELF_ATTN_WAVES * 64, 4) self_attn_fused_kernel(const SelfAttnArgs a) {
   // two stages of (K tile 16 KB | V^T tile 16 KB): keys are consumed in tiles of 32; the LDS-DMA fill of tile kt + 1 runs
   // under the MFMAs of tile kt (one barrier per tile), and two workgroups per CU cover each other's softmax sections

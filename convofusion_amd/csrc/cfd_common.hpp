@@ -53,7 +53,7 @@ __device__ __forceinline__ void split_f32(float v, sp_t& hi, sp_t& lo) {
 // probabilities, GELU / SiLU outputs) are bounded by construction; operands whose magnitude follows the CALLER's data -- the
 // weights, the centred memories a_s and the folded projections KA = A a_s, VA = VV a_s of them, and the
 // sample / latents handed to an entry point -- are counted when one of them leaves the range, and the entry points refuse to go
-// on (cfd_api.hip: check_saturation): a clamped key or value is a silently wrong attention.  The counters belong to the HANDLE
+// on (cfd_internal.hpp: check_saturation): a clamped key or value is a silently wrong attention.  The counters belong to the HANDLE
 // (cfd_handle_s::sat, two words: [CFD_SAT_MEM] weights / memories / their projections, [CFD_SAT_IN] sample / latents) and reach
 // the kernels through their arguments: a call reads what ITS launches counted, never another handle's or an earlier call's.
 // One compare per element; the atomic only fires on a fault.  sat == nullptr: not counted (micro-benchmarks).

@@ -19,6 +19,7 @@ __device__ __forceinline__ float act_f32(float x, int act) {   // 0 none, 1 nn.S
 }
 
 // + resid(z; m, n) (same strides as C; the residual connection) ; a_act: activation applied to A's elements as they are read
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(MatView A, MatView B, float* C, long long c_rs, long long c_cs, long long c_b1,
                                                        long long c_b2, int M, int N, int K, int nb2, const float* bias, float alpha,
                                                        int accumulate, const float* resid, int a_act) {
@@ -181,6 +182,7 @@ __device__ __forceinline__ void gemm_f32_rows16_tile(const MatView& A0, const Ma
   }
 }
 
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) gemm_f32_rows16_kernel(MatView A, MatView B, float* C, long long c_rs, long long c_cs, long long c_b1,
                                                               long long c_b2, int M, int N, int K, int nb2, const float* bias, float alpha,
                                                               int accumulate, const float* resid, int a_act) {
@@ -205,6 +207,7 @@ struct GemmGroups {
   int n;
   int zoff[GEMM_MAX_GROUPS + 1];
 };
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) gemm_f32_rows16_grouped_kernel(const GemmGroups gs) {
   int gi = 0;
   while (gi + 1 < gs.n && (int)blockIdx.z >= gs.zoff[gi + 1]) ++gi;
@@ -221,7 +224,7 @@ static inline void launch_gemm_f32_grouped(hipStream_t st, GemmGroups& gs) {
     nx = gs.g[i].N > nx ? gs.g[i].N : nx;
     gs.zoff[i + 1] = gs.zoff[i] + gs.g[i].nb1 * gs.g[i].nb2;
   }
-  hipLaunchKernelGGL(gemm_f32_rows16_grouped_kernel, dim3((unsigned)((nx + 15) / 16), (unsigned)((mx + 15) / 16), (unsigned)gs.zoff[gs.n]), dim3(256), 0, st,
+  hipLaunchKernelGGL(gemm_f32_rows16_grouped_kernel<>, dim3((unsigned)((nx + 15) / 16), (unsigned)((mx + 15) / 16), (unsigned)gs.zoff[gs.n]), dim3(256), 0, st,
                      gs);
 }
 
@@ -232,6 +235,7 @@ struct GemmSum {
   GemmSeg more[GEMM_MAX_GROUPS - 1];
   int n_more;
 };
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) gemm_f32_rows16_sum_kernel(const GemmSum s) {
   __shared__ GemmSeg more[GEMM_MAX_GROUPS - 1];        // the extra terms, out of the kernel-argument segment
   if (threadIdx.x < (unsigned)s.n_more) more[threadIdx.x] = s.more[threadIdx.x];
@@ -241,7 +245,7 @@ __global__ void __launch_bounds__(256) gemm_f32_rows16_sum_kernel(const GemmSum 
                              blockIdx.y, blockIdx.z, more, s.n_more);
 }
 static inline void launch_gemm_f32_sum(hipStream_t st, const GemmSum& s) {
-  hipLaunchKernelGGL(gemm_f32_rows16_sum_kernel, dim3((unsigned)((s.g.N + 15) / 16), (unsigned)((s.g.M + 15) / 16), (unsigned)(s.g.nb1 * s.g.nb2)),
+  hipLaunchKernelGGL(gemm_f32_rows16_sum_kernel<>, dim3((unsigned)((s.g.N + 15) / 16), (unsigned)((s.g.M + 15) / 16), (unsigned)(s.g.nb1 * s.g.nb2)),
                      dim3(256), 0, st, s);
 }
 
@@ -250,15 +254,16 @@ static inline void launch_gemm_f32(hipStream_t st, const MatView& a, const MatVi
                                    long long c_b2, int M, int N, int K, int nb1, int nb2, const float* bias, float alpha, int accumulate,
                                    const float* resid = nullptr, int a_act = 0) {
   if (M <= 256)
-    hipLaunchKernelGGL(gemm_f32_rows16_kernel, dim3((unsigned)((N + 15) / 16), (unsigned)((M + 15) / 16), (unsigned)(nb1 * nb2)), dim3(256), 0, st, a, b,
+    hipLaunchKernelGGL(gemm_f32_rows16_kernel<>, dim3((unsigned)((N + 15) / 16), (unsigned)((M + 15) / 16), (unsigned)(nb1 * nb2)), dim3(256), 0, st, a, b,
                        C, c_rs, c_cs, c_b1, c_b2, M, N, K, nb2, bias, alpha, accumulate, resid, a_act);
   else
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)(nb1 * nb2)), dim3(256), 0, st, a, b, C,
+    hipLaunchKernelGGL(gemm_f32_kernel<>, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)(nb1 * nb2)), dim3(256), 0, st, a, b, C,
                        c_rs, c_cs, c_b1, c_b2, M, N, K, nb2, bias, alpha, accumulate, resid, a_act);
 }
 
 // In-place softmax over the last axis of scores [rows][Lk]; key_padding_mask [batch][Lk] (1 = ignore), the batch of a
 // row is row / rows_per_batch.  One wave per row.
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) softmax_f32_kernel(float* s, const uint8_t* kpm, long long rows, int Lk, long long rows_per_batch) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -280,6 +285,7 @@ __global__ void __launch_bounds__(256) softmax_f32_kernel(float* s, const uint8_
 }
 
 // ds = p * ((dp + extra) - sum_k (dp + extra) p)   (softmax backward), in place on dp; one wave per row
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) softmax_bwd_f32_kernel(const float* p, float* dp, const float* extra, long long rows, int Lk) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -301,6 +307,7 @@ __global__ void __launch_bounds__(256) softmax_bwd_f32_kernel(const float* p, fl
 // with respect to its input); one wave per row, D <= 2048
 // With (tb_h, tb_e) the incoming gradient is first taken through the TimeBlock's SiLU and modulation:
 // dy <- dy * SiLU'(tb_h) * (1 + tb_e[d])   (tb_h the modulated LayerNorm output the forward kept, tb_e its [scale | shift] row).
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) layernorm_bwd_f32_kernel(const float* x, const float* g, const float* dy, float* dx, long long rows, int D,
                                                                 float eps, int accumulate, const float* tb_h, const float* tb_e) {
   const int lane = threadIdx.x & 63;
@@ -354,6 +361,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_f32_kernel(const float* x, 
 }
 
 // h = LayerNorm(x) * (1 + e[d]) + e[D + d]: the TimeBlock's norm and modulation in one pass (cross_attention.py:433-436)
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) layernorm_mod_f32_kernel(const float* x, const float* g, const float* b, const float* e, float* out, long long rows,
                                                                 int D, float eps) {
   const int lane = threadIdx.x & 63;
@@ -394,6 +402,7 @@ struct LnGroups {
   float* out[ROW_MAX_GROUPS];
   long long rows[ROW_MAX_GROUPS];
 };
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) layernorm_f32_grouped_kernel(const LnGroups gs, int D, float eps) {
   const int gi = blockIdx.y, lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -435,6 +444,7 @@ struct SoftmaxGroups {
   long long rows[ROW_MAX_GROUPS], rows_per_batch[ROW_MAX_GROUPS], s_bstride[ROW_MAX_GROUPS], p_bstride[ROW_MAX_GROUPS], e_bstride[ROW_MAX_GROUPS];
   int Lk[ROW_MAX_GROUPS];
 };
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) softmax_f32_grouped_kernel(const SoftmaxGroups gs) {
   const int gi = blockIdx.y, lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -456,6 +466,7 @@ __global__ void __launch_bounds__(256) softmax_f32_grouped_kernel(const SoftmaxG
   sum = wave_sum(sum);
   for (int c = lane; c < Lk; c += 64) r[c] = r[c] / sum;
 }
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) softmax_bwd_f32_grouped_kernel(const SoftmaxGroups gs) {
   const int gi = blockIdx.y, lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -479,6 +490,7 @@ enum { EW_SILU = 0, EW_GELU = 1, EW_SILU_BWD = 2, EW_GELU_BWD = 3, EW_AXPY = 4, 
 
 // TimeBlock backward between its output projection and its LayerNorm in one pass: out = a * SiLU'(h) * (1 + e[d])
 // (h the modulated LayerNorm output kept by the forward, e the block's [scale | shift] row)
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) tb_bwd_f32_kernel(const float* a, const float* h, const float* e, float* out, long long n, int D) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -495,6 +507,7 @@ __global__ void __launch_bounds__(256) tb_bwd_f32_kernel(const float* a, const f
 //   ADD_BCAST            out = a + b[r0 * s0 + r1 * s1 + d]            (temb / condition id / position rows)
 //   MODULATE             out = a * (1 + b[r1][d]) + b[r1][D + d]       (TimeBlock: b = emb_layers output [R1][2 D], scale first)
 //   MODULATE_BWD         out = a * (1 + b[r1][d])
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) ew_f32_kernel(int op, const float* a, const float* b, float* out, long long n, int D, int R1, long long s0,
                                                      long long s1, float alpha) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -543,6 +556,7 @@ __global__ void __launch_bounds__(256) ew_f32_kernel(int op, const float* a, con
 //   ws      workspace >= B * (3 * L * W + 3 * nt_max) 4-byte words, W = last - 1, nt_max >= tokens of any sample
 // outputs: losses [B] (mean over the sample's tokens of max(0, 1 - max attention)), max_att [tok_off[B]],
 //          d_att [B][NL][L][S] = d(mean_b losses[b]) / d att.  One workgroup per sample; phases separated by barriers.
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) weg_focus_kernel(const float* att, const int* tok_off, const int* tok_idx, int B, int NL, int L, int S,
                                                         int last, int nt_max, float k00, float k01, float k11, float* ws, float* losses,
                                                         float* max_att, float* d_att) {
@@ -651,6 +665,7 @@ __global__ void __launch_bounds__(256) weg_focus_kernel(const float* att, const 
 // bit-identical); 34 -> ~6 us at the product shape, where the general kernel's 16 active threads walk global memory serially.
 #define WEG_SMALL_CELLS 1024
 #define WEG_SMALL_TOK 64
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) weg_focus_small_kernel(const float* att, const int* tok_off, const int* tok_idx, int B, int NL, int L, int S,
                                                               int last, float k00, float k01, float k11, float* losses, float* max_att,
                                                               float* d_att) {

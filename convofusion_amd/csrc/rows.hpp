@@ -23,6 +23,7 @@ struct LnArgs {
   int trow0;
 };
 
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) ln_rows_kernel(const LnArgs a) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -81,6 +82,7 @@ struct MemPrepArgs {
   char* n_sp;         // SP [U*Sp][512]
 };
 
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) mem_prep_kernel(const MemPrepArgs a) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -131,6 +133,7 @@ struct MemCenterArgs {
   unsigned int* sat;  // the handle's saturation census (cfd_common.hpp), or null
 };
 
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) mem_center_kernel(const MemCenterArgs a) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -189,6 +192,7 @@ struct MemScaleAllArgs {
 
 __device__ __forceinline__ void mem_scale_rows(const MemScaleArgs& a, long long row, int lane);
 
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) mem_scale_all_kernel(const MemScaleAllArgs g) {
   int k = 0;
 #pragma unroll
@@ -233,6 +237,7 @@ __device__ __forceinline__ void mem_scale_rows(const MemScaleArgs& a, long long 
 }
 
 // b[t][:] = temb[t][:] - mean(temb[t]) as fp32 and SP, bsq[t] = |b|^2   (one wave per table row)
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) temb_center_kernel(const float* temb, int T, float* b, char* b_sp, float* bsq) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -286,6 +291,7 @@ __device__ __forceinline__ void softmax_store(const SoftmaxArgs& a, int g, int b
   }
 }
 
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) softmax_rows_kernel(const SoftmaxArgs a) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -404,6 +410,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const SoftmaxArgs a) 
 // Per-tile softmax statistics (EpiTileSoftmax) -> fold weights of the tile-relative P.V product:
 //   m = max_t m_t ;  l = sum_t l_t exp(m_t - m) ;  alpha_t = exp(m_t - m) / l
 // (a row whose keys are all masked gives 0 / 0 = NaN, as the reference's softmax does)
+template <int CFD_KI = 0>
 __global__ void attn_alpha_kernel(const float2* stats, float* alpha, long long rows, int ntiles) {
   const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= rows) return;
@@ -418,6 +425,7 @@ __global__ void attn_alpha_kernel(const float2* stats, float* alpha, long long r
 // ------------------------------------------------------------------------------------------------
 // fp32 [R][K] -> SP [R][K]   (K % 8 == 0); used for weights at load time
 // ------------------------------------------------------------------------------------------------
+template <int CFD_KI = 0>
 __global__ void to_split_kernel(const float* in, char* out, long long R, int K, long long ld_in, long long ld_out_bytes, unsigned int* sat) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int kc = K / 8;
@@ -437,6 +445,7 @@ __global__ void to_split_kernel(const float* in, char* out, long long R, int K, 
 // embeddings.py:298-305, cross_attention.py:432-434)
 //   in_act: 0 none, 1 silu on the input;  post: 0 none, 1 silu, 2 "first 512 columns get +1" (1+scale)
 // ------------------------------------------------------------------------------------------------
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) small_linear_kernel(const float* in, const int* in_rows, long long ld_in,
                                                            const float* W, const float* bias, float* out,
                                                            long long ld_out, int R, int N, int in_act, int post) {
@@ -540,6 +549,7 @@ __device__ __forceinline__ float4 philox_normal4(uint64_t seed, uint32_t group, 
 }
 
 // fill [B][L*128] with N(0,1): stream 1 = initial latents (convofusion.py:412-419)
+template <int CFD_KI = 0>
 __global__ void philox_fill_kernel(float* out, int B, int per_utt, uint64_t seed, uint32_t step, uint32_t utt0,
                                    uint32_t stream, float scale) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -565,6 +575,7 @@ struct BeginArgs {
   const int* d_step;
 };
 
+template <int CFD_KI = 0>
 __global__ void begin_step_kernel(const BeginArgs a) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one thread = 8 elements
   const long long n8 = (long long)a.B * a.L * (CFD_LAT / 8);
@@ -610,6 +621,7 @@ struct CfgStepArgs {
   unsigned int utt0;
 };
 
+template <int CFD_KI = 0>
 __global__ void cfg_step_kernel(const CfgStepArgs a) {
   const int per_utt = a.L * CFD_LAT;
   const long long n4 = (long long)a.B * per_utt / 4;
@@ -680,6 +692,7 @@ __global__ void cfg_step_kernel(const CfgStepArgs a) {
 
 // The in-painting overwrite of begin_step_kernel alone, ahead of the captured iteration (cfd_sample_inpaint): the WEG
 // branch of the rollout alters the latents AFTER the overwrite and BEFORE the replication (unbounded_synthesis.py:70-143).
+template <int CFD_KI = 0>
 __global__ void inpaint_now_kernel(const BeginArgs a, int* d_step) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long n = (long long)a.B * a.pl * CFD_LAT;
@@ -701,6 +714,7 @@ __global__ void inpaint_now_kernel(const BeginArgs a, int* d_step) {
 // LDS-tiled fp32 kernel: 32 rows x 64 outputs per 256-thread block, k in chunks of 32.
 //   act: 0 none, 1 GELU (erf form, nn.GELU()), 2 LeakyReLU(0.1)
 // ------------------------------------------------------------------------------------------------
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) linear_act_kernel(const float* __restrict__ x, long long n_rows, int K, const float* __restrict__ W,
                                                          const float* __restrict__ b, int N, int act, float* __restrict__ out) {
   __shared__ float xs[32][33];
@@ -756,6 +770,7 @@ __global__ void __launch_bounds__(256) linear_act_kernel(const float* __restrict
 // d_model 128, 2 heads, a few thousand rows, once per batch).  Plain and exact rather than fast.
 // ------------------------------------------------------------------------------------------------
 // out[r][:] = (x[r][:] - mean) * rstd * g + b   (nn.LayerNorm, eps 1e-5, biased variance); one wave per row, D <= 2048
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) layernorm_f32_kernel(const float* x, const float* g, const float* b, float* out, long long rows, int D,
                                                             float eps) {
   const int lane = threadIdx.x & 63;
@@ -792,6 +807,7 @@ __global__ void __launch_bounds__(256) layernorm_f32_kernel(const float* x, cons
 //   out[lq][b][h*hd + d] = sum_lk softmax_lk( scale * q.k  (+ -inf where key_padding_mask[b][lk]) ) v[lk][b][h*hd + d]
 // One wave per (lq, b, h): lanes <-> keys for the scores (kept in LDS), lanes <-> head features for the weighted sum.
 #define MHA_MAX_KEYS 1024
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) mha_f32_kernel(const float* q, const float* k, const float* v, const uint8_t* key_padding_mask, float* out,
                                                       int Lq, int Lk, int bs, int E, int H, float scale) {
   __shared__ float sc[4][MHA_MAX_KEYS];
@@ -829,10 +845,12 @@ __global__ void __launch_bounds__(256) mha_f32_kernel(const float* q, const floa
 }
 
 // x[i] += y[i]  (residual connections); optional row mask: rows with keep[row] == 0 are set to zero afterwards
+template <int CFD_KI = 0>
 __global__ void add_f32_kernel(float* x, const float* y, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] = x[i] + y[i];
 }
+template <int CFD_KI = 0>
 __global__ void zero_rows_f32_kernel(float* x, const uint8_t* keep, long long rows, int D) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < rows * D && !keep[i / D]) x[i] = 0.f;

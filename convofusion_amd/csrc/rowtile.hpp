@@ -443,6 +443,7 @@ struct RtSelfArgs {
   int L, tpr;
 };
 
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) rt_selfattn_kernel(const RtSelfArgs a) {
   RT_T(t_in);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -579,6 +580,7 @@ struct RtXArgs {
 //  is then exp(m_c - M) / sum.)
 
 #define RT_XS_LDS (16 * 2048 + 8192 + 8 * 8192 + 64 + 512)
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(512) rt_xscore_kernel(const RtXArgs a) {
   constexpr int NW = 8, NK = 2, STAGE_W = 2 * NK * 2048;     // per wave: 2 key tiles x NK k-groups
   RT_T(t_in);
@@ -878,6 +880,7 @@ struct RtStepRowsArgs {
   int ntab;
   const int* d_step;
 };
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) rt_step_rows_kernel(const RtStepRowsArgs a) {
   int k = 0;
 #pragma unroll
@@ -910,6 +913,7 @@ struct MemScaleTabArgs {
   float* tab;          // [T][nl + 1][rows]
 };
 
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) mem_scale_table_kernel(const MemScaleTabArgs a) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -259,6 +259,7 @@ struct RtXBwdArgs {
   float* dy;                    // B5 output [M][512]
 };
 
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(512) rt_xbwd_dp_kernel(const RtXBwdArgs a) {
   constexpr int NW = 8, K = CFD_D, RS = RT_BSTRIDE(CFD_D), NSTEP = K / (4 * NW);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -544,6 +545,7 @@ struct RtSelfBwdArgs {
   float qscale;       // 1 / sqrt(head_dim): dq is handed on as the gradient at the UNSCALED query projection (the forward's weights carry the scale)
 };
 
+template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) rt_selfattn_bwd_kernel(const RtSelfBwdArgs a) {
   constexpr int HD = CFD_HD, RSD = HD + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -6,7 +6,7 @@
 // the activations the backward needs, the objective (weg_focus_kernel), then the reverse sweep; only the query side
 // carries gradient (memories, time embedding, weights are constants).  Batch-major rows (r = b * L + l) so latents,
 // memories and the gradient need no permutation; every head split / transpose is a strided view of gemm_f32_kernel.
-// Included by cfd_api.hip after the handle definition.
+// Included by cfd_weg.hip after the handle definition (cfd_internal.hpp).
 #pragma once
 
 namespace weg {
@@ -96,25 +96,25 @@ struct Ctx {
   }
   void softmax(float* s, long long rows, int Lk, const uint8_t* kpm, long long rows_per_batch) {
     if (skip()) return;
-    hipLaunchKernelGGL(softmax_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, s, kpm, rows, Lk, rows_per_batch);
+    hipLaunchKernelGGL(softmax_f32_kernel<>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, s, kpm, rows, Lk, rows_per_batch);
   }
   void softmax_bwd(const float* p, float* dp, const float* extra, long long rows, int Lk) {
     if (skip()) return;
-    hipLaunchKernelGGL(softmax_bwd_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, dp, extra, rows, Lk);
+    hipLaunchKernelGGL(softmax_bwd_f32_kernel<>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, dp, extra, rows, Lk);
   }
   float* ln(const float* x, long long rows, const float* g, const float* b) {
     float* out = alloc((size_t)rows * D);
-    if (!skip()) hipLaunchKernelGGL(layernorm_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, g, b, out, rows, D, 1e-5f);
+    if (!skip()) hipLaunchKernelGGL(layernorm_f32_kernel<>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, g, b, out, rows, D, 1e-5f);
     return out;
   }
   void ln_bwd(const float* x, const float* g, const float* dy, float* dx, long long rows, int accumulate, const float* tb_h = nullptr,
               const float* tb_e = nullptr) {
     if (skip()) return;
-    hipLaunchKernelGGL(layernorm_bwd_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, g, dy, dx, rows, D, 1e-5f, accumulate, tb_h, tb_e);
+    hipLaunchKernelGGL(layernorm_bwd_f32_kernel<>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, g, dy, dx, rows, D, 1e-5f, accumulate, tb_h, tb_e);
   }
   float* ln_mod(const float* x, long long rows, const float* g, const float* b, const float* e) {
     float* out = alloc((size_t)rows * D);
-    if (!skip()) hipLaunchKernelGGL(layernorm_mod_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, g, b, e, out, rows, D, 1e-5f);
+    if (!skip()) hipLaunchKernelGGL(layernorm_mod_f32_kernel<>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, g, b, e, out, rows, D, 1e-5f);
     return out;
   }
   void gemm_sum(const GemmSum& gs) {
@@ -129,18 +129,18 @@ struct Ctx {
     if (skip()) return;
     long long mx = 0;
     for (int i = 0; i < n; ++i) mx = std::max(mx, gs.rows[i]);
-    hipLaunchKernelGGL(layernorm_f32_grouped_kernel, dim3((unsigned)((mx + 3) / 4), (unsigned)n), dim3(256), 0, st, gs, D, 1e-5f);
+    hipLaunchKernelGGL(layernorm_f32_grouped_kernel<>, dim3((unsigned)((mx + 3) / 4), (unsigned)n), dim3(256), 0, st, gs, D, 1e-5f);
   }
   void softmax_grouped(const SoftmaxGroups& gs, int n, bool backward) {
     if (skip()) return;
     long long mx = 0;
     for (int i = 0; i < n; ++i) mx = std::max(mx, gs.rows[i]);
-    if (backward) hipLaunchKernelGGL(softmax_bwd_f32_grouped_kernel, dim3((unsigned)((mx + 3) / 4), (unsigned)n), dim3(256), 0, st, gs);
-    else hipLaunchKernelGGL(softmax_f32_grouped_kernel, dim3((unsigned)((mx + 3) / 4), (unsigned)n), dim3(256), 0, st, gs);
+    if (backward) hipLaunchKernelGGL(softmax_bwd_f32_grouped_kernel<>, dim3((unsigned)((mx + 3) / 4), (unsigned)n), dim3(256), 0, st, gs);
+    else hipLaunchKernelGGL(softmax_f32_grouped_kernel<>, dim3((unsigned)((mx + 3) / 4), (unsigned)n), dim3(256), 0, st, gs);
   }
   void ew(int op, const float* a, const float* b, float* out, long long n, int Dd = 1, int R1 = 1, long long s0 = 0, long long s1 = 0, float alpha = 0.f) {
     if (skip()) return;
-    hipLaunchKernelGGL(ew_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, op, a, b, out, n, Dd, R1, s0, s1, alpha);
+    hipLaunchKernelGGL(ew_f32_kernel<>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, op, a, b, out, n, Dd, R1, s0, s1, alpha);
   }
 };
 
@@ -440,7 +440,7 @@ static void run(Ctx& x, const Args& a) {
   float* ws = x.alloc((size_t)B * (3 * (size_t)L * W + 3 * (size_t)a.nt_max));
   float* d_att = x.alloc((size_t)B * NL * L * St);
   if (!x.skip())
-    hipLaunchKernelGGL(weg_focus_kernel, dim3((unsigned)B), dim3(256), 0, x.st, att, a.tok_off, a.tok_idx, B, NL, L, St, a.last, a.nt_max, a.k3[0],
+    hipLaunchKernelGGL(weg_focus_kernel<>, dim3((unsigned)B), dim3(256), 0, x.st, att, a.tok_off, a.tok_idx, B, NL, L, St, a.last, a.nt_max, a.k3[0],
                        a.k3[1], a.k3[2], ws, a.losses, a.max_att, d_att);
   // ---- reverse sweep
   float* g = x.alloc((size_t)rows * D);                          // gradient at the current layer's output

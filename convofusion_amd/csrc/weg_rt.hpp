@@ -2,7 +2,7 @@
 // word-excitation-guidance evaluation for small problems (the reference needs test batch size 1 for WEG, word_excitation_guidance.py:25).
 // ~160 launches of ~5 us instead of weg_eval.hpp's ~400 launches of ~10 us, in the folded formulation the sampling loop itself uses.
 // The evaluation has a workspace of its own (Ctx::wk[1]): it runs between two replays of an open sampling run's captured graph.
-// Included by cfd_api.hip after weg_eval.hpp.
+// Included by cfd_weg.hip after weg_eval.hpp.
 #pragma once
 
 namespace wegrt {
@@ -111,7 +111,7 @@ static int enqueue(Ctx* c, hipStream_t st, bool full, const EvalArgs& e) {
   const int nl = c->nl, B = p.Be, L = p.L, tpr = (L + 15) / 16, ntile = B * tpr, St = p.S[2];
   const long long M = p.M;
   if (full) {
-    w->tt_key.clear();     // (this workspace's timestep-only tables are rebuilt from w->trows, whatever they held: cfd_api.hip, build_time_tables)
+    w->tt_key.clear();     // (this workspace's timestep-only tables are rebuilt from w->trows, whatever they held: cfd_problem.hip, build_time_tables)
     w->tt_mem_mask = 0;
     CHK(enqueue_time_tables(c, p.T, st));      // one row: the timestep index is in w->trows (copied in front of the launch sequence); full tables: row t = timestep t
     CHK(prepare_static_memside(c, st, 0, true));
@@ -120,17 +120,17 @@ static int enqueue(Ctx* c, hipStream_t st, bool full, const EvalArgs& e) {
   }
   {
     const long long n = M * (CFD_LAT / 8);
-    hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, e.latents, w->sample_sp.as<char>(), M, CFD_LAT,
+    hipLaunchKernelGGL(to_split_kernel<>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, e.latents, w->sample_sp.as<char>(), M, CFD_LAT,
                        (long long)CFD_LAT, (long long)CFD_LAT * 4, c->sat_in());
     HIPCHK(hipGetLastError());
   }
   CHK(enqueue_rows_rt(c, st, &s.sv));
   s.launches += 2 + 9 * nl - 3;
   if (L * (e.last - 1) <= WEG_SMALL_CELLS && e.nt_max <= WEG_SMALL_TOK && L <= 64)
-    hipLaunchKernelGGL(weg_focus_small_kernel, dim3((unsigned)B), dim3(256), 0, st, s.att, e.tok_off, e.tok_idx, B, nl, L, St, e.last, e.k3[0], e.k3[1],
+    hipLaunchKernelGGL(weg_focus_small_kernel<>, dim3((unsigned)B), dim3(256), 0, st, s.att, e.tok_off, e.tok_idx, B, nl, L, St, e.last, e.k3[0], e.k3[1],
                        e.k3[2], e.losses, e.max_att, s.d_att);
   else
-    hipLaunchKernelGGL(weg_focus_kernel, dim3((unsigned)B), dim3(256), 0, st, s.att, e.tok_off, e.tok_idx, B, nl, L, St, e.last, e.nt_max, e.k3[0], e.k3[1],
+    hipLaunchKernelGGL(weg_focus_kernel<>, dim3((unsigned)B), dim3(256), 0, st, s.att, e.tok_off, e.tok_idx, B, nl, L, St, e.last, e.nt_max, e.k3[0], e.k3[1],
                        e.k3[2], s.fws, e.losses, e.max_att, s.d_att);
   HIPCHK(hipGetLastError());
   ++s.launches;
@@ -145,7 +145,7 @@ static int enqueue(Ctx* c, hipStream_t st, bool full, const EvalArgs& e) {
                                16 * RT_BSTRIDE(512) * 4 + 8 * 1024 + 512 + 16 * 32 * 16 + 16 * 8 * 8));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_xbwd_dy_kernel<RT_MAX_KEYS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                16 * RT_BSTRIDE(RT_MAX_KEYS) * 4 + 8 * 1024 + 512 + 16 * 32 * 16 + 16 * 8 * 8));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_selfattn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_sa));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rt_selfattn_bwd_kernel<>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_sa));
     attr |= 1ull << (c->cfg.device & 63);
   }
   RtBwdArgs base;
@@ -203,7 +203,7 @@ static int enqueue(Ctx* c, hipStream_t st, bool full, const EvalArgs& e) {
         RtXBwdArgs a = x5;
         a.dz = s.dz; a.g = s.G[gi]; a.x = s.sv.x[l][3]; a.gamma = lw.tb2g; a.beta = lw.tb2b;
         a.ss = w->now_ss + (size_t)(2 * l + 1) * 2 * CFD_D; a.gout = s.G[(gi + 1) % 3];
-        hipLaunchKernelGGL(rt_xbwd_dp_kernel, dim3(nkb, ntile), dim3(512), lds_dp, st, a);
+        hipLaunchKernelGGL(rt_xbwd_dp_kernel<>, dim3(nkb, ntile), dim3(512), lds_dp, st, a);
         HIPCHK(hipGetLastError());
         ++s.launches;
         gi = (gi + 1) % 3;
@@ -235,7 +235,7 @@ static int enqueue(Ctx* c, hipStream_t st, bool full, const EvalArgs& e) {
     }
     {   // B8: attention core
       RtSelfBwdArgs a{s.sv.qk[l], s.sv.vt[l], s.dO, s.dqkv, L, (float)std::sqrt(1.0 / (double)CFD_HD)};
-      hipLaunchKernelGGL(rt_selfattn_bwd_kernel, dim3(CFD_NHEAD, B), dim3(256), lds_sa, st, a);
+      hipLaunchKernelGGL(rt_selfattn_bwd_kernel<>, dim3(CFD_NHEAD, B), dim3(256), lds_sa, st, a);
       HIPCHK(hipGetLastError());
       ++s.launches;
     }

@@ -17,10 +17,15 @@ def test_library_exports_every_declared_symbol():
     from convofusion_amd import _lib, build
     build.build()
     lib = _lib.load()
-    hdr = open(os.path.join(ROOT, "include", "cfdenoise.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(cfd_[a-z_0-9]+)\s*\(", hdr))
-    assert declared, "no declarations parsed"
+    declared = set()
+    for h in ("cfdenoise.h", "cfdenoise_dev.h"):      # the drop-in boundary, and the developer / test hooks beside it
+        hdr = open(os.path.join(ROOT, "include", h)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        found = set(re.findall(r"\b(cfd_[a-z_0-9]+)\s*\(", hdr))
+        assert found, "no declarations parsed in " + h
+        declared |= found
+    public = open(os.path.join(ROOT, "include", "cfdenoise.h")).read()
+    assert not re.search(r"cfd_(debug|test|bench)_", re.sub(r"/\*.*?\*/", "", public, flags=re.S)), "developer hooks belong in cfdenoise_dev.h"
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
@@ -229,7 +234,7 @@ def test_stale_library_is_detected_by_content():
     blob = open(build.LIB, "rb").read()
     k = blob.find(b"cfd-src-hash:")
     assert k >= 0 and blob[k + 13:k + 29].decode() == build.source_hash()
-    assert len(build.source_hash()) == 16 and set(build.DEPS) >= {"cfd_api.hip", "xattn_fused.hpp", os.path.join("..", "..", "include", "cfdenoise.h")}
+    assert len(build.source_hash()) == 16 and set(build.DEPS) >= {"cfd_core.hip", "cfd_forward.hip", "cfd_internal.hpp", "xattn_fused.hpp", os.path.join("..", "..", "include", "cfdenoise.h")}
 
 
 def test_no_edit_installer_binds_the_reference_entry_points():
@@ -282,14 +287,18 @@ def test_no_kernel_of_the_library_uses_scratch_memory():
     import subprocess
     import tempfile
     from convofusion_amd import build
-    src = os.path.join(build.CSRC, "cfd_api.hip")
-    with tempfile.TemporaryDirectory() as tmp:
-        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-c",
-                            "-Rpass-analysis=kernel-resource-usage", src, "-o", os.path.join(tmp, "cfd_api.o")],
-                           capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    names = re.findall(r"Function Name: (\S+)", r.stderr)
-    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    from concurrent.futures import ThreadPoolExecutor
+
+    def remarks(unit):
+        with tempfile.TemporaryDirectory() as tmp:
+            r = subprocess.run(["/opt/rocm/bin/hipcc", *build.FLAGS, "-c", "-Rpass-analysis=kernel-resource-usage", os.path.join(build.CSRC, unit),
+                                "-o", os.path.join(tmp, "unit.o")], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stderr
+    with ThreadPoolExecutor(max_workers=4) as ex:      # every translation unit of the library
+        err = "\n".join(ex.map(remarks, build.SOURCES))
+    names = re.findall(r"Function Name: (\S+)", err)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", err)]
     assert len(names) == len(scratch) and len(names) > 40
     bad = {n: s for n, s in zip(names, scratch) if s != 0}
     assert not bad, bad

@@ -12,9 +12,7 @@ set -u
 cd "$(dirname "$0")/.."
 if [ "${1:-}" = build ]; then
   for k in ${VARIANTS:-1 2 3 4 5 6 7}; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC -DCFD_EXP=$k \
-      -DCFD_SOURCE_HASH=\"exp$k\" convofusion_amd/csrc/cfd_api.hip -o tools/experiments/lib_exp$k.so &
-    if [ $((k % 3)) = 0 ]; then wait; fi
+    python -m convofusion_amd.build -DCFD_EXP=$k -o tools/experiments/lib_exp$k.so
   done
   wait
   ls -la tools/experiments/lib_exp*.so

@@ -57,7 +57,7 @@
 // same code, the extra terms vanish exactly.
 //
 // The segment list (which memory instance, which of the four waves take part) is built by the host per problem
-// (build_xattn_worklist, cfd_problem.hip): waves of a workgroup share every LDS tile, so a segment whose instance differs
+// (build_xattn_worklist, cfd_api.hip): waves of a workgroup share every LDS tile, so a segment whose instance differs
 // between the workgroup's batch rows is split into passes.
 #pragma once
 #include "cfd_common.hpp"
@@ -126,7 +126,7 @@ struct XAttnArgs {
   int L;
   const XaWg* wgs;
   const XaSeg* segs;
-  // layer-0 de-duplication (cfd_problem.hip, build_xattn_layer0_lists).  dd_out: the tiles' results (accumulated memories + their rank-one
+  // layer-0 de-duplication (cfd_api.hip, build_xattn_layer0_lists).  dd_out: the tiles' results (accumulated memories + their rank-one
   // terms, no bias) are STORED to dd_out[aux][query][512] and x is left alone.  dd_in: x += ... + dd_in[aux][query][512].
   float* dd_out;
   const float* dd_in;
@@ -134,7 +134,7 @@ struct XAttnArgs {
   //   rs_u (VA_u + VV b_t)      (u: the row's instance, rs_u: the key's scale at this step)
   // and the 32-key tile step that used to produce it (a K and a V^T fill of 64 KB each for one live key, three barriers) is replaced by one
   // 2 KB read in the flush.  one_j < 0: no such memory (or its key can be masked: then it stays a segment).  Such a memory has no segments
-  // in the work lists (cfd_problem.hip, build_xattn_worklist).
+  // in the work lists (cfd_api.hip, build_xattn_worklist).
   int one_j;                  // memory index, or -1
   int one_sp;                 // its padded length (row pitch of one_rs)
   const float* one_va;        // fp32 [U][512]: VA of its key, this layer
@@ -144,7 +144,6 @@ struct XAttnArgs {
 };
 
 // float32 copy of the value row of a one-key memory: out[(l * U + u) * 512 + f] = VA_l,u[f] (key 0 of V^T [nl][U][512][Sp], hi + lo)
-template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) one_key_va_kernel(const char* vt, long long n, int Sp, float* out) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -156,7 +155,6 @@ __global__ void __launch_bounds__(256) one_key_va_kernel(const char* vt, long lo
 // comment in the kernel).  One thread per 16-byte chunk (8 values: the `hi` halves, which are the values rounded to fp16).
 //   which = 0: V^T  in  SP [n_lu][512][Sp]      out [n_lu][T][512][64 B]
 //   which = 1: K    in  SP [n_lu * Sp][512]     out [n_lu][T][2][16][16][64 B]          (n_lu = layers x instances, T = Sp / 32)
-template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) xa_pack16_kernel(const char* in, char* out, long long n_chunks, int Sp, int which) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_chunks) return;
@@ -201,6 +199,9 @@ __device__ __forceinline__ T xa_sel(const T (&arr)[CFD_NMEM], int j) {
 #else
 #define XA_T(k) do { } while (0)
 #endif
+#ifndef XA_DB
+#define XA_DB 1       // 0: developer A/B -- the long memories' steps of the both-single-fp16 instance on the three-barrier loop instead of the double-buffered one
+#endif
 #ifndef XA_ABLATE
 #define XA_ABLATE 0   // developer timing experiments, bit mask: 1 = no fills, 2 = no MFMAs, 4 = no fragment reads, 8 = no softmax (results are garbage)
 #endif
@@ -220,7 +221,7 @@ __device__ __forceinline__ T xa_sel(const T (&arr)[CFD_NMEM], int j) {
 // ATT: the rows of XaAtt also store their attention maps.
 // OPF (operand format of the key tiles of LONG memories, round 6; DESIGN.md section 2 "operand policy"): the kernel is paced by the
 // L2 -> LDS fills of the K / V^T tiles (64 KB each as split pairs), so a run whose scheduler tolerates it may carry the tiles of its long
-// memories (segments flagged XA_F16 by the host: cfd_problem.hip, XA_F16_MIN_KEYS) as ONE fp16 per value:
+// memories (segments flagged XA_F16 by the host: cfd_api.hip, XA_F16_MIN_KEYS) as ONE fp16 per value:
 //   bit 0 (XA_V16): V^T tiles hold VA as single fp16 (32 KB per 32 keys); P' stays a pair, so P.V is 2 MFMAs per product
 //                   (VA_hi . P'_lo + VA_hi . P'_hi) -- the LINEAR path of the attention;
 //   bit 1 (XA_K16): K tiles hold KA as single fp16; Q stays a pair (2 MFMAs: KA_hi . q_lo + KA_hi . q_hi) -- the EXPONENTIATED path.
@@ -228,18 +229,10 @@ __device__ __forceinline__ T xa_sel(const T (&arr)[CFD_NMEM], int j) {
 // over N attended keys the absolute error falls like 1 / sqrt(N) -- for the 1500-key audio memory it is ~8x below that of a 24-key text
 // memory, whose tiles are 3 of a row's 50 anyway (measured: profiles/r06_xa_operands_*).  Segments without the flag run the split-pair
 // loop body; at a change of format between two segments the pipeline drains and is primed again (once per workgroup at the shipped shapes).
-// (With both formats single fp16 a K and a V^T tile are 32 KB each and the tile buffers hold two of each: a double-buffered pipeline -- every
-// fill a whole step ahead, two barriers per step instead of three -- was built and measured 0.6 % SLOWER on one box (78.0 vs 77.6 steps/s,
-// profiles/r06_xa_double_buffer_ab.log; tools/experiments/r06_variants/xattn_fused_double_buffer.hpp): the step is paced by the softmax's
-// vector work and the matrix pipe, which the two waves of a SIMD use one after the other, not by fills or barriers any more.)
 // The single-fp16 tiles come from xa_pack16_kernel (once per run, from the split-pair projections): tile-major and already in the LDS
 // image's order, so a fill is a linear copy of 1 KB pieces.  cfd_forward, DDIM runs, runs that keep attention maps and the memories of a
-// dynamic run keep pairs (cfd_sample.hip: operand policy of cfd_sample_begin).
+// dynamic run keep pairs (cfd_api.hip: operand policy of cfd_sample_begin).
 enum { XA_V16 = 1, XA_K16 = 2 };
-#ifndef XA_ALL_OPF
-#define XA_ALL_OPF 0    // 1: developer builds also instantiate the values-only / keys-only instances (OPF 1 / 2: measured in round 6, dominated by
-                        // OPF 3 -- 78.8 / 78.0 against 81.6 steps/s at 1.9e-5 / 1.2e-5 against 2.3e-5 on the DDPM-1000 golden -- and not shipped)
-#endif
 template <bool ATT, int OPF>
 __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAttnArgs a) {
   static_assert(!ATT || OPF == 0, "attention maps: split-pair tiles");
@@ -802,6 +795,116 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     ++step;
     XA_T(9);
   };
+  // One key-tile step with BOTH tiles as single fp16 (OPF = XA_V16 | XA_K16), double-buffered.  A K tile and a V^T tile are 32 KB each, so
+  // the two 64 KB tile buffers hold TWO of each: step n computes out of slot n & 1 while tile n + 1 lands in the other slot -- its K
+  // requested behind the step's first barrier, its V^T behind the second, i.e. every fill has a whole step (four sub-phases) to land instead
+  // of 1.5 - 2.5, and a step has TWO barriers instead of three:
+  //   B0  K(n) has landed and is visible; every wave is done with the other slot's tiles (K since B1 of step n - 1, V^T just now)
+  //   B1  V^T(n) has landed; the pair's partial scores are in the exchange area
+  // A wave's requests complete in order: behind B0 it has K(n + 1) (4 pieces + the key-bias piece) in flight behind V^T(n) (4), behind B1
+  // V^T(n + 1) behind K(n + 1) -- which is what the two counted waits count.
+  auto kt_step_db = [&](int kt) __attribute__((always_inline)) {
+    const bool last_in_seg = kt + 1 == cT;
+    Tile nxt;
+    nxt.k = last_in_seg ? nseg_t.k : cur.k + 32768;
+    nxt.v = last_in_seg ? nseg_t.v : cur.v + 32768;
+    nxt.cb = last_in_seg ? nseg_t.cb : cur.cb + XA_KEYS;
+    nxt.rowb = cur.rowb;
+    nxt.vlane = cur.vlane;
+    nxt.cblane = last_in_seg ? nseg_t.cblane : cur.cblane;
+    const int slot = step & 1;
+    auto fill_k_full = [&](const Tile& t, int sl) __attribute__((always_inline)) {
+      if (XA_ABLATE & 1) return;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        unsigned kl = lane16;
+        const char* b = t.k + (wid + 8 * n) * 1024;
+        asm volatile("" : "+v"(kl), "+s"(b));
+        __builtin_amdgcn_global_load_lds((gptr_t)(b + kl), (lptr_t)(smem + KOFF + sl * 32768 + (wid + 8 * n) * 1024), 16, 0, 0);
+      }
+      unsigned cl = t.cblane;
+      asm volatile("" : "+v"(cl));
+      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(t.cb) + cl), (lptr_t)(smem + XA_CBOFF + sl * 256), 4, 0, 0);
+    };
+    auto fill_v_full = [&](const Tile& t, int sl) __attribute__((always_inline)) {
+      if (XA_ABLATE & 1) return;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        unsigned vl = lane16;
+        const char* b = t.v + (wid + 8 * n) * 1024;
+        asm volatile("" : "+v"(vl), "+s"(b));
+        __builtin_amdgcn_global_load_lds((gptr_t)(b + vl), (lptr_t)(smem + VOFF + sl * 32768 + (wid + 8 * n) * 1024), 16, 0, 0);
+      }
+    };
+    if (!primed) {   // (re)start of the pipeline
+      fill_k_full(cur, slot);
+      fill_v_full(cur, slot);
+      primed = true;
+    }
+    const char* kb = kf_a + slot * 32768;
+    const char* vb = vf_a + slot * 32768;
+    auto rd_k = [&](spx8 (&fr)[8], int t, int hf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fr[i] = XA_FRAG(kb + t * 16384 + (4 * hf + i) * 1024);
+    };
+    auto rd_v = [&](spx8 (&fr)[8], int qf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fr[i] = XA_FRAG(vb + (4 * qf + i) * 1024);
+    };
+    f32x4 s0 = f32x4{cqh, cqh, cqh, cqh}, s1 = s0;
+    XA_T(1);
+    XA_WAIT_VM_LGKM0(4);                 // K(n) landed (V^T(n)'s 4 pieces are younger)
+    __builtin_amdgcn_s_barrier();        // B0
+    XA_T(2);
+    rd_k(fa, 0, 0);
+    rd_k(fb, 0, 1);
+    fill_k_full(nxt, slot ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_k(fmt_long{}, s0, fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    rd_k(fa, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) {
+      mfma_k(fmt_long{}, s0, fb, 1);
+      *reinterpret_cast<f32x4*>(xch_mine) = s0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    rd_k(fb, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_k(fmt_long{}, s1, fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) {
+      mfma_k(fmt_long{}, s1, fb, 1);
+      *reinterpret_cast<f32x4*>(xch_mine + 1024) = s1;
+    }
+    XA_T(3);
+    XA_WAIT_VM_LGKM0(5);                 // V^T(n) landed (K(n + 1): 4 pieces + key bias are younger); partial scores written
+    __builtin_amdgcn_s_barrier();        // B1
+    XA_T(4);
+    rd_v(fa, 0);
+    fill_v_full(nxt, slot ^ 1);
+    if (in_seg && !(XA_ABLATE & 8)) softmax_tile(s0, s1, slot, online, cj, kt);
+    XA_T(10);
+    rd_v(fb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fmt_long{}, fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    XA_T(5);
+    rd_v(fa, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fmt_long{}, fb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    rd_v(fb, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fmt_long{}, fa, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    XA_T(7);
+    if (in_seg) mfma_v(fmt_long{}, fb, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+    ++step;
+    XA_T(9);
+  };
   // The segments [s0, s1) of the workgroup's list, all in the format `fc`.
   auto seg_loop = [&](auto fc, int s0, int s1) __attribute__((always_inline)) {
   for (int si = s0; si < s1; ++si) {
@@ -816,7 +919,8 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     // add up to S_raw + c_q (a + b = b + a: the same in both waves of the pair)
     cqh = cq_mine[l15 * 5 + cj];
     XA_T(11);
-    for (int kt = 0; kt < cT; ++kt) kt_step(fc, kt);
+    if constexpr (XA_DB && decltype(fc)::value == (XA_V16 | XA_K16)) { for (int kt = 0; kt < cT; ++kt) kt_step_db(kt); }
+    else { for (int kt = 0; kt < cT; ++kt) kt_step(fc, kt); }
     if (in_seg) {
       float wsum = xlane_sum(wl);
       if (online) {   // normalise the finished online memory in registers (all keys dead: 0 * inf = NaN)
@@ -891,7 +995,6 @@ struct XaFixArgs {
   long long slot[CFD_NMEM];    // floats per ring slot
   const int* d_step;
 };
-template <int CFD_KI = 0>
 __global__ void __launch_bounds__(256) att_fixup_kernel(const XaFixArgs a) {
   const int l = blockIdx.y;
   const XaAtt at = a.att[l];

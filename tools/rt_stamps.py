@@ -1,6 +1,5 @@
 """Developer tool (GPU box): time line of the row-tile launches of a captured step, from a -DRT_STAMP=1 build of the library:
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC -DRT_STAMP=1 -DCFD_SOURCE_HASH=\\"x\\" \\
-          convofusion_amd/csrc/cfd_api.hip -o tools/experiments/lib_rtstamp.so
+    python -m convofusion_amd.build -DRT_STAMP=1 -o tools/experiments/lib_rtstamp.so
     CFD_LIB=$PWD/tools/experiments/lib_rtstamp.so python tools/rt_stamps.py
 Workgroup (0, 0) of every launch records s_memrealtime (100 MHz) at entry, when its operands have arrived and at exit."""
 import ctypes as C

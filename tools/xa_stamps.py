@@ -1,5 +1,6 @@
 """Developer tool (GPU box): per-section cycle breakdown of xattn_fused_kernel from an XA_STAMP build
-(CFD_LIB=tools/experiments/lib_xastamp.so python tools/xa_stamps.py)."""
+(python -m convofusion_amd.build -DXA_STAMP=1 -o tools/experiments/lib_xastamp.so;
+CFD_LIB=$PWD/tools/experiments/lib_xastamp.so python tools/xa_stamps.py)."""
 import ctypes as C
 import os
 import sys
