@@ -391,7 +391,7 @@ def gpu_state(device):
     both ends of the timed region, so that a +-3 % difference between two boxes of the pool -- or a power-capped box -- can be told from a
     regression.  Read OUTSIDE the timed region."""
     st = {}
-    for key, fn, scale in (("sclk_mhz", torch.cuda.clock_rate, 1.0), ("power_w", torch.cuda.power_draw, 1e-3), ("temperature_c", torch.cuda.temperature, 1.0)):
+    for key, fn, scale in (("sclk_mhz", torch.cuda.clock_rate, 1.0), ("power_w", torch.cuda.power_draw, 1.0), ("temperature_c", torch.cuda.temperature, 1.0)):
         try:
             st[key] = round(float(fn(device)) * scale, 1)
         except Exception:      # noqa: BLE001  (no amdsmi, no permission: the measurement goes on without the reading)

@@ -130,7 +130,9 @@ def roofline():
         k = (r["Kernel_Name"], int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]))
         acc[k][0] += 1
         acc[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
-    n_iter = sum(v[0] for k, v in acc.items() if k[0].startswith("cfg_step_kernel"))
+    def bare(name):       # (since round 6 every kernel is a template instance: rocprofv3 prints "void name<0>(...)")
+        return name[5:] if name.startswith("void ") else name
+    n_iter = sum(v[0] for k, v in acc.items() if bare(k[0]).startswith("cfg_step_kernel"))
     n_fwd = n_iter + 1
     busy, traffic = {}, {}
     p = os.path.join(OUT, f"{tag}_mfma_busy.csv")
@@ -141,6 +143,7 @@ def roofline():
         traffic = {(r["kernel"], int(r["grid_threads"])): (float(r["read_MB_per_launch_(2xFETCH)"]), float(r["write_MB_per_launch_(WRITE_SIZE)"])) for r in csv.DictReader(open(p))}
 
     def cls(name):
+        name = bare(name)
         if "gemm_sp_kernel" in name:
             return "gemm_mem" if ("EpiMemK" in name or "EpiMemV" in name) else "gemm_token"
         if "xattn_fused_kernel" in name:
