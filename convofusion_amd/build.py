@@ -61,7 +61,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
         src = os.path.join(CSRC, srcname)
         # (cfd_core.hip carries the source hash: it is recompiled whenever any source changed)
         fresh = os.path.exists(obj) and os.path.getmtime(obj) > max(newest_header, os.path.getmtime(src)) and srcname != "cfd_core.hip"
-        if fresh and not extra_flags:
+        if fresh and not extra_flags and not force:      # (force: every unit is recompiled -- the driver's "does it build" check)
             return obj
         cmd = [hipcc, *FLAGS, *extra_flags, define, "-c", src, "-o", obj]
         if verbose:
