@@ -591,6 +591,7 @@ def test_the_cross_attention_block_is_float32_exact_on_the_ill_conditioned_chunk
 
     lib = _lib.load()
     hip = {}
+    m.engine("cuda", mem_len=max(S))      # (the handle exists from the first forward on; the taps are set on it before that)
     try:
         for stage, key in ((3 + 4 * layer, "in"), (4 + 4 * layer, "out")):
             _lib.check(lib.cfd_debug_stop_stage(m._handle, stage))
