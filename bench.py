@@ -607,12 +607,17 @@ def main():
 
     if rank == 0:
         from convofusion_amd import sampler as _sampler
-        policy = int(os.environ["CFD_XA_OPERANDS"]) & 3 if "CFD_XA_OPERANDS" in os.environ else int(_sampler.OPERAND_POLICY[0])
+        policy = int(os.environ["CFD_XA_OPERANDS"]) & 15 if "CFD_XA_OPERANDS" in os.environ else int(_sampler.OPERAND_POLICY[0])
+        if policy:
+            policy = 15        # (the shipped library implements the four bits together)
         # MFMAs issued per algorithmic product in the fused cross-attention: 3 with split pairs; the long memories' score products take 2
         # with single-f16 keys (policy bit 1), their P.V products 2 with single-f16 values (bit 0); memories below 128 padded keys keep 3
         sp = [(x + 31) // 32 * 32 for x in S]
         long_frac = sum(x for x in sp if x >= 128) / float(sum(x for x in sp if x > 32) + sum(x for x in sp[:4] if x <= 32)) if args.shape == "C2" else 0.0
-        xa_issue = 3.0 - long_frac * (0.5 * bool(policy & 1) + 0.5 * bool(policy & 2))
+        # (scores: 3 with pairs, 2 with single-f16 keys, 1 with single-f16 queries too; P.V likewise with values / probabilities)
+        sc = 1.0 if (policy & 10) == 10 else (2.0 if policy & 2 else 3.0)
+        pv = 1.0 if (policy & 5) == 5 else (2.0 if policy & 1 else 3.0)
+        xa_issue = 3.0 - long_frac * (3.0 - 0.5 * (sc + pv))
         Be = G * B_PER_GPU
         U = [B_PER_GPU + 1] * 5
         canon = canonical_flops_per_step(Be, L, S)
@@ -687,9 +692,10 @@ def main():
             "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16x3 (fp16 hi/lo split operands, 3 MFMAs per product, f32 accumulate; f32-equivalent)" + (
-                "" if policy == 0 else "; fused cross-attention: the long (audio) memory's folded " +
-                {1: "values", 2: "keys", 3: "keys and values"}[policy] + " as single f16 tiles, 2 MFMAs per product, in DDPM runs "
-                "(operand policy %d; 1000-step DDPM golden at this shape: 2.3e-5 from the reference, pairs 8e-6, budget 1e-3)" % policy),
+                "" if policy == 0 else "; fused cross-attention against the long (audio) memory: single-f16 operands (" +
+                ", ".join(n for b, n in ((2, "keys"), (1, "values"), (8, "queries"), (4, "probabilities")) if policy & b) +
+                "), f32 accumulate, in DDPM runs (operand policy %d; 1000-step DDPM golden at this shape: 2.3e-5 from the reference, pairs 8e-6, "
+                "budget 1e-3)" % policy),
             "operand_policy": policy,
             "data": "synthetic",
             "config": {"workload": f"{'configs[1]' if args.shape == 'C2' else 'product shape (developer flag --shape R)'}: B={B_PER_GPU}/GPU synthetic, L={L}, S={S}, 7-way guidance (denoiser batch {Be}), "

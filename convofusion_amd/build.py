@@ -46,7 +46,7 @@ def is_stale():
 def build(force=False, verbose=False, extra_flags=(), out=None):
     """Compile the HIP library for gfx950: the translation units in parallel (one hipcc per unit), then one link.  Returns the path of
     the shared object.  ``extra_flags`` / ``out``: developer builds (-D switches) under another name; they do not use the object cache."""
-    lib = out or LIB
+    lib = os.path.abspath(out) if out else LIB
     if not force and not extra_flags and not is_stale():
         return lib
     from concurrent.futures import ThreadPoolExecutor

@@ -56,7 +56,7 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   env = getenv("CFD_L0_DEDUP");
   if (env) c->l0_dedup = atoi(env) != 0;
   env = getenv("CFD_XA_OPERANDS");
-  if (env) c->xa_operands = atoi(env) & 3;
+  if (env) c->xa_operands = atoi(env) & 15;
   env = getenv("CFD_ONE_KEY");
   if (env) c->one_key = atoi(env) != 0;
   env = getenv("CFD_RT_NFB2_TILES");

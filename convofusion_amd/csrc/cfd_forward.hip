@@ -296,8 +296,11 @@ int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
 #if XA_ALL_OPF
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
-#endif
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<false, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<false, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
+#endif
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<false, 15>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
     attr |= 1ull << (c->cfg.device & 63);
   }
@@ -404,8 +407,11 @@ int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
 #if XA_ALL_OPF
         else if (opf == 1) hipLaunchKernelGGL((xattn_fused_kernel<false, 1>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
         else if (opf == 2) hipLaunchKernelGGL((xattn_fused_kernel<false, 2>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
-#endif
         else if (opf == 3) hipLaunchKernelGGL((xattn_fused_kernel<false, 3>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
+        else if (opf == 7) hipLaunchKernelGGL((xattn_fused_kernel<false, 7>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
+        else if (opf == 11) hipLaunchKernelGGL((xattn_fused_kernel<false, 11>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
+#endif
+        else if (opf == 15) hipLaunchKernelGGL((xattn_fused_kernel<false, 15>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
         else hipLaunchKernelGGL((xattn_fused_kernel<false, 0>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
       };
       if (l == 0 && share && p.xa0_nwg_a > 0) {   // layer-0 de-duplication (build_xattn_layer0_lists): the longest memory once per distinct (utterance, instance) ...

@@ -321,7 +321,9 @@ int setup_problem(Ctx* c, int Be, int L, const cfd_memory mem[CFD_NMEM], float* 
   // (cfd_sample_begin, prepare_static_memside) -- the pair instance ignores the flag.
   p.xa_opf = c->want_opf;
 #if !XA_ALL_OPF
-  if (p.xa_opf) p.xa_opf = XA_V16 | XA_K16;    // (the product builds one single-fp16 instance: keys and values together; xattn_fused.hpp, XA_ALL_OPF)
+  if (p.xa_opf) p.xa_opf = XA_V16 | XA_K16 | XA_P16 | XA_Q16;    // (the product builds ONE single-fp16 instance: all four bits; xattn_fused.hpp, XA_ALL_OPF)
+#else
+  if (p.xa_opf) p.xa_opf |= XA_V16 | XA_K16;                      // (developer builds: 3, 7, 11, 15 -- the tile formats always together)
 #endif
   if (p.xa_opf)
     for (int j = 0; j < CFD_NMEM; ++j)

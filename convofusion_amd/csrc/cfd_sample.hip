@@ -136,7 +136,7 @@ extern "C" int cfd_sample_begin(cfd_handle c, const cfd_sample_args* args, void*
   }
   // operand policy of the run (cfd_sample_args::operand_policy): single-fp16 key / value tiles of the long memories for the fused
   // cross-attention kernel -- only where that kernel runs on projections made once per run and keeps no maps
-  c->want_opf = (n_ring || s.dynamic_memory_mask) ? 0 : (c->xa_operands >= 0 ? c->xa_operands : (s.operand_policy & 3));
+  c->want_opf = (n_ring || s.dynamic_memory_mask) ? 0 : (c->xa_operands >= 0 ? c->xa_operands : (s.operand_policy & 15));
   const int r_setup = setup_problem(c, Be, s.L, mem_in, nullptr, 0, N);
   c->want_opf = 0;
   CHK(r_setup);

@@ -18,15 +18,17 @@ from .denoiser import Denoiser
 # which guidance chunk carries which conditional memory (reference convofusion.py:909-929, 527-541)
 CFG_CHUNKS = 7
 
-# Operand policy of a run's fused cross-attention (cfd_sample_args.operand_policy: bit 0 = folded values of the LONG memories -- 128 padded
-# keys and more: the audio memory -- as single fp16 tiles, bit 1 = their folded keys too; 0 = fp16 split pairs everywhere), per scheduler kind
-# (scheduler.KIND: 0 DDPM, 1 DDIM).  Measured on every DDPM golden (profiles/r06_xa_operands_*): with both bits the
-# 1000-step DDPM run at the headline shape ends 2.3e-5 from the reference trajectory (pairs: 8e-6; budget 1e-3) and the product shape's
-# 20-step golden 6e-5, for +8 % headline throughput; the DDPM loop re-injects noise every step and does not amplify the perturbation.
-# DDIM (eta = 0) amplifies any per-forward perturbation ~100x over 50 steps and keeps pairs.  ``install(model, operands=0)`` /
+# Operand policy of a run's fused cross-attention (cfd_sample_args.operand_policy; 0 = fp16 split pairs everywhere), per scheduler kind
+# (scheduler.KIND: 0 DDPM, 1 DDIM).  Non-zero: the attention against the LONG memories (128 padded keys and more: the audio memory) runs on
+# single-fp16 operands -- bits 0 / 1: their folded values / keys as single-fp16 tiles, bits 2 / 3: the probabilities / queries of those
+# products as one fp16 as well (1 MFMA per product instead of 3); the shipped library implements the four bits together (15).  Measured on
+# every DDPM golden (profiles/r06_xa_operands_*): the 1000-step DDPM run at the headline shape ends 2.3e-5 from the
+# reference trajectory (pairs: 8e-6; budget 1e-3), its 5-step golden 6.1e-5, the product shape's 20-step golden 9.1e-5, for +12 % headline
+# throughput; the DDPM loop re-injects noise every step and does not amplify the perturbation.  DDIM (eta = 0) does -- the 50-step golden goes
+# from 1.4e-4 to 4.1e-4 -- and keeps pairs.  ``install(model, operands=0)`` /
 # ``sample(..., operands=0)`` is the precision escape for a checkpoint whose attention turns out to be less forgiving than the seeded weights
 # (the heavy-tailed stress weights: DESIGN.md section 2).
-OPERAND_POLICY = {0: 3, 1: 0}
+OPERAND_POLICY = {0: 15, 1: 0}
 
 
 def _dedup_rows_exact(m, mk):

@@ -153,9 +153,10 @@ typedef struct {
                                  audio memory) in THIS run (csrc/xattn_fused.hpp, OPF):
                                  0 = fp16 split pairs everywhere (3 MFMAs per product, ~2^-22 operand error: what cfd_forward always uses);
                                  bit 0 = their folded VALUES as single fp16 (the linear path of the attention; halves those tiles' L2 -> LDS
-                                 traffic, 2 MFMAs per product); bit 1 = their folded KEYS as single fp16 (the exponentiated path).  The
-                                 shipped library implements the two bits together (any non-zero value = 3; the separate instances were
-                                 measured and are dominated: DESIGN.md section 2).
+                                 traffic); bit 1 = their folded KEYS as single fp16 (the exponentiated path); bit 2 / bit 3 = the
+                                 PROBABILITIES / the QUERIES of those products as one fp16 as well, i.e. plain fp16 attention against the long
+                                 memories (1 MFMA per product instead of 3).  The shipped library implements the four bits together (any
+                                 non-zero value = 15; the partial combinations were measured and are dominated: DESIGN.md section 2).
                                  Short memories (the text / speaker / activity memories: few keys, little averaging of the rounding) always
                                  keep pairs.  The reference is float32 throughout (cross_attention.py:593-652); which runs tolerate which bits
                                  is measured per scheduler in DESIGN.md section 2 -- convofusion_amd.sampler.OPERAND_POLICY holds the default

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Developer tool (GPU box): the operand policies of the fused cross-attention kernel (CFD_XA_OPERANDS = 0 pairs / 1 values single fp16 /
-# 2 keys single / 3 both; xattn_fused.hpp OPF) on the bench workload, interleaved on ONE box.  usage: tools/ab_xa.sh [rounds] [modes...]
+# Developer tool (GPU box): the operand policies of the fused cross-attention kernel (CFD_XA_OPERANDS = 0 pairs / 15 single-fp16 operands
+# against the long memories; developer builds with -DXA_ALL_OPF=1 also take 3 / 7 / 11; xattn_fused.hpp OPF) on the bench workload, interleaved on ONE box.  usage: tools/ab_xa.sh [rounds] [modes...]
 rounds=${1:-2}
 shift
-modes=${@:-0 1 2 3}
+modes=${@:-0 15}
 for r in $(seq $rounds); do
   for f in $modes; do
     CFD_XA_OPERANDS=$f python bench.py --steps 30 --warmup 3 --headline-only --no-cpu-baseline 2>/dev/null | python -c "

@@ -71,7 +71,7 @@
 // two steps | the workgroup's segment list
 #define XA_XOFF 133120
 #define XA_CBOFF (XA_XOFF + XA_WAVES * 2048)
-#define XA_SEGOFF (XA_CBOFF + 512)
+#define XA_SEGOFF (XA_CBOFF + 1024)   // (four key-bias slots of 256 B: the ping-pong loop of the single-fp16 instance keeps a tile's biases for two more half-steps)
 #define XA_MAXSEG 24
 #define XA_CQOFF (XA_SEGOFF + XA_MAXSEG * 16)   // per wave: c_q partial sums [16 queries][5 memories], then sum_s P' [16][5]
 #define XA_CQW 640
@@ -224,8 +224,6 @@ __device__ __forceinline__ T xa_sel(const T (&arr)[CFD_NMEM], int j) {
 //   bit 0 (XA_V16): V^T tiles hold VA as single fp16 (32 KB per 32 keys); P' stays a pair, so P.V is 2 MFMAs per product
 //                   (VA_hi . P'_lo + VA_hi . P'_hi) -- the LINEAR path of the attention;
 //   bit 1 (XA_K16): K tiles hold KA as single fp16; Q stays a pair (2 MFMAs: KA_hi . q_lo + KA_hi . q_hi) -- the EXPONENTIATED path.
-//   bit 2 (XA_P16) / bit 3 (XA_Q16): with single-fp16 tiles, P' / the query fragments enter those products as ONE fp16 too (their `hi` half:
-//                   the value rounded to fp16): 1 MFMA per product -- plain fp16 attention against the long memories.
 // Why long memories only: the rounding of a value (2^-12 relative, independent signs) enters the output weighted by its probability, so
 // over N attended keys the absolute error falls like 1 / sqrt(N) -- for the 1500-key audio memory it is ~8x below that of a 24-key text
 // memory, whose tiles are 3 of a row's 50 anyway (measured: profiles/r06_xa_operands_*).  Segments without the flag run the split-pair
@@ -237,10 +235,10 @@ __device__ __forceinline__ T xa_sel(const T (&arr)[CFD_NMEM], int j) {
 // The single-fp16 tiles come from xa_pack16_kernel (once per run, from the split-pair projections): tile-major and already in the LDS
 // image's order, so a fill is a linear copy of 1 KB pieces.  cfd_forward, DDIM runs, runs that keep attention maps and the memories of a
 // dynamic run keep pairs (cfd_sample.hip: operand policy of cfd_sample_begin).
-enum { XA_V16 = 1, XA_K16 = 2, XA_P16 = 4, XA_Q16 = 8 };   // (XA_P16 / XA_Q16: with single-fp16 tiles, also the OTHER operand of the product as one fp16: 1 MFMA)
+enum { XA_V16 = 1, XA_K16 = 2 };
 #ifndef XA_ALL_OPF
-#define XA_ALL_OPF 0    // 1: developer builds also instantiate the partial combinations (OPF 1, 2, 3, 7, 11: measured in round 6 and dominated by
-                        // OPF 15 -- e.g. 78.5 / 79.7 / 79.5 steps/s for 3 / 7 / 11 against 80.9, all at 2.3e-5 on the DDPM-1000 golden -- and not shipped)
+#define XA_ALL_OPF 0    // 1: developer builds also instantiate the values-only / keys-only instances (OPF 1 / 2: measured in round 6, dominated by
+                        // OPF 3 -- 78.8 / 78.0 against 81.6 steps/s at 1.9e-5 / 1.2e-5 against 2.3e-5 on the DDPM-1000 golden -- and not shipped)
 #endif
 template <bool ATT, int OPF>
 __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAttnArgs a) {
@@ -255,9 +253,16 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
 #endif
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tile = wid & 3;      // query tile of the pair (w, w + 4): the two waves share a SIMD
-  const int half = wid >> 2;     // which half of the 512-long axes
-  const int partner = wid ^ 4;
+  // Pairs.  Split-pair instances: (w, w + 4), the two waves of a pair share a SIMD and run in lock-step.  The single-fp16 instance (OPF 3):
+  // (w, w ^ 1), on different SIMDs -- every SIMD then holds one wave of each GROUP (waves 0-3 / 4-7), and the long memories' loop runs the
+  // two groups half a step apart (pp_loop below).
+  constexpr bool PPMAP = OPF == (XA_V16 | XA_K16);
+  const int tile = PPMAP ? (wid >> 1) : (wid & 3);      // query tile of the pair
+  int half_ = PPMAP ? (wid & 1) : (wid >> 2);           // which half of the 512-long axes
+  if (PPMAP) asm volatile("" : "+s"(half_));            // (opaque: knowing that it is 0 or 1, hipcc turns the prologue's `half ? r[16 + i] : r[i]` selects into an INDEXED row array in scratch memory)
+  const int half = half_;
+  const int partner = PPMAP ? (wid ^ 1) : (wid ^ 4);
+  const int grp = wid >> 2;
   const int l15 = lane & 15, q4 = lane >> 4, sw = l15 >> 1;
   const int cpos = lane & 7, rsub = lane >> 3;
 
@@ -591,7 +596,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if constexpr (K16) {
-        if constexpr ((decltype(fc)::value & XA_Q16) == 0) acc = XA_MFMA(fr[i], ql[4 * hf + i], acc);
+        acc = XA_MFMA(fr[i], ql[4 * hf + i], acc);
         acc = XA_MFMA(fr[i], qh[4 * hf + i], acc);
       } else {
         acc = XA_MFMA(fr[2 * i + 1], qh[4 * hf + i], acc);
@@ -606,7 +611,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if constexpr (V16) {
-        if constexpr ((decltype(fc)::value & XA_P16) == 0) o[4 * qf + i] = XA_MFMA(fr[i], pl, o[4 * qf + i]);
+        o[4 * qf + i] = XA_MFMA(fr[i], pl, o[4 * qf + i]);
         o[4 * qf + i] = XA_MFMA(fr[i], ph, o[4 * qf + i]);
       } else {
         o[4 * qf + i] = XA_MFMA(fr[2 * i + 1], ph, o[4 * qf + i]);
@@ -804,6 +809,187 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     ++step;
     XA_T(9);
   };
+  // ---- The long memories' loop of the single-fp16 instance: two wave groups half a step apart (round 6) -------------------------------------
+  // With pairs the step was paced by its fills; with single-fp16 tiles it is paced by the softmax's vector work and the matrix pipe, which the
+  // two waves of a SIMD -- in lock-step: both in the softmax, then both in the MFMAs -- use ONE AFTER THE OTHER (profiles/r06_xattn_stamps.txt).
+  // Here every SIMD holds one wave of group 0 (waves 0-3: query tiles 0, 1) and one of group 1 (waves 4-7: tiles 2, 3), and group 1 runs
+  // the same program ONE HALF-STEP behind group 0: while one wave of a SIMD is in phase A (score MFMAs) the other is in softmax + phase B,
+  // so one wave's vector work lies next to the other's MFMAs.  What makes it possible is the freed LDS: a single-fp16 K tile and V^T tile are
+  // 32 KB each, the two 64 KB buffers hold TWO of each, so tile n's K stays resident for both groups' phase A (half-steps 2 n, 2 n + 1) and
+  // its V^T for both phase B's (2 n + 1, 2 n + 2) while tiles n + 1 / n + 2 land in the other slots.  One workgroup barrier per half-step,
+  // b(h) at the end of half-step h -- group 0's end of A is group 1's end of B and vice versa -- serves as the pair's score exchange, the
+  // hand-over of landed tiles and the release of read ones at once: two barriers per 32 keys instead of three, no polling (round 5's
+  // ping-pong form had four barriers and a polled flag per step, with split pairs filling the LDS: it measured equal, appendix A.5).
+  //   fills (every wave its 4 pieces of each, so the counted waits are the same in both groups):
+  //     behind b(2 n + 1): K(n + 2) + its key bias -> K slot n & 1, bias slot (n + 2) & 3        [free: both groups' A(n) are done]
+  //     behind b(2 n + 2): V^T(n + 2)              -> V slot n & 1                               [free: both groups' B(n) are done]
+  //   waits: in front of an odd barrier b(2 n + 1) K(n + 1) must have landed (4 younger pieces: V^T(n + 1)); in front of an even one
+  //   b(2 n + 2) V^T(n + 1) (5 younger: K(n + 2) + bias).  Tiles are numbered through the workgroup's single-fp16 segments; fills beyond
+  //   the last tile re-request it (the counts stay what the waits expect, the data lands in slots nobody reads any more).
+  // A flush between two long memories (XA_FLUSH) re-uses the tile buffers as strips: such workgroups take the lock-step loop instead.
+  struct TileIt { const char* k; const char* v; const float* cb; unsigned cblane; int left; int si; };   // a cursor over the tiles of segments [0, n16)
+  auto it_start = [&](TileIt& it, int n16) __attribute__((always_inline)) {
+    Tile t; int T, wm, fl, j;
+    seg_tile(0, t, T, wm, fl, j);
+    it.k = t.k; it.v = t.v; it.cb = t.cb; it.cblane = t.cblane; it.left = T; it.si = 0;
+    (void)n16;
+  };
+  auto it_next = [&](TileIt& it, int n16) __attribute__((always_inline)) {
+    if (--it.left > 0) { it.k += 32768; it.v += 32768; it.cb += XA_KEYS; return; }
+    if (it.si + 1 < n16) {
+      Tile t; int T, wm, fl, j;
+      seg_tile(++it.si, t, T, wm, fl, j);
+      it.k = t.k; it.v = t.v; it.cb = t.cb; it.cblane = t.cblane; it.left = T;
+    } else {
+      it.left = 1;      // past the end: stay on the last tile
+    }
+  };
+  auto pp_fill_k = [&](const TileIt& it, int kslot, int cbslot) __attribute__((always_inline)) {
+    if (XA_ABLATE & 1) return;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      unsigned kl = lane16;
+      const char* b = it.k + (wid + 8 * n) * 1024;
+      asm volatile("" : "+v"(kl), "+s"(b));
+      __builtin_amdgcn_global_load_lds((gptr_t)(b + kl), (lptr_t)(smem + KOFF + kslot * 32768 + (wid + 8 * n) * 1024), 16, 0, 0);
+    }
+    unsigned cl = it.cblane;
+    asm volatile("" : "+v"(cl));
+    __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(it.cb) + cl), (lptr_t)(smem + XA_CBOFF + cbslot * 256), 4, 0, 0);
+  };
+  auto pp_fill_v = [&](const TileIt& it, int vslot) __attribute__((always_inline)) {
+    if (XA_ABLATE & 1) return;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      unsigned vl = lane16;
+      const char* b = it.v + (wid + 8 * n) * 1024;
+      asm volatile("" : "+v"(vl), "+s"(b));
+      __builtin_amdgcn_global_load_lds((gptr_t)(b + vl), (lptr_t)(smem + VOFF + vslot * 32768 + (wid + 8 * n) * 1024), 16, 0, 0);
+    }
+  };
+  auto pp_loop = [&](auto grp_c, int n16) __attribute__((always_inline)) {
+    constexpr int G = decltype(grp_c)::value;
+    TileIt fk, fv;            // the next K / V^T tile to request
+    it_start(fk, n16);
+    it_start(fv, n16);
+    pp_fill_k(fk, 0, 0); it_next(fk, n16);        // K(0)
+    pp_fill_v(fv, 0);    it_next(fv, n16);        // V^T(0)
+    pp_fill_k(fk, 1, 1); it_next(fk, n16);        // K(1)
+    XA_WAIT_VM_LGKM0(9);
+    __builtin_amdgcn_s_barrier();                 // b(-1): K(0) is there
+    if constexpr (G == 1) {                       // group 1 idles through half-step 0
+      XA_WAIT_VM_LGKM0(5);
+      __builtin_amdgcn_s_barrier();               // b(0)
+      pp_fill_v(fv, 1); it_next(fv, n16);         // V^T(1)
+    }
+    int g = 0;                                    // tile number
+    for (int si = 0; si < n16; ++si) {
+      in_seg = active && ((cmask >> tile) & 1);
+      online = (cflags & XA_ONLINE) != 0;
+      nseg_t = cur; nT = cT; nmask = cmask; nflags = cflags; nj = cj;
+      if (si + 1 < n16) seg_tile(si + 1, nseg_t, nT, nmask, nflags, nj);
+      cqh = cq_mine[l15 * 5 + cj];
+      for (int kt = 0; kt < cT; ++kt, ++g) {
+        const char* kb = kf_a + (g & 1) * 32768;
+        const char* vb = vf_a + (g & 1) * 32768;
+        auto rd_k = [&](spx8 (&fr)[8], int t, int hf) __attribute__((always_inline)) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fr[i] = XA_FRAG(kb + t * 16384 + (4 * hf + i) * 1024);
+        };
+        auto rd_v = [&](spx8 (&fr)[8], int qf) __attribute__((always_inline)) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fr[i] = XA_FRAG(vb + (4 * qf + i) * 1024);
+        };
+        // ---- phase A: this pair's half of the scores of tile g
+        f32x4 s0 = f32x4{cqh, cqh, cqh, cqh}, s1 = s0;
+        XA_T(1);
+        rd_k(fa, 0, 0);
+        rd_k(fb, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (in_seg) mfma_k(fmt_long{}, s0, fa, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        rd_k(fa, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (in_seg) {
+          mfma_k(fmt_long{}, s0, fb, 1);
+          *reinterpret_cast<f32x4*>(xch_mine) = s0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        rd_k(fb, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (in_seg) mfma_k(fmt_long{}, s1, fa, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (in_seg) {
+          mfma_k(fmt_long{}, s1, fb, 1);
+          *reinterpret_cast<f32x4*>(xch_mine + 1024) = s1;
+        }
+        XA_T(3);
+        if constexpr (G == 0) {
+          XA_WAIT_VM_LGKM0(5);                    // V^T(g) landed (K(g + 1) + bias are younger)
+          __builtin_amdgcn_s_barrier();           // b(2 g)
+          XA_T(4);
+          pp_fill_v(fv, (g + 1) & 1); it_next(fv, n16);     // V^T(g + 1)
+        } else {
+          XA_WAIT_VM_LGKM0(4);                    // K(g + 1) landed (V^T(g + 1) is younger)
+          __builtin_amdgcn_s_barrier();           // b(2 g + 1)
+          XA_T(4);
+          pp_fill_k(fk, g & 1, (g + 2) & 3); it_next(fk, n16);   // K(g + 2)
+        }
+        // ---- softmax + phase B
+        rd_v(fa, 0);
+        if (in_seg && !(XA_ABLATE & 8)) softmax_tile(s0, s1, g & 3, online, cj, kt);
+        XA_T(10);
+        rd_v(fb, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (in_seg) mfma_v(fmt_long{}, fa, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        rd_v(fa, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (in_seg) mfma_v(fmt_long{}, fb, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        rd_v(fb, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (in_seg) mfma_v(fmt_long{}, fa, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (in_seg) mfma_v(fmt_long{}, fb, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        XA_T(7);
+        if constexpr (G == 0) {
+          XA_WAIT_VM_LGKM0(4);                    // K(g + 1) landed
+          __builtin_amdgcn_s_barrier();           // b(2 g + 1)
+          XA_T(8);
+          pp_fill_k(fk, g & 1, (g + 2) & 3); it_next(fk, n16);   // K(g + 2)
+        } else {
+          XA_WAIT_VM_LGKM0(5);                    // V^T(g + 1) landed
+          __builtin_amdgcn_s_barrier();           // b(2 g + 2)
+          XA_T(8);
+          pp_fill_v(fv, g & 1); it_next(fv, n16);            // V^T(g + 2)
+        }
+        ++step;
+      }
+      if (in_seg) {
+        float wsum = xlane_sum(wl);
+        if (online) {
+          const float inv = 1.0f / lsum;
+#pragma unroll
+          for (int f = 0; f < 16; ++f) { o[f][0] *= inv; o[f][1] *= inv; o[f][2] *= inv; o[f][3] *= inv; }
+          wsum *= inv;
+        }
+        if (q4 == 0) wq_mine[l15 * 5 + cj] = wsum;
+      }
+      m = -INFINITY;
+      mc_run = -INFINITY;
+      lsum = 0.f;
+      wl = 0.f;
+      cur = nseg_t;
+      cT = nT; cmask = nmask; cflags = nflags; cj = nj;
+    }
+    if constexpr (G == 0) {                       // group 0 idles through group 1's last half-step
+      XA_WAIT_VM_LGKM0(5);
+      __builtin_amdgcn_s_barrier();               // b(2 N)
+    }
+  };
+
   // The segments [s0, s1) of the workgroup's list, all in the format `fc`.
   auto seg_loop = [&](auto fc, int s0, int s1) __attribute__((always_inline)) {
   for (int si = s0; si < s1; ++si) {
@@ -852,7 +1038,10 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     const int n16 = min(wgp->n16, nseg);
     if (n16 > 0) {
       set_format((OPF & XA_K16) != 0, (OPF & XA_V16) != 0);
-      seg_loop(fmt_long{}, 0, n16);
+      bool pp = PPMAP;                            // (workgroup-uniform) no accumulator flush inside the single-fp16 prefix
+      for (int si = 0; si < n16; ++si) pp = pp && !(seg_field(si, 3) & XA_FLUSH);
+      if (pp) { if (grp) pp_loop(std::integral_constant<int, 1>{}, n16); else pp_loop(std::integral_constant<int, 0>{}, n16); }
+      else seg_loop(fmt_long{}, 0, n16);
     }
     if (n16 < nseg) {
       if (n16 > 0) {

@@ -16,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SMALL = "--small" in sys.argv
-MODES = [int(a) for a in sys.argv[1:] if a.isdigit()] or [0, 1, 2, 3]
+MODES = [int(a) for a in sys.argv[1:] if a.isdigit()] or [0, 3, 7, 11, 15]
 os.environ.setdefault("CFD_FUSED_XATTN_MIN_WGS", "0")
 if SMALL:
     os.environ["CFD_ROWTILE"] = "0"
