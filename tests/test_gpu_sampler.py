@@ -47,6 +47,8 @@ def test_sampler_matches_reference_trajectory(name):
     print(name, {k: f"{v:.2e}" for k, v in errs.items()})
     assert np.isfinite(lat).all()
     assert all(v < TRAJ_TOL for v in errs.values()), errs
+    if kind == "ddpm":      # (the operand policy's adoption gate; these small goldens mostly take the row-tile path, which has no policy)
+        assert all(v < 3e-4 for v in errs.values()), errs
 
 
 @pytest.mark.parametrize("B", [1, 3])
@@ -381,6 +383,10 @@ def test_headline_shape_loop_row_matches_reference(kind, variant):
     errs["final"] = rel_l2(lat[row], g["latents"][:, 0])
     print(kind, variant, {k: f"{v:.2e}" for k, v in errs.items()})
     assert np.isfinite(lat).all() and all(v < TRAJ_TOL for v in errs.values()), errs
+    if "ddpm" in kind:
+        # the adoption gate of the DDPM runs' operand policy (sampler.OPERAND_POLICY): every DDPM golden within 3e-4
+        # (measured 2.3e-5 - 6.1e-5 here with single-fp16 attention against the audio memory; 0.8e-5 - 2.0e-5 with split pairs)
+        assert all(v < 3e-4 for v in errs.values()), errs
 
 
 def test_small_goldens_on_the_default_attention_path():
