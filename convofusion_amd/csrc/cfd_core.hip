@@ -57,6 +57,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   if (env) c->l0_dedup = atoi(env) != 0;
   env = getenv("CFD_XA_OPERANDS");
   if (env) c->xa_operands = atoi(env) & 15;
+  env = getenv("CFD_XA_DB");
+  if (env) c->xa_db = atoi(env) != 0;
   env = getenv("CFD_ONE_KEY");
   if (env) c->one_key = atoi(env) != 0;
   env = getenv("CFD_RT_NFB2_TILES");

@@ -402,6 +402,8 @@ int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       Bracket br(c, CFD_PROF_XATTN, st);
       if (p.att_fused) a.att = c->w->xa_att_desc.as<XaAtt>() + l;
       const int opf = p.att_fused ? 0 : p.xa_opf;
+      const bool xa_db = XA_ALL_OPF ? c->xa_db != 0 : true;   // (developer builds: CFD_XA_DB=0 puts OPF 15 back on the three-barrier step)
+      (void)xa_db;
       auto launch_xa = [&](int nwg, const XAttnArgs& xa) {
         if (p.att_fused) hipLaunchKernelGGL((xattn_fused_kernel<true, 0>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
 #if XA_ALL_OPF
@@ -410,8 +412,9 @@ int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
         else if (opf == 3) hipLaunchKernelGGL((xattn_fused_kernel<false, 3>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
         else if (opf == 7) hipLaunchKernelGGL((xattn_fused_kernel<false, 7>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
         else if (opf == 11) hipLaunchKernelGGL((xattn_fused_kernel<false, 11>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
+        else if (opf == 15 && !xa_db) hipLaunchKernelGGL((xattn_fused_kernel<false, 15>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
 #endif
-        else if (opf == 15) hipLaunchKernelGGL((xattn_fused_kernel<false, 15>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
+        else if (opf == 15) hipLaunchKernelGGL((xattn_fused_kernel<false, 15 | XA_DBUF>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
         else hipLaunchKernelGGL((xattn_fused_kernel<false, 0>), dim3(nwg), dim3(XA_WAVES * 64), XA_LDS, st, xa);
       };
       if (l == 0 && share && p.xa0_nwg_a > 0) {   // layer-0 de-duplication (build_xattn_layer0_lists): the longest memory once per distinct (utterance, instance) ...

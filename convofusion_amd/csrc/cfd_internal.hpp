@@ -206,6 +206,7 @@ struct cfd_handle_s {
   int one_key = 1;              // CFD_ONE_KEY=0: a one-key memory (lsnemb) keeps its 32-key tile step in the fused cross-attention
   int want_opf = 0;             // cfd_sample_begin -> setup_problem: the operand policy the run asks for (0 everywhere else)
   int xa_operands = -1;         // CFD_XA_OPERANDS=<0..3>: overrides cfd_sample_args.operand_policy (developer A/B of the fused cross-attention's tile formats)
+  int xa_db = -1;               // CFD_XA_DB=0 (developer builds, -DXA_ALL_OPF=1): operand policy 15 on the three-barrier step instead of the double-buffered one
   bool hint_same_mem = false;   // cfd_forward_same_memories: the promise for the NEXT cfd_forward ...
   bool hint_now = false;        // ... taken (and cleared) at that call's very first line, before anything can fail: a call that returns early
                                 // must not leave the promise standing for the call after it

@@ -230,21 +230,26 @@ __device__ __forceinline__ T xa_sel(const T (&arr)[CFD_NMEM], int j) {
 // over N attended keys the absolute error falls like 1 / sqrt(N) -- for the 1500-key audio memory it is ~8x below that of a 24-key text
 // memory, whose tiles are 3 of a row's 50 anyway (measured: profiles/r06_xa_operands_*).  Segments without the flag run the split-pair
 // loop body; at a change of format between two segments the pipeline drains and is primed again (once per workgroup at the shipped shapes).
-// (With both formats single fp16 a K and a V^T tile are 32 KB each and the tile buffers hold two of each: a double-buffered pipeline -- every
-// fill a whole step ahead, two barriers per step instead of three -- was built and measured 0.6 % SLOWER on one box (78.0 vs 77.6 steps/s,
-// profiles/r06_xa_double_buffer_ab.log; tools/experiments/r06_variants/xattn_fused_double_buffer.hpp): the step is paced by the softmax's
-// vector work and the matrix pipe, which the two waves of a SIMD use one after the other, not by fills or barriers any more.)
+// XA_DBUF (bit 4, with both tiles single fp16): a K and a V^T tile are 32 KB each, so the two 64 KB tile buffers hold TWO of each and the
+// long memories' steps run a double-buffered pipeline (kt_step_db: every fill a whole step ahead, two barriers per step instead of three).
+// Measured on one box, three interleaved rounds (profiles/r06_xa_dbuf_ab.log): with all four operands single fp16 (OPF 15) the kernel is
+// 1.0 % faster at the headline shape (3.575 -> 3.539 ms; 81.4 -> 81.9 steps/s) and 2.9 % at the product shape (0.371 -> 0.360 ms), whose
+// workgroups run a handful of steps each and wait on fill latency -- so the shipped single-fp16 instance is OPF 15 | XA_DBUF.  (With pairs
+// as the other operands, OPF 3, the same pipeline had measured 0.6 % SLOWER, profiles/r06_xa_double_buffer_ab.log: there the step is
+// paced by the matrix pipe and the softmax's vector work, which the two waves of a SIMD use one after the other.)
 // The single-fp16 tiles come from xa_pack16_kernel (once per run, from the split-pair projections): tile-major and already in the LDS
 // image's order, so a fill is a linear copy of 1 KB pieces.  cfd_forward, DDIM runs, runs that keep attention maps and the memories of a
 // dynamic run keep pairs (cfd_sample.hip: operand policy of cfd_sample_begin).
-enum { XA_V16 = 1, XA_K16 = 2, XA_P16 = 4, XA_Q16 = 8 };   // (XA_P16 / XA_Q16: with single-fp16 tiles, also the OTHER operand of the product as one fp16: 1 MFMA)
+enum { XA_V16 = 1, XA_K16 = 2, XA_P16 = 4, XA_Q16 = 8, XA_DBUF = 16 };   // XA_DBUF (with XA_V16 | XA_K16): the double-buffered step, an instance of its own   // (XA_P16 / XA_Q16: with single-fp16 tiles, also the OTHER operand of the product as one fp16: 1 MFMA)
 #ifndef XA_ALL_OPF
 #define XA_ALL_OPF 0    // 1: developer builds also instantiate the partial combinations (OPF 1, 2, 3, 7, 11: measured in round 6 and dominated by
-                        // OPF 15 -- e.g. 78.5 / 79.7 / 79.5 steps/s for 3 / 7 / 11 against 80.9, all at 2.3e-5 on the DDPM-1000 golden -- and not shipped)
+                        // OPF 15 -- e.g. 78.5 / 79.7 / 79.5 steps/s for 3 / 7 / 11 against 80.9, all at 2.3e-5 on the DDPM-1000 golden -- and OPF 15 on the
+                        // three-barrier step, CFD_XA_DB=0: not shipped)
 #endif
 template <bool ATT, int OPF>
 __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAttnArgs a) {
   static_assert(!ATT || OPF == 0, "attention maps: split-pair tiles");
+  static_assert(!(OPF & XA_DBUF) || (OPF & 3) == 3, "double-buffered step: both tiles single fp16");
   typedef std::integral_constant<int, OPF> fmt_long;     // format tags of the loop-body instances: flagged segments / all others
   typedef std::integral_constant<int, 0> fmt_pair;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -804,6 +809,116 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     ++step;
     XA_T(9);
   };
+  // One key-tile step with BOTH tiles as single fp16, double-buffered (instances with XA_DBUF).  A K tile and a V^T tile are 32 KB each, so
+  // the two 64 KB tile buffers hold TWO of each: step n computes out of slot n & 1 while tile n + 1 lands in the other slot -- its K
+  // requested behind the step's first barrier, its V^T behind the second, i.e. every fill has a whole step (four sub-phases) to land instead
+  // of 1.5 - 2.5, and a step has TWO barriers instead of three:
+  //   B0  K(n) has landed and is visible; every wave is done with the other slot's tiles (K since B1 of step n - 1, V^T just now)
+  //   B1  V^T(n) has landed; the pair's partial scores are in the exchange area
+  // A wave's requests complete in order: behind B0 it has K(n + 1) (4 pieces + the key-bias piece) in flight behind V^T(n) (4), behind B1
+  // V^T(n + 1) behind K(n + 1) -- which is what the two counted waits count.
+  auto kt_step_db = [&](int kt) __attribute__((always_inline)) {
+    const bool last_in_seg = kt + 1 == cT;
+    Tile nxt;
+    nxt.k = last_in_seg ? nseg_t.k : cur.k + 32768;
+    nxt.v = last_in_seg ? nseg_t.v : cur.v + 32768;
+    nxt.cb = last_in_seg ? nseg_t.cb : cur.cb + XA_KEYS;
+    nxt.rowb = cur.rowb;
+    nxt.vlane = cur.vlane;
+    nxt.cblane = last_in_seg ? nseg_t.cblane : cur.cblane;
+    const int slot = step & 1;
+    auto fill_k_full = [&](const Tile& t, int sl) __attribute__((always_inline)) {
+      if (XA_ABLATE & 1) return;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        unsigned kl = lane16;
+        const char* b = t.k + (wid + 8 * n) * 1024;
+        asm volatile("" : "+v"(kl), "+s"(b));
+        __builtin_amdgcn_global_load_lds((gptr_t)(b + kl), (lptr_t)(smem + KOFF + sl * 32768 + (wid + 8 * n) * 1024), 16, 0, 0);
+      }
+      unsigned cl = t.cblane;
+      asm volatile("" : "+v"(cl));
+      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(t.cb) + cl), (lptr_t)(smem + XA_CBOFF + sl * 256), 4, 0, 0);
+    };
+    auto fill_v_full = [&](const Tile& t, int sl) __attribute__((always_inline)) {
+      if (XA_ABLATE & 1) return;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        unsigned vl = lane16;
+        const char* b = t.v + (wid + 8 * n) * 1024;
+        asm volatile("" : "+v"(vl), "+s"(b));
+        __builtin_amdgcn_global_load_lds((gptr_t)(b + vl), (lptr_t)(smem + VOFF + sl * 32768 + (wid + 8 * n) * 1024), 16, 0, 0);
+      }
+    };
+    if (!primed) {   // (re)start of the pipeline
+      fill_k_full(cur, slot);
+      fill_v_full(cur, slot);
+      primed = true;
+    }
+    const char* kb = kf_a + slot * 32768;
+    const char* vb = vf_a + slot * 32768;
+    auto rd_k = [&](spx8 (&fr)[8], int t, int hf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fr[i] = XA_FRAG(kb + t * 16384 + (4 * hf + i) * 1024);
+    };
+    auto rd_v = [&](spx8 (&fr)[8], int qf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fr[i] = XA_FRAG(vb + (4 * qf + i) * 1024);
+    };
+    f32x4 s0 = f32x4{cqh, cqh, cqh, cqh}, s1 = s0;
+    XA_T(1);
+    XA_WAIT_VM_LGKM0(4);                 // K(n) landed (V^T(n)'s 4 pieces are younger)
+    __builtin_amdgcn_s_barrier();        // B0
+    XA_T(2);
+    rd_k(fa, 0, 0);
+    rd_k(fb, 0, 1);
+    fill_k_full(nxt, slot ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_k(fmt_long{}, s0, fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    rd_k(fa, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) {
+      mfma_k(fmt_long{}, s0, fb, 1);
+      *reinterpret_cast<f32x4*>(xch_mine) = s0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    rd_k(fb, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_k(fmt_long{}, s1, fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) {
+      mfma_k(fmt_long{}, s1, fb, 1);
+      *reinterpret_cast<f32x4*>(xch_mine + 1024) = s1;
+    }
+    XA_T(3);
+    XA_WAIT_VM_LGKM0(5);                 // V^T(n) landed (K(n + 1): 4 pieces + key bias are younger); partial scores written
+    __builtin_amdgcn_s_barrier();        // B1
+    XA_T(4);
+    rd_v(fa, 0);
+    fill_v_full(nxt, slot ^ 1);
+    if (in_seg && !(XA_ABLATE & 8)) softmax_tile(s0, s1, slot, online, cj, kt);
+    XA_T(10);
+    rd_v(fb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fmt_long{}, fa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    XA_T(5);
+    rd_v(fa, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fmt_long{}, fb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    rd_v(fb, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (in_seg) mfma_v(fmt_long{}, fa, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    XA_T(7);
+    if (in_seg) mfma_v(fmt_long{}, fb, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+    ++step;
+    XA_T(9);
+  };
   // The segments [s0, s1) of the workgroup's list, all in the format `fc`.
   auto seg_loop = [&](auto fc, int s0, int s1) __attribute__((always_inline)) {
   for (int si = s0; si < s1; ++si) {
@@ -818,7 +933,11 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     // add up to S_raw + c_q (a + b = b + a: the same in both waves of the pair)
     cqh = cq_mine[l15 * 5 + cj];
     XA_T(11);
-    for (int kt = 0; kt < cT; ++kt) kt_step(fc, kt);
+    if constexpr ((decltype(fc)::value & XA_DBUF) != 0) {
+      for (int kt = 0; kt < cT; ++kt) kt_step_db(kt);
+    } else {
+      for (int kt = 0; kt < cT; ++kt) kt_step(fc, kt);
+    }
     if (in_seg) {
       float wsum = xlane_sum(wl);
       if (online) {   // normalise the finished online memory in registers (all keys dead: 0 * inf = NaN)
