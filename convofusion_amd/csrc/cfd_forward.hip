@@ -299,8 +299,9 @@ int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<false, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<false, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
-#endif
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<false, 15>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
+#endif
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<false, 15 | XA_DBUF>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fused_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS));
     attr |= 1ull << (c->cfg.device & 63);
   }

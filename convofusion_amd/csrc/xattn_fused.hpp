@@ -284,8 +284,8 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
 
   // Q fragments (B operand) of this wave's half of the feature axis, made here from the residual stream:
   //   q = LayerNorm2(x[token])  (cross_attention.py:578; two-pass mean / variance like ln_rows_kernel, eps 1e-5).
-  // Lane (q = l15, g = q4) holds d = 32 c + 8 g .. +7 of its query's row for every 32-chunk c = 0..15 (the four lanes of a
-  // query cover the row: statistics need one 4-lane reduction), and keeps chunks 8 half .. 8 half + 7 as its fragments.
+  // Lane (q = l15, g = q4) holds d = 32 c + 8 g .. +7 of its query's row for the 32-chunks c = 8 half .. 8 half + 7, its fragments (the four
+  // lanes of a query cover the half row: its statistics need one 4-lane reduction, the row's the partner wave's half as well).
   spx8 qh[8], ql[8];
   float* cq_mine = reinterpret_cast<float*>(smem + XA_CQOFF + wid * XA_CQW);
   float* wq_mine = cq_mine + 80;
@@ -306,36 +306,50 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(smem + KBOFF + wid * 2048), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gptr_t)(gp + 1024), (lptr_t)(smem + KBOFF + wid * 2048 + 1024), 16, 0, 0);
   }
-  float4 r[32];
-  float rstd;
+  // Each wave of the pair loads only ITS half of the 16 rows (the chunks it keeps as fragments): the prologue is paced by what a CU can take
+  // in (~11 B per clock with every CU in its prologue), and with whole rows in both waves a workgroup read its 128 KB of rows twice.  The
+  // row statistics are put together from the two halves' (mean, sum of squared deviations) -- Chan's pairwise update, two-pass inside a
+  // half -- exchanged through the pair's exchange area across the barrier below; both waves compute the same two sums of the same two
+  // operands, so they normalise with identical statistics.
+  float4 r[16];
+  float rstd, mean;
+  float mean_h, m2_h;
   {
-    const float* xr = a.x + (tok0 + min(l15, max(nq - 1, 0))) * CFD_D + q4 * 8;
+    const float* xr = a.x + (tok0 + min(l15, max(nq - 1, 0))) * CFD_D + 256 * half + q4 * 8;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
+    for (int c = 0; c < 8; ++c) {
       r[2 * c] = *reinterpret_cast<const float4*>(xr + 32 * c);
       r[2 * c + 1] = *reinterpret_cast<const float4*>(xr + 32 * c + 4);
     }
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) sum += (r[i].x + r[i].y) + (r[i].z + r[i].w);
-    const float mean = xlane_sum(sum) * (1.0f / CFD_D);
+    for (int i = 0; i < 16; ++i) sum += (r[i].x + r[i].y) + (r[i].z + r[i].w);
+    mean_h = xlane_sum(sum) * (2.0f / CFD_D);
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      r[i].x -= mean; r[i].y -= mean; r[i].z -= mean; r[i].w -= mean;
-      ss += (r[i].x * r[i].x + r[i].y * r[i].y) + (r[i].z * r[i].z + r[i].w * r[i].w);
+    for (int i = 0; i < 16; ++i) {
+      const float dx = r[i].x - mean_h, dy = r[i].y - mean_h, dz = r[i].z - mean_h, dw = r[i].w - mean_h;
+      ss += (dx * dx + dy * dy) + (dz * dz + dw * dw);
     }
-    rstd = 1.0f / sqrtf(xlane_sum(ss) * (1.0f / CFD_D) + 1e-5f);
+    m2_h = xlane_sum(ss);
+    if (q4 == 0) reinterpret_cast<float2*>(smem + XA_XOFF + wid * 2048)[l15] = float2{mean_h, m2_h};
   }
   XA_WAIT_VM_LGKM0(0);            // row loads consumed; A b, norm2's parameters landed
-  __builtin_amdgcn_s_barrier();   // ... and visible, with the segment list
+  __builtin_amdgcn_s_barrier();   // ... and visible, with the segment list and the partner's half-row statistics
+  {
+    const float2 oth = reinterpret_cast<const float2*>(smem + XA_XOFF + partner * 2048)[l15];
+    const float dm = mean_h - oth.x;
+    mean = 0.5f * (mean_h + oth.x);
+    rstd = 1.0f / sqrtf(((m2_h + oth.y) + dm * dm * (CFD_D / 4)) * (1.0f / CFD_D) + 1e-5f);
+  }
   {
     const float* lng = reinterpret_cast<const float*>(smem + KBOFF + CFD_NMEM * 2048);
     const float* lnb = reinterpret_cast<const float*>(smem + KBOFF + (CFD_NMEM + 1) * 2048);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const int c = 8 * half + ks;          // (half is wave-uniform: the two candidates are selected, not indexed)
-      const float4 v0 = half ? r[2 * (8 + ks)] : r[2 * ks], v1 = half ? r[2 * (8 + ks) + 1] : r[2 * ks + 1];
+      const float4 v0 = float4{r[2 * ks].x - mean, r[2 * ks].y - mean, r[2 * ks].z - mean, r[2 * ks].w - mean};
+      const float4 v1 = float4{r[2 * ks + 1].x - mean, r[2 * ks + 1].y - mean, r[2 * ks + 1].z - mean, r[2 * ks + 1].w - mean};
       const float* gp = lng + 32 * c + q4 * 8;
       const float* bp = lnb + 32 * c + q4 * 8;
       const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
