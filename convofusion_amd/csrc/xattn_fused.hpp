@@ -336,6 +336,10 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   }
   XA_WAIT_VM_LGKM0(0);            // row loads consumed; A b, norm2's parameters landed
   __builtin_amdgcn_s_barrier();   // ... and visible, with the segment list and the partner's half-row statistics
+  f32x4 o[16];   // O^T tiles of features 256 half + 16 f .. +15
+  // The second half of the prologue -- the fragments from the loaded half rows, c_q, the zeroed accumulators -- as a block that runs BEHIND the
+  // first tile's fill requests where the instance allows it (finish_queries() below: the fills' round trip then runs under this arithmetic).
+  auto finish_queries = [&]() __attribute__((always_inline)) {
   {
     const float2 oth = reinterpret_cast<const float2*>(smem + XA_XOFF + partner * 2048)[l15];
     const float dm = mean_h - oth.x;
@@ -388,11 +392,11 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     // the one-key memory: sum_s P'_s = rs_u for every query of the tile (its rank-one term is added with the others in the final flush)
     if (a.one_j >= 0 && my_one >= 0 && q4 == 0) wq_mine[l15 * 5 + a.one_j] = a.one_rs[(long long)my_one * a.one_sp];
   }
-  f32x4 o[16];   // O^T tiles of features 256 half + 16 f .. +15
 #pragma unroll
   for (int f = 0; f < 16; ++f) o[f] = f32x4{0.f, 0.f, 0.f, 0.f};
   XA_WAIT_VM_LGKM0(0);            // the counted waits of the loop start from an empty queue.  (No barrier: the c_q halves are wave-private, and
                                   // the parked A b is overwritten only behind the first step's mid-A0 barrier, which every wave reaches after this point.)
+  };
 
   // ---- staging: one piece = one global_load_lds_dwordx4 wave-instruction = 8 tile rows x 128 B; a 32 KB sub-buffer is
   //      32 pieces = 4 per wave.  K tile LDS image: [k-step 16][row 32][128 B]; LDS row rho = 16 t + i holds key
@@ -730,7 +734,41 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   int step = 0;
   Tile cur, nseg_t;
   int cT = 1, cmask = 0, cflags = 0, cj = 0, nT = 1, nmask = 0, nflags = 0, nj = 0;
+  // A whole single-fp16 K tile (+ its key-bias piece) / V^T tile into slot `sl` of its buffer: 4 (+1) / 4 pieces per wave (XA_DBUF instances)
+  auto fill_k_full = [&](const Tile& t, int sl) __attribute__((always_inline)) {
+    if (XA_ABLATE & 1) return;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      unsigned kl = lane16;
+      const char* b = t.k + (wid + 8 * n) * 1024;
+      asm volatile("" : "+v"(kl), "+s"(b));
+      __builtin_amdgcn_global_load_lds((gptr_t)(b + kl), (lptr_t)(smem + KOFF + sl * 32768 + (wid + 8 * n) * 1024), 16, 0, 0);
+    }
+    unsigned cl = t.cblane;
+    asm volatile("" : "+v"(cl));
+    __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(t.cb) + cl), (lptr_t)(smem + XA_CBOFF + sl * 256), 4, 0, 0);
+  };
+  auto fill_v_full = [&](const Tile& t, int sl) __attribute__((always_inline)) {
+    if (XA_ABLATE & 1) return;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      unsigned vl = lane16;
+      const char* b = t.v + (wid + 8 * n) * 1024;
+      asm volatile("" : "+v"(vl), "+s"(b));
+      __builtin_amdgcn_global_load_lds((gptr_t)(b + vl), (lptr_t)(smem + VOFF + sl * 32768 + (wid + 8 * n) * 1024), 16, 0, 0);
+    }
+  };
   if (nseg > 0) seg_tile(0, cur, cT, cmask, cflags, cj);
+  if constexpr ((OPF & XA_DBUF) != 0) {
+    // the first tile of a list that starts with a long memory: requested HERE, in front of the rest of the prologue.  (Slot 0 of both tile
+    // buffers: the parked A b / norm2 parameters sit beyond the V^T tile's 32 KB; nobody reads the tile buffers before the first step's B0.)
+    if (nseg > 0 && wgp->n16 > 0) {
+      fill_k_full(cur, 0);
+      fill_v_full(cur, 0);
+      primed = true;
+    }
+  }
+  finish_queries();
   XA_T(0);
   // One key-tile step in the format `fc` (fmt_long / fmt_pair): the tile `cur` and the tile after it, `nxt`, are BOTH in that format
   // (the segment loop below sees to it), so every piece count behind a counted wait is a compile-time constant of the instance.
@@ -841,29 +879,6 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     nxt.vlane = cur.vlane;
     nxt.cblane = last_in_seg ? nseg_t.cblane : cur.cblane;
     const int slot = step & 1;
-    auto fill_k_full = [&](const Tile& t, int sl) __attribute__((always_inline)) {
-      if (XA_ABLATE & 1) return;
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        unsigned kl = lane16;
-        const char* b = t.k + (wid + 8 * n) * 1024;
-        asm volatile("" : "+v"(kl), "+s"(b));
-        __builtin_amdgcn_global_load_lds((gptr_t)(b + kl), (lptr_t)(smem + KOFF + sl * 32768 + (wid + 8 * n) * 1024), 16, 0, 0);
-      }
-      unsigned cl = t.cblane;
-      asm volatile("" : "+v"(cl));
-      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(t.cb) + cl), (lptr_t)(smem + XA_CBOFF + sl * 256), 4, 0, 0);
-    };
-    auto fill_v_full = [&](const Tile& t, int sl) __attribute__((always_inline)) {
-      if (XA_ABLATE & 1) return;
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        unsigned vl = lane16;
-        const char* b = t.v + (wid + 8 * n) * 1024;
-        asm volatile("" : "+v"(vl), "+s"(b));
-        __builtin_amdgcn_global_load_lds((gptr_t)(b + vl), (lptr_t)(smem + VOFF + sl * 32768 + (wid + 8 * n) * 1024), 16, 0, 0);
-      }
-    };
     if (!primed) {   // (re)start of the pipeline
       fill_k_full(cur, slot);
       fill_v_full(cur, slot);
