@@ -195,7 +195,7 @@ __device__ __forceinline__ T xa_sel(const T (&arr)[CFD_NMEM], int j) {
 #ifndef XA_STAMP
 #define XA_STAMP 0    // developer build: s_memtime stamps around the sections of the kernel (adds ~10 % to its run time)
 #endif
-#define XA_NSTAMP 12
+#define XA_NSTAMP 16
 #if XA_STAMP
 #define XA_T(k) do { asm volatile("" ::: "memory"); const long long t_ = __builtin_amdgcn_s_memtime(); acc_[k] += t_ - tprev_; tprev_ = t_; asm volatile("" ::: "memory"); } while (0)
 #else
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KOFF = 0, VOFF = 65536;
 #if XA_STAMP
-  long long acc_[XA_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long acc_[XA_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (12 - 15: sections of the prologue)
   long long tprev_ = __builtin_amdgcn_s_memtime();
 #endif
   const int lane = threadIdx.x & 63;
@@ -334,6 +334,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     m2_h = xlane_sum(ss);
     if (q4 == 0) reinterpret_cast<float2*>(smem + XA_XOFF + wid * 2048)[l15] = float2{mean_h, m2_h};
   }
+  XA_T(12);
   XA_WAIT_VM_LGKM0(0);            // row loads consumed; A b, norm2's parameters landed
   __builtin_amdgcn_s_barrier();   // ... and visible, with the segment list and the partner's half-row statistics
   f32x4 o[16];   // O^T tiles of features 256 half + 16 f .. +15
@@ -369,6 +370,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       }
     }
   }
+  XA_T(14);
   // this wave's half of c_q = q . (A b) for every memory, from the fragments (q = hi + lo); kept in LDS, read back by this wave only
   {
     float qf[8][8];
@@ -392,6 +394,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     // the one-key memory: sum_s P'_s = rs_u for every query of the tile (its rank-one term is added with the others in the final flush)
     if (a.one_j >= 0 && my_one >= 0 && q4 == 0) wq_mine[l15 * 5 + a.one_j] = a.one_rs[(long long)my_one * a.one_sp];
   }
+  XA_T(15);
 #pragma unroll
   for (int f = 0; f < 16; ++f) o[f] = f32x4{0.f, 0.f, 0.f, 0.f};
   XA_WAIT_VM_LGKM0(0);            // the counted waits of the loop start from an empty queue.  (No barrier: the c_q halves are wave-private, and
@@ -768,6 +771,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       primed = true;
     }
   }
+  XA_T(13);
   finish_queries();
   XA_T(0);
   // One key-tile step in the format `fc` (fmt_long / fmt_pair): the tile `cur` and the tile after it, `nxt`, are BOTH in that format
