@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       for (int ks = 0; ks < 8; ++ks) {
         const f32x4 k0 = *reinterpret_cast<const f32x4*>(kp + 32 * ks), k1 = *reinterpret_cast<const f32x4*>(kp + 32 * ks + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc += qf[ks][e] * k0[e] + qf[ks][4 + e] * k1[e];
+        for (int e = 0; e < 4; ++e) acc = __builtin_fmaf(qf[ks][4 + e], k1[e], __builtin_fmaf(qf[ks][e], k0[e], acc));   // (the library is built with -ffp-contract=off)
       }
       acc = xlane_sum(acc);
       if (q4 == 0) { cq_mine[l15 * 5 + j] = acc; wq_mine[l15 * 5 + j] = 0.f; }
