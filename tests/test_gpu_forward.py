@@ -326,6 +326,37 @@ def test_a_row_with_a_fully_masked_memory_is_nan_like_the_reference(shape):
 
 
 @pytest.mark.parametrize("shape", ["row_tile", "tile_kernels"])
+@pytest.mark.parametrize("offset", ["all_features", "halves_apart"])
+def test_layernorms_of_rows_far_from_zero_mean(shape, offset):
+    """Residual-stream rows whose mean is far from zero, and rows whose two 256-feature halves sit far apart: every LayerNorm of the layer then
+    subtracts a mean much larger than the deviations it keeps.  The fused cross-attention kernel puts LayerNorm2's statistics together from
+    the two half rows its pair of waves loaded (mean and sum of squared deviations per half, Chan's pairwise update: xattn_fused.hpp prologue);
+    `halves_apart` makes the between-halves term the whole variance.  The offset enters through latent_embd.bias
+    (convofusion/models/architectures/denoiser.py:181: the residual stream starts as latent_embd(sample) + positional terms).  Against the numpy oracle."""
+    import torch
+    from convofusion_amd.denoiser import Denoiser
+    from oracle import denoiser_ref
+    from tests.gpu_helpers import ABL, DENOISER_KW, dev_inputs, to_dev
+    Be, L, S = (5, 16, (6, 20, 6, 8, 1)) if shape == "row_tile" else (9, 100, (20, 170, 24, 8, 1))
+    inp = inputs.make_plain_batch(seed=909, Be=Be, L=L, S=S, pad_tail=(2, 0, 3, 0, 0))
+    sd = {k: v.copy() for k, v in state_dict().items()}
+    if offset == "all_features":
+        sd["latent_embd.bias"] = (sd["latent_embd.bias"] + 25.0).astype(np.float32)
+    else:
+        sd["latent_embd.bias"] = (sd["latent_embd.bias"] + np.where(np.arange(512) < 256, 12.0, -12.0)).astype(np.float32)
+    want, _ = denoiser_ref.denoiser_forward(sd, inp["sample"], 420, inp["memories"], inp["masks"])
+    m = Denoiser(ablation=ABL, **DENOISER_KW)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.cuda().eval()
+    mems, masks = dev_inputs(inp)
+    with torch.no_grad():
+        out, _ = m(to_dev(inp["sample"]), torch.tensor(420), mems, mem_mask_dict=masks)
+    e = rel_l2(out.cpu().numpy(), want)
+    print(shape, offset, "rel L2 vs oracle", e)
+    assert e < FWD_TOL
+
+
+@pytest.mark.parametrize("shape", ["row_tile", "tile_kernels"])
 def test_key_padding_masks_with_holes(shape):
     """nn.MultiheadAttention's key_padding_mask is any boolean pattern, not only a padded tail (every other fixture masks tails): masks
     with holes -- the first key, isolated keys, whole 32-key tiles, different patterns per batch row -- on all five memories, against the
