@@ -500,6 +500,29 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   // x[token][256 half ..] += O^T (+ bias) for this wave's queries, then O = 0.  Every wave re-lays its 256 x 16 tile
   // through a private LDS strip (the caller has drained every fill and passed a barrier, so the tile buffers are free)
   // and moves whole 1 KB row pieces.
+  // The residual rows a flush adds to (and, in layer 0's second list, the stored results of the first): requested by flush_request(), which
+  // the FINAL flush calls in front of the kernel's last wait + barrier -- their round trip then runs under the barrier's skew and the
+  // trailing fills' landing instead of behind them; a flush between two online memories requests them itself.
+  float4 fl_old[16], fl_extra[16];
+  bool fl_requested = false;
+  auto flush_request = [&](bool add_bias) __attribute__((always_inline)) {
+    const XAttnArgs* ka = reinterpret_cast<const XAttnArgs*>((unsigned long long)__builtin_amdgcn_kernarg_segment_ptr());
+    asm volatile("" : "+s"(ka));
+    const float* xp = ka->x + tok0 * CFD_D + half * 256 + lane * 4;
+    const float* const dd_in = ka->dd_in;
+    const bool store_only = add_bias && ka->dd_out != nullptr;                  // (wave-uniform)
+    const bool add_extra = add_bias && dd_in != nullptr && my_aux >= 0;
+    const long long dd_off = ((long long)max(my_aux, 0) * a.L + my_q0) * CFD_D + half * 256 + lane * 4;
+    // all 16 rows are requested before the first is used: one memory round trip per flush instead of four
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      fl_old[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      fl_extra[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < nq && !store_only) fl_old[r] = *reinterpret_cast<const float4*>(xp + (long long)r * CFD_D);
+      if (r < nq && add_extra) fl_extra[r] = *reinterpret_cast<const float4*>(dd_in + dd_off + (long long)r * CFD_D);
+    }
+    fl_requested = true;
+  };
   auto flush = [&](bool add_bias) __attribute__((always_inline)) {
     // The arguments only the flush needs are re-read from the kernel-argument segment HERE (through a pointer the compiler cannot see
     // through): kept in SGPRs across the main loop they push the loop's own wave-uniform pointers into VGPRs and from there into
@@ -529,24 +552,15 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
       one_v = make_float4(rs1 * va.x, rs1 * va.y, rs1 * va.z, rs1 * va.w);
     }
     float* const dd_out = ka->dd_out;
-    const float* const dd_in = ka->dd_in;
     const bool store_only = add_bias && dd_out != nullptr;                      // (wave-uniform)
-    const bool add_extra = add_bias && dd_in != nullptr && my_aux >= 0;
     const long long dd_off = ((long long)max(my_aux, 0) * a.L + my_q0) * CFD_D + half * 256 + lane * 4;
-    // all 16 rows are requested before the first is used: one exposed memory round trip per flush instead of four
-    float4 old[16], extra[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      old[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-      extra[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < nq && !store_only) old[r] = *reinterpret_cast<const float4*>(xp + (long long)r * CFD_D);
-      if (r < nq && add_extra) extra[r] = *reinterpret_cast<const float4*>(dd_in + dd_off + (long long)r * CFD_D);
-    }
+    if (!fl_requested) flush_request(add_bias);
+    fl_requested = false;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(strip + r * RS + lane * 16);
       if (r < nq) {
-        float4 t = old[r];
+        float4 t = fl_old[r];
         float4 c = make_float4(v[0], v[1], v[2], v[3]);
         if (add_bias) {   // + (sum_s P'_s) VV b of every memory (the final flush only: the sums of all memories are complete)
 #pragma unroll
@@ -559,7 +573,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
         if (store_only) {
           *reinterpret_cast<float4*>(dd_out + dd_off + (long long)r * CFD_D) = c;
         } else {
-          const float4 e = extra[r];
+          const float4 e = fl_extra[r];
           t.x = ((t.x + bv.x) + e.x) + c.x; t.y = ((t.y + bv.y) + e.y) + c.y; t.z = ((t.z + bv.z) + e.z) + c.z; t.w = ((t.w + bv.w) + e.w) + c.w;
           *reinterpret_cast<float4*>(xp + (long long)r * CFD_D) = t;
         }
@@ -567,7 +581,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
     }
 #pragma unroll
     for (int f = 0; f < 16; ++f) o[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-    XA_WAIT_VM(0);                                       // the counted waits of the loop assume an empty queue
+    if (!add_bias) XA_WAIT_VM(0);                        // the counted waits of the loop assume an empty queue (the final flush's stores are left in flight)
   };
 
   float m = -INFINITY, lsum = 0.f, wl = 0.f, mc_run = -INFINITY;   // online softmax: maximum, sums, and the exponent reference the sums are relative to
@@ -1019,6 +1033,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   } else {
     seg_loop(fmt_pair{}, 0, nseg);
   }
+  flush_request(true);
   XA_WAIT_VM_LGKM0(0);
   __builtin_amdgcn_s_barrier();   // last B1 done everywhere and the trailing (unused) fills have landed: the tile buffers become the epilogue strips
   XA_T(11);
