@@ -57,6 +57,8 @@ extern "C" int cfd_create(const cfd_config* cfg, cfd_handle* out) {
   if (env) c->l0_dedup = atoi(env) != 0;
   env = getenv("CFD_XA_OPERANDS");
   if (env) c->xa_operands = atoi(env) & 15;
+  env = getenv("CFD_LN_FOLD");
+  if (env) c->ln_fold = atoi(env);
   env = getenv("CFD_XA_DB");
   if (env) c->xa_db = atoi(env) != 0;
   env = getenv("CFD_ONE_KEY");
@@ -109,7 +111,7 @@ extern "C" void cfd_destroy(cfd_handle c) {
   c->weg_rt_ws.release();
   c->sat.release();
   for (auto& kv : c->raw) kv.second.release();
-  DBuf* all[] = {&c->we_sp, &c->wp_sp, &c->we_all, &c->be_all, &c->tsin, &c->weg_ws, &c->weg_tok, &c->latents, &c->coef, &c->inoise};
+  DBuf* all[] = {&c->we_sp, &c->wp_sp, &c->wp_f, &c->ln_cd_p, &c->we_all, &c->be_all, &c->tsin, &c->weg_ws, &c->weg_tok, &c->latents, &c->coef, &c->inoise};
   for (DBuf* b : all) b->release();
   c->wk[0].release();
   c->wk[1].release();
@@ -117,7 +119,7 @@ extern "C" void cfd_destroy(cfd_handle c) {
     c->wk_all_sp[j].release(); c->wv_all_sp[j].release(); c->mem_own[j].release(); c->perm_map[j].release();
   }
   for (auto& l : c->lw) {
-    DBuf* lb[] = {&l.wqk_sp, &l.bqk, &l.wv_sp, &l.wo_sp, &l.bo2, &l.wtb1_sp, &l.wtb2_sp, &l.w1_sp, &l.w2_sp, &l.cross_bias};
+    DBuf* lb[] = {&l.wqk_f, &l.wv_f, &l.w1_f, &l.ln_cd, &l.wqk_sp, &l.bqk, &l.wv_sp, &l.wo_sp, &l.bo2, &l.wtb1_sp, &l.wtb2_sp, &l.w1_sp, &l.w2_sp, &l.cross_bias};
     for (DBuf* b : lb) b->release();
   }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -161,6 +163,37 @@ int enqueue_to_split(Ctx* c, int cls, hipStream_t st, const float* src, char* ds
   return CFD_OK;
 }
 
+// The LayerNorm fold's weight side (gemm_sp.hpp EpiLn), one workgroup per output feature r:
+//   Wf[r][k] = W[r][k] gamma[k]        c[r] = sum_k (hi + lo)(Wf[r][k])  -- the value the split-pair product sees --        d[r] = sum_k W[r][k] beta[k]
+template <int CFD_KI = 0>
+__global__ void __launch_bounds__(256) ln_fold_rows_kernel(const float* W, const float* gamma, const float* beta, float* Wf, float* cvec, float* dvec, int K) {
+  const int r = blockIdx.x;
+  double sc = 0.0, sd = 0.0;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float w = W[(long long)r * K + k];
+    const float wf = w * gamma[k];
+    Wf[(long long)r * K + k] = wf;
+    sp_t hi, lo;
+    split_f32(wf, hi, lo);
+    sc += (double)((float)hi + (float)lo);
+    sd += (double)w * (double)beta[k];
+  }
+  __shared__ double red[2][256];
+  red[0][threadIdx.x] = sc; red[1][threadIdx.x] = sd;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { cvec[r] = (float)red[0][0]; dvec[r] = (float)red[1][0]; }
+}
+static int ln_fold_weight(Ctx* c, const float* W, int R, int K, const float* gamma, const float* beta, DBuf& tmp, DBuf& dst_sp, float* cvec, float* dvec) {
+  CHK(tmp.ensure((size_t)R * K * 4));
+  hipLaunchKernelGGL(ln_fold_rows_kernel<>, dim3(R), dim3(256), 0, 0, W, gamma, beta, tmp.as<float>(), cvec, dvec, K);
+  HIPCHK(hipGetLastError());
+  return to_sp(c, tmp.as<float>(), R, K, dst_sp);
+}
+
 extern "C" int cfd_finalize_weights(cfd_handle c) {
   if (!c) return fail(CFD_E_ARG, "null handle");
   HIPCHK(hipSetDevice(c->cfg.device));
@@ -189,7 +222,7 @@ extern "C" int cfd_finalize_weights(cfd_handle c) {
 
   CHK(c->we_all.ensure((size_t)nl * 2 * 2 * D * D * 4));
   CHK(c->be_all.ensure((size_t)nl * 2 * 2 * D * 4));
-  DBuf tmpf, tmpd1, tmpd2, vd1, vd2, accd;
+  DBuf tmpf, tmpd1, tmpd2, vd1, vd2, accd, tmpfold;
   CHK(tmpf.ensure((size_t)3 * D * D * 4));
   CHK(tmpd1.ensure((size_t)D * D * 8));
   CHK(tmpd2.ensure((size_t)D * D * 8));
@@ -210,8 +243,10 @@ extern "C" int cfd_finalize_weights(cfd_handle c) {
     LayerW& w = c->lw[l];
     const std::string p = "decoder.layers." + std::to_string(l) + ".";
     const float *ipw, *ipb, *ow, *ob;
+    const float* ipw_self = nullptr;
     // -- self attention: q rows scaled by sqrt(1/head_dim) (F.multi_head_attention_forward "q_scaled")
     CHK(need(c, p + "self_attn.in_proj_weight", (size_t)3 * D * D, &ipw));
+    ipw_self = ipw;
     CHK(need(c, p + "self_attn.in_proj_bias", 3 * D, &ipb));
     CHK(need(c, p + "self_attn.out_proj.weight", (size_t)D * D, &ow));
     CHK(need(c, p + "self_attn.out_proj.bias", D, &ob));
@@ -248,6 +283,13 @@ extern "C" int cfd_finalize_weights(cfd_handle c) {
     CHK(need(c, p + "norm3.weight", D, &w.ln3g)); CHK(need(c, p + "norm3.bias", D, &w.ln3b));
     CHK(need(c, p + "linear1.weight", (size_t)CFD_FF * D, &t0)); CHK(to_sp(c, t0, CFD_FF, D, w.w1_sp));
     CHK(need(c, p + "linear1.bias", CFD_FF, &w.b1));
+    {   // the LayerNorm fold's operands: norm1 -> q | k (the scaled copy in tmpf) and v, norm3 -> FFN1
+      CHK(w.ln_cd.ensure(6144 * 4));
+      float* cd = w.ln_cd.as<float>();
+      CHK(ln_fold_weight(c, tmpf.as<float>(), 2 * D, D, w.ln1g, w.ln1b, tmpfold, w.wqk_f, cd, cd + 1024));
+      CHK(ln_fold_weight(c, ipw_self + (size_t)2 * D * D, D, D, w.ln1g, w.ln1b, tmpfold, w.wv_f, cd + 2048, cd + 2560));
+      CHK(ln_fold_weight(c, t0, CFD_FF, D, w.ln3g, w.ln3b, tmpfold, w.w1_f, cd + 3072, cd + 4096));
+    }
     CHK(need(c, p + "linear2.weight", (size_t)D * CFD_FF, &t0)); CHK(to_sp(c, t0, D, CFD_FF, w.w2_sp));
     CHK(need(c, p + "linear2.bias", D, &w.b2));
     // -- five single-head cross attentions + att_fuser, folded onto the memory side (DESIGN.md "Folding")
@@ -297,10 +339,18 @@ extern "C" int cfd_finalize_weights(cfd_handle c) {
     CHK(to_sp(c, wk_f[j].as<float>(), kfeat + 32, D, c->wk_all_sp[j]));
     CHK(to_sp(c, wv_f[j].as<float>(), kfeat, D, c->wv_all_sp[j]));
   }
+  {   // the decoder's final norm folded into latent_proj
+    const float *gF, *bF, *wpw;
+    CHK(need(c, "decoder.norm.weight", D, &gF));
+    CHK(need(c, "decoder.norm.bias", D, &bF));
+    CHK(need(c, "latent_proj.weight", (size_t)CFD_LAT * D, &wpw));
+    CHK(c->ln_cd_p.ensure(2 * CFD_LAT * 4));
+    CHK(ln_fold_weight(c, wpw, CFD_LAT, D, gF, bF, tmpfold, c->wp_f, c->ln_cd_p.as<float>(), c->ln_cd_p.as<float>() + CFD_LAT));
+  }
   HIPCHK(hipDeviceSynchronize());
   CHK(check_saturation(c, "cfd_finalize_weights (a weight or a folded weight product)"));
   for (int j = 0; j < CFD_NMEM; ++j) { wk_f[j].release(); wv_f[j].release(); }
-  tmpf.release(); tmpd1.release(); tmpd2.release(); vd1.release(); vd2.release(); accd.release();
+  tmpf.release(); tmpd1.release(); tmpd2.release(); vd1.release(); vd2.release(); accd.release(); tmpfold.release();
   c->finalized = true;
   ++c->wver;
   return CFD_OK;

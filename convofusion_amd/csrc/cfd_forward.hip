@@ -289,6 +289,22 @@ int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     CHK(token_gemm_resid(w, K, y, bias, rows));
     return ln(g, b, adaln, tbidx, c->w->h_sp.as<char>(), rows);
   };
+  // The algebraic LayerNorm fold (gemm_sp.hpp EpiLn / EpiResidStat) for mid-size problems at the product shape: norm3, the
+  // norm1 of layers 1.. and the decoder's final norm are not launched; the residual product in front of each stores the split pairs of the RAW rows and
+  // per-row slot statistics, and the consumer (q | k | v^T in one launch, FFN1, latent_proj) runs on W diag(gamma) and rescales its accumulators.
+  // Range: the launches launch_gemm gives the 64 x 64 / 128 x 64 classes anyway (launch_gemm_midsize); above it a ln_rows launch costs less than
+  // the producer's wider epilogue (measured at the headline shape: +25.8 us against 14).
+  const bool ln_fold = c->ln_fold != 0 && L == 16 && c->qkv_fused && !g_cfd_naive_gemm && !c->stop_stage && row0 == 0 && Be == p.Be &&
+                       (c->ln_fold > 0 || (M >= 512 && M <= 3840));   // (below: the row-tile path or a handful of workgroups; above: launch_gemm's 128 x 128 class)
+  if (ln_fold) CHK(c->w->ln_stat.ensure((size_t)M * LN_SLOTS * 2 * 4));
+  auto token_gemm_resid_stat = [&](const DBuf& w, int K, const char* y, const float* bias, long long rows, char* xs) -> int {
+    GemmArgs a = gemm_args();
+    a.X[0] = w.as<char>(); a.ldx[0] = (long long)K * 4; a.I[0] = CFD_D; a.Iclamp[0] = CFD_D; a.kt[0] = K / 32;
+    a.Y = y; a.ldy = (long long)K * 4; a.J = (int)rows; a.Jclamp = (int)rows;
+    EpiResidStat e{c->w->x.as<float>(), 0, bias, xs, c->w->ln_stat.as<float>()};
+    return run_gemm_midsize<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, st);
+  };
+  bool h_raw = false;     // h_sp holds the split pairs of the raw rows + ln_stat their statistics (ln_fold), not norm1(x)
   static unsigned long long attr = 0;   // per device (one bit per ordinal): a process may hold handles on several GPUs
   if (!((attr >> (c->cfg.device & 63)) & 1ull)) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fused_kernel<>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
@@ -335,6 +351,14 @@ int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
         ag.nslot = 2;
         ag.X[1] = w.wv_sp.as<char>(); ag.ldx[1] = ROWB; ag.I[1] = CFD_D; ag.Iclamp[1] = CFD_D; ag.kt[1] = CFD_D / 32;
         EpiQkvT eg{c->w->qk_sp.as<char>(), 2 * ROWB, w.bqk.as<float>(), c->w->vts_sp.as<char>(), c->qkv_fused == 1 ? 1 : 0};
+        if (h_raw) {   // (layers 1..: the previous layer's second FFN product left raw rows + statistics)
+          EpiLn<EpiQkvT> el;
+          static_cast<EpiQkvT&>(el) = eg;
+          const float* cd = w.ln_cd.as<float>();
+          el.ln_stat = c->w->ln_stat.as<float>(); el.ln_c[0] = cd; el.ln_d[0] = cd + 1024; el.ln_c[1] = cd + 2048; el.ln_d[1] = cd + 2560; el.ln_eps = 1e-5f;
+          ag.X[0] = w.wqk_f.as<char>(); ag.X[1] = w.wv_f.as<char>();
+          CHK((run_gemm_midsize<MODE_GROUPED>(c, CFD_PROF_GEMM_TOKEN, ag, el, st)));
+        } else
         CHK((run_gemm<MODE_GROUPED>(c, CFD_PROF_GEMM_TOKEN, ag, eg, 1, 1, st)));
         qkv_one_launch = true;
       } else {
@@ -527,13 +551,22 @@ int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     // ---- f. time block 2                                                        (:655)
     CHK(ln(w.tb2g, w.tb2b, 1, 2 * l + 1, c->w->h_sp.as<char>(), M));
     // time block 2's projection + residual, then norm3                           (:655, :659)
-    CHK(token_gemm_resid_ln(w.wtb2_sp, CFD_D, c->w->h_sp.as<char>(), w.btb2, M, w.ln3g, w.ln3b, 0, 0));
+    if (ln_fold) CHK(token_gemm_resid_stat(w.wtb2_sp, CFD_D, c->w->h_sp.as<char>(), w.btb2, M, c->w->o_sp.as<char>()));   // (o_sp: free since the out-projection)
+    else CHK(token_gemm_resid_ln(w.wtb2_sp, CFD_D, c->w->h_sp.as<char>(), w.btb2, M, w.ln3g, w.ln3b, 0, 0));
     // ---- g. FFN                                                                 (:659-661)
     {
       GemmArgs a = gemm_args();
       a.X[0] = w.w1_sp.as<char>(); a.ldx[0] = ROWB; a.I[0] = CFD_FF; a.Iclamp[0] = CFD_FF; a.kt[0] = CFD_D / 32;
       a.Y = c->w->h_sp.as<char>(); a.ldy = ROWB; a.J = (int)M; a.Jclamp = (int)M;
       EpiSplit e{c->w->u_sp.as<char>(), (long long)CFD_FF * 4, 0, 0, w.b1, 1, 0};
+      if (ln_fold) {
+        EpiLn<EpiSplit> el;
+        static_cast<EpiSplit&>(el) = e;
+        const float* cd = w.ln_cd.as<float>();
+        el.ln_stat = c->w->ln_stat.as<float>(); el.ln_c[0] = el.ln_c[1] = cd + 3072; el.ln_d[0] = el.ln_d[1] = cd + 4096; el.ln_eps = 1e-5f;
+        a.X[0] = w.w1_f.as<char>(); a.Y = c->w->o_sp.as<char>();
+        CHK((run_gemm_midsize<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, el, st)));
+      } else
       CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
     }
     // second FFN product + residual, then the next layer's norm1 (or the decoder's final norm)   (:661, :568; :238-239)
@@ -541,7 +574,8 @@ int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
       const float* ng = l + 1 < nl ? c->lw[l + 1].ln1g : rawp(c, "decoder.norm.weight");
       const float* nb = l + 1 < nl ? c->lw[l + 1].ln1b : rawp(c, "decoder.norm.bias");
       if (c->stop_stage == 5 + 4 * l) return token_gemm_resid(w.w2_sp, CFD_FF, c->w->u_sp.as<char>(), w.b2, M);
-      CHK(token_gemm_resid_ln(w.w2_sp, CFD_FF, c->w->u_sp.as<char>(), w.b2, M, ng, nb, 0, 0));
+      if (ln_fold) { CHK(token_gemm_resid_stat(w.w2_sp, CFD_FF, c->w->u_sp.as<char>(), w.b2, M, c->w->h_sp.as<char>())); h_raw = true; }
+      else CHK(token_gemm_resid_ln(w.w2_sp, CFD_FF, c->w->u_sp.as<char>(), w.b2, M, ng, nb, 0, 0));
       h_ready = true;
     }
   }
@@ -553,6 +587,14 @@ int enqueue_rows(Ctx* c, hipStream_t st, int row0, int Be) {
     EpiF32 e;
     memset(&e, 0, sizeof(e));
     e.out = eps_out; e.ldo = CFD_LAT; e.bias = rawp(c, "latent_proj.bias");
+    if (h_raw) {
+      EpiLn<EpiF32> el;
+      static_cast<EpiF32&>(el) = e;
+      const float* cd = c->ln_cd_p.as<float>();
+      el.ln_stat = c->w->ln_stat.as<float>(); el.ln_c[0] = el.ln_c[1] = cd; el.ln_d[0] = el.ln_d[1] = cd + CFD_LAT; el.ln_eps = 1e-5f;
+      a.X[0] = c->wp_f.as<char>();
+      CHK((run_gemm_midsize<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, el, st)));
+    } else
     CHK((run_gemm<MODE_PLAIN>(c, CFD_PROF_GEMM_TOKEN, a, e, 1, 1, st)));
   }
   if (p.att_fused && fused_x) {   // this step's maps: from what the nine cross-attention launches kept, into slot *d_step of the ring

@@ -59,6 +59,9 @@ struct DBuf {
 
 struct LayerW {
   DBuf wqk_sp, bqk, wv_sp, wo_sp, bo2, wtb1_sp, wtb2_sp, w1_sp, w2_sp, cross_bias;
+  // the LayerNorm fold's operands (gemm_sp.hpp EpiLn): W' = W diag(gamma) as split pairs for q | k, v and FFN1, and per output feature
+  // c = W' 1, d = W beta in ln_cd: [c_qk 1024][d_qk 1024][c_v 512][d_v 512][c_1 1024][d_1 1024]
+  DBuf wqk_f, wv_f, w1_f, ln_cd;
   const float *ln1g, *ln1b, *tb1g, *tb1b, *btb1, *ln2g, *ln2b, *tb2g, *tb2b, *btb2, *ln3g, *ln3b, *b1, *b2;
 };
 
@@ -130,6 +133,7 @@ struct WegRtState {
 struct Work {
   Problem pb;
   DBuf x, h_sp, qk_sp, vts_sp, ssc, sp_sp, o_sp, u_sp, sc, p_sp, eps, sample_sp;
+  DBuf ln_stat;                 // LayerNorm fold: per row 16 slots of (mean, M2) written by the producing residual product (EpiResidStat)
   DBuf n_sp[CFD_NMEM], kall_sp[CFD_NMEM], cb[CFD_NMEM], vt_all[CFD_NMEM];
   DBuf temb_tab, h1_tab, ss_tab, trows, iota, long_rows, short_rows, zero_mask;
   // timestep-independent memory-side projections (rows.hpp mem_center_kernel): per memory the dot products c_l . a_s (ca), |a_s|^2 (asq)
@@ -160,7 +164,7 @@ struct Work {
   const float* now_vb[CFD_NMEM] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   void release() {
     DBuf* all[] = {&x, &h_sp, &qk_sp, &vts_sp, &ssc, &sp_sp, &o_sp, &u_sp, &sc, &p_sp, &eps, &sample_sp, &temb_tab, &h1_tab, &ss_tab, &trows, &iota,
-                   &long_rows, &short_rows, &zero_mask, &b_tab, &b_sp, &bsq, &zeros512, &xa_wgs, &xa_segs, &xa_stamps, &xa0_wgs_a, &xa0_segs_a, &xa0_wgs_b, &xa0_segs_b, &xa_dedup, &xa_one_va, &xa_att_raw, &xa_att_mc, &xa_att_fin, &xa_att_desc, &d_step, &rt_vt, &rt_cur};
+                   &long_rows, &short_rows, &zero_mask, &ln_stat, &b_tab, &b_sp, &bsq, &zeros512, &xa_wgs, &xa_segs, &xa_stamps, &xa0_wgs_a, &xa0_segs_a, &xa0_wgs_b, &xa0_segs_b, &xa_dedup, &xa_one_va, &xa_att_raw, &xa_att_mc, &xa_att_fin, &xa_att_desc, &d_step, &rt_vt, &rt_cur};
     for (DBuf* b : all) b->release();
     for (int j = 0; j < CFD_NMEM; ++j) {
       n_sp[j].release(); kall_sp[j].release(); cb[j].release(); vt_all[j].release(); ca[j].release(); asq[j].release(); kbtab[j].release();
@@ -177,6 +181,7 @@ struct cfd_handle_s {
   std::map<std::string, size_t> raw_numel;
   // prepared weights
   DBuf we_sp, wp_sp, we_all, be_all;
+  DBuf wp_f, ln_cd_p;           // the final norm folded into latent_proj: W' as split pairs; [c 128][d 128]
   DBuf wk_all_sp[CFD_NMEM], wv_all_sp[CFD_NMEM];
   std::vector<LayerW> lw;
   int qpe_rows = 0, mpe_rows = 0;
@@ -215,6 +220,7 @@ struct cfd_handle_s {
   int step_rows = 1;            // CFD_STEP_ROWS=0: the tile kernels index the per-step tables with the device step counter themselves
   int att_fused = 1;            // CFD_ATT_FUSED=0: a forward that returns att_mats takes the three-launch cross-attention on the tile kernels (the fused
                                 // kernel's ATT instance keeps the maps otherwise: xattn_fused.hpp, XaAtt)
+  int ln_fold = -1;             // CFD_LN_FOLD: the algebraic LayerNorm fold of mid-size problems (cfd_forward.hip): -1 by shape, 0 off, 1 wherever the launches allow it
   int qkv_fused = 1;            // CFD_QKV_FUSED=0: batch rows of 16 tokens keep the separate v^T product (EpiQkvT, gemm_sp.hpp); 2: one launch, but
                                 // the flash self-attention kernel behind it (1: the row-tile path's attention core)
   int l0_dedup = 1;             // CFD_L0_DEDUP=0: layer 0's cross-attention as one launch over all rows (build_xattn_layer0_lists)
@@ -330,6 +336,14 @@ template <int MODE, class Epi>
 static int run_gemm(Ctx* c, int cls, const GemmArgs& a, const Epi& e, int nb, int nz, hipStream_t st, int cfg = 0) {
   Bracket br(c, cls, st);
   hipError_t err = launch_gemm<MODE, Epi>(a, e, nb, nz, st, cfg);
+  if (err != hipSuccess) return fail(CFD_E_HIP, "gemm launch failed: %s", hipGetErrorString(err));
+  return CFD_OK;
+}
+
+template <int MODE, class Epi>
+static int run_gemm_midsize(Ctx* c, int cls, const GemmArgs& a, const Epi& e, hipStream_t st) {
+  Bracket br(c, cls, st);
+  hipError_t err = launch_gemm_midsize<MODE, Epi>(a, e, st);
   if (err != hipSuccess) return fail(CFD_E_HIP, "gemm launch failed: %s", hipGetErrorString(err));
   return CFD_OK;
 }

@@ -243,6 +243,73 @@ struct EpiResid {  // x[(b*rows_per_b + j)][i] += v + bias[i]   (row length CFD_
   }
 };
 
+// ---- The algebraic LayerNorm fold (round 6; mid-size problems: cfd_forward.hip `ln_fold`) -------------------------
+//   W LN(x) + b = r_sigma (W' x - mu c) + d + b,    W' = W diag(gamma),  c = W' 1,  d = W beta
+// The PRODUCER of x (a residual product: EpiResidStat) also stores the split-pair copy of its new rows -- the consumer's operand -- and, per
+// row and 32-column slot, the slot's mean and sum of squared deviations (16 slots a row, no atomics).  The CONSUMER (any epilogue wrapped
+// in EpiLn) puts a row's statistics together from the 16 slots (Chan's pairwise update with equal counts) while its first operand tiles
+// are on their way, and rescales its accumulators in front of its own epilogue.  No ln_rows launch in between.
+#define LN_SLOTS 16          // slots per row (CFD_D / 32)
+// Sum over the aligned group of 8 consecutive lanes a lane belongs to, in the vector ALU (DPP: quad permutes, then the half-row mirror).
+__device__ __forceinline__ float lane_group8_sum(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));    // quad_perm [1, 0, 3, 2]
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));    // quad_perm [2, 3, 0, 1]
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  return x;
+}
+struct EpiResidStat {   // EpiResid + xs[row] = split(x_new[row]) + stat[row][slot] = (mean, M2) of the slot's 32 columns
+  float* x;
+  long long obs;  // floats per batch
+  const float* bias;
+  char* xs;       // SP [rows][512]
+  float* stat;    // [rows][LN_SLOTS][2]
+  static constexpr bool kPrefetch = false;
+  __device__ __forceinline__ void operator()(int g, int b, int z, int i, int j, f32x4 v) const {   // (narrow epilogue / naive kernel: not used with the fold)
+    float* p = x + (long long)b * obs + (long long)j * CFD_D + i;
+    float4 r = *reinterpret_cast<const float4*>(p);
+    if (bias) {
+      const float4 t = *reinterpret_cast<const float4*>(bias + i);
+      r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+    }
+    r.x += v[0]; r.y += v[1]; r.z += v[2]; r.w += v[3];
+    *reinterpret_cast<float4*>(p) = r;
+  }
+  static constexpr bool kBand = true;
+  static constexpr bool kRowStat = true;
+  __device__ __forceinline__ float4 tile_bias(int i) const {
+    return bias ? *reinterpret_cast<const float4*>(bias + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __device__ __forceinline__ float4 band_load(int g, int b, int z, int i, int j) const {
+    return *reinterpret_cast<const float4*>(x + (long long)b * obs + (long long)j * CFD_D + i);
+  }
+  // every lane of the wave takes part (the 8 lanes of a slot reduce in the vector ALU); `valid` = the lane's (i, j) is inside the matrix
+  __device__ __forceinline__ void band_store_stat(int g, int b, int z, int i, int j, f32x4 v, float4 r, float4 t, bool valid) const {
+    r.x = (r.x + t.x) + v[0]; r.y = (r.y + t.y) + v[1]; r.z = (r.z + t.z) + v[2]; r.w = (r.w + t.w) + v[3];   // same association as EpiResid
+    const long long row = (long long)b * obs / CFD_D + j;
+    if (valid) {
+      *reinterpret_cast<float4*>(x + row * CFD_D + i) = r;
+      sp_store4(xs + row * (CFD_D * 4), i, r.x, r.y, r.z, r.w);
+    }
+    const float mean = lane_group8_sum((r.x + r.y) + (r.z + r.w)) * (1.0f / 32.0f);
+    const float dx = r.x - mean, dy = r.y - mean, dz = r.z - mean, dw = r.w - mean;
+    const float m2 = lane_group8_sum((dx * dx + dy * dy) + (dz * dz + dw * dw));
+    if (valid && (threadIdx.x & 7) == 0) *reinterpret_cast<float2*>(stat + (row * LN_SLOTS + (i >> 5)) * 2) = make_float2(mean, m2);
+  }
+  __device__ __forceinline__ void band_store(int g, int b, int z, int i, int j, f32x4 v, float4 r, float4 t) const {   // (unused: the kernel calls band_store_stat)
+    band_store_stat(g, b, z, i, j, v, r, t, true);
+  }
+};
+// An epilogue E whose product runs on the RAW rows of x (split pairs stored by EpiResidStat) against W' = W diag(gamma): gemm_sp_body
+// rescales the accumulators with the rows' statistics before E sees them.  Group g of a grouped launch has its own c / d vectors.
+template <class E>
+struct EpiLn : E {
+  const float* ln_stat;      // [rows][LN_SLOTS][2]; rows indexed like the launch's j (un-batched launches only)
+  const float* ln_c[2];      // c = W' 1 per output feature of group g
+  const float* ln_d[2];      // d = W beta
+  float ln_eps;
+  static constexpr bool kLnFold = true;
+};
+
 struct EpiNull {  // timing experiments only: keeps the accumulators live, stores nothing
   static constexpr bool kPrefetch = false;
   float* sink;
@@ -344,6 +411,10 @@ template <class E, class = void> struct EpiHasStore8 { static constexpr bool val
 template <class E> struct EpiHasStore8<E, typename std::enable_if<E::kStore8>::type> { static constexpr bool value = true; };
 template <class E, class = void> struct EpiHasStoreT { static constexpr bool value = false; };
 template <class E> struct EpiHasStoreT<E, typename std::enable_if<E::kStoreT>::type> { static constexpr bool value = true; };
+template <class E, class = void> struct EpiHasRowStat { static constexpr bool value = false; };
+template <class E> struct EpiHasRowStat<E, typename std::enable_if<E::kRowStat>::type> { static constexpr bool value = true; };
+template <class E, class = void> struct EpiHasLnFold { static constexpr bool value = false; };
+template <class E> struct EpiHasLnFold<E, typename std::enable_if<E::kLnFold>::type> { static constexpr bool value = true; };
 template <class E, bool P = E::kPrefetch> struct EpiPre { struct type {}; };
 template <class E> struct EpiPre<E, true> { typedef typename E::Pre type; };
 
@@ -568,6 +639,46 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
     epi.tile_bias8(min(i8, Ig - 8), s8_t0, s8_t1);
   }
 
+  // LayerNorm fold (EpiLn): thread t < BJ requests the 16 (mean, M2) slots of row j0 + t now; ln_finish() -- called behind the first
+  // stage requests -- puts them together and parks (mu, r_sigma) behind the staging ring, where the epilogue reads them.
+  constexpr bool LNF = EpiHasLnFold<Epi>::value;
+  static_assert(!LNF || MODE != MODE_SEGK, "LayerNorm fold: plain or grouped launches");
+  float4 ln_raw[LNF ? LN_SLOTS / 2 : 1];
+  float4 ln_c4[LNF ? TI : 1], ln_d4[LNF ? TI : 1];
+  if constexpr (LNF) {
+    if ((int)threadIdx.x < BJ) {
+      const float4* sp = reinterpret_cast<const float4*>(epi.ln_stat + (long long)min(j0 + (int)threadIdx.x, a.J - 1) * (LN_SLOTS * 2));
+#pragma unroll
+      for (int q = 0; q < LN_SLOTS / 2; ++q) ln_raw[q] = sp[q];
+    }
+    const float* cg = g == 0 ? epi.ln_c[0] : epi.ln_c[1];
+    const float* dg = g == 0 ? epi.ln_d[0] : epi.ln_d[1];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+      const int i = min(i0 + (wi * TI + ti) * 16 + q4 * 4, Ig - 4);
+      ln_c4[ti] = *reinterpret_cast<const float4*>(cg + i);
+      ln_d4[ti] = *reinterpret_cast<const float4*>(dg + i);
+    }
+  }
+  auto ln_finish = [&]() __attribute__((always_inline)) {
+    if constexpr (LNF) {
+      if ((int)threadIdx.x < BJ) {
+        float ms = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < LN_SLOTS / 2; ++q) { ms += ln_raw[q].x + ln_raw[q].z; m2 += ln_raw[q].y + ln_raw[q].w; }
+        const float mu = ms * (1.0f / LN_SLOTS);
+        float dev = 0.f;
+#pragma unroll
+        for (int q = 0; q < LN_SLOTS / 2; ++q) {
+          const float d0 = ln_raw[q].x - mu, d1 = ln_raw[q].z - mu;
+          dev += d0 * d0 + d1 * d1;
+        }
+        const float var = (m2 + dev * 32.0f) * (1.0f / CFD_D);
+        reinterpret_cast<float2*>(smem + NSTAGE * STAGE)[threadIdx.x] = make_float2(mu, 1.0f / sqrtf(var + epi.ln_eps));
+      }
+    }
+  };
+
   auto compute2 = [&](const char* sbx, const char* sby) __attribute__((always_inline)) {   // sby: the Y tile's base MINUS BI * 128
     spx8 xh[TI], xl[TI], yh[TJ], yl[TJ];
 #pragma unroll
@@ -596,6 +707,7 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
 
   if constexpr (NSTAGE == 2) {
     stage(0, 0);
+    ln_finish();
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
       const int buf = kt & 1;
@@ -611,6 +723,7 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
     stage(0, 0);
     if (nkt > 1) {
       stage(1, 1);
+      ln_finish();
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPW) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -630,6 +743,20 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
     }
   }
 
+  if constexpr (LNF) {   // acc <- r_sigma (acc - mu c) + d: lane (l15, q4) holds row (wj TJ + tj) 16 + l15, features (wi TI + ti) 16 + 4 q4 .. + 3
+    const float2* sl = reinterpret_cast<const float2*>(smem + NSTAGE * STAGE);
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      const float2 mr = sl[(wj * TJ + tj) * 16 + l15];
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) {
+        acc[ti][tj][0] = mr.y * (acc[ti][tj][0] - mr.x * ln_c4[ti].x) + ln_d4[ti].x;
+        acc[ti][tj][1] = mr.y * (acc[ti][tj][1] - mr.x * ln_c4[ti].y) + ln_d4[ti].y;
+        acc[ti][tj][2] = mr.y * (acc[ti][tj][2] - mr.x * ln_c4[ti].z) + ln_d4[ti].z;
+        acc[ti][tj][3] = mr.y * (acc[ti][tj][3] - mr.x * ln_c4[ti].w) + ln_d4[ti].w;
+      }
+    }
+  }
   if constexpr (WIDE) {
     static_assert(NIT == TI, "one epilogue instruction per MFMA tile");
     // every wave re-lays its tile band by band through a private LDS strip (the staging ring is free now)
@@ -714,6 +841,10 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
         for (int it = 0; it < NIT; ++it) {
           int i, j;
           epi_ij(tj, it, i, j);
+          if constexpr (EpiHasRowStat<Epi>::value) {   // (every lane takes part in the slot reduction; out-of-range lanes store nothing)
+            static_assert(LPR == 8 || LPR == 16, "a 32-column slot = 8 lanes of one row");
+            epi.band_store_stat(g, b, z, min(i, Ig - 4), min(j, a.J - 1), bv[it], band_r[it], band_t, i < Ig && j < a.J);
+          } else
           if (i < Ig && j < a.J) epi.band_store(g, b, z, i, j, bv[it], band_r[it], band_t);
         }
 #pragma unroll
@@ -809,7 +940,7 @@ static hipError_t launch_cfg(GemmArgs a, const Epi& epi, int nb, int nz, hipStre
     total += a.tiles_i[g] * a.tiles_j;
   }
   a.tile_start[ng] = total;
-  constexpr int lds = NSTAGE * (BI + BJ) * 128;
+  constexpr int lds = NSTAGE * (BI + BJ) * 128 + (EpiHasLnFold<Epi>::value ? BJ * 8 : 0);   // (+ the rows' (mu, r_sigma) of the LayerNorm fold)
   // the attribute is per device: one bit per device ordinal (a process may hold handles on several GPUs)
   static unsigned long long attr_set = 0;
   int dev = 0;
@@ -874,4 +1005,21 @@ static hipError_t launch_gemm(GemmArgs a, const Epi& epi, int nb, int nz, hipStr
     case 24: return launch_cfg<2, 2, 4, 2, 3, MODE, Epi>(a, epi, nb, nz, st);
     default: return launch_cfg<4, 1, 2, 1, 2, MODE, Epi>(a, epi, nb, nz, st);
   }
+}
+
+// The launches of the LayerNorm fold (EpiResidStat producers, EpiLn<E> consumers): un-batched mid-size problems, for which launch_gemm
+// above picks the 64 x 64 class or, with more than 768 such tiles, the 128 x 64 class (cfd_forward.hip checks the range) -- only these
+// two are instantiated for the fold's epilogues.
+template <int MODE, class Epi>
+static hipError_t launch_gemm_midsize(GemmArgs a, const Epi& epi, hipStream_t st) {
+  if (a.nslot < 1) a.nslot = 1;
+  const int ng = (MODE == MODE_GROUPED) ? a.nslot : 1;
+  long long t64 = 0;
+  int imax = 0;
+  for (int g = 0; g < ng; ++g) {
+    t64 += (long long)((a.I[g] + 63) / 64) * ((a.J + 63) / 64);
+    imax = a.I[g] > imax ? a.I[g] : imax;
+  }
+  if (t64 > 768 && imax >= 128) return launch_cfg<2, 2, 4, 2, 3, MODE, Epi>(a, epi, 1, 1, st);
+  return launch_cfg<2, 2, 2, 2, 3, MODE, Epi>(a, epi, 1, 1, st);
 }

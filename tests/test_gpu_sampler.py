@@ -315,7 +315,7 @@ def test_ddim_with_eta_matches_oracle():
 
 @pytest.mark.parametrize("env", [{"CFD_NAIVE_GEMM": "1"}, {"CFD_RUNS": "0", "CFD_FUSED_XATTN": "0"}, {"CFD_FUSED_XATTN": "0"},
                                  {"CFD_HOIST_MEMSIDE": "0"}, {"CFD_ROWTILE": "0"}, {"CFD_ROWTILE": "0", "CFD_QKV_FUSED": "0"}, {"CFD_ROWTILE": "0", "CFD_QKV_FUSED": "2"}, {"CFD_ROWTILE": "0", "CFD_ATT_FUSED": "0"}, {"CFD_STEP_ROWS": "0"},
-                                 {"CFD_ONE_KEY": "0", "CFD_L0_DEDUP": "0"}])
+                                 {"CFD_ONE_KEY": "0", "CFD_L0_DEDUP": "0"}, {"CFD_ROWTILE": "0", "CFD_LN_FOLD": "1"}])
 def test_developer_knobs_keep_parity(env):
     """The debug switches that select another code path for the same arithmetic (read once at cfd_create) must not change
     results: CFD_NAIVE_GEMM=1 (one-thread-per-output products instead of the MFMA kernels, three-launch attention),
@@ -328,7 +328,8 @@ def test_developer_knobs_keep_parity(env):
     row-tile path's attention core), CFD_ROWTILE=0 with CFD_ATT_FUSED=0 (forwards that return att_mats on the
     three-launch cross-attention instead of the fused kernel's attention-map instance), CFD_STEP_ROWS=0 (the tile kernels index the per-step
     tables with the device step counter themselves instead of reading rows a launch at the start of the iteration has staged), CFD_ONE_KEY=0 with CFD_L0_DEDUP=0
-    (the fused cross-attention in its plain form: the one-key memory as a 32-key tile step, layer 0 as one launch).  Each leg runs the golden forward, the 20-step trajectory, the run-path
+    (the fused cross-attention in its plain form: the one-key memory as a 32-key tile step, layer 0 as one launch), CFD_ROWTILE=0 with CFD_LN_FOLD=1 (the small
+    goldens on the tile kernels with the algebraic LayerNorm fold of mid-size problems forced on: gemm_sp.hpp EpiResidStat / EpiLn).  Each leg runs the golden forward, the 20-step trajectory, the run-path
     test and the headline-shape loop rows in a child process."""
     import os
     import subprocess
@@ -697,6 +698,74 @@ def test_row_tile_path_is_race_free_and_shape_general():
         assert e < 1e-4
         for j in range(5):
             assert max_abs(att0[j].cpu().numpy(), watt[j]) < 1e-4
+
+
+@pytest.mark.parametrize("case", ["b10", "b32", "b10_rows_far_from_zero_mean", "b10_half_rows_apart"])
+def test_layernorm_fold_of_mid_size_problems(case):
+    """Between 1 024 and 3 840 token rows at the product shape (L = 16: `test.py`'s batches) norm3, the norm1 of layers 1.. and the decoder's
+    final norm are not launched: the residual product in front of each stores the raw rows' split pairs and per-row slot statistics, the consumer
+    runs on W diag(gamma) and rescales its accumulators (gemm_sp.hpp EpiResidStat / EpiLn; cross_attention.py:568-570, :659-661, :238-239).  The
+    forward with the fold (default) against the numpy oracle and against the same forward with the LayerNorms launched (CFD_LN_FOLD=0): 10 and 32
+    utterances of 7 guidance chunks (1 120 / 3 584 rows), and rows whose mean is 25 deviations away from zero / whose two halves sit 24 apart --
+    where W' x - mu c cancels most of its digits."""
+    import os
+    import torch
+    from convofusion_amd.denoiser import Denoiser
+    from oracle import denoiser_ref
+    from tests.gpu_helpers import ABL, DENOISER_KW, to_dev
+    Be, L, S = (224 if case == "b32" else 70), 16, (24, 161, 24, 8, 1)
+    inp = inputs.make_plain_batch(seed=77 + Be, Be=Be, L=L, S=S, pad_tail=(3, 17, 0, 0, 0))
+    sd = {k: v.copy() for k, v in state_dict().items()}
+    if case.endswith("zero_mean"):
+        sd["latent_embd.bias"] = (sd["latent_embd.bias"] + 25.0).astype(np.float32)
+    elif case.endswith("apart"):
+        sd["latent_embd.bias"] = (sd["latent_embd.bias"] + np.where(np.arange(512) < 256, 12.0, -12.0)).astype(np.float32)
+    want, _ = denoiser_ref.denoiser_forward(sd, inp["sample"], 577, inp["memories"], inp["masks"])
+    outs = {}
+    for fold in ("-1", "0"):
+        keep = os.environ.get("CFD_LN_FOLD")
+        os.environ["CFD_LN_FOLD"] = fold
+        try:
+            m = Denoiser(ablation=ABL, **DENOISER_KW)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+            m = m.cuda().eval()
+            m.engine(torch.device("cuda"))          # (the knobs are read when the handle is created)
+        finally:
+            if keep is None:
+                os.environ.pop("CFD_LN_FOLD", None)
+            else:
+                os.environ["CFD_LN_FOLD"] = keep
+        with torch.no_grad():
+            out, _ = m(to_dev(inp["sample"]), torch.tensor(577), [to_dev(x) for x in inp["memories"]],
+                       mem_mask_dict={k: to_dev(v) for k, v in inp["masks"].items()})
+            again, _ = m(to_dev(inp["sample"]), torch.tensor(577), [to_dev(x) for x in inp["memories"]],
+                         mem_mask_dict={k: to_dev(v) for k, v in inp["masks"].items()})
+        assert torch.equal(out, again)
+        outs[fold] = out.cpu().numpy()
+    e_fold, e_ln, e_pair = rel_l2(outs["-1"], want), rel_l2(outs["0"], want), rel_l2(outs["-1"], outs["0"])
+    print(f"{case}: fold vs oracle {e_fold:.2e}, launched LayerNorms vs oracle {e_ln:.2e}, fold vs launched {e_pair:.2e}")
+    assert e_fold < 1e-4 and e_ln < 1e-4
+    assert e_pair > 0.0, "the two legs ran the same launches"
+    assert e_pair < 5e-5
+
+
+def test_layernorm_fold_in_a_sampling_run():
+    """Eight guided DDPM steps of 10 utterances at the product shape (1 120 rows: the fold's range) with the fold and with the LayerNorms launched:
+    the captured iteration holds the fold's launches like the eager forward does."""
+    from convofusion_amd.sampler import sample
+    from tests.gpu_helpers import to_dev
+    B, L, S = 10, 16, (24, 161, 24, 8, 1)
+    cb = inputs.make_cfg_batch(seed=31, B=B, L=L, S=S, pad_tail=(4, 9, 6, 0, 0))
+    mems = [to_dev(x) for x in cb["memories"]]
+    masks = {k: to_dev(v) for k, v in cb["masks"].items()}
+    lat = {}
+    for fold in ("-1", "0"):
+        m = _handle_with_env({"CFD_LN_FOLD": fold})
+        lat[fold] = sample(m, _sched("ddpm"), mems, masks, B=B, L=L, num_inference_steps=8, seed=5).cpu().numpy()
+        assert np.isfinite(lat[fold]).all()
+    d = rel_l2(lat["-1"], lat["0"])
+    print("8 DDPM steps, fold vs launched LayerNorms: rel L2", d)
+    assert 0.0 < d < 2e-4        # (an 8-step schedule amplifies a 1e-6 rounding difference per forward ~50x)
 
 
 def test_row_tile_path_agrees_with_the_tile_kernels_on_random_shapes():
