@@ -339,6 +339,9 @@ def test_developer_knobs_keep_parity(env):
     tests = ["tests/test_gpu_forward.py::test_forward_matches_reference_golden",
              "tests/test_gpu_sampler.py::test_sampler_matches_reference_trajectory[ddpm20_b2]",
              "tests/test_gpu_sampler.py::test_shared_memory_run_path_matches_oracle"]
+    if env.get("CFD_LN_FOLD") == "1":   # the fold on the heavy-tailed weights (outlier LayerNorm gains, outlier rows) and their 1000-step trajectory
+        tests += ["tests/test_gpu_forward.py::test_heavy_tailed_weights_stress_case",
+                  "tests/test_gpu_sampler.py::test_heavy_tailed_weights_ddpm1000_trajectory"]
     if "CFD_NAIVE_GEMM" not in env:   # (the one-thread-per-output products would take minutes at the headline size)
         tests.append("tests/test_gpu_sampler.py::test_headline_shape_loop_row_matches_reference[b32-ddpm5]")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", *tests], cwd=root, env=e, capture_output=True, text=True, timeout=1200)
