@@ -641,12 +641,15 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
 
   // LayerNorm fold (EpiLn): thread t < BJ requests the 16 (mean, M2) slots of row j0 + t now; ln_finish() -- called behind the first
   // stage requests -- puts them together and parks (mu, r_sigma) behind the staging ring, where the epilogue reads them.
+#ifndef LNF_ABL
+#define LNF_ABL 0   // developer timing experiments (results are garbage): 1 = no statistics loads / combine, 2 = no rescale, 4 = no c / d loads
+#endif
   constexpr bool LNF = EpiHasLnFold<Epi>::value;
   static_assert(!LNF || MODE != MODE_SEGK, "LayerNorm fold: plain or grouped launches");
   float4 ln_raw[LNF ? LN_SLOTS / 2 : 1];
   float4 ln_c4[LNF ? TI : 1], ln_d4[LNF ? TI : 1];
   if constexpr (LNF) {
-    if ((int)threadIdx.x < BJ) {
+    if (!(LNF_ABL & 1) && (int)threadIdx.x < BJ) {
       const float4* sp = reinterpret_cast<const float4*>(epi.ln_stat + (long long)min(j0 + (int)threadIdx.x, a.J - 1) * (LN_SLOTS * 2));
 #pragma unroll
       for (int q = 0; q < LN_SLOTS / 2; ++q) ln_raw[q] = sp[q];
@@ -655,13 +658,14 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
     const float* dg = g == 0 ? epi.ln_d[0] : epi.ln_d[1];
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti) {
-      const int i = min(i0 + (wi * TI + ti) * 16 + q4 * 4, Ig - 4);
+      const int i = (LNF_ABL & 4) ? 0 : min(i0 + (wi * TI + ti) * 16 + q4 * 4, Ig - 4);
+      if (LNF_ABL & 4) { ln_c4[ti] = ln_d4[ti] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
       ln_c4[ti] = *reinterpret_cast<const float4*>(cg + i);
       ln_d4[ti] = *reinterpret_cast<const float4*>(dg + i);
     }
   }
   auto ln_finish = [&]() __attribute__((always_inline)) {
-    if constexpr (LNF) {
+    if constexpr (LNF && !(LNF_ABL & 1)) {
       if ((int)threadIdx.x < BJ) {
         float ms = 0.f, m2 = 0.f;
 #pragma unroll
@@ -743,7 +747,7 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
     }
   }
 
-  if constexpr (LNF) {   // acc <- r_sigma (acc - mu c) + d: lane (l15, q4) holds row (wj TJ + tj) 16 + l15, features (wi TI + ti) 16 + 4 q4 .. + 3
+  if constexpr (LNF && !(LNF_ABL & 2)) {   // acc <- r_sigma (acc - mu c) + d: lane (l15, q4) holds row (wj TJ + tj) 16 + l15, features (wi TI + ti) 16 + 4 q4 .. + 3
     const float2* sl = reinterpret_cast<const float2*>(smem + NSTAGE * STAGE);
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
