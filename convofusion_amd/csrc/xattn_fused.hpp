@@ -7,7 +7,7 @@
 // softmax_rows_kernel and the P.V products of the three-launch path (which stays for calls that want att_mats).
 //
 // Work decomposition.  A workgroup = 8 waves = 4 query tiles of 16 queries (each of ONE batch row) x 2 halves.  The two
-// waves of a pair (w, w + 4) share a query tile and split the two 512-long axes between them, so that a wave's resident
+// waves of a pair (2 t, 2 t + 1) share a query tile and split the two 512-long axes between them, so that a wave's resident
 // state -- its Q fragments (8 k-steps x hi/lo = 64 VGPRs) and its output accumulator O^T[256 features][16 queries]
 // (16 MFMA tiles = 64 VGPRs) -- leaves room for two waves per SIMD:
 //   phase A   partial S^T[32 keys][16 q] over ITS half of the 512-deep dot product: Kf tile (LDS, A operand) x Q
@@ -260,9 +260,21 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
 #endif
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifndef XA_PAIR_ADJACENT
+#define XA_PAIR_ADJACENT 1
+#endif
+#if XA_PAIR_ADJACENT
+  // The pair of a query tile = waves (2 t, 2 t + 1): on DIFFERENT SIMDs.  With all four tiles busy a SIMD still hosts two waves (of two tiles),
+  // which is what the main loop's accounting assumes; a short work list that gives a workgroup ONE tile (the product shape: make_xattn_worklist)
+  // then has its two computing waves on two SIMDs instead of taking turns on one.
+  const int tile = wid >> 1;     // query tile of the pair
+  const int half = wid & 1;      // which half of the 512-long axes
+  const int partner = wid ^ 1;
+#else
   const int tile = wid & 3;      // query tile of the pair (w, w + 4): the two waves share a SIMD
   const int half = wid >> 2;     // which half of the 512-long axes
   const int partner = wid ^ 4;
+#endif
   const int l15 = lane & 15, q4 = lane >> 4, sw = l15 >> 1;
   const int cpos = lane & 7, rsub = lane >> 3;
 
@@ -277,7 +289,7 @@ __global__ void __launch_bounds__(XA_WAVES * 64, 2) xattn_fused_kernel(const XAt
   const int nq = active ? min(16, a.L - my_q0) : 0;    // valid queries of this wave's tile
   bool att_on = false;                                 // (wave-uniform) this wave stores its tile's attention maps: one wave of the pair
   int my_att = -1;
-  if constexpr (ATT) { my_att = wgp->att[tile]; att_on = active && (wid >> 2) == 0 && my_att >= 0; }
+  if constexpr (ATT) { my_att = wgp->att[tile]; att_on = active && half == 0 && my_att >= 0; }
 
   // the segment list of this workgroup -> LDS (read back with ds_read: no vector-memory traffic inside the loop)
   if (threadIdx.x < nseg) reinterpret_cast<int4*>(smem + XA_SEGOFF)[threadIdx.x] = reinterpret_cast<const int4*>(a.segs + seg0)[threadIdx.x];
