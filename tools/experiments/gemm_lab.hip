@@ -1,6 +1,7 @@
 // Developer tool: stand-alone timing / checking harness for the split-pair MFMA GEMM (gemm_sp.hpp), built as a
 // plain HIP executable so that kernel experiments do not need the whole library:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/gemm_lab.hip -o gpurun_out/gemm_lab
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/experiments/gemm_lab.hip -o tools/experiments/gemm_lab
+//   (with r06_variants/gemm_register_staged_prefetch.patch applied and -DCFD_GEMM_RS=1: cfg 31 = the 128 x 128 tile with register-staged prefetch)
 //   gemm_lab J K I rounds  epi:cfg [epi:cfg ...]      epi: r = residual RMW, o = residual RMW without the late
 //                                                      prefetch, n = no stores, f = fp32 store, s = SP store
 // Variants are timed interleaved, `rounds` times, in one process (median and min are printed); the first launch of
@@ -58,13 +59,13 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&ref, (size_t)J * I * 4));
   CK(hipMalloc(&osp, (size_t)J * I * 4));
   long long n = (long long)I * K / 4;
-  hipLaunchKernelGGL(philox_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, xf, 1, I * K, 1ull, 0u, 0u, 3u, 0.05f);
+  hipLaunchKernelGGL(philox_fill_kernel<>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, xf, 1, I * K, 1ull, 0u, 0u, 3u, 0.05f);
   n = (long long)J * K / 4;
-  hipLaunchKernelGGL(philox_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, yf, 1, (int)((long long)J * K), 2ull, 0u, 0u, 3u, 1.0f);
+  hipLaunchKernelGGL(philox_fill_kernel<>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, yf, 1, (int)((long long)J * K), 2ull, 0u, 0u, 3u, 1.0f);
   n = (long long)I * (K / 8);
-  hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, xf, xs, (long long)I, K, (long long)K, (long long)K * 4);
+  hipLaunchKernelGGL(to_split_kernel<>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, xf, xs, (long long)I, K, (long long)K, (long long)K * 4, (unsigned int*)nullptr);
   n = (long long)J * (K / 8);
-  hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, yf, ys, (long long)J, K, (long long)K, (long long)K * 4);
+  hipLaunchKernelGGL(to_split_kernel<>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, yf, ys, (long long)J, K, (long long)K, (long long)K * 4, (unsigned int*)nullptr);
   CK(hipDeviceSynchronize());
 
   GemmArgs a;
