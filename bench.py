@@ -275,6 +275,19 @@ def secondary_configs(model, device):
         out["r_product_shape_b32"] = {"steps_per_s": 50 / dt, "ms_per_step": 1000 * dt / 50, "workload": f"B={B_PER_GPU}, L={L}, S={S}",
                                       "all_attention_maps_ms_per_step": 1000 * dt_ring / 50, "all_attention_maps_over_none": dt_ring / dt,
                                       "reference_python_loop_on_hip_denoiser_ms_per_step": 1000 * t_py}
+        # ... and the smaller batches of the same shape (8 / 16 utterances: 896 / 1 792 token rows), 200 replays each
+        for b_small in (8, 16):
+            mems, masks = make_inputs(b_small, device, seed=1234)
+            run = SamplingRun(model, ddpm, mems, masks, b_small, L, 1000, guidance_scale=7.5, seed=0)
+            run.steps(5)
+            run.read()
+            t0 = time.perf_counter()
+            run.steps(200)
+            run.read()
+            dt_small = time.perf_counter() - t0
+            run.close()
+            del run
+            out["r_product_shape_b32"][f"b{b_small}_ms_per_step"] = 1000 * dt_small / 200
         mems, masks = make_inputs(1, device, seed=1234)
         run = SamplingRun(model, ddpm, mems, masks, 1, L, 1000, guidance_scale=7.5, seed=0)
         run.steps(2)
