@@ -646,14 +646,22 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
 #endif
   constexpr bool LNF = EpiHasLnFold<Epi>::value;
   static_assert(!LNF || MODE != MODE_SEGK, "LayerNorm fold: plain or grouped launches");
-  float4 ln_raw[LNF ? LN_SLOTS / 2 : 1];
+  // The statistics are requested by inline assembly and waited for by hand in ln_finish: as ordinary loads hipcc drained the whole queue for them
+  // TWICE in the prologue (behind the first stage's requests and again behind the second's), i.e. the first two stages landed one after the other --
+  // +1.6 us on every consumer launch.
+  f32x4 ln_raw[LNF ? LN_SLOTS / 2 : 1];
   float4 ln_c4[LNF ? TI : 1], ln_d4[LNF ? TI : 1];
   if constexpr (LNF) {
     if (!(LNF_ABL & 1) && (int)threadIdx.x < BJ) {
-      const float4* sp = reinterpret_cast<const float4*>(epi.ln_stat + (long long)min(j0 + (int)threadIdx.x, a.J - 1) * (LN_SLOTS * 2));
+      const char* sp = reinterpret_cast<const char*>(epi.ln_stat + (long long)min(j0 + (int)threadIdx.x, a.J - 1) * (LN_SLOTS * 2));
 #pragma unroll
-      for (int q = 0; q < LN_SLOTS / 2; ++q) ln_raw[q] = sp[q];
+      for (int q = 0; q < LN_SLOTS / 2; ++q) {
+        const char* gp = sp + q * 16;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ln_raw[q]) : "v"(gp) : "memory");
+      }
     }
+    // c = W' 1 and d = W beta of this lane's features: requested in front of the stage requests (in-order completion: behind them, the
+    // counted waits of the loop would wait for them and with them for the stage in front), used behind the K loop
     const float* cg = g == 0 ? epi.ln_c[0] : epi.ln_c[1];
     const float* dg = g == 0 ? epi.ln_d[0] : epi.ln_d[1];
 #pragma unroll
@@ -663,22 +671,34 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
       ln_c4[ti] = *reinterpret_cast<const float4*>(cg + i);
       ln_d4[ti] = *reinterpret_cast<const float4*>(dg + i);
     }
+    __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks half of these requests behind the first stage's)
   }
-  auto ln_finish = [&]() __attribute__((always_inline)) {
-    if constexpr (LNF && !(LNF_ABL & 1)) {
-      if ((int)threadIdx.x < BJ) {
-        float ms = 0.f, m2 = 0.f;
+  // `younger`: the vector-memory requests this wave has issued since (the stage requests in front of the call)
+  auto ln_finish = [&](auto younger) __attribute__((always_inline)) {
+    if constexpr (LNF) {
+      if constexpr (!(LNF_ABL & 1)) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(younger)::value) : "memory");
+        if ((int)threadIdx.x < BJ) {
 #pragma unroll
-        for (int q = 0; q < LN_SLOTS / 2; ++q) { ms += ln_raw[q].x + ln_raw[q].z; m2 += ln_raw[q].y + ln_raw[q].w; }
-        const float mu = ms * (1.0f / LN_SLOTS);
-        float dev = 0.f;
+          for (int q = 0; q < LN_SLOTS / 2; ++q) asm volatile("" : "+v"(ln_raw[q]));
+          float ms = 0.f, m2 = 0.f;
 #pragma unroll
-        for (int q = 0; q < LN_SLOTS / 2; ++q) {
-          const float d0 = ln_raw[q].x - mu, d1 = ln_raw[q].z - mu;
-          dev += d0 * d0 + d1 * d1;
+          for (int q = 0; q < LN_SLOTS / 2; ++q) { ms += ln_raw[q][0] + ln_raw[q][2]; m2 += ln_raw[q][1] + ln_raw[q][3]; }
+          const float mu = ms * (1.0f / LN_SLOTS);
+          float dev = 0.f;
+#pragma unroll
+          for (int q = 0; q < LN_SLOTS / 2; ++q) {
+            const float d0 = ln_raw[q][0] - mu, d1 = ln_raw[q][2] - mu;
+            dev += d0 * d0 + d1 * d1;
+          }
+          const float var = (m2 + dev * 32.0f) * (1.0f / CFD_D);
+          // (an LDS write the compiler does not see: in front of one it does, it waits for EVERY pending LDS-DMA request -- it cannot tell that
+          //  the (mu, r_sigma) slots lie behind the staging ring -- and the first barrier would wait for both stages instead of the first)
+          typedef float f32x2_t __attribute__((ext_vector_type(2)));
+          const f32x2_t mr = {mu, 1.0f / sqrtf(var + epi.ln_eps)};
+          const unsigned la = (unsigned)(unsigned long long)(lptr_t)(smem + NSTAGE * STAGE + threadIdx.x * 8);
+          asm volatile("ds_write_b64 %0, %1" ::"v"(la), "v"(mr) : "memory");
         }
-        const float var = (m2 + dev * 32.0f) * (1.0f / CFD_D);
-        reinterpret_cast<float2*>(smem + NSTAGE * STAGE)[threadIdx.x] = make_float2(mu, 1.0f / sqrtf(var + epi.ln_eps));
       }
     }
   };
@@ -711,7 +731,7 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
 
   if constexpr (NSTAGE == 2) {
     stage(0, 0);
-    ln_finish();
+    ln_finish(std::integral_constant<int, GPW>{});
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
       const int buf = kt & 1;
@@ -727,7 +747,7 @@ __device__ __forceinline__ void gemm_sp_body(const GemmArgs& a, const Epi& epi, 
     stage(0, 0);
     if (nkt > 1) {
       stage(1, 1);
-      ln_finish();
+      ln_finish(std::integral_constant<int, 2 * GPW>{});
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPW) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
